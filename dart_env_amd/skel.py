@@ -1,0 +1,437 @@
+"""Model compiler: DART ``.skel`` XML  ->  flat :class:`ModelCard`.
+
+The reference never parses its models itself: ``DartEnv.__init__`` hands the
+path to ``pydart2.World(dt, path)`` (reference ``gym/envs/dart/dart_env.py:55``,
+``dart_world.py:5-8``) and DART's SkelParser builds the skeletons.  This module
+is our own reader of that file format.  Every place where DART's interpretation
+of a SKEL field matters is a named *knob*  with the
+DART-faithful value as default:
+
+* body order / DOF order  = joint order in the file, parents created first (A2)
+* ``<body><transformation>``   world pose of the body frame at q = 0
+* ``<joint><transformation>``  joint frame expressed in the *child* body frame
+* ``<axis><xyz>``               joint axis in the joint frame (normalised)
+* missing ``<moment_of_inertia>``  -> inertia of the body's first shape, in the
+  shape's own axes, *ignoring the shape's local transform* (A1,
+  ``inertia_ignores_shape_transform=True``)
+* ``x y z rx ry rz`` poses use R = Rz(rz) * Ry(ry) * Rx(rx)
+* capsule / cylinder long axis = shape-local z; ``<box><size>`` = full extents
+
+Nothing here touches the GPU; the card is plain numbers that the C ABI
+(``include/dart_stepper.h``) and the test oracle both consume.
+"""
+from __future__ import annotations
+
+import json
+import math
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+# joint type codes shared with include/dart_stepper.h
+JT_WELD, JT_PRISMATIC, JT_REVOLUTE, JT_TRANSLATIONAL, JT_EULER_XYZ, JT_EULER_ZYX, JT_UNIVERSAL, JT_FREE = range(8)
+JOINT_NDOF = {JT_WELD: 0, JT_PRISMATIC: 1, JT_REVOLUTE: 1, JT_TRANSLATIONAL: 3,
+              JT_EULER_XYZ: 3, JT_EULER_ZYX: 3, JT_UNIVERSAL: 2, JT_FREE: 6}
+# shape type codes
+SH_CAPSULE, SH_BOX, SH_SPHERE, SH_ELLIPSOID, SH_CYLINDER = range(5)
+
+MAX_BODIES = 32
+MAX_DOFS = 32
+MAX_SHAPES = 32
+
+
+# ----------------------------------------------------------------------------
+# small math helpers
+# ----------------------------------------------------------------------------
+def _rx(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float64)
+
+
+def _ry(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float64)
+
+
+def _rz(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
+
+
+def pose_from_xyzrpy(vals) -> np.ndarray:
+    """4x4 pose from SKEL ``x y z rx ry rz`` (R = Rz*Ry*Rx)."""
+    v = [float(x) for x in vals]
+    T = np.eye(4)
+    T[:3, :3] = _rz(v[5]) @ _ry(v[4]) @ _rx(v[3])
+    T[:3, 3] = v[:3]
+    return T
+
+
+def _floats(text: str) -> List[float]:
+    return [float(t) for t in text.split()]
+
+
+def capsule_inertia(mass: float, radius: float, height: float) -> np.ndarray:
+    """Solid capsule (cylinder + two hemispherical caps), long axis = z, about
+    its centre.  Standard closed form (same published formula DART cites)."""
+    r2 = radius * radius
+    v_cyl = math.pi * r2 * height
+    v_sph = 4.0 / 3.0 * math.pi * r2 * radius
+    dens = mass / (v_cyl + v_sph)
+    m_cyl, m_sph = dens * v_cyl, dens * v_sph
+    izz = 0.5 * m_cyl * r2 + 0.4 * m_sph * r2
+    ixx = m_cyl * (height * height / 12.0 + r2 / 4.0) + m_sph * (
+        0.4 * r2 + 0.25 * height * height + 0.375 * height * radius)
+    return np.diag([ixx, ixx, izz])
+
+
+def box_inertia(mass: float, size) -> np.ndarray:
+    x, y, z = size
+    return np.diag([mass / 12.0 * (y * y + z * z), mass / 12.0 * (x * x + z * z),
+                    mass / 12.0 * (x * x + y * y)])
+
+
+def sphere_inertia(mass: float, radius: float) -> np.ndarray:
+    return np.eye(3) * (0.4 * mass * radius * radius)
+
+
+def ellipsoid_inertia(mass: float, diam) -> np.ndarray:
+    a, b, c = (0.5 * d for d in diam)
+    return np.diag([mass / 5.0 * (b * b + c * c), mass / 5.0 * (a * a + c * c), mass / 5.0 * (a * a + b * b)])
+
+
+def cylinder_inertia(mass: float, radius: float, height: float) -> np.ndarray:
+    ixx = mass * (3 * radius * radius + height * height) / 12.0
+    return np.diag([ixx, ixx, 0.5 * mass * radius * radius])
+
+
+# ----------------------------------------------------------------------------
+# data classes
+# ----------------------------------------------------------------------------
+@dataclass
+class Shape:
+    body: int
+    kind: int
+    pose: np.ndarray            # 4x4 in body frame
+    size: np.ndarray            # capsule: (radius, height, 0); box: extents; sphere: (r,0,0)
+    collidable: bool = True     # collides with the ground plane
+
+
+@dataclass
+class Body:
+    name: str
+    parent: int                 # -1 = world
+    jname: str
+    jtype: int
+    dof_offset: int
+    ndof: int
+    mass: float
+    com: np.ndarray             # (3,) body frame
+    inertia: np.ndarray         # (3,3) about COM, body axes
+    T_pj: np.ndarray            # 4x4 joint frame in parent body frame (world frame for roots)
+    T_cj: np.ndarray            # 4x4 joint frame in child body frame
+    axes: np.ndarray            # (3,3) rows = axis k in joint frame
+
+
+@dataclass
+class ModelCard:
+    name: str
+    dt: float
+    gravity: np.ndarray
+    bodies: List[Body]
+    shapes: List[Shape]
+    lower: np.ndarray
+    upper: np.ndarray
+    limited: np.ndarray         # bool per dof (finite limit present -> enforced, dart_env.py:64-67)
+    damping: np.ndarray
+    stiffness: np.ndarray
+    rest: np.ndarray
+    init_pos: np.ndarray
+    init_vel: np.ndarray
+    ground_y: float             # top face of the immobile ground box
+    friction: float = 1.0       # DART default (no <friction> tags in the assets) (A6)
+    # constraint-solver constants (DART ContactConstraint / JointLimitConstraint defaults, A9)
+    erp: float = 0.01
+    max_erv: float = 10.0
+    cfm: float = 1e-9
+    limit_erp: float = 0.0      # DART 6 joint-limit rows carry no position correction (allowance 0)
+    dof_names: List[str] = field(default_factory=list)
+
+    @property
+    def ndofs(self) -> int:
+        return int(self.lower.shape[0])
+
+    @property
+    def nbodies(self) -> int:
+        return len(self.bodies)
+
+    @property
+    def total_mass(self) -> float:
+        return float(sum(b.mass for b in self.bodies))
+
+    # ---- (de)serialisation: our own JSON format, shipped under dart_env_amd/models ----
+    def to_json(self) -> str:
+        def arr(a):
+            return np.asarray(a, dtype=np.float64).tolist()
+        d = dict(
+            format="dart_env_amd.modelcard/1", name=self.name, dt=self.dt, gravity=arr(self.gravity),
+            ground_y=self.ground_y, friction=self.friction, erp=self.erp, max_erv=self.max_erv,
+            cfm=self.cfm, limit_erp=self.limit_erp, dof_names=self.dof_names,
+            lower=[None if not np.isfinite(x) else float(x) for x in self.lower],
+            upper=[None if not np.isfinite(x) else float(x) for x in self.upper],
+            limited=[bool(x) for x in self.limited], damping=arr(self.damping),
+            stiffness=arr(self.stiffness), rest=arr(self.rest), init_pos=arr(self.init_pos),
+            init_vel=arr(self.init_vel),
+            bodies=[dict(name=b.name, parent=b.parent, jname=b.jname, jtype=b.jtype,
+                         dof_offset=b.dof_offset, ndof=b.ndof, mass=b.mass, com=arr(b.com),
+                         inertia=arr(b.inertia), T_pj=arr(b.T_pj), T_cj=arr(b.T_cj), axes=arr(b.axes))
+                    for b in self.bodies],
+            shapes=[dict(body=s.body, kind=s.kind, pose=arr(s.pose), size=arr(s.size),
+                         collidable=bool(s.collidable)) for s in self.shapes],
+        )
+        return json.dumps(d, indent=1)
+
+    @staticmethod
+    def from_json(text: str) -> "ModelCard":
+        d = json.loads(text)
+        f = lambda a: np.asarray(a, dtype=np.float64)
+        lim = lambda a, fill: np.array([fill if x is None else x for x in a], dtype=np.float64)
+        bodies = [Body(name=b["name"], parent=b["parent"], jname=b["jname"], jtype=b["jtype"],
+                       dof_offset=b["dof_offset"], ndof=b["ndof"], mass=b["mass"], com=f(b["com"]),
+                       inertia=f(b["inertia"]), T_pj=f(b["T_pj"]), T_cj=f(b["T_cj"]), axes=f(b["axes"]))
+                  for b in d["bodies"]]
+        shapes = [Shape(body=s["body"], kind=s["kind"], pose=f(s["pose"]), size=f(s["size"]),
+                        collidable=s["collidable"]) for s in d["shapes"]]
+        return ModelCard(
+            name=d["name"], dt=d["dt"], gravity=f(d["gravity"]), bodies=bodies, shapes=shapes,
+            lower=lim(d["lower"], -np.inf), upper=lim(d["upper"], np.inf),
+            limited=np.asarray(d["limited"], dtype=bool), damping=f(d["damping"]),
+            stiffness=f(d["stiffness"]), rest=f(d["rest"]), init_pos=f(d["init_pos"]),
+            init_vel=f(d["init_vel"]), ground_y=d["ground_y"], friction=d["friction"], erp=d["erp"],
+            max_erv=d["max_erv"], cfm=d["cfm"], limit_erp=d["limit_erp"], dof_names=d["dof_names"])
+
+
+# ----------------------------------------------------------------------------
+# parser
+# ----------------------------------------------------------------------------
+_JOINT_TYPES = {"weld": JT_WELD, "prismatic": JT_PRISMATIC, "revolute": JT_REVOLUTE,
+                "translational": JT_TRANSLATIONAL, "universal": JT_UNIVERSAL, "free": JT_FREE}
+
+
+def _shape_from_xml(el, body_index: int) -> Optional[Shape]:
+    pose = np.eye(4)
+    t = el.find("transformation")
+    if t is not None and t.text:
+        pose = pose_from_xyzrpy(_floats(t.text))
+    g = el.find("geometry")
+    if g is None:
+        return None
+    if g.find("capsule") is not None:
+        c = g.find("capsule")
+        return Shape(body_index, SH_CAPSULE, pose,
+                     np.array([float(c.find("radius").text), float(c.find("height").text), 0.0]))
+    if g.find("box") is not None:
+        return Shape(body_index, SH_BOX, pose, np.array(_floats(g.find("box").find("size").text)))
+    if g.find("sphere") is not None:
+        return Shape(body_index, SH_SPHERE, pose, np.array([float(g.find("sphere").find("radius").text), 0, 0]))
+    if g.find("ellipsoid") is not None:
+        return Shape(body_index, SH_ELLIPSOID, pose, np.array(_floats(g.find("ellipsoid").find("size").text)))
+    if g.find("cylinder") is not None:
+        c = g.find("cylinder")
+        return Shape(body_index, SH_CYLINDER, pose,
+                     np.array([float(c.find("radius").text), float(c.find("height").text), 0.0]))
+    return None  # meshes: no primitive; caller falls back to collision shapes
+
+
+def shape_inertia(shape: Shape, mass: float) -> np.ndarray:
+    if shape.kind == SH_CAPSULE:
+        return capsule_inertia(mass, shape.size[0], shape.size[1])
+    if shape.kind == SH_BOX:
+        return box_inertia(mass, shape.size)
+    if shape.kind == SH_SPHERE:
+        return sphere_inertia(mass, shape.size[0])
+    if shape.kind == SH_ELLIPSOID:
+        return ellipsoid_inertia(mass, shape.size)
+    if shape.kind == SH_CYLINDER:
+        return cylinder_inertia(mass, shape.size[0], shape.size[1])
+    raise ValueError(shape.kind)
+
+
+def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
+               inertia_ignores_shape_transform: bool = True,
+               collidable_bodies: Optional[List[str]] = None) -> ModelCard:
+    """Compile the robot skeleton of a ``.skel`` world into a :class:`ModelCard`.
+
+    ``skeleton_index=-1`` mirrors ``robot_skeleton = skeletons[-1]``
+    (reference dart_env.py:62); ``dt`` overrides ``<time_step>`` as the
+    ``DartWorld(dt, path)`` constructor argument does (dart_env.py:55, A12).
+    ``collidable_bodies`` restricts ground contact to the named bodies
+    (None = every body with a collision shape).
+    """
+    root = ET.parse(path).getroot()
+    world = root.find("world")
+    phys = world.find("physics")
+    file_dt = float(phys.find("time_step").text)
+    gravity = np.array(_floats(phys.find("gravity").text))
+    skels = world.findall("skeleton")
+
+    # ---- ground: top face of the highest immobile box that spans the origin ----
+    ground_y = None
+    for sk in skels:
+        mob = sk.find("mobile")
+        if mob is None or mob.text.strip().lower() != "false":
+            continue
+        T_sk = np.eye(4)
+        if sk.find("transformation") is not None:
+            T_sk = pose_from_xyzrpy(_floats(sk.find("transformation").text))
+        for b in sk.findall("body"):
+            T_b = T_sk @ pose_from_xyzrpy(_floats(b.find("transformation").text))
+            for cs in b.findall("collision_shape"):
+                s = _shape_from_xml(cs, 0)
+                if s is None or s.kind != SH_BOX or s.size[0] < 100.0:
+                    continue  # only the big floor slab is the ground plane
+                top = (T_b @ s.pose)[1, 3] + 0.5 * s.size[1]
+                ground_y = top if ground_y is None else max(ground_y, top)
+    if ground_y is None:
+        ground_y = -np.inf  # no floor (e.g. reacher)
+
+    sk = skels[skeleton_index]
+    T_sk = np.eye(4)
+    if sk.find("transformation") is not None and sk.find("transformation").text:
+        T_sk = pose_from_xyzrpy(_floats(sk.find("transformation").text))
+
+    xml_bodies: Dict[str, ET.Element] = {b.get("name"): b for b in sk.findall("body")}
+    world_pose = {n: T_sk @ pose_from_xyzrpy(_floats(b.find("transformation").text))
+                  for n, b in xml_bodies.items()}
+    xml_joints = sk.findall("joint")
+    joint_by_child = {j.find("child").text.strip(): j for j in xml_joints}
+
+    # ---- creation order: joints in file order, ancestors first ----
+    order: List[ET.Element] = []
+    created = set()
+
+    def create(j):
+        child = j.find("child").text.strip()
+        if child in created:
+            return
+        parent = j.find("parent").text.strip()
+        if parent != "world" and parent not in created:
+            if parent not in joint_by_child:
+                raise ValueError("body %s has no parent joint" % parent)
+            create(joint_by_child[parent])
+        created.add(child)
+        order.append(j)
+
+    for j in xml_joints:
+        create(j)
+
+    body_index = {j.find("child").text.strip(): i for i, j in enumerate(order)}
+    bodies: List[Body] = []
+    shapes: List[Shape] = []
+    lower, upper, limited, damping, stiff, rest, ipos, ivel, dof_names = [], [], [], [], [], [], [], [], []
+    dof_off = 0
+    for i, j in enumerate(order):
+        cname = j.find("child").text.strip()
+        pname = j.find("parent").text.strip()
+        bx = xml_bodies[cname]
+        jt_text = j.get("type")
+        axes = np.zeros((3, 3))
+        if jt_text == "euler":
+            ao = j.find("axis_order").text.strip().lower()
+            jtype = {"xyz": JT_EULER_XYZ, "zyx": JT_EULER_ZYX}[ao]
+        else:
+            jtype = _JOINT_TYPES[jt_text]
+        ndof = JOINT_NDOF[jtype]
+        T_cj = np.eye(4)
+        if j.find("transformation") is not None and j.find("transformation").text:
+            T_cj = pose_from_xyzrpy(_floats(j.find("transformation").text))
+        W_child = world_pose[cname]
+        W_parent = np.eye(4) if pname == "world" else world_pose[pname]
+        T_pj = np.linalg.inv(W_parent) @ W_child @ T_cj
+
+        # per-dof properties
+        ax_tags = ["axis", "axis2", "axis3"]
+        jl = [-np.inf] * ndof
+        ju = [np.inf] * ndof
+        jd = [0.0] * ndof
+        jk = [0.0] * ndof
+        jr = [0.0] * ndof
+        for k in range(min(ndof, 3)):
+            a = j.find(ax_tags[k])
+            if a is None:
+                continue
+            if a.find("xyz") is not None:
+                v = np.array(_floats(a.find("xyz").text))
+                axes[k] = v / np.linalg.norm(v)
+            lim = a.find("limit")
+            if lim is not None:
+                if lim.find("lower") is not None:
+                    jl[k] = float(lim.find("lower").text)
+                if lim.find("upper") is not None:
+                    ju[k] = float(lim.find("upper").text)
+            dyn = a.find("dynamics")
+            if dyn is not None:
+                if dyn.find("damping") is not None:
+                    jd[k] = float(dyn.find("damping").text)
+                if dyn.find("spring_stiffness") is not None:
+                    jk[k] = float(dyn.find("spring_stiffness").text)
+                if dyn.find("spring_rest_position") is not None:
+                    jr[k] = float(dyn.find("spring_rest_position").text)
+        if jtype in (JT_EULER_XYZ, JT_EULER_ZYX, JT_TRANSLATIONAL):
+            axes = np.eye(3)
+        ip = _floats(j.find("init_pos").text) if j.find("init_pos") is not None and j.find("init_pos").text else []
+        iv = _floats(j.find("init_vel").text) if j.find("init_vel") is not None and j.find("init_vel").text else []
+        ip = (ip + [0.0] * ndof)[:ndof]
+        iv = (iv + [0.0] * ndof)[:ndof]
+
+        # inertia
+        mass, com, inertia = 1.0, np.zeros(3), np.eye(3)
+        ine = bx.find("inertia")
+        body_shapes: List[Shape] = []
+        for tag in ("visualization_shape", "collision_shape"):
+            for el in bx.findall(tag):
+                s = _shape_from_xml(el, i)
+                if s is not None:
+                    body_shapes.append(s)
+        if ine is not None:
+            mass = float(ine.find("mass").text)
+            if ine.find("offset") is not None:
+                com = np.array(_floats(ine.find("offset").text))
+            moi = ine.find("moment_of_inertia")
+            if moi is not None:
+                g = lambda n: float(moi.find(n).text)
+                inertia = np.array([[g("ixx"), g("ixy"), g("ixz")], [g("ixy"), g("iyy"), g("iyz")],
+                                    [g("ixz"), g("iyz"), g("izz")]])
+            elif body_shapes:
+                s0 = body_shapes[0]
+                inertia = shape_inertia(s0, mass)
+                if not inertia_ignores_shape_transform:
+                    R = s0.pose[:3, :3]
+                    inertia = R @ inertia @ R.T
+        for el in bx.findall("collision_shape"):
+            s = _shape_from_xml(el, i)
+            if s is not None:
+                s.collidable = collidable_bodies is None or cname in collidable_bodies
+                shapes.append(s)
+
+        bodies.append(Body(name=cname, parent=-1 if pname == "world" else body_index[pname],
+                           jname=j.get("name"), jtype=jtype, dof_offset=dof_off, ndof=ndof, mass=mass,
+                           com=com, inertia=inertia, T_pj=T_pj, T_cj=T_cj, axes=axes))
+        for k in range(ndof):
+            lower.append(jl[k]); upper.append(ju[k])
+            limited.append(bool(np.isfinite(jl[k]) or np.isfinite(ju[k])))
+            damping.append(jd[k]); stiff.append(jk[k]); rest.append(jr[k])
+            ipos.append(ip[k]); ivel.append(iv[k])
+            dof_names.append(j.get("name") if ndof == 1 else "%s_%d" % (j.get("name"), k))
+        dof_off += ndof
+
+    if len(bodies) > MAX_BODIES or dof_off > MAX_DOFS or len(shapes) > MAX_SHAPES:
+        raise ValueError("model exceeds ModelCard capacity")
+    f = lambda a: np.asarray(a, dtype=np.float64)
+    return ModelCard(name=sk.get("name"), dt=float(dt if dt is not None else file_dt), gravity=gravity,
+                     bodies=bodies, shapes=shapes, lower=f(lower), upper=f(upper),
+                     limited=np.asarray(limited, dtype=bool), damping=f(damping), stiffness=f(stiff),
+                     rest=f(rest), init_pos=f(ipos), init_vel=f(ivel), ground_y=float(ground_y),
+                     dof_names=dof_names)

@@ -1,0 +1,121 @@
+/* dart_model_card.h -- flat, POD description of one articulated model + task.
+ *
+ * This is the data half of the C ABI (the function half is dart_stepper.h).
+ * It carries what the reference obtains implicitly by handing a .skel path to
+ * pydart2 (reference gym/envs/dart/dart_env.py:55,62-67: load world, take the
+ * last skeleton, enforce every finite joint limit) plus the per-task constants
+ * hard-coded in the reference's env constructors (hopper.py:8-12,
+ * walker2d.py:8-12).  Filled by dart_env_amd/skel.py (model compiler).
+ *
+ * All lengths in metres, angles in radians, row-major matrices, doubles.
+ */
+#ifndef DART_MODEL_CARD_H
+#define DART_MODEL_CARD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DART_CARD_VERSION 1
+#define DART_MAX_BODIES 32
+#define DART_MAX_DOFS 32
+#define DART_MAX_SHAPES 32
+#define DART_MAX_ACTIONS 32
+
+/* joint types (DART joint classes named in the .skel `type=` attribute) */
+enum {
+  DART_JT_WELD = 0,
+  DART_JT_PRISMATIC = 1,
+  DART_JT_REVOLUTE = 2,
+  DART_JT_TRANSLATIONAL = 3,
+  DART_JT_EULER_XYZ = 4,
+  DART_JT_EULER_ZYX = 5,
+  DART_JT_UNIVERSAL = 6,
+  DART_JT_FREE = 7
+};
+
+/* collision shape types */
+enum { DART_SH_CAPSULE = 0, DART_SH_BOX = 1, DART_SH_SPHERE = 2, DART_SH_ELLIPSOID = 3, DART_SH_CYLINDER = 4 };
+
+/* task epilogues (reward / done / observation computed on device) */
+enum {
+  DART_TASK_NONE = 0,      /* physics only: obs = [q, dq], reward 0, done 0 */
+  DART_TASK_HOPPER = 1,    /* reference gym/envs/dart/hopper.py:36-74   */
+  DART_TASK_WALKER2D = 2   /* reference gym/envs/dart/walker2d.py:22-74 */
+};
+
+typedef struct DartModelCard {
+  int32_t version;       /* DART_CARD_VERSION */
+  int32_t struct_bytes;  /* sizeof(DartModelCard) as seen by the caller */
+  char name[32];
+
+  /* ---- world ---- */
+  double dt;          /* physics time step (dart_env.py:29,55) */
+  double gravity[3];
+  double ground_y;    /* top face of the immobile ground box; -inf = no floor */
+  double friction;    /* Coulomb mu of foot/ground pair (DART default 1.0) */
+  double erp;         /* contact error-reduction parameter (DART 0.01) */
+  double max_erv;     /* cap of the contact correction velocity (DART 10) */
+  double cfm;         /* constraint force mixing on diag(A) (DART 1e-9) */
+  double limit_erp;   /* joint-limit correction gain (DART 6: effectively 0) */
+
+  /* ---- bodies (creation order = joint order in file, parents first) ---- */
+  int32_t nbodies;
+  int32_t ndofs;
+  int32_t parent[DART_MAX_BODIES];   /* -1 = world */
+  int32_t jtype[DART_MAX_BODIES];
+  int32_t dof_offset[DART_MAX_BODIES];
+  int32_t ndof[DART_MAX_BODIES];
+  double mass[DART_MAX_BODIES];
+  double com[DART_MAX_BODIES][3];      /* body frame */
+  double inertia[DART_MAX_BODIES][9];  /* about COM, body axes */
+  double T_pj[DART_MAX_BODIES][16];    /* joint frame in parent body frame (4x4) */
+  double T_cj[DART_MAX_BODIES][16];    /* joint frame in child body frame (4x4) */
+  double axes[DART_MAX_BODIES][9];     /* rows: axis k in joint frame */
+
+  /* ---- degrees of freedom ---- */
+  double lower[DART_MAX_DOFS];
+  double upper[DART_MAX_DOFS];
+  int32_t limited[DART_MAX_DOFS];      /* finite limit -> enforced (dart_env.py:64-67) */
+  double damping[DART_MAX_DOFS];
+  double stiffness[DART_MAX_DOFS];
+  double rest[DART_MAX_DOFS];
+  double init_pos[DART_MAX_DOFS];
+  double init_vel[DART_MAX_DOFS];
+
+  /* ---- collision shapes of the robot (vs. ground plane) ---- */
+  int32_t nshapes;
+  int32_t shape_body[DART_MAX_SHAPES];
+  int32_t shape_type[DART_MAX_SHAPES];
+  int32_t shape_collidable[DART_MAX_SHAPES];
+  double shape_pose[DART_MAX_SHAPES][16];  /* in body frame */
+  double shape_size[DART_MAX_SHAPES][3];   /* capsule: radius,height,0; box: extents */
+
+  /* ---- task constants ---- */
+  int32_t task;             /* DART_TASK_* */
+  int32_t frame_skip;       /* hopper.py:12 */
+  int32_t act_dim;
+  int32_t obs_dim;
+  int32_t act_dof0;         /* first actuated dof: tau[act_dof0 + k] = clamp(a_k) * scale_k */
+  int32_t max_episode_steps;/* TimeLimit (gym/envs/__init__.py:210,269) */
+  int32_t height_body;      /* bodynodes[k].com()[1] used for height (hopper.py:42) */
+  int32_t penalty_dof;      /* hopper.py:46 `for j in [-2]` resolved to an index; -1 = none */
+  double act_scale[DART_MAX_ACTIONS];
+  double act_low[DART_MAX_ACTIONS];
+  double act_high[DART_MAX_ACTIONS];
+  double alive_bonus;       /* 1.0 */
+  double ctrl_cost;         /* 1e-3 */
+  double limit_penalty;     /* 0.5 * 1.5 per side within penalty_margin (hopper.py:45-58) */
+  double penalty_margin;    /* 0.05 */
+  double height_lo, height_hi, angle_max;   /* done thresholds (hopper.py:60-62) */
+  double state_abs_max;     /* 100 */
+  double obs_vel_clip;      /* 10 */
+  double reset_noise;       /* 0.005 (hopper.py:78-79) */
+} DartModelCard;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DART_MODEL_CARD_H */

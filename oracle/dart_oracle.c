@@ -1,0 +1,785 @@
+/* dart_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * fp64 CPU restatement of what one `dart_world.step()` does for the Dart envs
+ * (reference call site gym/envs/dart/dart_env.py:170-175) and of the task
+ * epilogues wrapped around it (hopper.py:24-74, walker2d.py:22-74).
+ *
+ * PARITY UNPINNED.  The arithmetic of World::step lives in pydart2 -> DART
+ * (C++, libdart6), an un-vendored, un-pinned third-party dependency that is
+ * absent from /root/reference and from this image (reference tox.ini:22,52-55
+ * and test.dockerfile:27-29 are its only, commented-out, mentions).  The
+ * reference holds no golden vector for this path (gym/envs/tests/rollout.json
+ * is `{}`; test_envs_semantics.py:68-70 is disabled).  This file therefore
+ * restates DART 6's *published algorithm* (SURVEY.md Appendix B):
+ *
+ *   1. forward dynamics with implicit joint damping/springs:
+ *        (M + dt D + dt^2 K) qdd = tau - C(q,qd) - D qd - K (q + dt qd - rest)
+ *      (DART GenericJoint::updateTotalForceDynamics / updateInvProjArtInertiaImplicit)
+ *   2. qd* = qd + dt qdd                        (Skeleton::integrateVelocities)
+ *   3. constraints detected at q_t: capsule/ground contacts (ODE capsule-box:
+ *      one contact at the lowest segment endpoint), joint limits (inclusive)
+ *   4. boxed LCP  A = J H^-1 J^T (1+cfm on diag), b = -J qd* + erp*depth/dt,
+ *      friction rows bounded by +-mu * (frictionless normal impulse) exactly as
+ *      the ODE Dantzig driver DART calls sets lo/hi when it reaches the first
+ *      findex row (two-stage solve)
+ *   5. qd = qd* + H^-1 J^T lambda ; q += dt qd  (Skeleton::integratePositions)
+ *
+ * It is pinned only by known-answer tests (tests/test_oracle_physics.py):
+ * closed-form free fall, total mass / standing normal force, M symmetric PD and
+ * M[:,i] = RNEA(q,0,e_i) - RNEA(q,0,0), an independent Lagrangian derivation in
+ * numpy, energy drift, LCP complementarity, PGS -> exact-solver limit.
+ *
+ * Formulation (deliberately different from the GPU kernel so the two check each
+ * other): full 3-D Featherstone spatial algebra in body coordinates, every
+ * multi-dof joint expanded into a chain of 1-dof links with massless carriers,
+ * dense Cholesky, block-principal-pivoting exact BLCP solver and a fixed-count
+ * PGS that mirrors the device iteration order.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/dart_model_card.h"
+
+#define MAXL 96  /* internal 1-dof links */
+#define MAXN DART_MAX_DOFS
+#define MAXC DART_MAX_SHAPES
+#define MAXM (3 * MAXC + MAXN)
+
+typedef struct {
+  double E[9]; /* rotation parent->child coords (rows = child axes in parent coords) */
+  double r[3]; /* child origin in parent coords */
+} Xform;
+
+typedef struct {
+  int parent;      /* link index, -1 world */
+  int jtype;       /* weld / prismatic / revolute */
+  int dof;         /* index into q, -1 for weld */
+  double axis[3];  /* joint frame */
+  double Tpre[16]; /* joint frame in parent link frame */
+  double Tpost[16];/* joint frame in child link frame */
+  double S[6];     /* motion subspace in child link frame [w; v], constant */
+  double I[36];    /* spatial inertia in link frame */
+  double mass, com[3];
+} Link;
+
+typedef struct OracleWorld {
+  DartModelCard card;
+  int nl, n;
+  Link L[MAXL];
+  int body_link[DART_MAX_BODIES];
+  /* state */
+  double q[MAXN], dq[MAXN], tau[MAXN];
+  double time;
+  /* solver options */
+  int solver;       /* 0 = exact (block principal pivoting), 1 = PGS fixed count */
+  int pgs_k1, pgs_k2;
+  int planar_drop_z;/* drop friction rows whose A_ii == 0 */
+  /* scratch / last-step diagnostics */
+  Xform X[MAXL];
+  double W[MAXL][16]; /* world pose of each link */
+  double M[MAXN * MAXN], C[MAXN];
+  int m_last;
+  double lambda_last[MAXM], w_last[MAXM], lo_last[MAXM], hi_last[MAXM];
+  int ncontacts_last;
+  double contact_last[MAXC][8]; /* body, px,py,pz, depth, fn, ft1, ft2 */
+  double lcp_residual_last;
+} OracleWorld;
+
+/* ------------------------------------------------------------------ small linear algebra */
+static void mat4_mul(const double* A, const double* B, double* C) {
+  double T[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0;
+      for (int k = 0; k < 4; k++) s += A[4 * i + k] * B[4 * k + j];
+      T[4 * i + j] = s;
+    }
+  memcpy(C, T, sizeof T);
+}
+static void mat4_inv_rigid(const double* A, double* B) {
+  double T[16] = {0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) T[4 * i + j] = A[4 * j + i];
+  for (int i = 0; i < 3; i++) {
+    double s = 0;
+    for (int j = 0; j < 3; j++) s += A[4 * j + i] * A[4 * j + 3];
+    T[4 * i + 3] = -s;
+  }
+  T[15] = 1;
+  memcpy(B, T, sizeof T);
+}
+static void mat4_identity(double* A) {
+  memset(A, 0, 16 * sizeof(double));
+  A[0] = A[5] = A[10] = A[15] = 1;
+}
+static void cross3(const double* a, const double* b, double* c) {
+  double t0 = a[1] * b[2] - a[2] * b[1], t1 = a[2] * b[0] - a[0] * b[2], t2 = a[0] * b[1] - a[1] * b[0];
+  c[0] = t0; c[1] = t1; c[2] = t2;
+}
+static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* Rodrigues rotation about unit axis a by angle t -> 3x3 row-major */
+static void rot_axis(const double* a, double t, double* R) {
+  double c = cos(t), s = sin(t), v = 1 - c;
+  R[0] = a[0] * a[0] * v + c;        R[1] = a[0] * a[1] * v - a[2] * s; R[2] = a[0] * a[2] * v + a[1] * s;
+  R[3] = a[1] * a[0] * v + a[2] * s; R[4] = a[1] * a[1] * v + c;        R[5] = a[1] * a[2] * v - a[0] * s;
+  R[6] = a[2] * a[0] * v - a[1] * s; R[7] = a[2] * a[1] * v + a[0] * s; R[8] = a[2] * a[2] * v + c;
+}
+
+/* spatial motion transform: vc = X vp */
+static void xf_motion(const Xform* X, const double* vp, double* vc) {
+  double t[3], u[3];
+  cross3(vp, X->r, t); /* w x r */
+  for (int i = 0; i < 3; i++) u[i] = vp[3 + i] + t[i];
+  for (int i = 0; i < 3; i++) {
+    vc[i] = X->E[3 * i] * vp[0] + X->E[3 * i + 1] * vp[1] + X->E[3 * i + 2] * vp[2];
+    vc[3 + i] = X->E[3 * i] * u[0] + X->E[3 * i + 1] * u[1] + X->E[3 * i + 2] * u[2];
+  }
+}
+/* spatial force transform child->parent: fp = X^T fc */
+static void xf_force_T(const Xform* X, const double* fc, double* fp) {
+  double n[3], f[3], t[3];
+  for (int i = 0; i < 3; i++) {
+    n[i] = X->E[i] * fc[0] + X->E[3 + i] * fc[1] + X->E[6 + i] * fc[2];
+    f[i] = X->E[i] * fc[3] + X->E[3 + i] * fc[4] + X->E[6 + i] * fc[5];
+  }
+  cross3(X->r, f, t);
+  for (int i = 0; i < 3; i++) { fp[i] = n[i] + t[i]; fp[3 + i] = f[i]; }
+}
+/* 6x6 of X (motion) */
+static void xf_matrix(const Xform* X, double* M6) {
+  /* [E 0; -E rx  E] */
+  double rx[9] = {0, -X->r[2], X->r[1], X->r[2], 0, -X->r[0], -X->r[1], X->r[0], 0};
+  memset(M6, 0, 36 * sizeof(double));
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      M6[6 * i + j] = X->E[3 * i + j];
+      M6[6 * (3 + i) + 3 + j] = X->E[3 * i + j];
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += X->E[3 * i + k] * rx[3 * k + j];
+      M6[6 * (3 + i) + j] = -s;
+    }
+}
+static void mat6_XtIX(const double* X6, const double* I6, double* out) {
+  double T[36];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += I6[6 * i + k] * X6[6 * k + j];
+      T[6 * i + j] = s;
+    }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += X6[6 * k + i] * T[6 * k + j];
+      out[6 * i + j] = s;
+    }
+}
+static void mat6_vec(const double* A, const double* x, double* y) {
+  for (int i = 0; i < 6; i++) {
+    double s = 0;
+    for (int k = 0; k < 6; k++) s += A[6 * i + k] * x[k];
+    y[i] = s;
+  }
+}
+/* v x m (motion cross motion) */
+static void crm(const double* v, const double* m, double* out) {
+  double a[3], b[3], c[3];
+  cross3(v, m, a);
+  cross3(v, m + 3, b);
+  cross3(v + 3, m, c);
+  for (int i = 0; i < 3; i++) { out[i] = a[i]; out[3 + i] = b[i] + c[i]; }
+}
+/* v x* f (motion cross force) */
+static void crf(const double* v, const double* f, double* out) {
+  double a[3], b[3], c[3];
+  cross3(v, f, a);
+  cross3(v + 3, f + 3, b);
+  cross3(v, f + 3, c);
+  for (int i = 0; i < 3; i++) { out[i] = a[i] + b[i]; out[3 + i] = c[i]; }
+}
+
+static void spatial_inertia(double m, const double* c, const double* Ic, double* I6) {
+  double cx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+  memset(I6, 0, 36 * sizeof(double));
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double cc = 0;
+      for (int k = 0; k < 3; k++) cc += cx[3 * i + k] * cx[3 * k + j];
+      I6[6 * i + j] = Ic[3 * i + j] - m * cc;
+      I6[6 * i + 3 + j] = m * cx[3 * i + j];
+      I6[6 * (3 + i) + j] = -m * cx[3 * i + j];
+    }
+  for (int i = 0; i < 3; i++) I6[6 * (3 + i) + 3 + i] = m;
+}
+
+/* ------------------------------------------------------------------ model build */
+static void link_set_S(Link* l) {
+  /* joint-frame twist -> child link frame via Tpost (joint frame in child frame) */
+  double wj[3] = {0, 0, 0}, vj[3] = {0, 0, 0};
+  memset(l->S, 0, sizeof l->S);
+  if (l->jtype == DART_JT_REVOLUTE) memcpy(wj, l->axis, sizeof wj);
+  else if (l->jtype == DART_JT_PRISMATIC) memcpy(vj, l->axis, sizeof vj);
+  else return;
+  double R[9], p[3] = {l->Tpost[3], l->Tpost[7], l->Tpost[11]};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[3 * i + j] = l->Tpost[4 * i + j];
+  double w[3], v[3], t[3];
+  for (int i = 0; i < 3; i++) {
+    w[i] = R[3 * i] * wj[0] + R[3 * i + 1] * wj[1] + R[3 * i + 2] * wj[2];
+    v[i] = R[3 * i] * vj[0] + R[3 * i + 1] * vj[1] + R[3 * i + 2] * vj[2];
+  }
+  cross3(p, w, t); /* v(body origin) = v(joint origin) + w x (O_B - O_J) = v_J + p x w */
+  for (int i = 0; i < 3; i++) { l->S[i] = w[i]; l->S[3 + i] = v[i] + t[i]; }
+}
+
+static int add_link(OracleWorld* w, int parent, int jtype, int dof, const double* axis, const double* Tpre,
+                    const double* Tpost) {
+  Link* l = &w->L[w->nl];
+  memset(l, 0, sizeof *l);
+  l->parent = parent; l->jtype = jtype; l->dof = dof;
+  if (axis) memcpy(l->axis, axis, 3 * sizeof(double));
+  if (Tpre) memcpy(l->Tpre, Tpre, 16 * sizeof(double)); else mat4_identity(l->Tpre);
+  if (Tpost) memcpy(l->Tpost, Tpost, 16 * sizeof(double)); else mat4_identity(l->Tpost);
+  link_set_S(l);
+  return w->nl++;
+}
+
+OracleWorld* oracle_create(const DartModelCard* card) {
+  if (!card || card->version != DART_CARD_VERSION || card->struct_bytes != (int32_t)sizeof(DartModelCard)) return NULL;
+  OracleWorld* w = (OracleWorld*)calloc(1, sizeof(OracleWorld));
+  w->card = *card;
+  w->n = card->ndofs;
+  w->solver = 0; w->pgs_k1 = 30; w->pgs_k2 = 30; w->planar_drop_z = 1;
+  static const double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, ez[3] = {0, 0, 1};
+  for (int b = 0; b < card->nbodies; b++) {
+    int pl = card->parent[b] < 0 ? -1 : w->body_link[card->parent[b]];
+    int d0 = card->dof_offset[b];
+    const double* Tpj = card->T_pj[b];
+    const double* Tcj = card->T_cj[b];
+    const double* ax = card->axes[b];
+    int last = -1;
+    switch (card->jtype[b]) {
+      case DART_JT_WELD: last = add_link(w, pl, DART_JT_WELD, -1, NULL, Tpj, Tcj); break;
+      case DART_JT_PRISMATIC: last = add_link(w, pl, DART_JT_PRISMATIC, d0, ax, Tpj, Tcj); break;
+      case DART_JT_REVOLUTE: last = add_link(w, pl, DART_JT_REVOLUTE, d0, ax, Tpj, Tcj); break;
+      case DART_JT_TRANSLATIONAL: {
+        int a = add_link(w, pl, DART_JT_PRISMATIC, d0, ex, Tpj, NULL);
+        int c = add_link(w, a, DART_JT_PRISMATIC, d0 + 1, ey, NULL, NULL);
+        last = add_link(w, c, DART_JT_PRISMATIC, d0 + 2, ez, NULL, Tcj);
+      } break;
+      case DART_JT_EULER_XYZ: { /* R = Rx(q0) Ry(q1) Rz(q2) */
+        int a = add_link(w, pl, DART_JT_REVOLUTE, d0, ex, Tpj, NULL);
+        int c = add_link(w, a, DART_JT_REVOLUTE, d0 + 1, ey, NULL, NULL);
+        last = add_link(w, c, DART_JT_REVOLUTE, d0 + 2, ez, NULL, Tcj);
+      } break;
+      case DART_JT_EULER_ZYX: { /* R = Rz(q0) Ry(q1) Rx(q2) */
+        int a = add_link(w, pl, DART_JT_REVOLUTE, d0, ez, Tpj, NULL);
+        int c = add_link(w, a, DART_JT_REVOLUTE, d0 + 1, ey, NULL, NULL);
+        last = add_link(w, c, DART_JT_REVOLUTE, d0 + 2, ex, NULL, Tcj);
+      } break;
+      case DART_JT_UNIVERSAL: {
+        int a = add_link(w, pl, DART_JT_REVOLUTE, d0, ax, Tpj, NULL);
+        last = add_link(w, a, DART_JT_REVOLUTE, d0 + 1, ax + 3, NULL, Tcj);
+      } break;
+      default: free(w); return NULL;
+    }
+    w->body_link[b] = last;
+    Link* l = &w->L[last];
+    l->mass = card->mass[b];
+    memcpy(l->com, card->com[b], sizeof l->com);
+    spatial_inertia(card->mass[b], card->com[b], card->mass[b] > 0 ? card->inertia[b] : (const double[9]){0}, l->I);
+  }
+  for (int i = 0; i < w->n; i++) { w->q[i] = card->init_pos[i]; w->dq[i] = card->init_vel[i]; }
+  return w;
+}
+void oracle_destroy(OracleWorld* w) { free(w); }
+void oracle_set_solver(OracleWorld* w, int solver, int k1, int k2) { w->solver = solver; w->pgs_k1 = k1; w->pgs_k2 = k2; }
+void oracle_set_state(OracleWorld* w, const double* q, const double* dq) {
+  memcpy(w->q, q, w->n * sizeof(double)); memcpy(w->dq, dq, w->n * sizeof(double));
+}
+void oracle_get_state(const OracleWorld* w, double* q, double* dq) {
+  memcpy(q, w->q, w->n * sizeof(double)); memcpy(dq, w->dq, w->n * sizeof(double));
+}
+void oracle_set_forces(OracleWorld* w, const double* tau) { memcpy(w->tau, tau, w->n * sizeof(double)); }
+/* pydart2 World.reset: time 0, positions/velocities back to initial, forces cleared (dart_world.py:20-22) */
+void oracle_reset(OracleWorld* w) {
+  for (int i = 0; i < w->n; i++) { w->q[i] = w->card.init_pos[i]; w->dq[i] = w->card.init_vel[i]; w->tau[i] = 0; }
+  w->time = 0;
+}
+
+/* ------------------------------------------------------------------ kinematics */
+static void kinematics(OracleWorld* w) {
+  for (int i = 0; i < w->nl; i++) {
+    Link* l = &w->L[i];
+    double TJ[16];
+    mat4_identity(TJ);
+    if (l->jtype == DART_JT_REVOLUTE) {
+      double R[9];
+      rot_axis(l->axis, w->q[l->dof], R);
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) TJ[4 * a + b] = R[3 * a + b];
+    } else if (l->jtype == DART_JT_PRISMATIC) {
+      for (int a = 0; a < 3; a++) TJ[4 * a + 3] = l->axis[a] * w->q[l->dof];
+    }
+    double Tinv[16], T[16];
+    mat4_inv_rigid(l->Tpost, Tinv);
+    mat4_mul(l->Tpre, TJ, T);
+    mat4_mul(T, Tinv, T); /* child link frame in parent link frame */
+    for (int a = 0; a < 3; a++) {
+      for (int b = 0; b < 3; b++) w->X[i].E[3 * a + b] = T[4 * b + a];
+      w->X[i].r[a] = T[4 * a + 3];
+    }
+    if (l->parent < 0) memcpy(w->W[i], T, sizeof T);
+    else mat4_mul(w->W[l->parent], T, w->W[i]);
+  }
+}
+
+/* RNEA: tau = ID(q, dq, ddq) with gravity; ddq may be NULL (=0) */
+static void rnea(OracleWorld* w, const double* dq, const double* ddq, int with_gravity, double* tau) {
+  double v[MAXL][6], a[MAXL][6], f[MAXL][6];
+  double a0[6] = {0, 0, 0, 0, 0, 0};
+  if (with_gravity) for (int i = 0; i < 3; i++) a0[3 + i] = -w->card.gravity[i];
+  for (int i = 0; i < w->nl; i++) {
+    Link* l = &w->L[i];
+    double vp[6] = {0}, ap[6];
+    if (l->parent < 0) { memcpy(ap, a0, sizeof ap); }
+    else { memcpy(vp, v[l->parent], sizeof vp); memcpy(ap, a[l->parent], sizeof ap); }
+    double vJ[6] = {0};
+    xf_motion(&w->X[i], vp, v[i]);
+    xf_motion(&w->X[i], ap, a[i]);
+    if (l->dof >= 0) {
+      double qd = dq ? dq[l->dof] : 0.0, qdd = ddq ? ddq[l->dof] : 0.0;
+      for (int k = 0; k < 6; k++) vJ[k] = l->S[k] * qd;
+      double c[6];
+      for (int k = 0; k < 6; k++) v[i][k] += vJ[k];
+      crm(v[i], vJ, c);
+      for (int k = 0; k < 6; k++) a[i][k] += l->S[k] * qdd + c[k];
+    }
+    double Iv[6], Ia[6], t[6];
+    mat6_vec(l->I, v[i], Iv);
+    mat6_vec(l->I, a[i], Ia);
+    crf(v[i], Iv, t);
+    for (int k = 0; k < 6; k++) f[i][k] = Ia[k] + t[k];
+  }
+  for (int i = w->nl - 1; i >= 0; i--) {
+    Link* l = &w->L[i];
+    if (l->dof >= 0) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += l->S[k] * f[i][k];
+      tau[l->dof] = s;
+    }
+    if (l->parent >= 0) {
+      double fp[6];
+      xf_force_T(&w->X[i], f[i], fp);
+      for (int k = 0; k < 6; k++) f[l->parent][k] += fp[k];
+    }
+  }
+}
+
+/* CRBA -> dense M (n x n) */
+static void crba(OracleWorld* w, double* M) {
+  static double Ic[MAXL][36];
+  int n = w->n;
+  memset(M, 0, n * n * sizeof(double));
+  for (int i = 0; i < w->nl; i++) memcpy(Ic[i], w->L[i].I, 36 * sizeof(double));
+  for (int i = w->nl - 1; i >= 0; i--) {
+    Link* l = &w->L[i];
+    if (l->parent >= 0) {
+      double X6[36], T[36];
+      xf_matrix(&w->X[i], X6);
+      mat6_XtIX(X6, Ic[i], T);
+      for (int k = 0; k < 36; k++) Ic[l->parent][k] += T[k];
+    }
+  }
+  for (int i = 0; i < w->nl; i++) {
+    Link* l = &w->L[i];
+    if (l->dof < 0) continue;
+    double F[6];
+    mat6_vec(Ic[i], l->S, F);
+    double s = 0;
+    for (int k = 0; k < 6; k++) s += l->S[k] * F[k];
+    M[l->dof * n + l->dof] = s;
+    int j = i;
+    while (w->L[j].parent >= 0) {
+      double Fp[6];
+      xf_force_T(&w->X[j], F, Fp);
+      memcpy(F, Fp, sizeof F);
+      j = w->L[j].parent;
+      if (w->L[j].dof >= 0) {
+        double t = 0;
+        for (int k = 0; k < 6; k++) t += w->L[j].S[k] * F[k];
+        M[l->dof * n + w->L[j].dof] = t;
+        M[w->L[j].dof * n + l->dof] = t;
+      }
+    }
+  }
+}
+
+/* Jacobian row: d . velocity of world point P rigidly attached to link li */
+static void point_jacobian(OracleWorld* w, int li, const double* P, const double* d, double* J) {
+  for (int k = 0; k < w->n; k++) J[k] = 0;
+  for (int j = li; j >= 0; j = w->L[j].parent) {
+    Link* l = &w->L[j];
+    if (l->dof < 0) continue;
+    const double* Wm = w->W[j];
+    double ww[3], vw[3], rel[3], t[3];
+    for (int a = 0; a < 3; a++) {
+      ww[a] = Wm[4 * a] * l->S[0] + Wm[4 * a + 1] * l->S[1] + Wm[4 * a + 2] * l->S[2];
+      vw[a] = Wm[4 * a] * l->S[3] + Wm[4 * a + 1] * l->S[4] + Wm[4 * a + 2] * l->S[5];
+      rel[a] = P[a] - Wm[4 * a + 3];
+    }
+    cross3(ww, rel, t);
+    J[l->dof] = d[0] * (vw[0] + t[0]) + d[1] * (vw[1] + t[1]) + d[2] * (vw[2] + t[2]);
+  }
+}
+
+/* ------------------------------------------------------------------ dense SPD solve */
+static int cholesky(double* A, int n) { /* in place lower, row-major */
+  for (int j = 0; j < n; j++) {
+    double s = A[j * n + j];
+    for (int k = 0; k < j; k++) s -= A[j * n + k] * A[j * n + k];
+    if (s <= 0) return -1;
+    A[j * n + j] = sqrt(s);
+    for (int i = j + 1; i < n; i++) {
+      double t = A[i * n + j];
+      for (int k = 0; k < j; k++) t -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = t / A[j * n + j];
+    }
+  }
+  return 0;
+}
+static void chol_solve(const double* Lm, int n, double* x) {
+  for (int i = 0; i < n; i++) {
+    double s = x[i];
+    for (int k = 0; k < i; k++) s -= Lm[i * n + k] * x[k];
+    x[i] = s / Lm[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= Lm[k * n + i] * x[k];
+    x[i] = s / Lm[i * n + i];
+  }
+}
+
+/* ------------------------------------------------------------------ boxed LCP solvers
+ * find x, w = A x - b with  lo<=x<=hi,  (x==lo -> w>=0), (x==hi -> w<=0), (lo<x<hi -> w==0)
+ * rows listed in idx[0..m) of the full system of stride `ld`. */
+long oracle_bpp_hist[64];
+static int blcp_exact(const double* A, const double* b, const double* lo, const double* hi, const int* idx, int m,
+                      int ld, double* x) {
+  /* block principal pivoting with single-pivot (least index) fallback; sets: 0 free, 1 at lo, 2 at hi */
+  int set[MAXM];
+  for (int i = 0; i < m; i++) {
+    int g = idx[i];
+    set[i] = (lo[g] == 0.0 && hi[g] > 0) ? 1 : (hi[g] == 0.0 && lo[g] < 0 ? 2 : (lo[g] == hi[g] ? 1 : 0));
+    if (set[i] == 0 && x[g] <= lo[g]) set[i] = 1;
+    if (set[i] == 0 && x[g] >= hi[g]) set[i] = 2;
+  }
+  int best = m + 1, patience = 10, single = 0;
+  for (int iter = 0; iter < 4000; iter++) {
+    int fi[MAXM], nf = 0;
+    for (int i = 0; i < m; i++) if (set[i] == 0) fi[nf++] = i;
+    static double AF[MAXM * MAXM];
+    double rhs[MAXM];
+    for (int a = 0; a < nf; a++) {
+      int ga = idx[fi[a]];
+      double s = b[ga];
+      for (int j = 0; j < m; j++) if (set[j] != 0) s -= A[ga * ld + idx[j]] * (set[j] == 1 ? lo[idx[j]] : hi[idx[j]]);
+      rhs[a] = s;
+      for (int c = 0; c < nf; c++) AF[a * nf + c] = A[ga * ld + idx[fi[c]]];
+    }
+    if (nf > 0) {
+      if (cholesky(AF, nf) != 0) return -1;
+      chol_solve(AF, nf, rhs);
+    }
+    for (int i = 0; i < m; i++) x[idx[i]] = set[i] == 1 ? lo[idx[i]] : (set[i] == 2 ? hi[idx[i]] : 0.0);
+    for (int a = 0; a < nf; a++) x[idx[fi[a]]] = rhs[a];
+    /* infeasibilities */
+    int bad[MAXM], nb = 0;
+    for (int i = 0; i < m; i++) {
+      int g = idx[i];
+      if (set[i] == 0) {
+        if (x[g] < lo[g] - 1e-14 * (1 + fabs(lo[g])) || x[g] > hi[g] + 1e-14 * (1 + fabs(hi[g]))) bad[nb++] = i;
+      } else {
+        double wv = -b[g];
+        for (int j = 0; j < m; j++) wv += A[g * ld + idx[j]] * x[idx[j]];
+        if (lo[g] == hi[g]) continue; /* pinned */
+        if ((set[i] == 1 && wv < -1e-13) || (set[i] == 2 && wv > 1e-13)) bad[nb++] = i;
+      }
+    }
+    if (nb == 0) { oracle_bpp_hist[iter < 63 ? iter : 63]++; return 0; }
+    if (nb < best) { best = nb; patience = 10; single = 0; }
+    else if (--patience <= 0) single = 1;
+    int from = single ? nb - 1 : 0; /* single: switch only the largest index (Murty) */
+    for (int k = from; k < nb; k++) {
+      int i = bad[k], g = idx[i];
+      if (set[i] == 0) set[i] = x[g] < lo[g] ? 1 : 2;
+      else set[i] = 0;
+    }
+  }
+  return -2;
+}
+
+static void pgs_sweeps(const double* A, const double* b, const double* lo, const double* hi, const int* idx, int m,
+                       int ld, int iters, double* x) {
+  for (int it = 0; it < iters; it++)
+    for (int i = 0; i < m; i++) {
+      int g = idx[i];
+      double r = b[g];
+      for (int j = 0; j < m; j++) r -= A[g * ld + idx[j]] * x[idx[j]];
+      double xn = x[g] + r / A[g * ld + g];
+      x[g] = xn < lo[g] ? lo[g] : (xn > hi[g] ? hi[g] : xn);
+    }
+}
+
+/* ------------------------------------------------------------------ World::step */
+int oracle_step(OracleWorld* w) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double dt = c->dt;
+  kinematics(w);
+  crba(w, w->M);
+  rnea(w, w->dq, NULL, 1, w->C);
+  /* H = M + dt D + dt^2 K ; rhs = tau - C - D dq - K (q + dt dq - rest) */
+  static double H[MAXN * MAXN];
+  double rhs[MAXN];
+  memcpy(H, w->M, n * n * sizeof(double));
+  for (int i = 0; i < n; i++) {
+    H[i * n + i] += dt * c->damping[i] + dt * dt * c->stiffness[i];
+    rhs[i] = w->tau[i] - w->C[i] - c->damping[i] * w->dq[i] -
+             c->stiffness[i] * (w->q[i] + dt * w->dq[i] - c->rest[i]);
+  }
+  if (cholesky(H, n) != 0) return -1;
+  chol_solve(H, n, rhs);
+  double vs[MAXN];
+  for (int i = 0; i < n; i++) vs[i] = w->dq[i] + dt * rhs[i];
+
+  /* ---- constraints at q_t ---- */
+  static double J[MAXM][MAXN], Y[MAXM][MAXN], A[MAXM * MAXM];
+  double b[MAXM], lo[MAXM], hi[MAXM], x[MAXM];
+  int findex[MAXM];
+  int m = 0;
+  w->ncontacts_last = 0;
+  for (int s = 0; s < c->nshapes; s++) {
+    if (!c->shape_collidable[s] || !isfinite(c->ground_y)) continue;
+    if (c->shape_type[s] != DART_SH_CAPSULE) continue; /* planar configs: capsules only */
+    int li = w->body_link[c->shape_body[s]];
+    double Ts[16];
+    mat4_mul(w->W[li], c->shape_pose[s], Ts);
+    double r = c->shape_size[s][0], hl = 0.5 * c->shape_size[s][1];
+    double p1[3], p2[3];
+    for (int a = 0; a < 3; a++) { p1[a] = Ts[4 * a + 3] + hl * Ts[4 * a + 2]; p2[a] = Ts[4 * a + 3] - hl * Ts[4 * a + 2]; }
+    const double* pe = (p2[1] < p1[1]) ? p2 : p1; /* lowest endpoint; exact tie -> +axis end (ODE t=0) */
+    double d = pe[1] - c->ground_y;
+    if (d > r) continue;
+    double depth = r - d;
+    /* ODE dCollideSpheres(pl, r, pb, 0): pos = pl - n (r + d)/2 */
+    double P[3] = {pe[0], pe[1] - 0.5 * (r + d), pe[2]};
+    double nrm[3] = {0, 1, 0}, t1[3] = {-1, 0, 0}, t2[3] = {0, 0, 1}; /* t1 = normalize(z x n), t2 = n x t1 */
+    int base = m;
+    point_jacobian(w, li, P, nrm, J[m]); lo[m] = 0; hi[m] = INFINITY; findex[m] = -1;
+    {
+      double bounce = depth * c->erp / dt;
+      if (bounce > c->max_erv) bounce = c->max_erv;
+      double rel = 0;
+      for (int k = 0; k < n; k++) rel += J[m][k] * vs[k];
+      b[m] = -rel + bounce;
+    }
+    m++;
+    const double* tt[2] = {t1, t2};
+    for (int k2 = 0; k2 < 2; k2++) {
+      point_jacobian(w, li, P, tt[k2], J[m]);
+      double rel = 0, nn = 0;
+      for (int k = 0; k < n; k++) { rel += J[m][k] * vs[k]; nn += J[m][k] * J[m][k]; }
+      if (w->planar_drop_z && nn == 0.0) continue; /* out-of-plane direction of a planar model */
+      b[m] = -rel; lo[m] = -c->friction; hi[m] = c->friction; findex[m] = base;
+      m++;
+    }
+    double* cl = w->contact_last[w->ncontacts_last++];
+    cl[0] = c->shape_body[s]; cl[1] = P[0]; cl[2] = P[1]; cl[3] = P[2]; cl[4] = depth; cl[5] = base;
+  }
+  for (int i = 0; i < n; i++) {
+    if (!c->limited[i]) continue;
+    int side = 0;
+    double viol = 0;
+    if (w->q[i] <= c->lower[i]) { side = -1; viol = w->q[i] - c->lower[i]; }
+    else if (w->q[i] >= c->upper[i]) { side = +1; viol = w->q[i] - c->upper[i]; }
+    if (!side) continue;
+    memset(J[m], 0, sizeof J[m]);
+    J[m][i] = 1.0;
+    double bounce = -viol * c->limit_erp / dt;
+    if (bounce > c->max_erv) bounce = c->max_erv;
+    if (bounce < -c->max_erv) bounce = -c->max_erv;
+    b[m] = -vs[i] + bounce;
+    if (side < 0) { lo[m] = 0; hi[m] = INFINITY; } else { lo[m] = -INFINITY; hi[m] = 0; }
+    findex[m] = -1;
+    m++;
+  }
+  w->m_last = m;
+  w->lcp_residual_last = 0;
+  if (m > 0) {
+    for (int i = 0; i < m; i++) {
+      memcpy(Y[i], J[i], n * sizeof(double));
+      chol_solve(H, n, Y[i]);
+    }
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < m; j++) {
+        double s = 0;
+        for (int k = 0; k < n; k++) s += J[i][k] * Y[j][k];
+        A[i * m + j] = s;
+      }
+    for (int i = 0; i < m; i++) A[i * m + i] *= (1.0 + c->cfm);
+    /* stage 1: rows without findex */
+    int idx1[MAXM], m1 = 0, idx2[MAXM];
+    for (int i = 0; i < m; i++) { x[i] = 0; idx2[i] = i; if (findex[i] < 0) idx1[m1++] = i; }
+    int has_fric = (m1 != m);
+    if (w->solver == 0) {
+      if (blcp_exact(A, b, lo, hi, idx1, m1, m, x) != 0) return -2;
+    } else {
+      pgs_sweeps(A, b, lo, hi, idx1, m1, m, has_fric ? w->pgs_k1 : w->pgs_k1 + w->pgs_k2, x);
+    }
+    if (has_fric) {
+      /* ODE lcp.cpp: at the first findex row, hi = |hi * x[findex]|, lo = -hi (0 if the normal impulse is 0) */
+      for (int i = 0; i < m; i++)
+        if (findex[i] >= 0) { double wf = x[findex[i]]; hi[i] = fabs(hi[i] * wf); lo[i] = -hi[i]; }
+      if (w->solver == 0) {
+        if (blcp_exact(A, b, lo, hi, idx2, m, m, x) != 0) return -3;
+      } else {
+        pgs_sweeps(A, b, lo, hi, idx2, m, m, w->pgs_k2, x);
+      }
+    }
+    for (int i = 0; i < m; i++) {
+      for (int k = 0; k < n; k++) vs[k] += Y[i][k] * x[i];
+    }
+    /* diagnostics: complementarity residual */
+    double res = 0;
+    for (int i = 0; i < m; i++) {
+      double wv = -b[i];
+      for (int j = 0; j < m; j++) wv += A[i * m + j] * x[j];
+      w->lambda_last[i] = x[i]; w->w_last[i] = wv; w->lo_last[i] = lo[i]; w->hi_last[i] = hi[i];
+      double e;
+      if (x[i] <= lo[i]) e = wv < 0 ? -wv : 0;
+      else if (x[i] >= hi[i]) e = wv > 0 ? wv : 0;
+      else e = fabs(wv);
+      if (e > res) res = e;
+    }
+    w->lcp_residual_last = res;
+    for (int k = 0; k < w->ncontacts_last; k++) {
+      int base = (int)w->contact_last[k][5];
+      w->contact_last[k][5] = x[base];
+      w->contact_last[k][6] = (base + 1 < m && findex[base + 1] == base) ? x[base + 1] : 0.0;
+      w->contact_last[k][7] = (base + 2 < m && findex[base + 2] == base) ? x[base + 2] : 0.0;
+    }
+  }
+  for (int i = 0; i < n; i++) { w->dq[i] = vs[i]; w->q[i] += dt * vs[i]; w->tau[i] = 0; }
+  w->time += dt;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ introspection (known-answer tests) */
+void oracle_mass_matrix(OracleWorld* w, double* M) { kinematics(w); crba(w, w->M); memcpy(M, w->M, w->n * w->n * sizeof(double)); }
+void oracle_bias(OracleWorld* w, double* C) { kinematics(w); rnea(w, w->dq, NULL, 1, C); }
+void oracle_inverse_dynamics(OracleWorld* w, const double* dq, const double* ddq, int with_gravity, double* tau) {
+  kinematics(w); rnea(w, dq, ddq, with_gravity, tau);
+}
+void oracle_body_pose(OracleWorld* w, int body, double* T16) { kinematics(w); memcpy(T16, w->W[w->body_link[body]], 16 * sizeof(double)); }
+void oracle_body_com(OracleWorld* w, int body, double* out3) {
+  kinematics(w);
+  const double* T = w->W[w->body_link[body]];
+  const double* cm = w->card.com[body];
+  for (int a = 0; a < 3; a++) out3[a] = T[4 * a] * cm[0] + T[4 * a + 1] * cm[1] + T[4 * a + 2] * cm[2] + T[4 * a + 3];
+}
+int oracle_last_lcp(const OracleWorld* w, double* lambda, double* wv, double* lo, double* hi, double* residual) {
+  for (int i = 0; i < w->m_last; i++) { lambda[i] = w->lambda_last[i]; wv[i] = w->w_last[i]; lo[i] = w->lo_last[i]; hi[i] = w->hi_last[i]; }
+  *residual = w->lcp_residual_last;
+  return w->m_last;
+}
+int oracle_last_contacts(const OracleWorld* w, double* out8) {
+  memcpy(out8, w->contact_last, w->ncontacts_last * 8 * sizeof(double));
+  return w->ncontacts_last;
+}
+/* total mechanical energy (kinetic + gravitational potential) */
+double oracle_energy(OracleWorld* w) {
+  kinematics(w); crba(w, w->M);
+  double ke = 0, pe = 0;
+  for (int i = 0; i < w->n; i++) for (int j = 0; j < w->n; j++) ke += 0.5 * w->dq[i] * w->M[i * w->n + j] * w->dq[j];
+  for (int b = 0; b < w->card.nbodies; b++) {
+    double cm[3];
+    const double* T = w->W[w->body_link[b]];
+    const double* cb = w->card.com[b];
+    for (int a = 0; a < 3; a++) cm[a] = T[4 * a] * cb[0] + T[4 * a + 1] * cb[1] + T[4 * a + 2] * cb[2] + T[4 * a + 3];
+    pe -= w->card.mass[b] * dot3(w->card.gravity, cm);
+  }
+  return ke + pe;
+}
+
+/* ------------------------------------------------------------------ task epilogue (hopper.py:24-74, walker2d.py:22-74)
+ * One env-step for the planar locomotion tasks; actions already float64.  Returns done. */
+int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double tau[MAXN] = {0};
+  double sq = 0;
+  for (int k = 0; k < c->act_dim; k++) {
+    double cl = a[k];
+    if (cl > c->act_high[k]) cl = c->act_high[k];
+    if (cl < c->act_low[k]) cl = c->act_low[k];
+    tau[c->act_dof0 + k] = cl * c->act_scale[k];
+    sq += a[k] * a[k]; /* reward uses the UNclamped action (hopper.py:55) */
+  }
+  double posbefore = w->q[0];
+  int rc = 0;
+  for (int f = 0; f < c->frame_skip; f++) {
+    oracle_set_forces(w, tau);  /* forces are cleared by every world step (dart_env.py:174) */
+    rc |= oracle_step(w);
+  }
+  double posafter = w->q[0], ang = w->q[2];
+  double cm[3];
+  oracle_body_com(w, c->height_body, cm);
+  double height = cm[1];
+  double pen = 0;
+  if (c->penalty_dof >= 0) {
+    int j = c->penalty_dof;
+    if ((c->lower[j] - w->q[j]) > -c->penalty_margin) pen += 1.5;
+    if ((c->upper[j] - w->q[j]) < c->penalty_margin) pen += 1.5;
+  }
+  double envdt = c->dt * c->frame_skip;
+  double r = (posafter - posbefore) / envdt;
+  r += c->alive_bonus;
+  r -= c->ctrl_cost * sq;
+  r -= c->limit_penalty * pen;
+  *reward = r;
+  int ok = 1;
+  for (int i = 0; i < n; i++) {
+    if (!isfinite(w->q[i]) || !isfinite(w->dq[i])) ok = 0;
+    if (i >= 2 && !(fabs(w->q[i]) < c->state_abs_max)) ok = 0;
+    if (!(fabs(w->dq[i]) < c->state_abs_max)) ok = 0;
+  }
+  if (!(height > c->height_lo && height < c->height_hi && fabs(ang) < c->angle_max)) ok = 0;
+  for (int i = 1; i < n; i++) obs[i - 1] = w->q[i];
+  for (int i = 0; i < n; i++) {
+    double v = w->dq[i];
+    obs[n - 1 + i] = v < -c->obs_vel_clip ? -c->obs_vel_clip : (v > c->obs_vel_clip ? c->obs_vel_clip : v);
+  }
+  obs[0] = height;
+  (void)rc;
+  return !ok;
+}
+void oracle_env_obs(OracleWorld* w, double* obs) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double cm[3];
+  oracle_body_com(w, c->height_body, cm);
+  for (int i = 1; i < n; i++) obs[i - 1] = w->q[i];
+  for (int i = 0; i < n; i++) {
+    double v = w->dq[i];
+    obs[n - 1 + i] = v < -c->obs_vel_clip ? -c->obs_vel_clip : (v > c->obs_vel_clip ? c->obs_vel_clip : v);
+  }
+  obs[0] = cm[1];
+}

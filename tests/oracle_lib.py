@@ -1,0 +1,168 @@
+"""ctypes binding of oracle/libdart_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Builds the library on demand with oracle/Makefile (gcc).  Nothing under
+dart_env_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dart_env_amd.model_card import DartModelCard
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB_PATH = os.path.join(_ROOT, "oracle", "libdart_oracle.so")
+_lib = None
+
+
+def build():
+    src = os.path.join(_ROOT, "oracle", "dart_oracle.c")
+    if (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.POINTER(DartModelCard)]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oracle_set_state.argtypes = [C.c_void_p, dp, dp]
+        L.oracle_get_state.argtypes = [C.c_void_p, dp, dp]
+        L.oracle_set_forces.argtypes = [C.c_void_p, dp]
+        L.oracle_reset.argtypes = [C.c_void_p]
+        L.oracle_step.argtypes = [C.c_void_p]
+        L.oracle_step.restype = C.c_int
+        L.oracle_mass_matrix.argtypes = [C.c_void_p, dp]
+        L.oracle_bias.argtypes = [C.c_void_p, dp]
+        L.oracle_inverse_dynamics.argtypes = [C.c_void_p, dp, dp, C.c_int, dp]
+        L.oracle_body_pose.argtypes = [C.c_void_p, C.c_int, dp]
+        L.oracle_body_com.argtypes = [C.c_void_p, C.c_int, dp]
+        L.oracle_last_lcp.argtypes = [C.c_void_p, dp, dp, dp, dp, dp]
+        L.oracle_last_lcp.restype = C.c_int
+        L.oracle_last_contacts.argtypes = [C.c_void_p, dp]
+        L.oracle_last_contacts.restype = C.c_int
+        L.oracle_energy.argtypes = [C.c_void_p]
+        L.oracle_energy.restype = C.c_double
+        L.oracle_env_step.argtypes = [C.c_void_p, dp, dp, dp]
+        L.oracle_env_step.restype = C.c_int
+        L.oracle_env_obs.argtypes = [C.c_void_p, dp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleWorld:
+    """One fp64 world (one env)."""
+    EXACT, PGS = 0, 1
+
+    def __init__(self, card: DartModelCard, solver=EXACT, k1=30, k2=30):
+        self.card = card
+        self.L = lib()
+        self.h = self.L.oracle_create(C.byref(card))
+        if not self.h:
+            raise RuntimeError("oracle_create failed")
+        self.n = card.ndofs
+        self.set_solver(solver, k1, k2)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def set_solver(self, solver, k1=30, k2=30):
+        self.L.oracle_set_solver(self.h, solver, k1, k2)
+
+    def set_state(self, q, dq):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        dq = np.ascontiguousarray(dq, dtype=np.float64)
+        self.L.oracle_set_state(self.h, _p(q), _p(dq))
+
+    def get_state(self):
+        q = np.zeros(self.n)
+        dq = np.zeros(self.n)
+        self.L.oracle_get_state(self.h, _p(q), _p(dq))
+        return q, dq
+
+    @property
+    def q(self):
+        return self.get_state()[0]
+
+    @property
+    def dq(self):
+        return self.get_state()[1]
+
+    def set_forces(self, tau):
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        self.L.oracle_set_forces(self.h, _p(tau))
+
+    def reset(self):
+        self.L.oracle_reset(self.h)
+
+    def step(self):
+        rc = self.L.oracle_step(self.h)
+        if rc != 0:
+            raise RuntimeError("oracle_step rc=%d" % rc)
+
+    def mass_matrix(self):
+        M = np.zeros((self.n, self.n))
+        self.L.oracle_mass_matrix(self.h, _p(M))
+        return M
+
+    def bias(self):
+        c = np.zeros(self.n)
+        self.L.oracle_bias(self.h, _p(c))
+        return c
+
+    def inverse_dynamics(self, dq, ddq, with_gravity=True):
+        dq = np.ascontiguousarray(dq, dtype=np.float64)
+        ddq = np.ascontiguousarray(ddq, dtype=np.float64)
+        tau = np.zeros(self.n)
+        self.L.oracle_inverse_dynamics(self.h, _p(dq), _p(ddq), int(with_gravity), _p(tau))
+        return tau
+
+    def body_pose(self, b):
+        T = np.zeros(16)
+        self.L.oracle_body_pose(self.h, b, _p(T))
+        return T.reshape(4, 4)
+
+    def body_com(self, b):
+        c = np.zeros(3)
+        self.L.oracle_body_com(self.h, b, _p(c))
+        return c
+
+    def last_lcp(self):
+        m = 3 * 32 + 32
+        lam, w, lo, hi = (np.zeros(m) for _ in range(4))
+        res = C.c_double(0)
+        k = self.L.oracle_last_lcp(self.h, _p(lam), _p(w), _p(lo), _p(hi), C.byref(res))
+        return lam[:k], w[:k], lo[:k], hi[:k], res.value
+
+    def last_contacts(self):
+        buf = np.zeros((32, 8))
+        k = self.L.oracle_last_contacts(self.h, _p(buf))
+        return buf[:k]
+
+    def energy(self):
+        return self.L.oracle_energy(self.h)
+
+    def env_step(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        obs = np.zeros(self.card.obs_dim)
+        rew = C.c_double(0)
+        done = self.L.oracle_env_step(self.h, _p(a), _p(obs), C.byref(rew))
+        return obs, rew.value, bool(done)
+
+    def env_obs(self):
+        obs = np.zeros(self.card.obs_dim)
+        self.L.oracle_env_obs(self.h, _p(obs))
+        return obs

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched HIP stepper on BASELINE.json's headline config.
+
+A "step" is one batched env.step() of DartHopper-v1 over `--envs` (default 65 536) environments per GPU:
+clamp/scale action, frame_skip=4 world steps (dynamics + contact/limit LCP + integration), reward, done,
+TimeLimit, observation and on-device auto-reset -- one kernel launch.  Inputs (a ring of random action
+batches, U[-1,1) float32) are resident in HBM before the timed region; outputs stay in HBM.
+
+    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 2000 --warmup 200
+
+Multi-GPU: envs are independent, so ranks own disjoint env shards (Philox streams keyed by global env index) and
+there is NO collective inside the timed region; one RCCL all_gather of the last step's obs/reward/done runs after it
+(the "gather rollouts" exchange of the north star) and is reported separately as gather_ms.
+
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      HBM roofline of the step kernel from HIP-event timing of the same launches
+  cpu_baseline  (N=1 only) the fp64 CPU oracle timed on one host core on a bounded sample, plus the RMS state
+                error of the GPU against it on that sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def algorithmic_bytes(card) -> int:
+    """read q,dq (8n) + actions (4 act) + write q,dq (8n) + obs (4 obs) + reward 4 + done 1."""
+    return 16 * card.ndofs + 4 * card.act_dim + 4 * card.obs_dim + 4 + 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--env-id", default="DartHopper-v1")
+    ap.add_argument("--precision", type=int, default=32)
+    ap.add_argument("--solver", default="bpp", choices=["bpp", "pgs"])
+    ap.add_argument("--pgs-iters", type=int, default=30)
+    ap.add_argument("--ring", type=int, default=16, help="distinct action batches resident in HBM")
+    ap.add_argument("--block", type=int, default=0, help="envs per wave64 workgroup (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=4096)
+    ap.add_argument("--cpu-steps", type=int, default=200)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from dart_env_amd.model_card import card_for
+    from dart_env_amd import stepper as st
+
+    card = card_for(args.env_id)
+    n = args.envs
+    env = st.HipStepper(card, n, device=local_rank, precision=args.precision)
+    env.configure(st.CFG_AUTORESET, 1)
+    env.configure(st.CFG_SEED, 0)
+    env.configure(st.CFG_ENV_OFFSET, rank * n)
+    if args.block:
+        env.configure(st.CFG_BLOCK_THREADS, args.block)
+    if args.solver == "pgs":
+        env.configure(st.CFG_SOLVER, st.SOLVER_PGS)
+        env.configure(st.CFG_ITERS_STAGE1, args.pgs_iters)
+        env.configure(st.CFG_ITERS_STAGE2, args.pgs_iters)
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    ring = (torch.rand((args.ring, n, card.act_dim), device=dev, generator=gen, dtype=torch.float32) * 2 - 1).contiguous()
+    obs = torch.empty((n, card.obs_dim), device=dev, dtype=torch.float32)
+    rew = torch.empty((n,), device=dev, dtype=torch.float32)
+    done = torch.empty((n,), device=dev, dtype=torch.uint8)
+    trunc = torch.empty((n,), device=dev, dtype=torch.uint8)
+    stride = n * card.act_dim * 4
+    env.reset_device(0, obs.data_ptr())
+    env.sync()
+
+    def run(k, base=0):
+        for i in range(k):
+            env.step_device(ring.data_ptr() + ((base + i) % args.ring) * stride, obs.data_ptr(), rew.data_ptr(),
+                            done.data_ptr(), trunc.data_ptr())
+
+    run(args.warmup)
+    env.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    env.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    done_frac = float(done.float().mean().item())
+
+    # ---- kernel-only timing with HIP events on the stepper's own stream (roofline figure)
+    ms_kernel = env.time_steps(ring.data_ptr(), args.ring, min(args.steps, 500), obs.data_ptr(), rew.data_ptr(),
+                               done.data_ptr(), trunc.data_ptr())
+
+    # ---- the north star's "gather rollouts" exchange: one RCCL all_gather, outside the timed region
+    gather_ms = None
+    if dist is not None:
+        packed = torch.cat([obs.reshape(-1), rew, done.float()]).contiguous()
+        out = torch.empty((world, packed.numel()), device=dev, dtype=torch.float32)
+        dist.all_gather_into_tensor(out, packed)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dist.all_gather_into_tensor(out, packed)
+        e1.record(); torch.cuda.synchronize()
+        gather_ms = e0.elapsed_time(e1) / 10
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    abytes = algorithmic_bytes(card)
+    total_steps = world * n * args.steps
+    value = total_steps / elapsed
+    achieved = abytes * n / (ms_kernel * 1e-3) / 1e9
+    result = {
+        "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
+        "config": {"workload": "%s batch %d per GPU, random actions U[-1,1), on-device auto-reset" % (args.env_id, n),
+                   "envs_per_gpu": n, "frame_skip": int(card.frame_skip), "physics_dt": card.dt,
+                   "lcp_solver": "two-stage boxed LCP, %s" % ("block principal pivoting (exact)" if args.solver == "bpp"
+                                                               else "PGS x%d" % args.pgs_iters),
+                   "parallelism": "env-sharded x%d, no data-path collective" % world,
+                   "done_fraction_last_step": done_frac},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                     "traffic": None, "algorithmic_bytes_per_env_step": abytes, "kernel_ms": ms_kernel,
+                     "note": "kernel is VALU-issue bound (fp32 vector), not HBM or MFMA bound; see DESIGN.md"},
+    }
+    if gather_ms is not None:
+        result["gather_ms"] = gather_ms
+
+    if world == 1 and not args.no_cpu_baseline:
+        from tests import oracle_lib as ol  # cpu_baseline leg: the only place bench.py touches the oracle
+        ne, ns = args.cpu_envs, args.cpu_steps
+        acts = np.random.RandomState(7).uniform(-1, 1, (ns, ne, card.act_dim)).astype(np.float32)
+        t0 = time.perf_counter()
+        ref = ol.rollout(card, acts, seed=0, env_offset=0, solver=0)
+        cpu_s = time.perf_counter() - t0
+        small = st.HipStepper(card, ne, device=local_rank, precision=args.precision)
+        small.configure(st.CFG_AUTORESET, 1); small.configure(st.CFG_SEED, 0); small.configure(st.CFG_ENV_OFFSET, 0)
+        d_acts = torch.from_numpy(acts).to(dev)
+        small.reset_device(0, 0)
+        for t in range(ns):
+            small.step_device(d_acts.data_ptr() + t * ne * card.act_dim * 4)
+        small.sync()
+        qg, dqg = small.get_state()
+        el, ep = small.counters()
+        same = (ep == ref["episode"]) & (el == ref["elapsed"])
+        eq = (qg - ref["q"])[same]; edq = (dqg - ref["dq"])[same]
+        result["cpu_baseline"] = {
+            "value": ref["env_steps"] / cpu_s, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d env-steps of %s, same Philox reset streams and action tensor as the GPU check; "
+                      "fp64 DART-semantics restatement (oracle/), not DART" % (ne, ns, args.env_id),
+            "host_cpus": os.cpu_count(),
+            "rms_state_err": {"q": float(np.sqrt(np.mean(eq ** 2))), "dq": float(np.sqrt(np.mean(edq ** 2))),
+                              "envs_same_episode_history": int(same.sum()), "envs": ne, "env_steps": ns},
+        }
+        small.close()
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

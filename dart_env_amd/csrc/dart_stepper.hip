@@ -1,0 +1,461 @@
+// dart_stepper.hip -- host side of the C ABI declared in include/dart_stepper.h.
+//
+// Owns the SoA world state in HBM, validates a DartModelCard against the compiled planar topologies,
+// packs the runtime parameters into a kernel argument, and launches the fused step / reset kernels of
+// planar_kernel.hpp on one HIP stream per handle.  No CPU compute path exists here by design.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/dart_stepper.h"
+#include "planar_kernel.hpp"
+
+using namespace dartk;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Impl {
+  virtual ~Impl() {}
+  virtual hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act,
+                          float* obs, float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed,
+                          uint64_t off) = 0;
+  virtual hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
+                           const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off) = 0;
+  virtual hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) = 0;
+  virtual void set_solver(int solver, int it1, int it2) = 0;
+  virtual int slots() const = 0;
+  int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
+};
+
+template <class Real, class T>
+struct ImplT : Impl {
+  Params<Real, T> P;
+  hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
+                  float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
+    dim3 grid((unsigned)((n + block_threads - 1) / block_threads)), block(block_threads);
+    hipLaunchKernelGGL((step_kernel<Real, T>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew,
+                       done, trunc, autoreset, seed, off);
+    return hipGetLastError();
+  }
+  hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
+                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((reset_kernel<Real, T>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, mask, qn, vn, obs,
+                       seed, off);
+    return hipGetLastError();
+  }
+  hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((state_io_kernel<Real, T::NDOF>), grid, block, 0, s, n, (Real*)q, (Real*)dq, qh, dqh, to_device);
+    return hipGetLastError();
+  }
+  void set_solver(int solver, int it1, int it2) override { P.solver = solver; P.iters1 = it1; P.iters2 = it2; }
+  int slots() const override { return 2 * T::NC + n_limited<T>(); }
+};
+
+bool is_identity3(const double* T16, double tol = 1e-12) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      if (std::fabs(T16[4 * i + j] - (i == j ? 1.0 : 0.0)) > tol) return false;
+  return true;
+}
+
+// Validate the card against topology T and fill the kernel parameters.  Returns "" or the reason it does not fit.
+template <class Real, class T>
+std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
+  constexpr int NL = T::NL;
+  if (c.nbodies != NL + 2 || c.ndofs != T::NDOF) return "body/dof count";
+  if (c.act_dim != T::NA || c.act_dof0 != T::NDOF - T::NA) return "action layout";
+  if (c.obs_dim != 2 * T::NDOF - 1 && c.task != DART_TASK_NONE) return "obs_dim";
+  if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
+  // floating base: prismatic x, prismatic y, revolute +-z
+  if (c.jtype[0] != DART_JT_PRISMATIC || c.jtype[1] != DART_JT_PRISMATIC || c.parent[0] != -1 || c.parent[1] != 0)
+    return "root carriers";
+  if (std::fabs(c.axes[0][0] - 1) > 1e-12 || std::fabs(c.axes[1][1] - 1) > 1e-12) return "root prismatic axes";
+  if (c.mass[0] != 0 || c.mass[1] != 0) return "root carriers must be massless";
+  double x0 = 0, y0 = 0;
+  for (int b = 0; b < 3; b++) {
+    if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated root frames";
+    x0 += c.T_pj[b][3] - c.T_cj[b][3];
+    y0 += c.T_pj[b][7] - c.T_cj[b][7];
+    if (c.T_pj[b][11] != 0 || c.T_cj[b][11] != 0) return "root z offset";
+  }
+  P.root_x0 = (Real)x0; P.root_y0 = (Real)y0;
+  for (int k = 0; k < NL; k++) {
+    int b = k + 2;
+    if (c.jtype[b] != DART_JT_REVOLUTE) return "non-revolute link joint";
+    if (std::fabs(std::fabs(c.axes[b][2]) - 1) > 1e-12) return "link axis must be +-z";
+    if (k > 0) {
+      if (c.parent[b] - 2 != T::parent(k)) return "tree shape";
+      if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated joint frames";
+      if (c.T_pj[b][11] != 0 || c.T_cj[b][3] != 0 || c.T_cj[b][7] != 0 || c.T_cj[b][11] != 0) return "joint offsets";
+      P.jx[k] = (Real)c.T_pj[b][3]; P.jy[k] = (Real)c.T_pj[b][7];
+    } else {
+      if (c.parent[b] != 1) return "root link parent";
+      P.jx[0] = 0; P.jy[0] = 0;
+    }
+    if (c.com[b][2] != 0) return "com off plane";
+    P.sigma[k] = (Real)(c.axes[b][2] > 0 ? 1.0 : -1.0);
+    P.mass[k] = (Real)c.mass[b]; P.cx[k] = (Real)c.com[b][0]; P.cy[k] = (Real)c.com[b][1];
+    P.izz[k] = (Real)c.inertia[b][8];
+    int d = 2 + k;
+    if (c.stiffness[d] != 0) return "joint springs";
+    bool lim = c.limited[d] != 0;
+    if (lim && !T::limited(k)) return "limit on unlimited link";
+    P.lo[k] = (Real)(lim ? c.lower[d] : -INFINITY);
+    P.hi[k] = (Real)(lim ? c.upper[d] : INFINITY);
+  }
+  for (int d = 0; d < T::NDOF; d++) {
+    if (d < 2 && (c.limited[d] || c.stiffness[d] != 0)) return "limits/springs on root translation";
+    P.damp[d] = (Real)c.damping[d]; P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
+  }
+  int nc = 0;
+  for (int s = 0; s < c.nshapes; s++) {
+    if (!c.shape_collidable[s]) continue;
+    if (c.shape_type[s] != DART_SH_CAPSULE) return "collidable non-capsule shape";
+    if (nc >= T::NC) return "too many collidable shapes";
+    if (c.shape_body[s] - 2 != T::clink(nc)) return "collidable shape on unexpected link";
+    const double* S = c.shape_pose[s];
+    double hl = 0.5 * c.shape_size[s][1];
+    if (std::fabs(S[10]) > 1e-9 || S[11] != 0) return "capsule axis off plane";
+    P.e1x[nc] = (Real)(S[3] + hl * S[2]); P.e1y[nc] = (Real)(S[7] + hl * S[6]);
+    P.e2x[nc] = (Real)(S[3] - hl * S[2]); P.e2y[nc] = (Real)(S[7] - hl * S[6]);
+    P.rad[nc] = (Real)c.shape_size[s][0];
+    nc++;
+  }
+  if (nc != T::NC) return "collidable shape count";
+  P.dt = (Real)c.dt; P.ground_y = (Real)c.ground_y; P.g = (Real)(-c.gravity[1]); P.mu = (Real)c.friction;
+  P.erp_dt = (Real)(c.erp / c.dt); P.max_erv = (Real)c.max_erv; P.limit_erp_dt = (Real)(c.limit_erp / c.dt);
+  for (int k = 0; k < T::NA; k++) {
+    P.act_scale[k] = (Real)c.act_scale[k]; P.act_lo[k] = (Real)c.act_low[k]; P.act_hi[k] = (Real)c.act_high[k];
+  }
+  P.alive = (Real)c.alive_bonus; P.ctrl_cost = (Real)c.ctrl_cost; P.pen_each = (Real)(c.limit_penalty * 1.5);
+  P.pen_margin = (Real)c.penalty_margin; P.h_lo = (Real)c.height_lo; P.h_hi = (Real)c.height_hi;
+  P.ang_max = (Real)c.angle_max; P.s_max = (Real)c.state_abs_max; P.v_clip = (Real)c.obs_vel_clip;
+  P.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip)); P.noise = (Real)c.reset_noise;
+  P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task;
+  P.penalty_link = c.penalty_dof >= 2 ? c.penalty_dof - 2 : -1;
+  if (c.task != DART_TASK_NONE && c.height_body != 2) return "height body must be the root link";
+  P.solver = 0; P.iters1 = 24; P.iters2 = 24;
+  return "";
+}
+
+template <class Real>
+std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why) {
+  {
+    auto p = std::make_unique<ImplT<Real, HopperTopo>>();
+    std::string w = fill_params<Real, HopperTopo>(c, p->P);
+    if (w.empty()) return p;
+    why = "hopper-chain: " + w;
+  }
+  {
+    auto p = std::make_unique<ImplT<Real, Walker2dTopo>>();
+    std::string w = fill_params<Real, Walker2dTopo>(c, p->P);
+    if (w.empty()) return p;
+    why += "; walker2d-tree: " + w;
+  }
+  return nullptr;
+}
+
+}  // namespace
+
+struct DartStepper {
+  DartModelCard card;
+  int64_t n = 0;
+  int device = 0, precision = 32;
+  hipStream_t stream = nullptr;
+  std::unique_ptr<Impl> impl;
+  void *q = nullptr, *dq = nullptr;
+  int32_t* elapsed = nullptr;
+  uint32_t* episode = nullptr;
+  float *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr;
+  uint8_t *d_done = nullptr, *d_trunc = nullptr, *d_mask = nullptr;
+  double *d_qn = nullptr, *d_vn = nullptr;
+  float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
+  uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
+  double *h_qn = nullptr, *h_vn = nullptr;
+  int solver = 0, it1 = 24, it2 = 24, autoreset = 0;
+  uint64_t seed = 0, env_offset = 0;
+  bool pending = false;
+  std::string err;
+};
+
+#define CHK(h, expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                          \
+      return DART_E_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+extern "C" {
+
+const char* dart_last_error(const DartStepper* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int dart_create(const DartModelCard* card, int64_t num_envs, int device, int precision, DartStepper** out) {
+  if (!out) { g_err = "out is NULL"; return DART_E_INVALID; }
+  *out = nullptr;
+  if (!card || card->version != DART_CARD_VERSION || card->struct_bytes != (int32_t)sizeof(DartModelCard)) {
+    g_err = "model card version/size mismatch"; return DART_E_INVALID;
+  }
+  if (num_envs <= 0 || (precision != 32 && precision != 64)) { g_err = "bad num_envs/precision"; return DART_E_INVALID; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_err = "no HIP device available (this library has no CPU path)"; return DART_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { g_err = "device index out of range"; return DART_E_INVALID; }
+  std::string why;
+  std::unique_ptr<Impl> impl = precision == 32 ? make_impl<float>(*card, why) : make_impl<double>(*card, why);
+  if (!impl) { g_err = "no compiled kernel for this model: " + why; return DART_E_UNSUPPORTED; }
+  auto h = new DartStepper();
+  h->card = *card; h->n = num_envs; h->device = device; h->precision = precision; h->impl = std::move(impl);
+  h->impl->set_solver(h->solver, h->it1, h->it2);
+  int rc = [&]() -> int {
+    CHK(h, hipSetDevice(device));
+    CHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    size_t rs = precision == 32 ? 4 : 8, nd = (size_t)card->ndofs, N = (size_t)num_envs;
+    CHK(h, hipMalloc(&h->q, rs * nd * N));
+    CHK(h, hipMalloc(&h->dq, rs * nd * N));
+    CHK(h, hipMalloc((void**)&h->elapsed, 4 * N));
+    CHK(h, hipMalloc((void**)&h->episode, 4 * N));
+    CHK(h, hipMalloc((void**)&h->d_act, 4 * N * card->act_dim));
+    CHK(h, hipMalloc((void**)&h->d_obs, 4 * N * card->obs_dim));
+    CHK(h, hipMalloc((void**)&h->d_rew, 4 * N));
+    CHK(h, hipMalloc((void**)&h->d_done, N));
+    CHK(h, hipMalloc((void**)&h->d_trunc, N));
+    CHK(h, hipMalloc((void**)&h->d_mask, N));
+    CHK(h, hipMalloc((void**)&h->d_qn, 8 * N * nd));
+    CHK(h, hipMalloc((void**)&h->d_vn, 8 * N * nd));
+    CHK(h, hipHostMalloc((void**)&h->h_act, 4 * N * card->act_dim));
+    CHK(h, hipHostMalloc((void**)&h->h_obs, 4 * N * card->obs_dim));
+    CHK(h, hipHostMalloc((void**)&h->h_rew, 4 * N));
+    CHK(h, hipHostMalloc((void**)&h->h_done, N));
+    CHK(h, hipHostMalloc((void**)&h->h_trunc, N));
+    CHK(h, hipHostMalloc((void**)&h->h_mask, N));
+    CHK(h, hipHostMalloc((void**)&h->h_qn, 8 * N * nd));
+    CHK(h, hipHostMalloc((void**)&h->h_vn, 8 * N * nd));
+    CHK(h, hipMemsetAsync(h->elapsed, 0, 4 * N, h->stream));
+    CHK(h, hipMemsetAsync(h->episode, 0, 4 * N, h->stream));
+    // initial state = init_pos / init_vel for every env
+    for (size_t i = 0; i < N; i++)
+      for (size_t d = 0; d < nd; d++) { h->h_qn[i * nd + d] = card->init_pos[d]; h->h_vn[i * nd + d] = card->init_vel[d]; }
+    CHK(h, hipMemcpyAsync(h->d_qn, h->h_qn, 8 * N * nd, hipMemcpyHostToDevice, h->stream));
+    CHK(h, hipMemcpyAsync(h->d_vn, h->h_vn, 8 * N * nd, hipMemcpyHostToDevice, h->stream));
+    CHK(h, h->impl->state_io(h->stream, h->n, h->q, h->dq, h->d_qn, h->d_vn, 1));
+    CHK(h, hipStreamSynchronize(h->stream));
+    return DART_OK;
+  }();
+  if (rc != DART_OK) { g_err = h->err; dart_destroy(h); return rc; }
+  *out = h;
+  return DART_OK;
+}
+
+int dart_destroy(DartStepper* h) {
+  if (!h) return DART_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn};
+  for (void* p : dev) if (p) hipFree(p);
+  void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
+  for (void* p : host) if (p) hipHostFree(p);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return DART_OK;
+}
+
+int dart_query(const DartStepper* h, int what, int64_t* out) {
+  if (!h || !out) return DART_E_INVALID;
+  switch (what) {
+    case DART_Q_NUM_ENVS: *out = h->n; break;
+    case DART_Q_NDOFS: *out = h->card.ndofs; break;
+    case DART_Q_OBS_DIM: *out = h->card.obs_dim; break;
+    case DART_Q_ACT_DIM: *out = h->card.act_dim; break;
+    case DART_Q_FRAME_SKIP: *out = h->card.frame_skip; break;
+    case DART_Q_PRECISION: *out = h->precision; break;
+    case DART_Q_DEVICE: *out = h->device; break;
+    case DART_Q_LCP_SLOTS: *out = h->impl->slots(); break;
+    default: return DART_E_INVALID;
+  }
+  return DART_OK;
+}
+
+int dart_configure(DartStepper* h, int key, double value) {
+  if (!h) return DART_E_INVALID;
+  switch (key) {
+    case DART_CFG_SOLVER: h->solver = (int)value; break;
+    case DART_CFG_ITERS_STAGE1: h->it1 = (int)value; break;
+    case DART_CFG_ITERS_STAGE2: h->it2 = (int)value; break;
+    case DART_CFG_AUTORESET: h->autoreset = value != 0; break;
+    case DART_CFG_SEED: h->seed = (uint64_t)value; break;
+    case DART_CFG_ENV_OFFSET: h->env_offset = (uint64_t)value; break;
+    case DART_CFG_BLOCK_THREADS:
+      if (value != 64 && value != 32 && value != 16) { h->err = "block threads must be 16, 32 or 64"; return DART_E_INVALID; }
+      h->impl->block_threads = (int)value; break;
+    default: h->err = "unknown configure key"; return DART_E_INVALID;
+  }
+  if (h->solver < 0 || h->solver > 1 || h->it1 < 0 || h->it2 < 0) { h->err = "bad solver setting"; return DART_E_INVALID; }
+  h->impl->set_solver(h->solver, h->it1, h->it2);
+  return DART_OK;
+}
+
+int dart_reset(DartStepper* h, const uint8_t* mask, const double* qpos_noise, const double* qvel_noise, float* obs_out) {
+  if (!h) return DART_E_INVALID;
+  if ((qpos_noise == nullptr) != (qvel_noise == nullptr)) { h->err = "give both noise arrays or neither"; return DART_E_INVALID; }
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  size_t N = (size_t)h->n, nd = (size_t)h->card.ndofs;
+  const uint8_t* dmask = nullptr;
+  if (mask) {
+    memcpy(h->h_mask, mask, N);
+    CHK(h, hipMemcpyAsync(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice, h->stream));
+    dmask = h->d_mask;
+  }
+  const double *dqn = nullptr, *dvn = nullptr;
+  if (qpos_noise) {
+    // world.reset() puts q, dq at init_pos/init_vel before the noise is added (hopper.py:77-79)
+    for (size_t i = 0; i < N; i++) {
+      if (mask && !mask[i]) continue;
+      for (size_t d = 0; d < nd; d++) {
+        h->h_qn[i * nd + d] = h->card.init_pos[d] + qpos_noise[i * nd + d];
+        h->h_vn[i * nd + d] = h->card.init_vel[d] + qvel_noise[i * nd + d];
+      }
+    }
+    CHK(h, hipMemcpyAsync(h->d_qn, h->h_qn, 8 * N * nd, hipMemcpyHostToDevice, h->stream));
+    CHK(h, hipMemcpyAsync(h->d_vn, h->h_vn, 8 * N * nd, hipMemcpyHostToDevice, h->stream));
+    dqn = h->d_qn; dvn = h->d_vn;
+  }
+  CHK(h, h->impl->reset(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, dmask, dqn, dvn,
+                        obs_out ? h->d_obs : nullptr, h->seed, h->env_offset));
+  if (obs_out) CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
+  CHK(h, hipStreamSynchronize(h->stream));
+  if (obs_out) memcpy(obs_out, h->h_obs, 4 * N * h->card.obs_dim);
+  return DART_OK;
+}
+
+int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void* hip_stream) {
+  if (!h) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  CHK(h, h->impl->reset(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_mask, nullptr, nullptr, d_obs, h->seed, h->env_offset));
+  return DART_OK;
+}
+
+static int state_copy(DartStepper* h, double* q, double* dq, int to_device) {
+  if (!h || !q || !dq) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  size_t bytes = 8 * (size_t)h->n * h->card.ndofs;
+  if (to_device) {
+    memcpy(h->h_qn, q, bytes); memcpy(h->h_vn, dq, bytes);
+    CHK(h, hipMemcpyAsync(h->d_qn, h->h_qn, bytes, hipMemcpyHostToDevice, h->stream));
+    CHK(h, hipMemcpyAsync(h->d_vn, h->h_vn, bytes, hipMemcpyHostToDevice, h->stream));
+    CHK(h, h->impl->state_io(h->stream, h->n, h->q, h->dq, h->d_qn, h->d_vn, 1));
+    CHK(h, hipStreamSynchronize(h->stream));
+  } else {
+    CHK(h, h->impl->state_io(h->stream, h->n, h->q, h->dq, h->d_qn, h->d_vn, 0));
+    CHK(h, hipMemcpyAsync(h->h_qn, h->d_qn, bytes, hipMemcpyDeviceToHost, h->stream));
+    CHK(h, hipMemcpyAsync(h->h_vn, h->d_vn, bytes, hipMemcpyDeviceToHost, h->stream));
+    CHK(h, hipStreamSynchronize(h->stream));
+    memcpy(q, h->h_qn, bytes); memcpy(dq, h->h_vn, bytes);
+  }
+  return DART_OK;
+}
+int dart_set_state(DartStepper* h, const double* q, const double* dq) { return state_copy(h, (double*)q, (double*)dq, 1); }
+int dart_get_state(DartStepper* h, double* q, double* dq) { return state_copy(h, q, dq, 0); }
+
+int dart_step_async(DartStepper* h, const float* actions) {
+  if (!h || !actions) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async called while a step is pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  size_t N = (size_t)h->n;
+  memcpy(h->h_act, actions, 4 * N * h->card.act_dim);
+  CHK(h, hipMemcpyAsync(h->d_act, h->h_act, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
+  CHK(h, h->impl->step(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done,
+                       h->d_trunc, h->autoreset, h->seed, h->env_offset));
+  CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
+  CHK(h, hipMemcpyAsync(h->h_rew, h->d_rew, 4 * N, hipMemcpyDeviceToHost, h->stream));
+  CHK(h, hipMemcpyAsync(h->h_done, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
+  CHK(h, hipMemcpyAsync(h->h_trunc, h->d_trunc, N, hipMemcpyDeviceToHost, h->stream));
+  h->pending = true;
+  return DART_OK;
+}
+
+int dart_step_wait(DartStepper* h, float* obs_out, double* reward_out, uint8_t* done_out, uint8_t* truncated_out) {
+  if (!h) return DART_E_INVALID;
+  if (!h->pending) { h->err = "step_wait called without step_async"; return DART_E_NOT_PENDING; }
+  h->pending = false;
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  size_t N = (size_t)h->n;
+  if (obs_out) memcpy(obs_out, h->h_obs, 4 * N * h->card.obs_dim);
+  if (reward_out) for (size_t i = 0; i < N; i++) reward_out[i] = (double)h->h_rew[i];
+  if (done_out) memcpy(done_out, h->h_done, N);
+  if (truncated_out) memcpy(truncated_out, h->h_trunc, N);
+  return DART_OK;
+}
+
+int dart_step(DartStepper* h, const float* actions, float* obs_out, double* reward_out, uint8_t* done_out,
+              uint8_t* truncated_out) {
+  int rc = dart_step_async(h, actions);
+  if (rc != DART_OK) return rc;
+  return dart_step_wait(h, obs_out, reward_out, done_out, truncated_out);
+}
+
+int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done,
+                     uint8_t* d_truncated, void* hip_stream) {
+  if (!h || !d_actions) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  CHK(h, h->impl->step(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_actions, d_obs ? d_obs : h->d_obs,
+                       d_reward ? d_reward : h->d_rew, d_done ? d_done : h->d_done,
+                       d_truncated ? d_truncated : h->d_trunc, h->autoreset, h->seed, h->env_offset));
+  return DART_OK;
+}
+
+int dart_get_counters(DartStepper* h, int32_t* elapsed, uint32_t* episode) {
+  if (!h) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  if (elapsed) CHK(h, hipMemcpy(elapsed, h->elapsed, 4 * (size_t)h->n, hipMemcpyDeviceToHost));
+  if (episode) CHK(h, hipMemcpy(episode, h->episode, 4 * (size_t)h->n, hipMemcpyDeviceToHost));
+  return DART_OK;
+}
+
+int dart_sync(DartStepper* h) {
+  if (!h) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  return DART_OK;
+}
+
+int dart_time_steps(DartStepper* h, const float* d_actions, int action_batches, float* d_obs, float* d_reward,
+                    uint8_t* d_done, uint8_t* d_truncated, int steps, double* ms_per_step) {
+  if (!h || !d_actions || action_batches <= 0 || steps <= 0 || !ms_per_step) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  hipEvent_t e0, e1;
+  CHK(h, hipEventCreate(&e0));
+  CHK(h, hipEventCreate(&e1));
+  size_t stride = (size_t)h->n * h->card.act_dim;
+  CHK(h, hipEventRecord(e0, h->stream));
+  for (int i = 0; i < steps; i++) {
+    int rc = dart_step_device(h, d_actions + (size_t)(i % action_batches) * stride, d_obs, d_reward, d_done, d_truncated, nullptr);
+    if (rc != DART_OK) return rc;
+  }
+  CHK(h, hipEventRecord(e1, h->stream));
+  CHK(h, hipEventSynchronize(e1));
+  float ms = 0;
+  CHK(h, hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *ms_per_step = (double)ms / steps;
+  return DART_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,636 @@
+// planar_kernel.hpp -- gfx950 device code of the batched planar articulated-body stepper.
+//
+// Replaces, for one env per lane, what the reference does per env in Python + DART:
+//   DartEnv.do_simulation      reference gym/envs/dart/dart_env.py:158-175
+//   DartHopperEnv.advance/step reference gym/envs/dart/hopper.py:24-74
+//   DartWalker2dEnv.step       reference gym/envs/dart/walker2d.py:22-74
+//   TimeLimit.step             reference gym/wrappers/time_limit.py:14-21
+//   SyncVectorEnv auto-reset   reference gym/vector/sync_vector_env.py:73-84
+//
+// Design (MI355X-first): one env per lane, the whole skeleton block -- H (packed), H^-1,
+// constraint Jacobians, Delassus matrix A -- lives in VGPRs (the models of configs 1-3,5 fit;
+// LDS is left for the spatial kernel of the 21/29-dof models), state is struct-of-arrays
+// `q[dof][env]` so every global access is a fully coalesced 256 B wave transaction, all
+// `frame_skip` substeps + reward/done/obs + auto-reset are fused into one launch, and the
+// constraint solver votes across the 64-lane wavefront (`__all`) to leave its loop early.
+// Topology is a compile-time trait (loops unroll to straight-line register code); every
+// numeric model parameter is a runtime kernel argument held in SGPRs.
+//
+// Dynamics formulation: planar composite-rigid-body algorithm in world-aligned, root-relative
+// coordinates (closed forms below) -- a different derivation from the oracle's 6-D spatial
+// algebra, so the two cross-check each other.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace dartk {
+
+// ------------------------------------------------------------------ compile-time loops
+template <int B, int E, class F>
+__device__ __host__ __forceinline__ void sfor(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    sfor<B + 1, E>(f);
+  }
+}
+template <int B, int E, class F>
+__device__ __host__ __forceinline__ void sfor_rev(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, E - 1>{});
+    sfor_rev<B, E - 1>(f);
+  }
+}
+__device__ __host__ constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// ------------------------------------------------------------------ topologies
+// Link 0 is the floating root (dofs 0,1,2 = x, y, rot); link k>=1 hangs on a revolute joint (dof 2+k).
+struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - shin - foot
+  static constexpr int NL = 4, NDOF = NL + 2, NC = 1, NA = 3;
+  __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
+  __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3}; return L[c]; }
+  __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
+};
+struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin foot) x 2
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6;
+  __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
+  __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3, 6}; return L[c]; }
+  __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
+};
+
+template <class T>
+__device__ __host__ constexpr bool is_anc(int j, int k) {  // j ancestor-or-self of k
+  while (k >= 0) {
+    if (k == j) return true;
+    k = T::parent(k);
+  }
+  return false;
+}
+template <class T>
+__device__ __host__ constexpr int n_limited() {
+  int n = 0;
+  for (int k = 0; k < T::NL; k++) n += T::limited(k) ? 1 : 0;
+  return n;
+}
+template <class T>
+__device__ __host__ constexpr int limit_slot(int k) {  // LCP slot of link k's limit row
+  int s = 2 * T::NC;
+  for (int j = 0; j < k; j++) s += T::limited(j) ? 1 : 0;
+  return s;
+}
+
+// ------------------------------------------------------------------ runtime parameters (kernel argument -> SGPRs)
+template <class Real, class T>
+struct Params {
+  Real dt, ground_y, g, mu, erp_dt, max_erv, limit_erp_dt;
+  Real root_x0, root_y0;
+  Real sigma[T::NL], mass[T::NL], cx[T::NL], cy[T::NL], izz[T::NL], jx[T::NL], jy[T::NL];
+  Real lo[T::NL], hi[T::NL];
+  Real damp[T::NDOF], q0[T::NDOF], dq0[T::NDOF];  // joint damping; world.reset() state
+  Real e1x[T::NC], e1y[T::NC], e2x[T::NC], e2y[T::NC], rad[T::NC];
+  Real act_scale[T::NA], act_lo[T::NA], act_hi[T::NA];
+  Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise;
+  int frame_skip, max_steps, penalty_link, task;
+  int solver, iters1, iters2;  // solver 0: block principal pivoting (exact); 1: PGS sweeps
+};
+
+// ------------------------------------------------------------------ math helpers
+template <class Real> __device__ __forceinline__ void sincos_(Real x, Real& s, Real& c);
+template <> __device__ __forceinline__ void sincos_<float>(float x, float& s, float& c) { sincosf(x, &s, &c); }
+template <> __device__ __forceinline__ void sincos_<double>(double x, double& s, double& c) { sincos(x, &s, &c); }
+template <class Real> __device__ __forceinline__ Real inf_() { return Real(__builtin_huge_valf()); }
+template <class Real> __device__ __forceinline__ Real tol_() { return sizeof(Real) == 4 ? Real(2e-6) : Real(1e-12); }
+
+// In-place inverse of a packed symmetric positive definite matrix (lower, tri(i,j)) via LDL^T.
+template <class Real, int N>
+__device__ __forceinline__ void spd_inverse(Real (&a)[N * (N + 1) / 2]) {
+  Real invd[N];
+  // factor: a(i,j), i>j becomes L(i,j); a(j,j) becomes d_j
+  sfor<0, N>([&](auto J) {
+    constexpr int j = J;
+    Real d = a[tri(j, j)];
+    sfor<0, j>([&](auto K) { constexpr int k = K; d -= a[tri(j, k)] * a[tri(j, k)] * a[tri(k, k)]; });
+    a[tri(j, j)] = d;
+    invd[j] = Real(1) / d;
+    sfor<j + 1, N>([&](auto I) {
+      constexpr int i = I;
+      Real t = a[tri(i, j)];
+      sfor<0, j>([&](auto K) { constexpr int k = K; t -= a[tri(i, k)] * a[tri(j, k)] * a[tri(k, k)]; });
+      a[tri(i, j)] = t * invd[j];
+    });
+  });
+  // invert the unit lower factor in place: Li(i,j) = -sum_{k=j}^{i-1} L(i,k) Li(k,j)
+  sfor<0, N>([&](auto J) {
+    constexpr int j = J;
+    sfor<j + 1, N>([&](auto I) {
+      constexpr int i = I;
+      Real t = a[tri(i, j)];  // k = j term: L(i,j) * Li(j,j)=1
+      sfor<j + 1, i>([&](auto K) { constexpr int k = K; t += a[tri(i, k)] * a[tri(k, j)]; });
+      a[tri(i, j)] = -t;
+    });
+  });
+  // note: the loop above must read L(i,k) (k>j) untouched and Li(k,j) (k<i) already inverted: column j is
+  // finished top-down before column j+1 starts, and L(i,k) for k>j lives in later columns -> correct.
+  // Hinv(i,j) = sum_{k>=i} Li(k,i) invd_k Li(k,j)   (i>=j), computed column-major so inputs stay intact
+  Real out[N * (N + 1) / 2];
+  sfor<0, N>([&](auto I) {
+    constexpr int i = I;
+    sfor<0, i + 1>([&](auto J) {
+      constexpr int j = J;
+      Real t = (i == j) ? invd[i] : a[tri(i, j)] * invd[i];  // k = i term (Li(i,i) = 1)
+      sfor<i + 1, N>([&](auto K) { constexpr int k = K; t += a[tri(k, i)] * invd[k] * a[tri(k, j)]; });
+      out[tri(i, j)] = t;
+    });
+  });
+  sfor<0, N*(N + 1) / 2>([&](auto I) { a[I] = out[I]; });
+}
+
+// Solve the masked symmetric system for the free set of a boxed LCP iteration.
+//   free[i] in {0,1};  row i not free:  x_i = rhs_i ;  free rows:  sum_j A_ij x_j = rhs_i over free j
+template <class Real, int M>
+__device__ __forceinline__ void masked_solve(const Real (&A)[M * (M + 1) / 2], const Real (&fr)[M], Real (&x)[M]) {
+  Real L[M * (M + 1) / 2], invd[M];
+  sfor<0, M>([&](auto J) {
+    constexpr int j = J;
+    Real d = fr[j] * A[tri(j, j)] + (Real(1) - fr[j]);
+    sfor<0, j>([&](auto K) { constexpr int k = K; d -= L[tri(j, k)] * L[tri(j, k)] * L[tri(k, k)]; });
+    L[tri(j, j)] = d;
+    invd[j] = Real(1) / d;
+    sfor<j + 1, M>([&](auto I) {
+      constexpr int i = I;
+      Real t = A[tri(i, j)] * fr[i] * fr[j];
+      sfor<0, j>([&](auto K) { constexpr int k = K; t -= L[tri(i, k)] * L[tri(j, k)] * L[tri(k, k)]; });
+      L[tri(i, j)] = t * invd[j];
+    });
+  });
+  sfor<0, M>([&](auto I) {  // forward: L y = rhs
+    constexpr int i = I;
+    sfor<0, i>([&](auto K) { constexpr int k = K; x[i] -= L[tri(i, k)] * x[k]; });
+  });
+  sfor<0, M>([&](auto I) { x[I] *= invd[I]; });
+  sfor_rev<0, M>([&](auto I) {  // backward: L^T x = y
+    constexpr int i = I;
+    sfor<i + 1, M>([&](auto K) { constexpr int k = K; x[i] -= L[tri(k, i)] * x[k]; });
+  });
+}
+
+// Boxed LCP:  w = A x - b,  lo <= x <= hi,  complementarity.  Block principal pivoting (Judice-Pires) with a
+// least-index fallback, one lane per problem, wavefront vote to stop.  `pin[i]` rows are held at xpin (0).
+template <class Real, int M>
+__device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
+                                         const Real (&hi)[M], const bool (&pin)[M], int (&st)[M], Real (&x)[M],
+                                         int max_iter) {
+  const Real tol = tol_<Real>();
+  int best = M + 1, patience = 3;
+  bool conv = false;
+  for (int it = 0; it < max_iter; ++it) {
+    Real fr[M], xb[M], r[M];
+    sfor<0, M>([&](auto I) {
+      constexpr int i = I;
+      fr[i] = (st[i] == 0) ? Real(1) : Real(0);
+      xb[i] = (st[i] == 1) ? lo[i] : ((st[i] == 2) ? hi[i] : Real(0));
+    });
+    sfor<0, M>([&](auto I) {
+      constexpr int i = I;
+      Real t = b[i];
+      sfor<0, M>([&](auto J) { constexpr int j = J; t -= A[tri(i, j)] * xb[j]; });
+      r[i] = (st[i] == 0) ? t : xb[i];
+    });
+    masked_solve<Real, M>(A, fr, r);
+    int ninf = 0, last = -1;
+    bool bad[M];
+    sfor<0, M>([&](auto I) {
+      constexpr int i = I;
+      Real w = -b[i];
+      sfor<0, M>([&](auto J) { constexpr int j = J; w += A[tri(i, j)] * r[j]; });
+      bool inf;
+      if (st[i] == 0) inf = (r[i] < lo[i] - tol * (Real(1) + fabs(lo[i]))) || (r[i] > hi[i] + tol * (Real(1) + fabs(hi[i])));
+      else inf = !pin[i] && ((st[i] == 1 && w < -tol) || (st[i] == 2 && w > tol));
+      bad[i] = inf;
+      if (inf) { ninf++; last = i; }
+    });
+    if (!conv) sfor<0, M>([&](auto I) { x[I] = r[I]; });
+    if (ninf == 0) conv = true;
+    if (__all(conv)) break;
+    if (!conv) {
+      bool single = false;
+      if (ninf < best) { best = ninf; patience = 3; }
+      else if (patience > 0) patience--;
+      else single = true;
+      sfor<0, M>([&](auto I) {
+        constexpr int i = I;
+        if (bad[i] && (!single || i == last)) {
+          if (st[i] == 0) st[i] = (r[i] < lo[i]) ? 1 : 2;
+          else st[i] = 0;
+        }
+      });
+    }
+  }
+  // iteration cap reached without a feasible complementary point (not observed in tests): stay in the box
+  sfor<0, M>([&](auto I) { constexpr int i = I; x[i] = fmin(fmax(x[i], lo[i]), hi[i]); });
+}
+
+template <class Real, int M>
+__device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
+                                         const Real (&hi)[M], const bool (&skip)[M], Real (&x)[M], int iters) {
+  Real invd[M];
+  sfor<0, M>([&](auto I) { constexpr int i = I; invd[i] = Real(1) / A[tri(i, i)]; });
+  for (int it = 0; it < iters; ++it) {
+    sfor<0, M>([&](auto I) {
+      constexpr int i = I;
+      Real r = b[i];
+      sfor<0, M>([&](auto J) { constexpr int j = J; r -= A[tri(i, j)] * x[j]; });
+      Real xn = x[i] + r * invd[i];
+      xn = fmin(fmax(xn, lo[i]), hi[i]);
+      x[i] = skip[i] ? x[i] : xn;
+    });
+  }
+}
+
+// ------------------------------------------------------------------ one World::step (dt) for one env
+template <class Real, class T>
+__device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
+                                           const Real (&tau)[T::NDOF]) {
+  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * T::NC + n_limited<T>();
+  Real c[NL], s[NL], px[NL], py[NL], rx[NL], ry[NL], om[NL];
+  Real apx[NL], apy[NL];
+  Real mc[NL], hx[NL], hy[NL], Ic[NL], Fx[NL], Fy[NL], Nz[NL];
+  // ---- forward pass: kinematics, velocity-product accelerations, per-link wrench about the root origin
+  sfor<0, NL>([&](auto K) {
+    constexpr int k = K;
+    Real sj, cj;
+    sincos_<Real>(q[2 + k], sj, cj);
+    sj *= P.sigma[k];
+    if constexpr (k == 0) {
+      c[0] = cj; s[0] = sj; px[0] = Real(0); py[0] = Real(0); om[0] = P.sigma[0] * dq[2];
+      apx[0] = Real(0); apy[0] = Real(0);
+    } else {
+      constexpr int p = T::parent(k);
+      c[k] = c[p] * cj - s[p] * sj;
+      s[k] = s[p] * cj + c[p] * sj;
+      Real lx = c[p] * P.jx[k] - s[p] * P.jy[k], ly = s[p] * P.jx[k] + c[p] * P.jy[k];
+      px[k] = px[p] + lx; py[k] = py[p] + ly;
+      om[k] = om[p] + P.sigma[k] * dq[2 + k];
+      Real w2 = om[p] * om[p];
+      apx[k] = apx[p] - w2 * lx; apy[k] = apy[p] - w2 * ly;
+    }
+    Real ox = c[k] * P.cx[k] - s[k] * P.cy[k], oy = s[k] * P.cx[k] + c[k] * P.cy[k];
+    rx[k] = px[k] + ox; ry[k] = py[k] + oy;
+    Real w2 = om[k] * om[k];
+    Real fx = P.mass[k] * (apx[k] - w2 * ox), fy = P.mass[k] * (apy[k] - w2 * oy + P.g);
+    mc[k] = P.mass[k]; hx[k] = P.mass[k] * rx[k]; hy[k] = P.mass[k] * ry[k];
+    Ic[k] = P.izz[k] + P.mass[k] * (rx[k] * rx[k] + ry[k] * ry[k]);
+    Fx[k] = fx; Fy[k] = fy; Nz[k] = rx[k] * fy - ry[k] * fx;
+  });
+  // ---- backward pass: composite bodies
+  sfor_rev<1, NL>([&](auto K) {
+    constexpr int k = K, p = T::parent(k);
+    mc[p] += mc[k]; hx[p] += hx[k]; hy[p] += hy[k]; Ic[p] += Ic[k];
+    Fx[p] += Fx[k]; Fy[p] += Fy[k]; Nz[p] += Nz[k];
+  });
+  // ---- H = M + dt D (packed lower), rhs = tau - C - D dq
+  Real H[N * (N + 1) / 2], rhs[N];
+  H[tri(0, 0)] = mc[0]; H[tri(1, 0)] = Real(0); H[tri(1, 1)] = mc[0];
+  rhs[0] = tau[0] - Fx[0] - P.damp[0] * dq[0];
+  rhs[1] = tau[1] - Fy[0] - P.damp[1] * dq[1];
+  sfor<0, NL>([&](auto K) {
+    constexpr int k = K, i = 2 + k;
+    Real dkx = hx[k] - mc[k] * px[k], dky = hy[k] - mc[k] * py[k];
+    Real Ip = Ic[k] - Real(2) * (px[k] * hx[k] + py[k] * hy[k]) + mc[k] * (px[k] * px[k] + py[k] * py[k]);
+    H[tri(i, 0)] = -P.sigma[k] * dky;
+    H[tri(i, 1)] = P.sigma[k] * dkx;
+    sfor<0, k + 1>([&](auto J) {
+      constexpr int j = J;
+      if constexpr (is_anc<T>(j, k)) {
+        Real v = Ip + dkx * (px[k] - px[j]) + dky * (py[k] - py[j]);
+        H[tri(i, 2 + j)] = P.sigma[k] * P.sigma[j] * v;
+      } else {
+        H[tri(i, 2 + j)] = Real(0);
+      }
+    });
+    Real Ck = P.sigma[k] * (Nz[k] - (px[k] * Fy[k] - py[k] * Fx[k]));
+    rhs[i] = tau[i] - Ck - P.damp[i] * dq[i];
+  });
+  sfor<0, N>([&](auto I) { constexpr int i = I; H[tri(i, i)] += P.dt * P.damp[i]; });
+  spd_inverse<Real, N>(H);  // H now holds H^-1
+  Real vs[N];
+  sfor<0, N>([&](auto I) {
+    constexpr int i = I;
+    Real a = Real(0);
+    sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(i, j)] * rhs[j]; });
+    vs[i] = dq[i] + P.dt * a;
+  });
+
+  // ---- constraints at q_t
+  Real A[M * (M + 1) / 2], b[M], lo[M], hi[M], x[M];
+  bool act[M];
+  Real Jn[NC][N], Jt[NC][N], Yn[NC][N], Yt[NC][N];
+  bool any = false;
+  sfor<0, NC>([&](auto Cc) {
+    constexpr int cidx = Cc, k = T::clink(cidx);
+    Real x1 = px[k] + c[k] * P.e1x[cidx] - s[k] * P.e1y[cidx], y1 = py[k] + s[k] * P.e1x[cidx] + c[k] * P.e1y[cidx];
+    Real x2 = px[k] + c[k] * P.e2x[cidx] - s[k] * P.e2y[cidx], y2 = py[k] + s[k] * P.e2x[cidx] + c[k] * P.e2y[cidx];
+    bool second = y2 < y1;  // lowest endpoint; exact tie -> first (+axis) end
+    Real ex = second ? x2 : x1, ey = second ? y2 : y1;
+    Real d = (P.root_y0 + q[1] + ey) - P.ground_y;
+    bool on = d <= P.rad[cidx];
+    Real depth = P.rad[cidx] - d;
+    Real Px = ex, Py = ey - Real(0.5) * (P.rad[cidx] + d);  // ODE sphere-sphere contact position
+    Jn[cidx][0] = Real(0); Jn[cidx][1] = Real(1);
+    Jt[cidx][0] = Real(-1); Jt[cidx][1] = Real(0);
+    sfor<0, NL>([&](auto J) {
+      constexpr int j = J;
+      if constexpr (is_anc<T>(j, k)) {
+        Jn[cidx][2 + j] = P.sigma[j] * (Px - px[j]);
+        Jt[cidx][2 + j] = P.sigma[j] * (Py - py[j]);
+      } else {
+        Jn[cidx][2 + j] = Real(0); Jt[cidx][2 + j] = Real(0);
+      }
+    });
+    Real rn = Real(0), rt = Real(0);
+    sfor<0, N>([&](auto I) { constexpr int i = I; rn += Jn[cidx][i] * vs[i]; rt += Jt[cidx][i] * vs[i]; });
+    Real bounce = fmin(depth * P.erp_dt, P.max_erv);
+    constexpr int sn = 2 * cidx, stt = 2 * cidx + 1;
+    act[sn] = on; act[stt] = on;
+    b[sn] = on ? (bounce - rn) : Real(0);
+    b[stt] = on ? -rt : Real(0);
+    lo[sn] = Real(0); hi[sn] = on ? inf_<Real>() : Real(0);
+    lo[stt] = Real(0); hi[stt] = Real(0);  // friction rows are pinned at 0 during stage 1
+    any = any || on;
+  });
+  sfor<0, NL>([&](auto K) {
+    constexpr int k = K;
+    if constexpr (T::limited(k)) {
+      constexpr int sl = limit_slot<T>(k), i = 2 + k;
+      bool low = q[i] <= P.lo[k], up = (!low) && (q[i] >= P.hi[k]);
+      Real viol = low ? (q[i] - P.lo[k]) : (q[i] - P.hi[k]);
+      Real bounce = fmin(fmax(-viol * P.limit_erp_dt, -P.max_erv), P.max_erv);
+      bool on = low || up;
+      act[sl] = on;
+      b[sl] = on ? (bounce - vs[i]) : Real(0);
+      lo[sl] = low ? Real(0) : (up ? -inf_<Real>() : Real(0));
+      hi[sl] = low ? inf_<Real>() : Real(0);
+      any = any || on;
+    }
+  });
+
+  if (__any(any)) {
+    // Y = H^-1 J^T for contact rows (limit rows: columns of H^-1), Delassus matrix A = J H^-1 J^T
+    sfor<0, NC>([&](auto Cc) {
+      constexpr int cidx = Cc;
+      sfor<0, N>([&](auto I) {
+        constexpr int i = I;
+        Real a = Real(0), t = Real(0);
+        sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(i, j)] * Jn[cidx][j]; t += H[tri(i, j)] * Jt[cidx][j]; });
+        Yn[cidx][i] = a; Yt[cidx][i] = t;
+      });
+    });
+    sfor<0, NC>([&](auto Ca) {
+      constexpr int a = Ca;
+      sfor<0, a + 1>([&](auto Cb) {
+        constexpr int bb = Cb;
+        Real nn = Real(0), nt = Real(0), tn = Real(0), ttv = Real(0);
+        sfor<0, N>([&](auto I) {
+          constexpr int i = I;
+          nn += Jn[a][i] * Yn[bb][i]; nt += Jn[a][i] * Yt[bb][i];
+          tn += Jt[a][i] * Yn[bb][i]; ttv += Jt[a][i] * Yt[bb][i];
+        });
+        A[tri(2 * a, 2 * bb)] = nn;
+        A[tri(2 * a + 1, 2 * bb + 1)] = ttv;
+        A[tri(2 * a + 1, 2 * bb)] = tn;
+        if constexpr (a != bb) A[tri(2 * a, 2 * bb + 1)] = nt;
+      });
+    });
+    sfor<0, NL>([&](auto K) {
+      constexpr int k = K;
+      if constexpr (T::limited(k)) {
+        constexpr int sl = limit_slot<T>(k), i = 2 + k;
+        sfor<0, NC>([&](auto Cc) {
+          constexpr int cidx = Cc;
+          A[tri(sl, 2 * cidx)] = Yn[cidx][i];
+          A[tri(sl, 2 * cidx + 1)] = Yt[cidx][i];
+        });
+        sfor<0, k + 1>([&](auto J) {
+          constexpr int j = J;
+          if constexpr (T::limited(j)) A[tri(sl, limit_slot<T>(j))] = H[tri(i, 2 + j)];
+        });
+      }
+    });
+    // inactive slots: decouple (unit diagonal keeps the factorisations regular)
+    sfor<0, M>([&](auto I) {
+      constexpr int i = I;
+      if (!act[i]) A[tri(i, i)] = Real(1);
+      sfor<0, i>([&](auto J) { constexpr int j = J; if (!act[i] || !act[j]) A[tri(i, j)] = Real(0); });
+    });
+
+    bool pin[M];
+    int st[M];
+    bool has_contact = false;
+    sfor<0, M>([&](auto I) {
+      constexpr int i = I;
+      x[i] = Real(0);
+      pin[i] = !(lo[i] < hi[i]);
+      st[i] = (lo[i] == Real(0)) ? 1 : 2;  // start at the finite bound
+    });
+    sfor<0, NC>([&](auto Cc) { has_contact = has_contact || act[2 * Cc]; });
+
+    if (P.solver == 0) blcp_bpp<Real, M>(A, b, lo, hi, pin, st, x, P.iters1);
+    else blcp_pgs<Real, M>(A, b, lo, hi, pin, x, P.iters1);
+
+    if (__any(has_contact)) {
+      // ODE/DART friction bounds: +-mu * (normal impulse of the frictionless solve), then the full problem
+      sfor<0, NC>([&](auto Cc) {
+        constexpr int sn = 2 * Cc, stt = 2 * Cc + 1;
+        Real hb = act[sn] ? fabs(P.mu * x[sn]) : Real(0);
+        hi[stt] = hb; lo[stt] = -hb;
+        pin[stt] = !(hb > Real(0));
+        st[stt] = pin[stt] ? 1 : 0;
+      });
+      if (P.solver == 0) blcp_bpp<Real, M>(A, b, lo, hi, pin, st, x, P.iters2);
+      else {
+        bool none[M];
+        sfor<0, M>([&](auto I) { none[I] = false; });
+        blcp_pgs<Real, M>(A, b, lo, hi, none, x, P.iters2);
+      }
+    }
+    // velocity change  H^-1 J^T lambda
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      Real dv = Real(0);
+      sfor<0, NC>([&](auto Cc) { constexpr int cidx = Cc; dv += Yn[cidx][i] * x[2 * cidx] + Yt[cidx][i] * x[2 * cidx + 1]; });
+      sfor<0, NL>([&](auto K) {
+        constexpr int k = K;
+        if constexpr (T::limited(k)) dv += H[tri(i, 2 + k)] * x[limit_slot<T>(k)];
+      });
+      vs[i] += dv;
+    });
+  }
+  sfor<0, N>([&](auto I) { constexpr int i = I; dq[i] = vs[i]; q[i] += P.dt * vs[i]; });
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 (counter-based reset noise)
+__device__ __host__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// reset noise for env `gid`, episode `ep`: q_i = -r + 2r*u(2i block...), same stream on host and device
+template <class Real, int N>
+__device__ __host__ inline void reset_noise(uint64_t seed, uint64_t gid, uint32_t ep, Real r, Real (&q)[N], Real (&dq)[N]) {
+  constexpr int NW = 2 * N;
+  Real u[(NW + 3) / 4 * 4];
+  for (int blk = 0; blk < (NW + 3) / 4; ++blk) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), ep, (uint32_t)blk, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    for (int j = 0; j < 4; ++j) u[4 * blk + j] = Real(o[j] >> 8) * Real(1.0 / 16777216.0);
+  }
+  for (int i = 0; i < N; ++i) { q[i] = -r + Real(2) * r * u[i]; dq[i] = -r + Real(2) * r * u[N + i]; }
+}
+
+// ------------------------------------------------------------------ observation (hopper.py:67-74, walker2d.py:67-74)
+template <class Real, class T>
+__device__ __forceinline__ Real root_height(const Params<Real, T>& P, const Real (&q)[T::NDOF]) {
+  Real h = P.root_y0 + q[1];
+  if (P.cx[0] != Real(0) || P.cy[0] != Real(0)) {
+    Real sj, cj;
+    sincos_<Real>(q[2], sj, cj);
+    h += P.sigma[0] * sj * P.cx[0] + cj * P.cy[0];
+  }
+  return h;
+}
+template <class Real, class T>
+__device__ __forceinline__ void write_obs(const Params<Real, T>& P, const Real (&q)[T::NDOF], const Real (&dq)[T::NDOF],
+                                          Real height, float* __restrict__ obs_row) {
+  constexpr int N = T::NDOF;
+  obs_row[0] = (float)height;
+  sfor<2, N>([&](auto I) { constexpr int i = I; obs_row[i - 1] = (float)q[i]; });
+  sfor<0, N>([&](auto I) {
+    constexpr int i = I;
+    obs_row[N - 1 + i] = (float)fmin(fmax(dq[i], -P.v_clip), P.v_clip);
+  });
+}
+
+// ------------------------------------------------------------------ kernels
+// One batched env.step(): clamp+scale action, frame_skip world steps, reward, done, TimeLimit, observation,
+// optional on-device auto-reset (post-reset observation is returned, as SyncVectorEnv does).
+template <class Real, class T>
+__global__ void __launch_bounds__(64) step_kernel(Params<Real, T> P, int64_t n_envs, Real* __restrict__ qs,
+                                                   Real* __restrict__ dqs, int32_t* __restrict__ elapsed,
+                                                   uint32_t* __restrict__ episode, const float* __restrict__ actions,
+                                                   float* __restrict__ obs, float* __restrict__ reward,
+                                                   uint8_t* __restrict__ done, uint8_t* __restrict__ truncated,
+                                                   int autoreset, uint64_t seed, uint64_t env_offset) {
+  constexpr int N = T::NDOF, NA = T::NA;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = e < n_envs;
+  int64_t ec = valid ? e : n_envs - 1;  // tail lanes shadow the last env so wave votes stay uniform
+  Real q[N], dq[N], tau[N];
+  sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + ec]; dq[i] = dqs[(int64_t)i * n_envs + ec]; });
+  Real a2 = Real(0);
+  sfor<0, N>([&](auto I) { tau[I] = Real(0); });
+  sfor<0, NA>([&](auto K) {
+    constexpr int k = K;
+    Real a = (Real)actions[ec * NA + k];
+    a2 += a * a;  // control cost uses the unclamped action (hopper.py:55)
+    Real cl = fmin(fmax(a, P.act_lo[k]), P.act_hi[k]);
+    tau[N - NA + k] = cl * P.act_scale[k];
+  });
+  Real x_before = q[0];
+  Real dx = Real(0);
+#pragma unroll 1
+  for (int f = 0; f < P.frame_skip; ++f) {
+    world_step<Real, T>(P, q, dq, tau);
+    dx += P.dt * dq[0];
+  }
+  (void)x_before;
+  Real height = root_height<Real, T>(P, q);
+  Real ang = q[2];
+  Real pen = Real(0);
+  if (P.penalty_link >= 0) {
+    sfor<1, T::NL>([&](auto K) {
+      constexpr int k = K;
+      if (P.penalty_link == k) {
+        if ((P.lo[k] - q[2 + k]) > -P.pen_margin) pen += P.pen_each;
+        if ((P.hi[k] - q[2 + k]) < P.pen_margin) pen += P.pen_each;
+      }
+    });
+  }
+  Real rew = dx * P.inv_envdt + P.alive - P.ctrl_cost * a2 - pen;
+  bool ok = true;
+  sfor<0, N>([&](auto I) {
+    constexpr int i = I;
+    ok = ok && isfinite(q[i]) && isfinite(dq[i]) && (fabs(dq[i]) < P.s_max);
+    if constexpr (i >= 2) ok = ok && (fabs(q[i]) < P.s_max);
+  });
+  ok = ok && (height > P.h_lo) && (height < P.h_hi) && (fabs(ang) < P.ang_max);
+  bool task_done = (P.task != 0) && !ok;
+  int el = elapsed[ec] + 1;
+  bool trunc = (P.max_steps > 0) && (el >= P.max_steps);
+  bool dn = task_done || trunc;
+  if (autoreset && dn) {
+    uint32_t ep = episode[ec] + 1;
+    reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, q, dq);
+    sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
+    el = 0;
+    height = root_height<Real, T>(P, q);
+    if (valid) episode[e] = ep;
+  }
+  if (valid) {
+    sfor<0, N>([&](auto I) { constexpr int i = I; qs[(int64_t)i * n_envs + e] = q[i]; dqs[(int64_t)i * n_envs + e] = dq[i]; });
+    elapsed[e] = el;
+    write_obs<Real, T>(P, q, dq, height, obs + e * (2 * N - 1));
+    reward[e] = (float)rew;
+    done[e] = dn ? 1 : 0;
+    truncated[e] = (trunc && !task_done) ? 1 : 0;
+  }
+}
+
+// Masked reset: q = init + noise (host-supplied rows, or Philox when noise pointers are null), elapsed = 0, obs.
+template <class Real, class T>
+__global__ void __launch_bounds__(256) reset_kernel(Params<Real, T> P, int64_t n_envs, Real* __restrict__ qs,
+                                                     Real* __restrict__ dqs, int32_t* __restrict__ elapsed,
+                                                     uint32_t* __restrict__ episode, const uint8_t* __restrict__ mask,
+                                                     const double* __restrict__ qnoise, const double* __restrict__ vnoise,
+                                                     float* __restrict__ obs, uint64_t seed, uint64_t env_offset) {
+  constexpr int N = T::NDOF;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_envs) return;
+  Real q[N], dq[N];
+  bool m = (mask == nullptr) || mask[e];
+  if (m) {
+    if (qnoise) {
+      sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = (Real)qnoise[e * N + i]; dq[i] = (Real)vnoise[e * N + i]; });
+    } else {
+      uint32_t ep = episode[e] + 1;
+      reset_noise<Real, N>(seed, env_offset + (uint64_t)e, ep, P.noise, q, dq);
+      sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
+      episode[e] = ep;
+    }
+    sfor<0, N>([&](auto I) { constexpr int i = I; qs[(int64_t)i * n_envs + e] = q[i]; dqs[(int64_t)i * n_envs + e] = dq[i]; });
+    elapsed[e] = 0;
+  } else {
+    sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + e]; dq[i] = dqs[(int64_t)i * n_envs + e]; });
+  }
+  if (obs) write_obs<Real, T>(P, q, dq, root_height<Real, T>(P, q), obs + e * (2 * N - 1));
+}
+
+// (N, n) row-major doubles  <->  SoA state, for set_state / get_state (dart_env.py:145-148, 211-215)
+template <class Real, int N>
+__global__ void state_io_kernel(int64_t n_envs, Real* __restrict__ qs, Real* __restrict__ dqs, double* __restrict__ qh,
+                                double* __restrict__ dqh, int to_device) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_envs) return;
+  for (int i = 0; i < N; ++i) {
+    if (to_device) { qs[(int64_t)i * n_envs + e] = (Real)qh[e * N + i]; dqs[(int64_t)i * n_envs + e] = (Real)dqh[e * N + i]; }
+    else { qh[e * N + i] = (double)qs[(int64_t)i * n_envs + e]; dqh[e * N + i] = (double)dqs[(int64_t)i * n_envs + e]; }
+  }
+}
+
+}  // namespace dartk

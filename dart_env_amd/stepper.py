@@ -1,0 +1,203 @@
+"""ctypes binding of ``libdart_stepper.so`` (C ABI: ``include/dart_stepper.h``).
+
+This is the only way the Python env layer reaches the physics: there is no
+Python or CPU implementation behind it.  If the shared library is missing, or
+no HIP device is present, construction raises -- loudly, never a fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .model_card import DartModelCard
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libdart_stepper.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+# error codes / keys (include/dart_stepper.h)
+DART_OK, E_INVALID, E_NO_DEVICE, E_UNSUPPORTED, E_HIP, E_PENDING, E_NOT_PENDING = 0, -1, -2, -3, -4, -5, -6
+Q_NUM_ENVS, Q_NDOFS, Q_OBS_DIM, Q_ACT_DIM, Q_FRAME_SKIP, Q_PRECISION, Q_DEVICE, Q_LCP_SLOTS = range(8)
+CFG_SOLVER, CFG_ITERS_STAGE1, CFG_ITERS_STAGE2, CFG_AUTORESET, CFG_SEED, CFG_ENV_OFFSET, CFG_BLOCK_THREADS = range(7)
+SOLVER_BPP, SOLVER_PGS = 0, 1
+
+EXPORTS = [
+    "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
+    "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters",
+]
+
+
+class StepperError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dart_stepper error %d: %s" % (code, msg))
+        self.code = code
+
+
+class AlreadyPendingCallError(StepperError):
+    """Mirrors gym.error.AlreadyPendingCallError (reference gym/error.py:143-150)."""
+
+
+class NoAsyncCallError(StepperError):
+    """Mirrors gym.error.NoAsyncCallError (reference gym/error.py:152-159)."""
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the HIP library and declare prototypes.  Raises OSError when it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError("%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    L = C.CDLL(p)
+    vp, i64, dp, fp, u8 = C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    L.dart_last_error.restype = C.c_char_p
+    L.dart_last_error.argtypes = [vp]
+    L.dart_create.argtypes = [C.POINTER(DartModelCard), i64, C.c_int, C.c_int, C.POINTER(vp)]
+    L.dart_destroy.argtypes = [vp]
+    L.dart_query.argtypes = [vp, C.c_int, C.POINTER(i64)]
+    L.dart_configure.argtypes = [vp, C.c_int, C.c_double]
+    L.dart_reset.argtypes = [vp, u8, dp, dp, fp]
+    L.dart_set_state.argtypes = [vp, dp, dp]
+    L.dart_get_state.argtypes = [vp, dp, dp]
+    L.dart_step.argtypes = [vp, fp, fp, dp, u8, u8]
+    L.dart_step_async.argtypes = [vp, fp]
+    L.dart_step_wait.argtypes = [vp, fp, dp, u8, u8]
+    L.dart_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.dart_reset_device.argtypes = [vp, vp, vp, vp]
+    L.dart_sync.argtypes = [vp]
+    L.dart_get_counters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    L.dart_time_steps.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, dp]
+    for name in EXPORTS:
+        if name != "dart_last_error":
+            getattr(L, name).restype = C.c_int
+    if path is None:
+        _lib = L
+    return L
+
+
+def _ptr(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+class HipStepper:
+    """N batched worlds resident on one MI355X (one handle per GPU)."""
+
+    def __init__(self, card: DartModelCard, num_envs: int, device: int = 0, precision: int = 32):
+        self.L = load_library()
+        self.card = card
+        self.h = C.c_void_p()
+        rc = self.L.dart_create(C.byref(card), int(num_envs), int(device), int(precision), C.byref(self.h))
+        if rc != DART_OK:
+            msg = self.L.dart_last_error(None).decode()
+            self.h = None
+            raise StepperError(rc, msg)
+        self.num_envs = int(num_envs)
+        self.ndofs, self.obs_dim, self.act_dim = card.ndofs, card.obs_dim, card.act_dim
+        self.device, self.precision = device, precision
+
+    # -- plumbing --
+    def _check(self, rc):
+        if rc == DART_OK:
+            return
+        msg = self.L.dart_last_error(self.h).decode()
+        if rc == E_PENDING:
+            raise AlreadyPendingCallError(rc, msg)
+        if rc == E_NOT_PENDING:
+            raise NoAsyncCallError(rc, msg)
+        raise StepperError(rc, msg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dart_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def query(self, what: int) -> int:
+        out = C.c_int64(0)
+        self._check(self.L.dart_query(self.h, what, C.byref(out)))
+        return out.value
+
+    def configure(self, key: int, value: float):
+        self._check(self.L.dart_configure(self.h, key, float(value)))
+
+    # -- state --
+    def reset(self, mask=None, qpos_noise=None, qvel_noise=None, want_obs=True):
+        n = self.num_envs
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        qn = None if qpos_noise is None else np.ascontiguousarray(qpos_noise, dtype=np.float64).reshape(n, self.ndofs)
+        vn = None if qvel_noise is None else np.ascontiguousarray(qvel_noise, dtype=np.float64).reshape(n, self.ndofs)
+        obs = np.empty((n, self.obs_dim), dtype=np.float32) if want_obs else None
+        self._check(self.L.dart_reset(self.h, _ptr(m, C.c_uint8), _ptr(qn, C.c_double), _ptr(vn, C.c_double),
+                                      _ptr(obs, C.c_float)))
+        return obs
+
+    def set_state(self, q, dq):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(self.num_envs, self.ndofs)
+        dq = np.ascontiguousarray(dq, dtype=np.float64).reshape(self.num_envs, self.ndofs)
+        self._check(self.L.dart_set_state(self.h, _ptr(q, C.c_double), _ptr(dq, C.c_double)))
+
+    def get_state(self):
+        q = np.empty((self.num_envs, self.ndofs), dtype=np.float64)
+        dq = np.empty_like(q)
+        self._check(self.L.dart_get_state(self.h, _ptr(q, C.c_double), _ptr(dq, C.c_double)))
+        return q, dq
+
+    # -- stepping (host buffers) --
+    def _outs(self):
+        n = self.num_envs
+        return (np.empty((n, self.obs_dim), dtype=np.float32), np.empty(n, dtype=np.float64),
+                np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8))
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim)
+        obs, rew, done, trunc = self._outs()
+        self._check(self.L.dart_step(self.h, _ptr(a, C.c_float), _ptr(obs, C.c_float), _ptr(rew, C.c_double),
+                                     _ptr(done, C.c_uint8), _ptr(trunc, C.c_uint8)))
+        return obs, rew, done.astype(np.bool_), trunc.astype(np.bool_)
+
+    def step_async(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim)
+        self._check(self.L.dart_step_async(self.h, _ptr(a, C.c_float)))
+
+    def step_wait(self):
+        obs, rew, done, trunc = self._outs()
+        self._check(self.L.dart_step_wait(self.h, _ptr(obs, C.c_float), _ptr(rew, C.c_double),
+                                          _ptr(done, C.c_uint8), _ptr(trunc, C.c_uint8)))
+        return obs, rew, done.astype(np.bool_), trunc.astype(np.bool_)
+
+    # -- stepping (device pointers: ints / torch data_ptr()) --
+    def step_device(self, d_actions, d_obs=0, d_reward=0, d_done=0, d_truncated=0, stream=0):
+        self._check(self.L.dart_step_device(self.h, d_actions, d_obs or None, d_reward or None, d_done or None,
+                                            d_truncated or None, stream or None))
+
+    def reset_device(self, d_mask=0, d_obs=0, stream=0):
+        self._check(self.L.dart_reset_device(self.h, d_mask or None, d_obs or None, stream or None))
+
+    def counters(self):
+        el = np.empty(self.num_envs, dtype=np.int32)
+        ep = np.empty(self.num_envs, dtype=np.uint32)
+        self._check(self.L.dart_get_counters(self.h, _ptr(el, C.c_int32), _ptr(ep, C.c_uint32)))
+        return el, ep
+
+    def sync(self):
+        self._check(self.L.dart_sync(self.h))
+
+    def time_steps(self, d_actions, action_batches, steps, d_obs=0, d_reward=0, d_done=0, d_truncated=0) -> float:
+        ms = C.c_double(0)
+        self._check(self.L.dart_time_steps(self.h, d_actions, int(action_batches), d_obs or None, d_reward or None,
+                                           d_done or None, d_truncated or None, int(steps), C.byref(ms)))
+        return ms.value

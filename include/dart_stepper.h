@@ -1,0 +1,122 @@
+/* dart_stepper.h -- C ABI of the MI355X batched Dart stepper (libdart_stepper.so).
+ *
+ * The reference has no C boundary for this path: its envs drive DART through the
+ * pydart2 *Python object* API.  Each entry point below names the reference call
+ * sites it replaces for a whole batch of N environments at once (SURVEY.md 8b,
+ * Appendix D).  Conventions mirror the reference's: the library owns the world
+ * state (one "world" per env, SoA in HBM), getters/setters copy, the caller
+ * serialises calls per handle (one in-flight call, like one DART world per env),
+ * different handles (one per GPU) may be driven from different threads/processes.
+ * Host buffers are caller-owned, row-major (N, k) exactly as numpy lays them out.
+ *
+ * Every function returns 0 on success or a negative DART_E_* code;
+ * dart_last_error() gives the message (library-owned string).
+ *
+ * There is NO CPU fallback: with no HIP device dart_create fails with
+ * DART_E_NO_DEVICE.
+ */
+#ifndef DART_STEPPER_H
+#define DART_STEPPER_H
+
+#include <stdint.h>
+
+#include "dart_model_card.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct DartStepper DartStepper;
+
+enum {
+  DART_OK = 0,
+  DART_E_INVALID = -1,     /* bad argument / null handle */
+  DART_E_NO_DEVICE = -2,   /* no HIP device (this library never computes on the CPU) */
+  DART_E_UNSUPPORTED = -3, /* model topology has no compiled kernel */
+  DART_E_HIP = -4,         /* HIP runtime error, see dart_last_error */
+  DART_E_PENDING = -5,     /* step_async already pending (gym.error.AlreadyPendingCallError) */
+  DART_E_NOT_PENDING = -6  /* step_wait without step_async (gym.error.NoAsyncCallError) */
+};
+
+/* dart_query keys */
+enum {
+  DART_Q_NUM_ENVS = 0, DART_Q_NDOFS = 1, DART_Q_OBS_DIM = 2, DART_Q_ACT_DIM = 3, DART_Q_FRAME_SKIP = 4,
+  DART_Q_PRECISION = 5, DART_Q_DEVICE = 6, DART_Q_LCP_SLOTS = 7
+};
+
+/* dart_configure keys */
+enum {
+  DART_CFG_SOLVER = 0,      /* 0 = block principal pivoting (exact, default), 1 = projected Gauss-Seidel */
+  DART_CFG_ITERS_STAGE1 = 1,/* iteration cap (solver 0) / sweep count (solver 1) of the frictionless stage */
+  DART_CFG_ITERS_STAGE2 = 2,/* same for the friction stage */
+  DART_CFG_AUTORESET = 3,   /* 1: done envs are reset inside dart_step with on-device Philox noise */
+  DART_CFG_SEED = 4,        /* Philox key (low 53 bits of the double are used) */
+  DART_CFG_ENV_OFFSET = 5,  /* global index of env 0 of this handle (multi-GPU sharding keeps streams distinct) */
+  DART_CFG_BLOCK_THREADS = 6/* envs (active lanes) per wave64 workgroup of the step kernel: 64, 32 or 16 */
+};
+
+/* Library-level error text for failures that happen before a handle exists (handle == NULL). */
+const char* dart_last_error(const DartStepper* h);
+
+/* Replaces DartEnv.__init__'s world construction for N envs: pydart.World(dt, skel), skeletons[-1], limit
+ * enforcement (reference gym/envs/dart/dart_env.py:55,62-67).  precision: 32 (product) or 64 (validation).
+ * State starts at the model's init_pos/init_vel, elapsed = 0. */
+int dart_create(const DartModelCard* card, int64_t num_envs, int device, int precision, DartStepper** out);
+
+/* Frees device and pinned host memory.  NULL is accepted. */
+int dart_destroy(DartStepper* h);
+
+int dart_query(const DartStepper* h, int what, int64_t* out);
+int dart_configure(DartStepper* h, int key, double value);
+
+/* Replaces DartEnv.reset()/reset_model() (dart_env.py:140-143, hopper.py:76-84) for the envs with mask[i] != 0
+ * (mask == NULL: all): world.reset() then q = init + qpos_noise[i], dq = init + qvel_noise[i], elapsed = 0.
+ * qpos_noise/qvel_noise: (N, ndofs) float64, rows of unmasked envs are ignored; both NULL -> on-device Philox
+ * U(-reset_noise, +reset_noise).  obs_out: (N, obs_dim) float32 of ALL envs (may be NULL). */
+int dart_reset(DartStepper* h, const uint8_t* mask, const double* qpos_noise, const double* qvel_noise,
+               float* obs_out);
+
+/* Replaces DartEnv.set_state / state_vector (dart_env.py:145-148, 211-215) for the whole batch.
+ * q, dq: (N, ndofs) float64. */
+int dart_set_state(DartStepper* h, const double* q, const double* dq);
+int dart_get_state(DartStepper* h, double* q, double* dq);
+
+/* Replaces one env.step(a) per env (hopper.py:36-65 / walker2d.py:22-65 incl. do_simulation, dart_env.py:158-175,
+ * and TimeLimit.step, wrappers/time_limit.py:14-21).
+ *   actions        (N, act_dim) float32   host
+ *   obs_out        (N, obs_dim) float32   host
+ *   reward_out     (N,)         float64   host   (reference rewards are numpy float64)
+ *   done_out       (N,)         uint8     host   task done OR time-limit
+ *   truncated_out  (N,)         uint8     host   info['TimeLimit.truncated'] (may be NULL)
+ * Without DART_CFG_AUTORESET the caller resets done envs with dart_reset(mask, ...). */
+int dart_step(DartStepper* h, const float* actions, float* obs_out, double* reward_out, uint8_t* done_out,
+              uint8_t* truncated_out);
+
+/* VectorEnv.step_async / step_wait (reference gym/vector/vector_env.py:68-92): same as dart_step, split. */
+int dart_step_async(DartStepper* h, const float* actions);
+int dart_step_wait(DartStepper* h, float* obs_out, double* reward_out, uint8_t* done_out, uint8_t* truncated_out);
+
+/* Device-resident variant for GPU learners / benchmarks: all pointers are HBM addresses on the handle's device,
+ * reward is float32.  Enqueued on `hip_stream` (a hipStream_t, NULL = the handle's own stream); returns
+ * without synchronising. */
+int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done,
+                     uint8_t* d_truncated, void* hip_stream);
+int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void* hip_stream);
+
+/* Per-env bookkeeping: steps since reset (TimeLimit._elapsed_steps, wrappers/time_limit.py:17,24) and the number of
+ * on-device (Philox) resets so far.  Either pointer may be NULL. */
+int dart_get_counters(DartStepper* h, int32_t* elapsed, uint32_t* episode);
+
+/* Wait for everything enqueued on the handle's stream. */
+int dart_sync(DartStepper* h);
+
+/* Times `steps` back-to-back dart_step_device launches on the handle's stream with HIP events
+ * (used by bench.py for the live roofline figure).  d_actions holds `action_batches` consecutive (N, act_dim)
+ * batches that are cycled.  Returns average kernel-to-kernel milliseconds per step in *ms_per_step. */
+int dart_time_steps(DartStepper* h, const float* d_actions, int action_batches, float* d_obs, float* d_reward,
+                    uint8_t* d_done, uint8_t* d_truncated, int steps, double* ms_per_step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DART_STEPPER_H */

@@ -642,7 +642,7 @@ int oracle_step(OracleWorld* w) {
     if (w->solver == 0) {
       if (blcp_exact(A, b, lo, hi, idx1, m1, m, x) != 0) return -2;
     } else {
-      pgs_sweeps(A, b, lo, hi, idx1, m1, m, has_fric ? w->pgs_k1 : w->pgs_k1 + w->pgs_k2, x);
+      pgs_sweeps(A, b, lo, hi, idx1, m1, m, w->pgs_k1, x); /* device: stage 2 only runs for envs with a contact */
     }
     if (has_fric) {
       /* ODE lcp.cpp: at the first findex row, hi = |hi * x[findex]|, lo = -hi (0 if the normal impulse is 0) */
@@ -782,4 +782,76 @@ void oracle_env_obs(OracleWorld* w, double* obs) {
     obs[n - 1 + i] = v < -c->obs_vel_clip ? -c->obs_vel_clip : (v > c->obs_vel_clip ? c->obs_vel_clip : v);
   }
   obs[0] = cm[1];
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 reset noise
+ * Same counter-based stream as the device auto-reset (dart_env_amd/csrc/planar_kernel.hpp reset_noise):
+ * counter = (env lo, env hi, episode, block), key = (seed lo, seed hi), u = (x >> 8) * 2^-24. */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void oracle_philox_noise(uint64_t seed, uint64_t gid, uint32_t ep, double r, int n, double* q, double* dq) {
+  double u[2 * MAXN + 4];
+  int nw = 2 * n;
+  for (int blk = 0; blk < (nw + 3) / 4; ++blk) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), ep, (uint32_t)blk, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    for (int j = 0; j < 4; ++j) u[4 * blk + j] = (double)(o[j] >> 8) * (1.0 / 16777216.0);
+  }
+  for (int i = 0; i < n; i++) { q[i] = -r + 2.0 * r * u[i]; dq[i] = -r + 2.0 * r * u[n + i]; }
+}
+
+/* Rollout of `n_envs` independent envs for `steps` env-steps with auto-reset (Philox noise), used as the timed CPU
+ * baseline and as the reference for bench.py's RMS-state-error figure.
+ *   actions: [steps][n_envs][act_dim] float32 (the same buffer the GPU ring holds)
+ *   q_out/dq_out: [n_envs][ndofs] final states; episode_out/elapsed_out: per-env counters (history fingerprint)
+ * Returns the number of env-steps executed. */
+int64_t oracle_rollout(const DartModelCard* card, int solver, int64_t n_envs, int steps, const float* actions,
+                       uint64_t seed, uint64_t env_offset, double* q_out, double* dq_out, uint32_t* episode_out,
+                       int32_t* elapsed_out, double* reward_sum_out) {
+  OracleWorld* w = oracle_create(card);
+  if (!w) return -1;
+  w->solver = solver;
+  int n = w->n, na = card->act_dim;
+  int64_t count = 0;
+  double obs[2 * MAXN], a[DART_MAX_ACTIONS];
+  for (int64_t e = 0; e < n_envs; e++) {
+    uint32_t ep = 1;
+    int elapsed = 0;
+    double qn[MAXN], vn[MAXN], rs = 0;
+    oracle_reset(w);
+    oracle_philox_noise(seed, env_offset + (uint64_t)e, ep, card->reset_noise, n, qn, vn);
+    for (int i = 0; i < n; i++) { w->q[i] += qn[i]; w->dq[i] += vn[i]; }
+    for (int t = 0; t < steps; t++) {
+      const float* at = actions + ((size_t)t * n_envs + e) * na;
+      for (int k = 0; k < na; k++) a[k] = (double)at[k];
+      double r;
+      int done = oracle_env_step(w, a, obs, &r);
+      rs += r;
+      elapsed++;
+      count++;
+      if (card->max_episode_steps > 0 && elapsed >= card->max_episode_steps) done = 1;
+      if (done) {
+        ep++;
+        oracle_reset(w);
+        oracle_philox_noise(seed, env_offset + (uint64_t)e, ep, card->reset_noise, n, qn, vn);
+        for (int i = 0; i < n; i++) { w->q[i] += qn[i]; w->dq[i] += vn[i]; }
+        elapsed = 0;
+      }
+    }
+    if (q_out) memcpy(q_out + e * n, w->q, n * sizeof(double));
+    if (dq_out) memcpy(dq_out + e * n, w->dq, n * sizeof(double));
+    if (episode_out) episode_out[e] = ep;
+    if (elapsed_out) elapsed_out[e] = elapsed;
+    if (reward_sum_out) reward_sum_out[e] = rs;
+  }
+  oracle_destroy(w);
+  return count;
 }

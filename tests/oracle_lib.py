@@ -53,6 +53,10 @@ def lib():
         L.oracle_env_step.argtypes = [C.c_void_p, dp, dp, dp]
         L.oracle_env_step.restype = C.c_int
         L.oracle_env_obs.argtypes = [C.c_void_p, dp]
+        L.oracle_rollout.restype = C.c_int64
+        L.oracle_rollout.argtypes = [C.POINTER(DartModelCard), C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float),
+                                     C.c_uint64, C.c_uint64, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), dp]
+        L.oracle_philox_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_int, dp, dp]
         _lib = L
     return _lib
 
@@ -166,3 +170,23 @@ class OracleWorld:
         obs = np.zeros(self.card.obs_dim)
         self.L.oracle_env_obs(self.h, _p(obs))
         return obs
+
+
+def rollout(card, actions, seed=0, env_offset=0, solver=0):
+    """Auto-resetting (Philox) rollout of actions[steps][n][act] on the fp64 oracle.
+    Returns dict(q, dq, episode, elapsed, reward_sum, env_steps)."""
+    actions = np.ascontiguousarray(actions, dtype=np.float32)
+    steps, n, _ = actions.shape
+    nd = card.ndofs
+    q = np.zeros((n, nd)); dq = np.zeros((n, nd)); rs = np.zeros(n)
+    ep = np.zeros(n, dtype=np.uint32); el = np.zeros(n, dtype=np.int32)
+    cnt = lib().oracle_rollout(C.byref(card), solver, n, steps, actions.ctypes.data_as(C.POINTER(C.c_float)), seed,
+                               env_offset, _p(q), _p(dq), ep.ctypes.data_as(C.POINTER(C.c_uint32)),
+                               el.ctypes.data_as(C.POINTER(C.c_int32)), _p(rs))
+    return dict(q=q, dq=dq, episode=ep, elapsed=el, reward_sum=rs, env_steps=cnt)
+
+
+def philox_noise(seed, gid, ep, r, n):
+    q = np.zeros(n); dq = np.zeros(n)
+    lib().oracle_philox_noise(seed, gid, ep, r, n, _p(q), _p(dq))
+    return q, dq

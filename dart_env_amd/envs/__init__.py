@@ -1,0 +1,3 @@
+from .dart_env import BatchedDartEnv  # noqa: F401
+from .hopper import DartHopperEnv  # noqa: F401
+from .walker2d import DartWalker2dEnv  # noqa: F401

@@ -1,0 +1,151 @@
+"""Batched counterpart of the reference's ``DartEnv`` base class (reference gym/envs/dart/dart_env.py:25-215).
+
+The reference builds ONE pydart2 world per env object and steps it from Python.  Here one object owns
+``num_envs`` worlds that live in HBM behind the C ABI (``include/dart_stepper.h``); everything the reference
+computes per step in Python (clamp/scale, reward, done, observation, TimeLimit) happens inside the fused HIP kernel.
+What stays on the host is what the reference also keeps there: seeding and reset noise from
+``np_random`` (MT19937, reference hopper.py:78-79), spaces, and the auto-reset policy of the vector wrapper.
+
+Reset noise modes
+  * ``noise="mt19937"`` (default): bit-exact with the reference -- env i owns ``seeding.np_random(seed_i)`` and a reset
+    draws ``uniform(-r, r, ndofs)`` for qpos then for qvel (hopper.py:78-79).
+  * ``noise="philox"``: counter-based noise generated on the device (throughput mode, used by bench.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from .. import seeding, spaces
+from ..model_card import DartModelCard, TASKS, card_for
+from .. import stepper as _st
+
+
+class SkeletonView:
+    """The few ``robot_skeleton`` attributes the reference's task code reads (hopper.py:39-49,69-70), batched."""
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def ndofs(self):
+        return self._env.ndofs
+
+    @property
+    def q(self):
+        return self._env._stepper.get_state()[0]
+
+    @property
+    def dq(self):
+        return self._env._stepper.get_state()[1]
+
+    @property
+    def q_lower(self):
+        c = self._env.card
+        return np.array([c.lower[i] for i in range(c.ndofs)])
+
+    @property
+    def q_upper(self):
+        c = self._env.card
+        return np.array([c.upper[i] for i in range(c.ndofs)])
+
+
+class BatchedDartEnv:
+    """num_envs Dart worlds stepped in lock-step on one GPU.  No auto-reset here (see DartVectorEnv)."""
+
+    metadata = {"render.modes": []}
+
+    def __init__(self, env_id: str, num_envs: int = 1, device: int = 0, precision: int = 32, noise: str = "mt19937",
+                 max_episode_steps: Optional[int] = None, card: Optional[DartModelCard] = None,
+                 stepper_factory: Optional[Callable] = None):
+        if noise not in ("mt19937", "philox"):
+            raise ValueError("noise must be 'mt19937' or 'philox'")
+        self.env_id = env_id
+        self.task = TASKS[env_id]
+        self.card = card if card is not None else card_for(env_id)
+        if max_episode_steps is not None:
+            self.card.max_episode_steps = int(max_episode_steps)
+        self.num_envs = int(num_envs)
+        self.ndofs, self.obs_dim, self.act_dim = self.card.ndofs, self.card.obs_dim, self.card.act_dim
+        self.frame_skip = self.card.frame_skip
+        self.noise = noise
+        factory = stepper_factory or _st.HipStepper  # no CPU fallback: HipStepper raises without lib/GPU
+        self._stepper = factory(self.card, self.num_envs, device, precision)
+        # spaces exactly as DartEnv.__init__ builds them (dart_env.py:85-86, 97-100)
+        hi = np.array([self.card.act_high[k] for k in range(self.act_dim)])
+        lo = np.array([self.card.act_low[k] for k in range(self.act_dim)])
+        self.action_space = spaces.Box(lo, hi)
+        inf = np.inf * np.ones(self.obs_dim)
+        self.observation_space = spaces.Box(-inf, inf)
+        self.robot_skeleton = SkeletonView(self)
+        self._rngs = [None] * self.num_envs
+        self._seeds = [None] * self.num_envs
+        self.seed(None)
+
+    # ---- reference API -------------------------------------------------------------------------------------
+    @property
+    def dt(self):
+        return self.card.dt * self.frame_skip  # dart_env.py:154-156
+
+    def seed(self, seeds=None):
+        """int s -> env i seeded s+i (sync_vector_env.py:50-58); list -> per env; None -> OS entropy."""
+        if seeds is None:
+            seeds = [None] * self.num_envs
+        elif isinstance(seeds, (int, np.integer)):
+            seeds = [int(seeds) + i for i in range(self.num_envs)]
+        assert len(seeds) == self.num_envs
+        self._pending_seeds = list(seeds)
+        self._rngs = [None] * self.num_envs   # RandomStates are built lazily, on an env's first reset
+        if self.noise == "philox":
+            s0 = seeding.create_seed(seeds[0])
+            self._stepper.configure(_st.CFG_SEED, float(s0 % (1 << 53)))
+        return list(seeds)
+
+    def _rng(self, i):
+        if self._rngs[i] is None:
+            self._rngs[i], self._seeds[i] = seeding.np_random(self._pending_seeds[i])
+        return self._rngs[i]
+
+    def _draw_noise(self, mask):
+        r = self.card.reset_noise
+        qn = np.zeros((self.num_envs, self.ndofs))
+        vn = np.zeros((self.num_envs, self.ndofs))
+        idx = range(self.num_envs) if mask is None else np.flatnonzero(mask)
+        for i in idx:
+            rng = self._rng(i)
+            qn[i] = rng.uniform(low=-r, high=r, size=self.ndofs)   # qpos first (hopper.py:78)
+            vn[i] = rng.uniform(low=-r, high=r, size=self.ndofs)   # qvel second (hopper.py:79)
+        return qn, vn
+
+    def reset(self, mask=None):
+        """reset_model() for the masked envs (all when None); returns the (num_envs, obs_dim) float32 observations."""
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if self.noise == "philox":
+            return self._stepper.reset(m, None, None)
+        qn, vn = self._draw_noise(m)
+        return self._stepper.reset(m, qn, vn)
+
+    def step(self, actions):
+        """-> obs (N,obs) f32, reward (N,) f64, done (N,) bool, truncated (N,) bool   (no auto-reset)"""
+        return self._stepper.step(actions)
+
+    def step_async(self, actions):
+        self._stepper.step_async(actions)
+
+    def step_wait(self):
+        return self._stepper.step_wait()
+
+    def set_state(self, qpos, qvel):
+        qpos = np.asarray(qpos, dtype=np.float64).reshape(self.num_envs, self.ndofs)
+        qvel = np.asarray(qvel, dtype=np.float64).reshape(self.num_envs, self.ndofs)
+        self._stepper.set_state(qpos, qvel)
+
+    def state_vector(self):
+        q, dq = self._stepper.get_state()
+        return np.concatenate([q, dq], axis=1)  # dart_env.py:211-215, one row per env
+
+    def close(self):
+        if self._stepper is not None:
+            self._stepper.close()
+            self._stepper = None

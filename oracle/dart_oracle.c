@@ -664,7 +664,8 @@ int oracle_step(OracleWorld* w) {
       for (int j = 0; j < m; j++) wv += A[i * m + j] * x[j];
       w->lambda_last[i] = x[i]; w->w_last[i] = wv; w->lo_last[i] = lo[i]; w->hi_last[i] = hi[i];
       double e;
-      if (x[i] <= lo[i]) e = wv < 0 ? -wv : 0;
+      if (lo[i] == hi[i]) e = 0; /* pinned row (friction under a zero normal impulse): any w is admissible */
+      else if (x[i] <= lo[i]) e = wv < 0 ? -wv : 0;
       else if (x[i] >= hi[i]) e = wv > 0 ? wv : 0;
       else e = fabs(wv);
       if (e > res) res = e;

@@ -1,0 +1,134 @@
+"""CPU-side checks: the C-ABI library loads and exports everything include/dart_stepper.h declares, fails loudly
+without a GPU (no CPU fallback), the model compiler's cards are sane, and the host layer's error behaviour."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dart_env_amd
+from dart_env_amd import stepper as st
+from dart_env_amd.model_card import DartModelCard, card_for, load_model
+from dart_env_amd.distributed import shard_layout
+from tests.conftest import gpu_available
+from tests.fake_stepper import OracleStepper
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dart_stepper.h")).read()
+    declared = sorted(set(re.findall(r"\b(dart_[a-z_]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    assert sorted(st.EXPORTS) == declared, (sorted(st.EXPORTS), declared)
+    L = st.load_library()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_card_struct_layout_matches_c():
+    # oracle_create() compares struct_bytes with its own sizeof(DartModelCard): passing means ctypes == C layout
+    from tests.oracle_lib import OracleWorld
+    c = card_for("DartHopper-v1")
+    assert c.struct_bytes == C.sizeof(DartModelCard)
+    OracleWorld(c)
+
+
+@pytest.mark.skipif(gpu_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    with pytest.raises(st.StepperError) as e:
+        st.HipStepper(card_for("DartHopper-v1"), 8)
+    assert e.value.code == st.E_NO_DEVICE and "no CPU path" in str(e.value)
+    with pytest.raises(st.StepperError):
+        dart_env_amd.make("DartHopper-v1")
+    with pytest.raises(st.StepperError):
+        dart_env_amd.vector.make("DartHopper-v1", 4)
+
+
+def test_create_rejects_bad_arguments():
+    L = st.load_library()
+    h = C.c_void_p()
+    bad = card_for("DartHopper-v1")
+    bad.version = 99
+    assert L.dart_create(C.byref(bad), 4, 0, 32, C.byref(h)) == st.E_INVALID
+    assert L.dart_create(C.byref(card_for("DartHopper-v1")), 0, 0, 32, C.byref(h)) == st.E_INVALID
+    assert L.dart_create(C.byref(card_for("DartHopper-v1")), 4, 0, 16, C.byref(h)) == st.E_INVALID
+    assert L.dart_destroy(None) == st.DART_OK
+    assert L.dart_step(None, None, None, None, None, None) == st.E_INVALID
+
+
+def test_model_cards():
+    h = load_model("hopper")
+    assert h.ndofs == 6 and [b.name for b in h.bodies][:3] == ["h_pelvis_aux2", "h_pelvis_aux", "h_pelvis"]
+    assert h.total_mass == pytest.approx(15.26499871)
+    assert h.bodies[2].axes[0][2] == -1.0                      # j_pelvis_rot axis -z (hopper_capsule.skel:188)
+    assert list(h.limited) == [False, False, False, True, True, True]
+    assert h.upper[3] == 0.0 and h.lower[5] == pytest.approx(-0.785398)
+    assert h.ground_y == 0.0 and h.dt == 0.002
+    # A1: inertia = first shape's own-frame tensor, capsule axis z -> body Izz is the AXIAL moment
+    assert h.bodies[2].inertia[2, 2] == pytest.approx(0.004292, abs=1e-6)
+    w = load_model("walker2d")
+    assert w.ndofs == 9 and w.bodies[2].axes[0][2] == 1.0 and w.total_mass == pytest.approx(22.69800692)
+    assert [b.parent for b in w.bodies] == [-1, 0, 1, 2, 3, 4, 2, 6, 7]
+    assert load_model("walker3d").ndofs == 21 and load_model("humanwalker").ndofs == 29
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference"), reason="reference assets only exist in the build container")
+def test_model_compiler_reproduces_committed_cards():
+    from dart_env_amd.skel import parse_skel
+    a = parse_skel("/root/reference/gym/envs/dart/assets/hopper_capsule.skel", dt=0.002)
+    assert a.to_json() == load_model("hopper").to_json()
+
+
+def test_vector_env_api_errors_and_shapes():
+    venv = dart_env_amd.vector.make("DartHopper-v1", 3, stepper_factory=OracleStepper)
+    assert venv.observation_space.shape == (3, 11) and venv.single_action_space.shape == (3,)
+    assert len(venv.action_space) == 3 and venv.single_observation_space.dtype == np.float32
+    venv.seed(0)
+    venv.reset()
+    with pytest.raises(st.NoAsyncCallError):
+        venv.step_wait()
+    venv.step_async(np.zeros((3, 3)))
+    with pytest.raises(st.AlreadyPendingCallError):
+        venv.step_async(np.zeros((3, 3)))
+    obs, rew, done, infos = venv.step_wait()
+    assert obs.shape == (3, 11) and rew.shape == (3,) and done.shape == (3,) and len(infos) == 3
+    a = venv.action_space.sample()
+    assert len(a) == 3 and a[0].dtype == np.float32
+    venv.close()
+    venv.close()  # idempotent
+    with pytest.raises(dart_env_amd.vector.ClosedEnvironmentError):
+        venv.reset()
+
+
+def test_determinism_like_reference_test():
+    """reference gym/envs/tests/test_determinism.py:6-54: two fresh envs, same seeds, 4 steps, exact equality."""
+    outs = []
+    for _ in range(2):
+        env = dart_env_amd.make("DartHopper-v1", stepper_factory=OracleStepper)
+        env.seed(0); env.action_space.seed(0)
+        rec = [env.reset()]
+        for _ in range(4):
+            ob, r, d, info = env.step(env.action_space.sample())
+            rec += [ob, np.array(r), np.array(d)]
+        outs.append(rec)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_smoke_like_reference_test_envs():
+    """reference gym/envs/tests/test_envs.py:10-37: reset in obs space, one random step, scalar reward, bool done."""
+    for env_id in ("DartHopper-v1", "DartWalker2d-v1"):
+        env = dart_env_amd.make(env_id, stepper_factory=OracleStepper)
+        ob = env.reset()
+        assert env.observation_space.contains(ob.astype(np.float32))
+        ob, r, d, info = env.step(env.action_space.sample())
+        assert env.observation_space.contains(ob.astype(np.float32)) and np.isscalar(r) and isinstance(d, bool)
+        env.close()
+
+
+def test_shard_layout():
+    assert [shard_layout(524288, 8, r) for r in range(8)] == [(r * 65536, 65536) for r in range(8)]
+    lay = [shard_layout(10, 4, r) for r in range(4)]
+    assert lay == [(0, 3), (3, 3), (6, 2), (8, 2)]

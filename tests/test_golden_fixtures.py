@@ -1,0 +1,123 @@
+"""The committed fixtures (tests/golden/*.npz) were produced by the REFERENCE's Python running on the oracle
+(tests/golden/make_golden.py).  They pin seeding, action sampling and the task logic; here the repo's own host
+layer and the oracle's C task epilogue are checked against them bit-for-bit (fp64) / to fp32 rounding."""
+import os
+
+import numpy as np
+import pytest
+
+import dart_env_amd
+from dart_env_amd import seeding, spaces
+from dart_env_amd.model_card import card_for
+from dart_env_amd.envs import DartHopperEnv, DartWalker2dEnv
+from dart_env_amd.wrappers import TimeLimit
+from tests.fake_stepper import OracleStepper
+from tests.oracle_lib import OracleWorld
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+IDS = {"hopper": "DartHopper-v1", "walker2d": "DartWalker2d-v1"}
+CLS = {"hopper": DartHopperEnv, "walker2d": DartWalker2dEnv}
+
+
+def test_seeding_and_reset_noise_stream():
+    d = np.load(os.path.join(G, "seeding.npz"))
+    for s in range(8):
+        assert int(d["hash_%d" % s]) == seeding.hash_seed(s)
+        for n in (6, 9, 21, 29):
+            rng, _ = seeding.np_random(s)
+            got = np.stack([rng.uniform(-.005, .005, n), rng.uniform(-.005, .005, n)])
+            assert np.array_equal(got, d["noise_s%d_n%d" % (s, n)])
+    # SURVEY Appendix E probe 4 value
+    assert d["noise_s0_n6"][0][0] == pytest.approx(-0.0044564, abs=1e-7)
+
+
+def test_box_action_stream():
+    d = np.load(os.path.join(G, "seeding.npz"))
+    for k in range(4):
+        b = spaces.Box(-np.ones(3), np.ones(3))
+        b.seed(k)
+        got = np.stack([b.sample() for _ in range(1000)])
+        assert got.dtype == np.float32 and np.array_equal(got, d["box3_seed%d" % k])
+    with pytest.raises(seeding.SeedError):
+        seeding.np_random(-1)
+    with pytest.raises(seeding.SeedError):
+        seeding.np_random(1.5)
+
+
+@pytest.mark.parametrize("tag,fix", [("hopper", "single_seed0"), ("walker2d", "single_seed0"),
+                                     ("hopper", "single_seed5_small"), ("walker2d", "single_seed5_small")])
+def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
+    """C restatement of hopper.py:36-74 / walker2d.py:22-74 == the reference's numpy code, fp64 bit-for-bit."""
+    d = np.load(os.path.join(G, "%s_%s.npz" % (tag, fix)))
+    w = OracleWorld(card_for(IDS[tag]))
+    seed = 0 if "seed0" in fix else 5
+    rng, _ = seeding.np_random(seed)
+    n = w.n
+
+    def do_reset():
+        w.reset()
+        w.set_state(w.q + rng.uniform(-.005, .005, n), w.dq + rng.uniform(-.005, .005, n))
+        return w.env_obs()
+    assert np.array_equal(do_reset(), d["obs0"])
+    steps = min(len(d["done"]), 400)
+    for t in range(steps):
+        ob, r, done = w.env_step(d["actions"][t].astype(np.float64))
+        assert np.array_equal(ob, d["obs"][t]), t
+        assert r == d["reward"][t] and done == bool(d["done"][t])
+        assert np.array_equal(w.q, d["q"][t]) and np.array_equal(w.dq, d["dq"][t])
+        if done:
+            assert np.array_equal(do_reset(), d["reset_obs"][t])
+
+
+@pytest.mark.parametrize("tag", ["hopper", "walker2d"])
+def test_single_env_facade_vs_reference(tag):
+    """make(id): seed -> reset -> step loop reproduces the reference's obs/reward/done (obs cross the ABI as float32)."""
+    d = np.load(os.path.join(G, "%s_single_seed0.npz" % tag))
+    env = TimeLimit(CLS[tag](stepper_factory=OracleStepper), max_episode_steps=1000)
+    env.seed(0)
+    ob = env.reset()
+    assert ob.dtype == np.float64 and np.allclose(ob, d["obs0"], atol=1e-7)
+    for t in range(150):
+        ob, r, done, info = env.step(d["actions"][t])
+        assert np.allclose(ob, d["obs"][t], rtol=0, atol=2e-6), t
+        assert r == d["reward"][t] and isinstance(done, bool) and done == bool(d["done"][t]) and info == {}
+        assert np.allclose(env.state_vector(), np.concatenate([d["q"][t], d["dq"][t]]), atol=0)
+        if done:
+            assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-7)
+    assert env.dt == pytest.approx(0.008)
+    env.close()
+
+
+@pytest.mark.parametrize("tag", ["hopper", "walker2d"])
+def test_time_limit_truncation_vs_reference(tag):
+    d = np.load(os.path.join(G, "%s_single_seed2_limit20.npz" % tag))
+    env = TimeLimit(CLS[tag](stepper_factory=OracleStepper), max_episode_steps=20)
+    env.seed(2)
+    env.reset()
+    for t in range(len(d["done"])):
+        ob, r, done, info = env.step(d["actions"][t])
+        assert done == bool(d["done"][t])
+        assert bool(info.get("TimeLimit.truncated", False)) == bool(d["truncated"][t])
+        if done:
+            env.reset()
+    assert d["truncated"].sum() >= 3
+
+
+@pytest.mark.parametrize("tag", ["hopper", "walker2d"])
+def test_vector_env_vs_reference_syncvectorenv(tag):
+    """seed(int) fan-out s+i, auto-reset returning the post-reset observation, dtypes (sync_vector_env.py:50-84)."""
+    d = np.load(os.path.join(G, "%s_vector4_seed3.npz" % tag))
+    venv = dart_env_amd.vector.make(IDS[tag], 4, stepper_factory=OracleStepper)
+    venv.seed(3)
+    ob = venv.reset()
+    assert ob.dtype == np.float32 and ob.shape == d["obs0"].shape and np.array_equal(ob, d["obs0"])
+    for t in range(len(d["done"])):
+        ob, r, done, infos = venv.step(d["actions"][t])
+        assert ob.dtype == np.float32 and r.dtype == np.float64 and done.dtype == np.bool_
+        assert np.array_equal(done, d["done"][t]), t
+        assert np.allclose(ob, d["obs"][t], rtol=0, atol=2e-6)
+        assert np.array_equal(r, d["reward"][t])
+        assert len(infos) == 4 and all(isinstance(i, dict) for i in infos)
+    assert d["done"].sum() > 10
+    assert str(d["obs_dtype"]) == "float32" and str(d["reward_dtype"]) == "float64" and str(d["done_dtype"]) == "bool"
+    venv.close()

@@ -132,6 +132,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   if (nc != T::NC) return "collidable shape count";
   P.dt = (Real)c.dt; P.ground_y = (Real)c.ground_y; P.g = (Real)(-c.gravity[1]); P.mu = (Real)c.friction;
   P.erp_dt = (Real)(c.erp / c.dt); P.max_erv = (Real)c.max_erv; P.limit_erp_dt = (Real)(c.limit_erp / c.dt);
+  P.cfm1 = (Real)(1.0 + c.cfm);
   for (int k = 0; k < T::NA; k++) {
     P.act_scale[k] = (Real)c.act_scale[k]; P.act_lo[k] = (Real)c.act_low[k]; P.act_hi[k] = (Real)c.act_high[k];
   }

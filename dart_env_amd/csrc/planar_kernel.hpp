@@ -41,6 +41,12 @@ __device__ __host__ __forceinline__ void sfor_rev(F&& f) {
     sfor_rev<B, E - 1>(f);
   }
 }
+template <int N>
+#ifdef DART_ROOT_FIRST
+__device__ __host__ constexpr int rev(int i) { return i; }
+#else
+__device__ __host__ constexpr int rev(int i) { return N - 1 - i; }
+#endif
 __device__ __host__ constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // ------------------------------------------------------------------ topologies
@@ -82,7 +88,7 @@ __device__ __host__ constexpr int limit_slot(int k) {  // LCP slot of link k's l
 // ------------------------------------------------------------------ runtime parameters (kernel argument -> SGPRs)
 template <class Real, class T>
 struct Params {
-  Real dt, ground_y, g, mu, erp_dt, max_erv, limit_erp_dt;
+  Real dt, ground_y, g, mu, erp_dt, max_erv, limit_erp_dt, cfm1;  // cfm1 = 1 + cfm (DART scales diag(A))
   Real root_x0, root_y0;
   Real sigma[T::NL], mass[T::NL], cx[T::NL], cy[T::NL], izz[T::NL], jx[T::NL], jy[T::NL];
   Real lo[T::NL], hi[T::NL];
@@ -252,10 +258,12 @@ template <class Real, class T>
 __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
                                            const Real (&tau)[T::NDOF]) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * T::NC + n_limited<T>();
-  Real c[NL], s[NL], px[NL], py[NL], rx[NL], ry[NL], om[NL];
+  Real c[NL], s[NL], px[NL], py[NL], lx[NL], ly[NL], om[NL];
   Real apx[NL], apy[NL];
-  Real mc[NL], hx[NL], hy[NL], Ic[NL], Fx[NL], Fy[NL], Nz[NL];
-  // ---- forward pass: kinematics, velocity-product accelerations, per-link wrench about the root origin
+  // composite-body quantities, each expressed about the link's OWN joint origin (no large-offset cancellation in
+  // fp32): mass, first moment d = sum m (r - p_k), inertia Ip about p_k, force F and moment Nz about p_k
+  Real mc[NL], dcx[NL], dcy[NL], Ip[NL], Fx[NL], Fy[NL], Nz[NL];
+  // ---- forward pass: kinematics, velocity-product accelerations, per-link wrench
   sfor<0, NL>([&](auto K) {
     constexpr int k = K;
     Real sj, cj;
@@ -263,61 +271,63 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
     sj *= P.sigma[k];
     if constexpr (k == 0) {
       c[0] = cj; s[0] = sj; px[0] = Real(0); py[0] = Real(0); om[0] = P.sigma[0] * dq[2];
+      lx[0] = Real(0); ly[0] = Real(0);
       apx[0] = Real(0); apy[0] = Real(0);
     } else {
       constexpr int p = T::parent(k);
       c[k] = c[p] * cj - s[p] * sj;
       s[k] = s[p] * cj + c[p] * sj;
-      Real lx = c[p] * P.jx[k] - s[p] * P.jy[k], ly = s[p] * P.jx[k] + c[p] * P.jy[k];
-      px[k] = px[p] + lx; py[k] = py[p] + ly;
+      lx[k] = c[p] * P.jx[k] - s[p] * P.jy[k]; ly[k] = s[p] * P.jx[k] + c[p] * P.jy[k];
+      px[k] = px[p] + lx[k]; py[k] = py[p] + ly[k];
       om[k] = om[p] + P.sigma[k] * dq[2 + k];
       Real w2 = om[p] * om[p];
-      apx[k] = apx[p] - w2 * lx; apy[k] = apy[p] - w2 * ly;
+      apx[k] = apx[p] - w2 * lx[k]; apy[k] = apy[p] - w2 * ly[k];
     }
     Real ox = c[k] * P.cx[k] - s[k] * P.cy[k], oy = s[k] * P.cx[k] + c[k] * P.cy[k];
-    rx[k] = px[k] + ox; ry[k] = py[k] + oy;
     Real w2 = om[k] * om[k];
     Real fx = P.mass[k] * (apx[k] - w2 * ox), fy = P.mass[k] * (apy[k] - w2 * oy + P.g);
-    mc[k] = P.mass[k]; hx[k] = P.mass[k] * rx[k]; hy[k] = P.mass[k] * ry[k];
-    Ic[k] = P.izz[k] + P.mass[k] * (rx[k] * rx[k] + ry[k] * ry[k]);
-    Fx[k] = fx; Fy[k] = fy; Nz[k] = rx[k] * fy - ry[k] * fx;
+    mc[k] = P.mass[k]; dcx[k] = P.mass[k] * ox; dcy[k] = P.mass[k] * oy;
+    Ip[k] = P.izz[k] + P.mass[k] * (ox * ox + oy * oy);
+    Fx[k] = fx; Fy[k] = fy; Nz[k] = ox * fy - oy * fx;
   });
-  // ---- backward pass: composite bodies
+  // ---- backward pass: fold each composite into its parent, shifting the reference point by the link vector
   sfor_rev<1, NL>([&](auto K) {
     constexpr int k = K, p = T::parent(k);
-    mc[p] += mc[k]; hx[p] += hx[k]; hy[p] += hy[k]; Ic[p] += Ic[k];
-    Fx[p] += Fx[k]; Fy[p] += Fy[k]; Nz[p] += Nz[k];
+    Ip[p] += Ip[k] + Real(2) * (lx[k] * dcx[k] + ly[k] * dcy[k]) + mc[k] * (lx[k] * lx[k] + ly[k] * ly[k]);
+    dcx[p] += dcx[k] + mc[k] * lx[k]; dcy[p] += dcy[k] + mc[k] * ly[k];
+    mc[p] += mc[k];
+    Nz[p] += Nz[k] + (lx[k] * Fy[k] - ly[k] * Fx[k]);
+    Fx[p] += Fx[k]; Fy[p] += Fy[k];
   });
-  // ---- H = M + dt D (packed lower), rhs = tau - C - D dq
+  // ---- H = M + dt D, rhs = tau - C - D dq.  Stored with REVERSED dof order (rev<N>(i) = N-1-i) so that the LDL^T below
+  // eliminates leaf joints first and the floating base last (Featherstone's LTDL order = articulated-body
+  // recursion numerically): pivots are articulated inertias instead of small differences of large numbers.
   Real H[N * (N + 1) / 2], rhs[N];
-  H[tri(0, 0)] = mc[0]; H[tri(1, 0)] = Real(0); H[tri(1, 1)] = mc[0];
+  H[tri(rev<N>(0), rev<N>(0))] = mc[0]; H[tri(rev<N>(1), rev<N>(0))] = Real(0); H[tri(rev<N>(1), rev<N>(1))] = mc[0];
   rhs[0] = tau[0] - Fx[0] - P.damp[0] * dq[0];
   rhs[1] = tau[1] - Fy[0] - P.damp[1] * dq[1];
   sfor<0, NL>([&](auto K) {
     constexpr int k = K, i = 2 + k;
-    Real dkx = hx[k] - mc[k] * px[k], dky = hy[k] - mc[k] * py[k];
-    Real Ip = Ic[k] - Real(2) * (px[k] * hx[k] + py[k] * hy[k]) + mc[k] * (px[k] * px[k] + py[k] * py[k]);
-    H[tri(i, 0)] = -P.sigma[k] * dky;
-    H[tri(i, 1)] = P.sigma[k] * dkx;
+    H[tri(rev<N>(i), rev<N>(0))] = -P.sigma[k] * dcy[k];
+    H[tri(rev<N>(i), rev<N>(1))] = P.sigma[k] * dcx[k];
     sfor<0, k + 1>([&](auto J) {
       constexpr int j = J;
       if constexpr (is_anc<T>(j, k)) {
-        Real v = Ip + dkx * (px[k] - px[j]) + dky * (py[k] - py[j]);
-        H[tri(i, 2 + j)] = P.sigma[k] * P.sigma[j] * v;
+        Real v = Ip[k] + dcx[k] * (px[k] - px[j]) + dcy[k] * (py[k] - py[j]);
+        H[tri(rev<N>(i), rev<N>(2 + j))] = P.sigma[k] * P.sigma[j] * v;
       } else {
-        H[tri(i, 2 + j)] = Real(0);
+        H[tri(rev<N>(i), rev<N>(2 + j))] = Real(0);
       }
     });
-    Real Ck = P.sigma[k] * (Nz[k] - (px[k] * Fy[k] - py[k] * Fx[k]));
-    rhs[i] = tau[i] - Ck - P.damp[i] * dq[i];
+    rhs[i] = tau[i] - P.sigma[k] * Nz[k] - P.damp[i] * dq[i];
   });
-  sfor<0, N>([&](auto I) { constexpr int i = I; H[tri(i, i)] += P.dt * P.damp[i]; });
-  spd_inverse<Real, N>(H);  // H now holds H^-1
+  sfor<0, N>([&](auto I) { constexpr int i = I; H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.damp[i]; });
+  spd_inverse<Real, N>(H);  // H now holds H^-1 (reversed dof order)
   Real vs[N];
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
     Real a = Real(0);
-    sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(i, j)] * rhs[j]; });
+    sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(rev<N>(i), rev<N>(j))] * rhs[j]; });
     vs[i] = dq[i] + P.dt * a;
   });
 
@@ -381,7 +391,7 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
       sfor<0, N>([&](auto I) {
         constexpr int i = I;
         Real a = Real(0), t = Real(0);
-        sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(i, j)] * Jn[cidx][j]; t += H[tri(i, j)] * Jt[cidx][j]; });
+        sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(rev<N>(i), rev<N>(j))] * Jn[cidx][j]; t += H[tri(rev<N>(i), rev<N>(j))] * Jt[cidx][j]; });
         Yn[cidx][i] = a; Yt[cidx][i] = t;
       });
     });
@@ -412,14 +422,14 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
         });
         sfor<0, k + 1>([&](auto J) {
           constexpr int j = J;
-          if constexpr (T::limited(j)) A[tri(sl, limit_slot<T>(j))] = H[tri(i, 2 + j)];
+          if constexpr (T::limited(j)) A[tri(sl, limit_slot<T>(j))] = H[tri(rev<N>(i), rev<N>(2 + j))];
         });
       }
     });
     // inactive slots: decouple (unit diagonal keeps the factorisations regular)
     sfor<0, M>([&](auto I) {
       constexpr int i = I;
-      if (!act[i]) A[tri(i, i)] = Real(1);
+      A[tri(i, i)] = act[i] ? A[tri(i, i)] * P.cfm1 : Real(1);
       sfor<0, i>([&](auto J) { constexpr int j = J; if (!act[i] || !act[j]) A[tri(i, j)] = Real(0); });
     });
 
@@ -460,7 +470,7 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
       sfor<0, NC>([&](auto Cc) { constexpr int cidx = Cc; dv += Yn[cidx][i] * x[2 * cidx] + Yt[cidx][i] * x[2 * cidx + 1]; });
       sfor<0, NL>([&](auto K) {
         constexpr int k = K;
-        if constexpr (T::limited(k)) dv += H[tri(i, 2 + k)] * x[limit_slot<T>(k)];
+        if constexpr (T::limited(k)) dv += H[tri(rev<N>(i), rev<N>(2 + k))] * x[limit_slot<T>(k)];
       });
       vs[i] += dv;
     });

@@ -16,7 +16,7 @@ from .model_card import DartModelCard
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libdart_stepper.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("DART_STEPPER_LIB", os.path.join(_HERE, LIB_NAME))
 
 # error codes / keys (include/dart_stepper.h)
 DART_OK, E_INVALID, E_NO_DEVICE, E_UNSUPPORTED, E_HIP, E_PENDING, E_NOT_PENDING = 0, -1, -2, -3, -4, -5, -6

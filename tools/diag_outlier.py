@@ -1,0 +1,40 @@
+"""Diagnostic (GPU box): find the first step where an fp32 env departs from the oracle by > thr and dump context."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from dart_env_amd.model_card import card_for
+from dart_env_amd.stepper import HipStepper
+from tests.batch_oracle import OracleBatch
+np.set_printoptions(precision=6, linewidth=220, suppress=True)
+env_id = sys.argv[1] if len(sys.argv) > 1 else "DartHopper-v1"
+n, steps, thr = 256, 60, 5e-3
+card = card_for(env_id); nd, na = card.ndofs, card.act_dim
+rng = np.random.RandomState(0)
+gpu = HipStepper(card, n, precision=32); g64 = HipStepper(card, n, precision=64); ora = OracleBatch(card, n)
+qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+gpu.reset(None, qn, vn); ora.reset(None, qn, vn); g64.reset(None, qn, vn)
+found = 0
+for t in range(steps):
+    a = rng.uniform(-1, 1, (n, na)).astype(np.float32)
+    qb, dqb = ora.state()
+    qgb, dqgb = gpu.get_state()
+    og, rg, dg, tg = gpu.step(a); oo, ro, do, to = ora.step(a); g64.step(a)
+    qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+    edq = np.abs(dqg - dqo).max(1)
+    for e in np.flatnonzero(edq > thr)[:2]:
+        found += 1
+        print("step", t, "env", e, "edq", edq[e], "pre-step err q", np.abs(qgb[e]-qb[e]).max(), "dq", np.abs(dqgb[e]-dqb[e]).max())
+        print("  q before ", qb[e]); print("  dq before", dqb[e]); print("  action", a[e])
+        print("  dq oracle", dqo[e]); print("  dq gpu32 ", dqg[e])
+        # replay the 4 substeps on a fresh oracle world to see contacts / lcp
+        from tests.oracle_lib import OracleWorld
+        w = OracleWorld(card); w.set_state(qb[e], dqb[e])
+        tau = np.zeros(nd); tau[3:] = np.clip(a[e], -1, 1) * np.array(card.act_scale[:na])
+        for f in range(4):
+            w.set_forces(tau); w.step()
+            lam, wv, lo, hi, res = w.last_lcp()
+            print("   sub", f, "lam", lam, "lo", lo, "hi", hi, "contacts", w.last_contacts()[:, [0,1,2,4]] if len(w.last_contacts()) else None)
+    if found >= 3: break
+    if do.any():
+        qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+        gpu.reset(do.astype(np.uint8), qn, vn, want_obs=False); ora.reset(do, qn, vn); g64.reset(do.astype(np.uint8), qn, vn, want_obs=False)

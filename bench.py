@@ -167,6 +167,17 @@ def main():
     }
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
+    # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction) -- only valid for the profiled configuration
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        key = "%s/%d/f%d" % (args.env_id, n, args.precision)
+        if key in pmc:
+            result["roofline"]["traffic"] = pmc[key]["bytes_per_launch"]
+            result["roofline"]["traffic_source"] = pmc[key]["source"]
+    except OSError:
+        pass
 
     if world == 1 and not args.no_cpu_baseline:
         from tests import oracle_lib as ol  # cpu_baseline leg: the only place bench.py touches the oracle
@@ -186,12 +197,17 @@ def main():
         el, ep = small.counters()
         same = (ep == ref["episode"]) & (el == ref["elapsed"])
         eq = (qg - ref["q"])[same]; edq = (dqg - ref["dq"])[same]
+        close = np.abs(eq).max(axis=1) < 1e-4   # envs that did not take a contact event a substep early/late
         result["cpu_baseline"] = {
             "value": ref["env_steps"] / cpu_s, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "%d envs x %d env-steps of %s, same Philox reset streams and action tensor as the GPU check; "
                       "fp64 DART-semantics restatement (oracle/), not DART" % (ne, ns, args.env_id),
             "host_cpus": os.cpu_count(),
             "rms_state_err": {"q": float(np.sqrt(np.mean(eq ** 2))), "dq": float(np.sqrt(np.mean(edq ** 2))),
+                              "q_trimmed": float(np.sqrt(np.mean(eq[close] ** 2))),
+                              "dq_trimmed": float(np.sqrt(np.mean(edq[close] ** 2))),
+                              "median_abs_q": float(np.median(np.abs(eq))), "median_abs_dq": float(np.median(np.abs(edq))),
+                              "envs_within_1e-4": int(close.sum()),
                               "envs_same_episode_history": int(same.sum()), "envs": ne, "env_steps": ns},
         }
         small.close()

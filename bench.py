@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--pgs-iters", type=int, default=30)
     ap.add_argument("--ring", type=int, default=16, help="distinct action batches resident in HBM")
     ap.add_argument("--block", type=int, default=0, help="envs per wave64 workgroup (0 = library default)")
+    ap.add_argument("--stats", action="store_true", help="print wave-level pivoting iteration histograms")
+    ap.add_argument("--iters", type=int, default=0, help="pivoting iteration cap per stage (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=200)
@@ -79,6 +81,10 @@ def main():
     env.configure(st.CFG_AUTORESET, 1)
     env.configure(st.CFG_SEED, 0)
     env.configure(st.CFG_ENV_OFFSET, rank * n)
+    if args.stats:
+        env.configure(st.CFG_STATS, 1)
+    if args.iters:
+        env.configure(st.CFG_ITERS_STAGE1, args.iters); env.configure(st.CFG_ITERS_STAGE2, args.iters)
     if args.block:
         env.configure(st.CFG_BLOCK_THREADS, args.block)
     if args.solver == "pgs":
@@ -122,6 +128,10 @@ def main():
         elapsed = float(t.item())
 
     done_frac = float(done.float().mean().item())
+    if args.stats and rank == 0:
+        h1, h2 = env.solver_stats()
+        print("pivoting iterations per wave, stage 1:", h1.tolist(), file=sys.stderr)
+        print("pivoting iterations per wave, stage 2:", h2.tolist(), file=sys.stderr)
 
     # ---- kernel-only timing with HIP events on the stepper's own stream (roofline figure)
     ms_kernel = env.time_steps(ring.data_ptr(), args.ring, min(args.steps, 500), obs.data_ptr(), rew.data_ptr(),

@@ -7,12 +7,14 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
 
 #include "../../include/dart_stepper.h"
 #include "planar_kernel.hpp"
+#include "static_models.hpp"
 
 using namespace dartk;
 
@@ -29,24 +31,26 @@ struct Impl {
                            const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off) = 0;
   virtual hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) = 0;
   virtual void set_solver(int solver, int it1, int it2) = 0;
+  virtual void set_stats(unsigned long long* p) = 0;
   virtual int slots() const = 0;
   int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
+  bool is_static = false;  // true: model constants are compile-time immediates (static_models.hpp)
 };
 
-template <class Real, class T>
+template <class Real, class T, class PT = Params<Real, T>>
 struct ImplT : Impl {
-  Params<Real, T> P;
+  PT P;
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
                   float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
     dim3 grid((unsigned)((n + block_threads - 1) / block_threads)), block(block_threads);
-    hipLaunchKernelGGL((step_kernel<Real, T>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew,
+    hipLaunchKernelGGL((step_kernel<Real, T, PT>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew,
                        done, trunc, autoreset, seed, off);
     return hipGetLastError();
   }
   hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
                    const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off) override {
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL((reset_kernel<Real, T>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, mask, qn, vn, obs,
+    hipLaunchKernelGGL((reset_kernel<Real, T, PT>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, mask, qn, vn, obs,
                        seed, off);
     return hipGetLastError();
   }
@@ -56,6 +60,7 @@ struct ImplT : Impl {
     return hipGetLastError();
   }
   void set_solver(int solver, int it1, int it2) override { P.solver = solver; P.iters1 = it1; P.iters2 = it2; }
+  void set_stats(unsigned long long* p) override { P.stats = p; }
   int slots() const override { return 2 * T::NC + n_limited<T>(); }
 };
 
@@ -143,24 +148,34 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task;
   P.penalty_link = c.penalty_dof >= 2 ? c.penalty_dof - 2 : -1;
   if (c.task != DART_TASK_NONE && c.height_body != 2) return "height body must be the root link";
-  P.solver = 0; P.iters1 = 24; P.iters2 = 24;
+  P.solver = 0; P.iters1 = 24; P.iters2 = 24; P.stats = nullptr;
   return "";
 }
 
+// generic (runtime-parameter) kernel, or the compile-time specialisation when the card is bit-identical to a baked one
+template <class Real, class T, class Static>
+std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why, bool allow_static) {
+  Params<Real, T> R;
+  std::string w = fill_params<Real, T>(c, R);
+  if (!w.empty()) { why += w; return nullptr; }
+  if (allow_static && Static::matches(R)) {
+    auto p = std::make_unique<ImplT<Real, T, Static>>();
+    p->P.max_steps = R.max_steps; p->P.solver = R.solver; p->P.iters1 = R.iters1; p->P.iters2 = R.iters2;
+    p->P.stats = nullptr;
+    p->is_static = true;
+    return p;
+  }
+  auto p = std::make_unique<ImplT<Real, T>>();
+  p->P = R;
+  return p;
+}
+
 template <class Real>
-std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why) {
-  {
-    auto p = std::make_unique<ImplT<Real, HopperTopo>>();
-    std::string w = fill_params<Real, HopperTopo>(c, p->P);
-    if (w.empty()) return p;
-    why = "hopper-chain: " + w;
-  }
-  {
-    auto p = std::make_unique<ImplT<Real, Walker2dTopo>>();
-    std::string w = fill_params<Real, Walker2dTopo>(c, p->P);
-    if (w.empty()) return p;
-    why += "; walker2d-tree: " + w;
-  }
+std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why, bool allow_static) {
+  why = "hopper-chain: ";
+  if (auto p = make_for_topology<Real, HopperTopo, HopperStatic<Real>>(c, why, allow_static)) return p;
+  why += "; walker2d-tree: ";
+  if (auto p = make_for_topology<Real, Walker2dTopo, Walker2dStatic<Real>>(c, why, allow_static)) return p;
   return nullptr;
 }
 
@@ -178,6 +193,7 @@ struct DartStepper {
   float *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr;
   uint8_t *d_done = nullptr, *d_trunc = nullptr, *d_mask = nullptr;
   double *d_qn = nullptr, *d_vn = nullptr;
+  unsigned long long* d_stats = nullptr;
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
   double *h_qn = nullptr, *h_vn = nullptr;
@@ -214,7 +230,10 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
   }
   if (device < 0 || device >= ndev) { g_err = "device index out of range"; return DART_E_INVALID; }
   std::string why;
-  std::unique_ptr<Impl> impl = precision == 32 ? make_impl<float>(*card, why) : make_impl<double>(*card, why);
+  const char* gen = getenv("DART_GENERIC_KERNEL");   // debugging aid: force the runtime-parameter kernel
+  bool allow_static = !(gen && gen[0] == '1');
+  std::unique_ptr<Impl> impl = precision == 32 ? make_impl<float>(*card, why, allow_static)
+                                                : make_impl<double>(*card, why, allow_static);
   if (!impl) { g_err = "no compiled kernel for this model: " + why; return DART_E_UNSUPPORTED; }
   auto h = new DartStepper();
   h->card = *card; h->n = num_envs; h->device = device; h->precision = precision; h->impl = std::move(impl);
@@ -263,7 +282,7 @@ int dart_destroy(DartStepper* h) {
   if (!h) return DART_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -283,6 +302,7 @@ int dart_query(const DartStepper* h, int what, int64_t* out) {
     case DART_Q_PRECISION: *out = h->precision; break;
     case DART_Q_DEVICE: *out = h->device; break;
     case DART_Q_LCP_SLOTS: *out = h->impl->slots(); break;
+    case DART_Q_STATIC_KERNEL: *out = h->impl->is_static ? 1 : 0; break;
     default: return DART_E_INVALID;
   }
   return DART_OK;
@@ -297,6 +317,13 @@ int dart_configure(DartStepper* h, int key, double value) {
     case DART_CFG_AUTORESET: h->autoreset = value != 0; break;
     case DART_CFG_SEED: h->seed = (uint64_t)value; break;
     case DART_CFG_ENV_OFFSET: h->env_offset = (uint64_t)value; break;
+    case DART_CFG_STATS:
+      if (value != 0 && !h->d_stats) {
+        CHK(h, hipMalloc((void**)&h->d_stats, 64 * sizeof(unsigned long long)));
+        CHK(h, hipMemset(h->d_stats, 0, 64 * sizeof(unsigned long long)));
+      }
+      h->impl->set_stats(value != 0 ? h->d_stats : nullptr);
+      break;
     case DART_CFG_BLOCK_THREADS:
       if (value != 64 && value != 32 && value != 16) { h->err = "block threads must be 16, 32 or 64"; return DART_E_INVALID; }
       h->impl->block_threads = (int)value; break;
@@ -427,6 +454,16 @@ int dart_get_counters(DartStepper* h, int32_t* elapsed, uint32_t* episode) {
   CHK(h, hipStreamSynchronize(h->stream));
   if (elapsed) CHK(h, hipMemcpy(elapsed, h->elapsed, 4 * (size_t)h->n, hipMemcpyDeviceToHost));
   if (episode) CHK(h, hipMemcpy(episode, h->episode, 4 * (size_t)h->n, hipMemcpyDeviceToHost));
+  return DART_OK;
+}
+
+int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear) {
+  if (!h || !hist64) return DART_E_INVALID;
+  if (!h->d_stats) { h->err = "enable DART_CFG_STATS first"; return DART_E_INVALID; }
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  CHK(h, hipMemcpy(hist64, h->d_stats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (clear) CHK(h, hipMemset(h->d_stats, 0, 64 * sizeof(unsigned long long)));
   return DART_OK;
 }
 

@@ -88,6 +88,9 @@ __device__ __host__ constexpr int limit_slot(int k) {  // LCP slot of link k's l
 // ------------------------------------------------------------------ runtime parameters (kernel argument -> SGPRs)
 template <class Real, class T>
 struct Params {
+  using Topo = T;
+  static constexpr bool is_static = false;  // static_models.hpp holds the compile-time variants
+  __device__ __host__ static constexpr bool zero(int, int) { return false; }
   Real dt, ground_y, g, mu, erp_dt, max_erv, limit_erp_dt, cfm1;  // cfm1 = 1 + cfm (DART scales diag(A))
   Real root_x0, root_y0;
   Real sigma[T::NL], mass[T::NL], cx[T::NL], cy[T::NL], izz[T::NL], jx[T::NL], jy[T::NL];
@@ -98,12 +101,45 @@ struct Params {
   Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise;
   int frame_skip, max_steps, penalty_link, task;
   int solver, iters1, iters2;  // solver 0: block principal pivoting (exact); 1: PGS sweeps
+  unsigned long long* stats;   // optional [2][32] histogram of wave-level pivoting iterations per stage (debug), or null
 };
+
+// compile-time "is this model parameter exactly zero" (always false for the runtime block): lets the specialised
+// kernels drop whole terms without asking the compiler for non-IEEE x*0 folding
+enum { ZF_jx = 0, ZF_jy = 1, ZF_cx = 2, ZF_cy = 3, ZF_damp = 4 };
+#define DART_ZERO(PT, field, k) (PT::zero(ZF_##field, k))
 
 // ------------------------------------------------------------------ math helpers
 template <class Real> __device__ __forceinline__ void sincos_(Real x, Real& s, Real& c);
-template <> __device__ __forceinline__ void sincos_<float>(float x, float& s, float& c) { sincosf(x, &s, &c); }
+// fp32 sin/cos without the Payne-Hanek slow path: 3-term Cody-Waite reduction by pi/2 (exact products via fma, good
+// for |x| < ~1e4 rad; joint angles are bounded by limits / termination long before that) + minimax polynomials on
+// [-pi/4, pi/4] (max error ~1 ulp).  ~25 VALU instructions, branch-free.
+template <> __device__ __forceinline__ void sincos_<float>(float x, float& s, float& c) {
+  const float kf = rintf(x * 0.63661977236758134f);
+  const int k = (int)kf;
+  float r = fmaf(kf, -1.5707962512969971f, x);
+  r = fmaf(kf, -7.5497894158615964e-8f, r);
+  r = fmaf(kf, -5.3903029534742384e-15f, r);
+  const float r2 = r * r;
+  float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, r2, -1.6666654611e-1f);
+  const float sn = fmaf(ps * r2, r, r);
+  float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, r2, 4.166664568298827e-2f);
+  const float cs = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
+  const bool swap = k & 1;
+  const float s0 = swap ? cs : sn, c0 = swap ? sn : cs;
+  s = (k & 2) ? -s0 : s0;
+  c = ((k + 1) & 2) ? -c0 : c0;
+}
 template <> __device__ __forceinline__ void sincos_<double>(double x, double& s, double& c) { sincos(x, &s, &c); }
+// reciprocal: hardware v_rcp_f32 (1 ulp) + one Newton step in fp32; IEEE division in fp64
+template <class Real> __device__ __forceinline__ Real rcp_(Real x);
+template <> __device__ __forceinline__ float rcp_<float>(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+template <> __device__ __forceinline__ double rcp_<double>(double x) { return 1.0 / x; }
 template <class Real> __device__ __forceinline__ Real inf_() { return Real(__builtin_huge_valf()); }
 template <class Real> __device__ __forceinline__ Real tol_() { return sizeof(Real) == 4 ? Real(2e-6) : Real(1e-12); }
 
@@ -117,7 +153,7 @@ __device__ __forceinline__ void spd_inverse(Real (&a)[N * (N + 1) / 2]) {
     Real d = a[tri(j, j)];
     sfor<0, j>([&](auto K) { constexpr int k = K; d -= a[tri(j, k)] * a[tri(j, k)] * a[tri(k, k)]; });
     a[tri(j, j)] = d;
-    invd[j] = Real(1) / d;
+    invd[j] = rcp_<Real>(d);
     sfor<j + 1, N>([&](auto I) {
       constexpr int i = I;
       Real t = a[tri(i, j)];
@@ -161,7 +197,7 @@ __device__ __forceinline__ void masked_solve(const Real (&A)[M * (M + 1) / 2], c
     Real d = fr[j] * A[tri(j, j)] + (Real(1) - fr[j]);
     sfor<0, j>([&](auto K) { constexpr int k = K; d -= L[tri(j, k)] * L[tri(j, k)] * L[tri(k, k)]; });
     L[tri(j, j)] = d;
-    invd[j] = Real(1) / d;
+    invd[j] = rcp_<Real>(d);
     sfor<j + 1, M>([&](auto I) {
       constexpr int i = I;
       Real t = A[tri(i, j)] * fr[i] * fr[j];
@@ -181,66 +217,72 @@ __device__ __forceinline__ void masked_solve(const Real (&A)[M * (M + 1) / 2], c
 }
 
 // Boxed LCP:  w = A x - b,  lo <= x <= hi,  complementarity.  Block principal pivoting (Judice-Pires) with a
-// least-index fallback, one lane per problem, wavefront vote to stop.  `pin[i]` rows are held at xpin (0).
+// least-index fallback, one lane per problem, wavefront vote to stop.  The active set is two per-lane bit masks
+// (F: free rows, U: rows held at their upper bound; the rest sit at the lower bound) so a set flip is a handful of
+// integer ops instead of per-row branches.  Rows in `pinmask` (lo == hi) never move.
 template <class Real, int M>
 __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
-                                         const Real (&hi)[M], const bool (&pin)[M], int (&st)[M], Real (&x)[M],
-                                         int max_iter) {
-  const Real tol = tol_<Real>();
+                                         const Real (&hi)[M], uint32_t pinmask, uint32_t& F, uint32_t& U,
+                                         Real (&x)[M], int max_iter, unsigned long long* stats) {
+  // feasibility tolerances scale with the problem: |b|_inf bounds the size of w and (through A^-1) of x
+  Real bmax = Real(0);
+  sfor<0, M>([&](auto I) { bmax = fmax(bmax, fabs(b[I])); });
+  const Real tol = tol_<Real>() * (Real(1) + bmax);
   int best = M + 1, patience = 3;
   bool conv = false;
-  for (int it = 0; it < max_iter; ++it) {
+  int it = 0;
+  for (; it < max_iter; ++it) {
     Real fr[M], xb[M], r[M];
     sfor<0, M>([&](auto I) {
       constexpr int i = I;
-      fr[i] = (st[i] == 0) ? Real(1) : Real(0);
-      xb[i] = (st[i] == 1) ? lo[i] : ((st[i] == 2) ? hi[i] : Real(0));
+      const bool f = (F >> i) & 1u, u = (U >> i) & 1u;
+      fr[i] = f ? Real(1) : Real(0);
+      xb[i] = f ? Real(0) : (u ? hi[i] : lo[i]);
     });
     sfor<0, M>([&](auto I) {
       constexpr int i = I;
       Real t = b[i];
       sfor<0, M>([&](auto J) { constexpr int j = J; t -= A[tri(i, j)] * xb[j]; });
-      r[i] = (st[i] == 0) ? t : xb[i];
+      r[i] = ((F >> i) & 1u) ? t : xb[i];
     });
     masked_solve<Real, M>(A, fr, r);
-    int ninf = 0, last = -1;
-    bool bad[M];
+    uint32_t B = 0, GT = 0;
     sfor<0, M>([&](auto I) {
       constexpr int i = I;
       Real w = -b[i];
       sfor<0, M>([&](auto J) { constexpr int j = J; w += A[tri(i, j)] * r[j]; });
-      bool inf;
-      if (st[i] == 0) inf = (r[i] < lo[i] - tol * (Real(1) + fabs(lo[i]))) || (r[i] > hi[i] + tol * (Real(1) + fabs(hi[i])));
-      else inf = !pin[i] && ((st[i] == 1 && w < -tol) || (st[i] == 2 && w > tol));
-      bad[i] = inf;
-      if (inf) { ninf++; last = i; }
+      const bool f = (F >> i) & 1u, u = (U >> i) & 1u, pinned = (pinmask >> i) & 1u;
+      const bool over = r[i] > hi[i] + tol * (Real(1) + fabs(hi[i]));
+      const bool under = r[i] < lo[i] - tol * (Real(1) + fabs(lo[i]));
+      const bool wbad = u ? (w > tol) : (w < -tol);
+      const bool inf = f ? (over || under) : (wbad && !pinned);
+      B |= inf ? (1u << i) : 0u;
+      GT |= (r[i] > hi[i]) ? (1u << i) : 0u;
     });
-    if (!conv) sfor<0, M>([&](auto I) { x[I] = r[I]; });
-    if (ninf == 0) conv = true;
+    sfor<0, M>([&](auto I) { x[I] = conv ? x[I] : r[I]; });
+    conv = conv || (B == 0u);
     if (__all(conv)) break;
-    if (!conv) {
-      bool single = false;
-      if (ninf < best) { best = ninf; patience = 3; }
-      else if (patience > 0) patience--;
-      else single = true;
-      sfor<0, M>([&](auto I) {
-        constexpr int i = I;
-        if (bad[i] && (!single || i == last)) {
-          if (st[i] == 0) st[i] = (r[i] < lo[i]) ? 1 : 2;
-          else st[i] = 0;
-        }
-      });
-    }
+    const int ninf = __popc(B);
+    const bool improved = ninf < best;
+    const bool single = !improved && patience == 0;
+    best = improved ? ninf : best;
+    patience = improved ? 3 : (patience > 0 ? patience - 1 : 0);
+    uint32_t Bs = single ? (1u << (31 - __clz((int)B))) : B;   // Murty: only the highest infeasible index
+    Bs = conv ? 0u : Bs;
+    const uint32_t toBound = Bs & F, toFree = Bs & ~F;
+    F = (F & ~toBound) | toFree;
+    U = (U & ~(toFree | toBound)) | (toBound & GT);
   }
-  // iteration cap reached without a feasible complementary point (not observed in tests): stay in the box
+  // iteration cap reached without a feasible complementary point: stay in the box
   sfor<0, M>([&](auto I) { constexpr int i = I; x[i] = fmin(fmax(x[i], lo[i]), hi[i]); });
+  if (stats && (threadIdx.x & 63) == 0) atomicAdd(&stats[it < 31 ? it : 31], 1ull);
 }
 
 template <class Real, int M>
 __device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
                                          const Real (&hi)[M], const bool (&skip)[M], Real (&x)[M], int iters) {
   Real invd[M];
-  sfor<0, M>([&](auto I) { constexpr int i = I; invd[i] = Real(1) / A[tri(i, i)]; });
+  sfor<0, M>([&](auto I) { constexpr int i = I; invd[i] = rcp_<Real>(A[tri(i, i)]); });
   for (int it = 0; it < iters; ++it) {
     sfor<0, M>([&](auto I) {
       constexpr int i = I;
@@ -254,8 +296,8 @@ __device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const
 }
 
 // ------------------------------------------------------------------ one World::step (dt) for one env
-template <class Real, class T>
-__device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
+template <class Real, class T, class PT>
+__device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
                                            const Real (&tau)[T::NDOF]) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * T::NC + n_limited<T>();
   Real c[NL], s[NL], px[NL], py[NL], lx[NL], ly[NL], om[NL];
@@ -277,18 +319,29 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
       constexpr int p = T::parent(k);
       c[k] = c[p] * cj - s[p] * sj;
       s[k] = s[p] * cj + c[p] * sj;
-      lx[k] = c[p] * P.jx[k] - s[p] * P.jy[k]; ly[k] = s[p] * P.jx[k] + c[p] * P.jy[k];
+      if constexpr (DART_ZERO(PT, jx, k)) { lx[k] = -s[p] * P.jy[k]; ly[k] = c[p] * P.jy[k]; }
+      else if constexpr (DART_ZERO(PT, jy, k)) { lx[k] = c[p] * P.jx[k]; ly[k] = s[p] * P.jx[k]; }
+      else { lx[k] = c[p] * P.jx[k] - s[p] * P.jy[k]; ly[k] = s[p] * P.jx[k] + c[p] * P.jy[k]; }
       px[k] = px[p] + lx[k]; py[k] = py[p] + ly[k];
       om[k] = om[p] + P.sigma[k] * dq[2 + k];
       Real w2 = om[p] * om[p];
       apx[k] = apx[p] - w2 * lx[k]; apy[k] = apy[p] - w2 * ly[k];
     }
-    Real ox = c[k] * P.cx[k] - s[k] * P.cy[k], oy = s[k] * P.cx[k] + c[k] * P.cy[k];
-    Real w2 = om[k] * om[k];
-    Real fx = P.mass[k] * (apx[k] - w2 * ox), fy = P.mass[k] * (apy[k] - w2 * oy + P.g);
-    mc[k] = P.mass[k]; dcx[k] = P.mass[k] * ox; dcy[k] = P.mass[k] * oy;
-    Ip[k] = P.izz[k] + P.mass[k] * (ox * ox + oy * oy);
-    Fx[k] = fx; Fy[k] = fy; Nz[k] = ox * fy - oy * fx;
+    mc[k] = P.mass[k];
+    if constexpr (DART_ZERO(PT, cx, k) && DART_ZERO(PT, cy, k)) {   // COM on the joint axis
+      Fx[k] = P.mass[k] * apx[k]; Fy[k] = P.mass[k] * (apy[k] + P.g);
+      dcx[k] = Real(0); dcy[k] = Real(0); Ip[k] = P.izz[k]; Nz[k] = Real(0);
+    } else {
+      Real ox, oy;
+      if constexpr (DART_ZERO(PT, cx, k)) { ox = -s[k] * P.cy[k]; oy = c[k] * P.cy[k]; }
+      else if constexpr (DART_ZERO(PT, cy, k)) { ox = c[k] * P.cx[k]; oy = s[k] * P.cx[k]; }
+      else { ox = c[k] * P.cx[k] - s[k] * P.cy[k]; oy = s[k] * P.cx[k] + c[k] * P.cy[k]; }
+      Real w2 = om[k] * om[k];
+      Real fx = P.mass[k] * (apx[k] - w2 * ox), fy = P.mass[k] * (apy[k] - w2 * oy + P.g);
+      dcx[k] = P.mass[k] * ox; dcy[k] = P.mass[k] * oy;
+      Ip[k] = P.izz[k] + P.mass[k] * (ox * ox + oy * oy);
+      Fx[k] = fx; Fy[k] = fy; Nz[k] = ox * fy - oy * fx;
+    }
   });
   // ---- backward pass: fold each composite into its parent, shifting the reference point by the link vector
   sfor_rev<1, NL>([&](auto K) {
@@ -304,8 +357,10 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
   // recursion numerically): pivots are articulated inertias instead of small differences of large numbers.
   Real H[N * (N + 1) / 2], rhs[N];
   H[tri(rev<N>(0), rev<N>(0))] = mc[0]; H[tri(rev<N>(1), rev<N>(0))] = Real(0); H[tri(rev<N>(1), rev<N>(1))] = mc[0];
-  rhs[0] = tau[0] - Fx[0] - P.damp[0] * dq[0];
-  rhs[1] = tau[1] - Fy[0] - P.damp[1] * dq[1];
+  rhs[0] = tau[0] - Fx[0];
+  rhs[1] = tau[1] - Fy[0];
+  if constexpr (!DART_ZERO(PT, damp, 0)) rhs[0] -= P.damp[0] * dq[0];
+  if constexpr (!DART_ZERO(PT, damp, 1)) rhs[1] -= P.damp[1] * dq[1];
   sfor<0, NL>([&](auto K) {
     constexpr int k = K, i = 2 + k;
     H[tri(rev<N>(i), rev<N>(0))] = -P.sigma[k] * dcy[k];
@@ -319,9 +374,13 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
         H[tri(rev<N>(i), rev<N>(2 + j))] = Real(0);
       }
     });
-    rhs[i] = tau[i] - P.sigma[k] * Nz[k] - P.damp[i] * dq[i];
+    rhs[i] = tau[i] - P.sigma[k] * Nz[k];
+    if constexpr (!DART_ZERO(PT, damp, i)) rhs[i] -= P.damp[i] * dq[i];
   });
-  sfor<0, N>([&](auto I) { constexpr int i = I; H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.damp[i]; });
+  sfor<0, N>([&](auto I) {
+    constexpr int i = I;
+    if constexpr (!DART_ZERO(PT, damp, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.damp[i];
+  });
   spd_inverse<Real, N>(H);  // H now holds H^-1 (reversed dof order)
   Real vs[N];
   sfor<0, N>([&](auto I) {
@@ -433,19 +492,31 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
       sfor<0, i>([&](auto J) { constexpr int j = J; if (!act[i] || !act[j]) A[tri(i, j)] = Real(0); });
     });
 
-    bool pin[M];
-    int st[M];
+    // initial active set: every row at its finite bound, except rows that x = 0 already violates (w = -b has the
+    // wrong sign) -- those start free, which is what the first pivoting iteration would have found
+    uint32_t pinmask = 0, F = 0, U = 0;
     bool has_contact = false;
+    Real bmax0 = Real(0);
+    sfor<0, M>([&](auto I) { bmax0 = fmax(bmax0, fabs(b[I])); });
+    const Real tol0 = tol_<Real>() * (Real(1) + bmax0);
     sfor<0, M>([&](auto I) {
       constexpr int i = I;
       x[i] = Real(0);
-      pin[i] = !(lo[i] < hi[i]);
-      st[i] = (lo[i] == Real(0)) ? 1 : 2;  // start at the finite bound
+      const bool pinned = !(lo[i] < hi[i]);
+      const bool upper = !(lo[i] == Real(0));   // (-inf, 0] rows rest on their upper bound
+      const bool start_free = !pinned && (upper ? (b[i] < -tol0) : (b[i] > tol0));
+      pinmask |= pinned ? (1u << i) : 0u;
+      F |= start_free ? (1u << i) : 0u;
+      U |= (upper && !start_free) ? (1u << i) : 0u;
     });
     sfor<0, NC>([&](auto Cc) { has_contact = has_contact || act[2 * Cc]; });
 
-    if (P.solver == 0) blcp_bpp<Real, M>(A, b, lo, hi, pin, st, x, P.iters1);
-    else blcp_pgs<Real, M>(A, b, lo, hi, pin, x, P.iters1);
+    if (P.solver == 0) blcp_bpp<Real, M>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
+    else {
+      bool skip[M];
+      sfor<0, M>([&](auto I) { skip[I] = (pinmask >> I) & 1u; });
+      blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters1);
+    }
 
     if (__any(has_contact)) {
       // ODE/DART friction bounds: +-mu * (normal impulse of the frictionless solve), then the full problem
@@ -453,14 +524,16 @@ __device__ __forceinline__ void world_step(const Params<Real, T>& P, Real (&q)[T
         constexpr int sn = 2 * Cc, stt = 2 * Cc + 1;
         Real hb = act[sn] ? fabs(P.mu * x[sn]) : Real(0);
         hi[stt] = hb; lo[stt] = -hb;
-        pin[stt] = !(hb > Real(0));
-        st[stt] = pin[stt] ? 1 : 0;
+        const bool pinned = !(hb > Real(0));
+        pinmask = pinned ? (pinmask | (1u << stt)) : (pinmask & ~(1u << stt));
+        F = pinned ? (F & ~(1u << stt)) : (F | (1u << stt));   // friction rows start free
+        U &= ~(1u << stt);
       });
-      if (P.solver == 0) blcp_bpp<Real, M>(A, b, lo, hi, pin, st, x, P.iters2);
+      if (P.solver == 0) blcp_bpp<Real, M>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr);
       else {
-        bool none[M];
-        sfor<0, M>([&](auto I) { none[I] = false; });
-        blcp_pgs<Real, M>(A, b, lo, hi, none, x, P.iters2);
+        bool skip[M];
+        sfor<0, M>([&](auto I) { skip[I] = !has_contact; });   // per-env semantics: no contact -> no second stage
+        blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters2);
       }
     }
     // velocity change  H^-1 J^T lambda
@@ -505,9 +578,10 @@ __device__ __host__ inline void reset_noise(uint64_t seed, uint64_t gid, uint32_
 }
 
 // ------------------------------------------------------------------ observation (hopper.py:67-74, walker2d.py:67-74)
-template <class Real, class T>
-__device__ __forceinline__ Real root_height(const Params<Real, T>& P, const Real (&q)[T::NDOF]) {
+template <class Real, class T, class PT>
+__device__ __forceinline__ Real root_height(const PT& P, const Real (&q)[T::NDOF]) {
   Real h = P.root_y0 + q[1];
+  if constexpr (DART_ZERO(PT, cx, 0) && DART_ZERO(PT, cy, 0)) return h;
   if (P.cx[0] != Real(0) || P.cy[0] != Real(0)) {
     Real sj, cj;
     sincos_<Real>(q[2], sj, cj);
@@ -515,8 +589,8 @@ __device__ __forceinline__ Real root_height(const Params<Real, T>& P, const Real
   }
   return h;
 }
-template <class Real, class T>
-__device__ __forceinline__ void write_obs(const Params<Real, T>& P, const Real (&q)[T::NDOF], const Real (&dq)[T::NDOF],
+template <class Real, class T, class PT>
+__device__ __forceinline__ void write_obs(const PT& P, const Real (&q)[T::NDOF], const Real (&dq)[T::NDOF],
                                           Real height, float* __restrict__ obs_row) {
   constexpr int N = T::NDOF;
   obs_row[0] = (float)height;
@@ -530,8 +604,8 @@ __device__ __forceinline__ void write_obs(const Params<Real, T>& P, const Real (
 // ------------------------------------------------------------------ kernels
 // One batched env.step(): clamp+scale action, frame_skip world steps, reward, done, TimeLimit, observation,
 // optional on-device auto-reset (post-reset observation is returned, as SyncVectorEnv does).
-template <class Real, class T>
-__global__ void __launch_bounds__(64) step_kernel(Params<Real, T> P, int64_t n_envs, Real* __restrict__ qs,
+template <class Real, class T, class PT>
+__global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __restrict__ qs,
                                                    Real* __restrict__ dqs, int32_t* __restrict__ elapsed,
                                                    uint32_t* __restrict__ episode, const float* __restrict__ actions,
                                                    float* __restrict__ obs, float* __restrict__ reward,
@@ -556,11 +630,11 @@ __global__ void __launch_bounds__(64) step_kernel(Params<Real, T> P, int64_t n_e
   Real dx = Real(0);
 #pragma unroll 1
   for (int f = 0; f < P.frame_skip; ++f) {
-    world_step<Real, T>(P, q, dq, tau);
+    world_step<Real, T, PT>(P, q, dq, tau);
     dx += P.dt * dq[0];
   }
   (void)x_before;
-  Real height = root_height<Real, T>(P, q);
+  Real height = root_height<Real, T, PT>(P, q);
   Real ang = q[2];
   Real pen = Real(0);
   if (P.penalty_link >= 0) {
@@ -589,13 +663,13 @@ __global__ void __launch_bounds__(64) step_kernel(Params<Real, T> P, int64_t n_e
     reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, q, dq);
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
     el = 0;
-    height = root_height<Real, T>(P, q);
+    height = root_height<Real, T, PT>(P, q);
     if (valid) episode[e] = ep;
   }
   if (valid) {
     sfor<0, N>([&](auto I) { constexpr int i = I; qs[(int64_t)i * n_envs + e] = q[i]; dqs[(int64_t)i * n_envs + e] = dq[i]; });
     elapsed[e] = el;
-    write_obs<Real, T>(P, q, dq, height, obs + e * (2 * N - 1));
+    write_obs<Real, T, PT>(P, q, dq, height, obs + e * (2 * N - 1));
     reward[e] = (float)rew;
     done[e] = dn ? 1 : 0;
     truncated[e] = (trunc && !task_done) ? 1 : 0;
@@ -603,8 +677,8 @@ __global__ void __launch_bounds__(64) step_kernel(Params<Real, T> P, int64_t n_e
 }
 
 // Masked reset: q = init + noise (host-supplied rows, or Philox when noise pointers are null), elapsed = 0, obs.
-template <class Real, class T>
-__global__ void __launch_bounds__(256) reset_kernel(Params<Real, T> P, int64_t n_envs, Real* __restrict__ qs,
+template <class Real, class T, class PT>
+__global__ void __launch_bounds__(256) reset_kernel(PT P, int64_t n_envs, Real* __restrict__ qs,
                                                      Real* __restrict__ dqs, int32_t* __restrict__ elapsed,
                                                      uint32_t* __restrict__ episode, const uint8_t* __restrict__ mask,
                                                      const double* __restrict__ qnoise, const double* __restrict__ vnoise,
@@ -628,7 +702,7 @@ __global__ void __launch_bounds__(256) reset_kernel(Params<Real, T> P, int64_t n
   } else {
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + e]; dq[i] = dqs[(int64_t)i * n_envs + e]; });
   }
-  if (obs) write_obs<Real, T>(P, q, dq, root_height<Real, T>(P, q), obs + e * (2 * N - 1));
+  if (obs) write_obs<Real, T, PT>(P, q, dq, root_height<Real, T, PT>(P, q), obs + e * (2 * N - 1));
 }
 
 // (N, n) row-major doubles  <->  SoA state, for set_state / get_state (dart_env.py:145-148, 211-215)

@@ -20,14 +20,14 @@ LIB_PATH = os.environ.get("DART_STEPPER_LIB", os.path.join(_HERE, LIB_NAME))
 
 # error codes / keys (include/dart_stepper.h)
 DART_OK, E_INVALID, E_NO_DEVICE, E_UNSUPPORTED, E_HIP, E_PENDING, E_NOT_PENDING = 0, -1, -2, -3, -4, -5, -6
-Q_NUM_ENVS, Q_NDOFS, Q_OBS_DIM, Q_ACT_DIM, Q_FRAME_SKIP, Q_PRECISION, Q_DEVICE, Q_LCP_SLOTS = range(8)
-CFG_SOLVER, CFG_ITERS_STAGE1, CFG_ITERS_STAGE2, CFG_AUTORESET, CFG_SEED, CFG_ENV_OFFSET, CFG_BLOCK_THREADS = range(7)
+Q_NUM_ENVS, Q_NDOFS, Q_OBS_DIM, Q_ACT_DIM, Q_FRAME_SKIP, Q_PRECISION, Q_DEVICE, Q_LCP_SLOTS, Q_STATIC_KERNEL = range(9)
+CFG_SOLVER, CFG_ITERS_STAGE1, CFG_ITERS_STAGE2, CFG_AUTORESET, CFG_SEED, CFG_ENV_OFFSET, CFG_BLOCK_THREADS, CFG_STATS = range(8)
 SOLVER_BPP, SOLVER_PGS = 0, 1
 
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats",
 ]
 
 
@@ -74,6 +74,7 @@ def load_library(path: Optional[str] = None):
     L.dart_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.dart_reset_device.argtypes = [vp, vp, vp, vp]
     L.dart_sync.argtypes = [vp]
+    L.dart_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.dart_get_counters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
     L.dart_time_steps.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, dp]
     for name in EXPORTS:
@@ -192,6 +193,11 @@ class HipStepper:
         ep = np.empty(self.num_envs, dtype=np.uint32)
         self._check(self.L.dart_get_counters(self.h, _ptr(el, C.c_int32), _ptr(ep, C.c_uint32)))
         return el, ep
+
+    def solver_stats(self, clear=True):
+        h = np.zeros(64, dtype=np.uint64)
+        self._check(self.L.dart_get_stats(self.h, _ptr(h, C.c_uint64), int(clear)))
+        return h[:32], h[32:]
 
     def sync(self):
         self._check(self.L.dart_sync(self.h))

@@ -41,7 +41,8 @@ enum {
 /* dart_query keys */
 enum {
   DART_Q_NUM_ENVS = 0, DART_Q_NDOFS = 1, DART_Q_OBS_DIM = 2, DART_Q_ACT_DIM = 3, DART_Q_FRAME_SKIP = 4,
-  DART_Q_PRECISION = 5, DART_Q_DEVICE = 6, DART_Q_LCP_SLOTS = 7
+  DART_Q_PRECISION = 5, DART_Q_DEVICE = 6, DART_Q_LCP_SLOTS = 7,
+  DART_Q_STATIC_KERNEL = 8 /* 1: the card matched a model baked in at build time (csrc/static_models.hpp) */
 };
 
 /* dart_configure keys */
@@ -52,7 +53,8 @@ enum {
   DART_CFG_AUTORESET = 3,   /* 1: done envs are reset inside dart_step with on-device Philox noise */
   DART_CFG_SEED = 4,        /* Philox key (low 53 bits of the double are used) */
   DART_CFG_ENV_OFFSET = 5,  /* global index of env 0 of this handle (multi-GPU sharding keeps streams distinct) */
-  DART_CFG_BLOCK_THREADS = 6/* envs (active lanes) per wave64 workgroup of the step kernel: 64, 32 or 16 */
+  DART_CFG_BLOCK_THREADS = 6,/* envs (active lanes) per wave64 workgroup of the step kernel: 64, 32 or 16 */
+  DART_CFG_STATS = 7        /* 1: histogram the wave-level pivoting iteration counts (dart_get_stats) */
 };
 
 /* Library-level error text for failures that happen before a handle exists (handle == NULL). */
@@ -106,6 +108,10 @@ int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void*
 /* Per-env bookkeeping: steps since reset (TimeLimit._elapsed_steps, wrappers/time_limit.py:17,24) and the number of
  * on-device (Philox) resets so far.  Either pointer may be NULL. */
 int dart_get_counters(DartStepper* h, int32_t* elapsed, uint32_t* episode);
+
+/* Solver diagnostics: hist64[0..31] = number of wavefronts whose frictionless-stage pivoting loop ran k iterations,
+ * hist64[32..63] the same for the friction stage.  Needs DART_CFG_STATS = 1. */
+int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear);
 
 /* Wait for everything enqueued on the handle's stream. */
 int dart_sync(DartStepper* h);

@@ -150,14 +150,15 @@ __device__ __forceinline__ void spd_inverse(Real (&a)[N * (N + 1) / 2]) {
   // factor: a(i,j), i>j becomes L(i,j); a(j,j) becomes d_j
   sfor<0, N>([&](auto J) {
     constexpr int j = J;
+    Real W[N];  // W[k] = L(j,k) d_k, shared by the pivot and every entry of column j
     Real d = a[tri(j, j)];
-    sfor<0, j>([&](auto K) { constexpr int k = K; d -= a[tri(j, k)] * a[tri(j, k)] * a[tri(k, k)]; });
+    sfor<0, j>([&](auto K) { constexpr int k = K; W[k] = a[tri(j, k)] * a[tri(k, k)]; d -= a[tri(j, k)] * W[k]; });
     a[tri(j, j)] = d;
     invd[j] = rcp_<Real>(d);
     sfor<j + 1, N>([&](auto I) {
       constexpr int i = I;
       Real t = a[tri(i, j)];
-      sfor<0, j>([&](auto K) { constexpr int k = K; t -= a[tri(i, k)] * a[tri(j, k)] * a[tri(k, k)]; });
+      sfor<0, j>([&](auto K) { constexpr int k = K; t -= a[tri(i, k)] * W[k]; });
       a[tri(i, j)] = t * invd[j];
     });
   });
@@ -180,7 +181,7 @@ __device__ __forceinline__ void spd_inverse(Real (&a)[N * (N + 1) / 2]) {
     sfor<0, i + 1>([&](auto J) {
       constexpr int j = J;
       Real t = (i == j) ? invd[i] : a[tri(i, j)] * invd[i];  // k = i term (Li(i,i) = 1)
-      sfor<i + 1, N>([&](auto K) { constexpr int k = K; t += a[tri(k, i)] * invd[k] * a[tri(k, j)]; });
+      sfor<i + 1, N>([&](auto K) { constexpr int k = K; t += (a[tri(k, i)] * invd[k]) * a[tri(k, j)]; });
       out[tri(i, j)] = t;
     });
   });
@@ -194,15 +195,17 @@ __device__ __forceinline__ void masked_solve(const Real (&A)[M * (M + 1) / 2], c
   Real L[M * (M + 1) / 2], invd[M];
   sfor<0, M>([&](auto J) {
     constexpr int j = J;
+    Real W[M];
     Real d = fr[j] * A[tri(j, j)] + (Real(1) - fr[j]);
-    sfor<0, j>([&](auto K) { constexpr int k = K; d -= L[tri(j, k)] * L[tri(j, k)] * L[tri(k, k)]; });
+    sfor<0, j>([&](auto K) { constexpr int k = K; W[k] = L[tri(j, k)] * L[tri(k, k)]; d -= L[tri(j, k)] * W[k]; });
     L[tri(j, j)] = d;
     invd[j] = rcp_<Real>(d);
+    const Real fj = fr[j] * invd[j];
     sfor<j + 1, M>([&](auto I) {
       constexpr int i = I;
-      Real t = A[tri(i, j)] * fr[i] * fr[j];
-      sfor<0, j>([&](auto K) { constexpr int k = K; t -= L[tri(i, k)] * L[tri(j, k)] * L[tri(k, k)]; });
-      L[tri(i, j)] = t * invd[j];
+      Real t = A[tri(i, j)] * fr[i];          // rows / columns outside the free set drop out (their L entries stay 0)
+      sfor<0, j>([&](auto K) { constexpr int k = K; t -= L[tri(i, k)] * W[k]; });
+      L[tri(i, j)] = t * fj;
     });
   });
   sfor<0, M>([&](auto I) {  // forward: L y = rhs
@@ -220,7 +223,8 @@ __device__ __forceinline__ void masked_solve(const Real (&A)[M * (M + 1) / 2], c
 // least-index fallback, one lane per problem, wavefront vote to stop.  The active set is two per-lane bit masks
 // (F: free rows, U: rows held at their upper bound; the rest sit at the lower bound) so a set flip is a handful of
 // integer ops instead of per-row branches.  Rows in `pinmask` (lo == hi) never move.
-template <class Real, int M>
+// ZERO_BOUNDS: every finite bound is 0 (the frictionless stage) -> the bound contribution to the rhs vanishes.
+template <class Real, int M, bool ZERO_BOUNDS>
 __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
                                          const Real (&hi)[M], uint32_t pinmask, uint32_t& F, uint32_t& U,
                                          Real (&x)[M], int max_iter, unsigned long long* stats) {
@@ -242,7 +246,7 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
     sfor<0, M>([&](auto I) {
       constexpr int i = I;
       Real t = b[i];
-      sfor<0, M>([&](auto J) { constexpr int j = J; t -= A[tri(i, j)] * xb[j]; });
+      if constexpr (!ZERO_BOUNDS) sfor<0, M>([&](auto J) { constexpr int j = J; t -= A[tri(i, j)] * xb[j]; });
       r[i] = ((F >> i) & 1u) ? t : xb[i];
     });
     masked_solve<Real, M>(A, fr, r);
@@ -251,6 +255,7 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
       constexpr int i = I;
       Real w = -b[i];
       sfor<0, M>([&](auto J) { constexpr int j = J; w += A[tri(i, j)] * r[j]; });
+      asm volatile("" : "+v"(w));  // keep w unconditional: otherwise the compiler sinks it into per-row exec-mask branches
       const bool f = (F >> i) & 1u, u = (U >> i) & 1u, pinned = (pinmask >> i) & 1u;
       const bool over = r[i] > hi[i] + tol * (Real(1) + fabs(hi[i]));
       const bool under = r[i] < lo[i] - tol * (Real(1) + fabs(lo[i]));
@@ -511,7 +516,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     });
     sfor<0, NC>([&](auto Cc) { has_contact = has_contact || act[2 * Cc]; });
 
-    if (P.solver == 0) blcp_bpp<Real, M>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
+    if (P.solver == 0) blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
     else {
       bool skip[M];
       sfor<0, M>([&](auto I) { skip[I] = (pinmask >> I) & 1u; });
@@ -529,7 +534,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
         F = pinned ? (F & ~(1u << stt)) : (F | (1u << stt));   // friction rows start free
         U &= ~(1u << stt);
       });
-      if (P.solver == 0) blcp_bpp<Real, M>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr);
+      if (P.solver == 0) blcp_bpp<Real, M, false>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr);
       else {
         bool skip[M];
         sfor<0, M>([&](auto I) { skip[I] = !has_contact; });   // per-env semantics: no contact -> no second stage

@@ -53,12 +53,14 @@ __device__ __host__ constexpr int tri(int i, int j) { return i >= j ? i * (i + 1
 // Link 0 is the floating root (dofs 0,1,2 = x, y, rot); link k>=1 hangs on a revolute joint (dof 2+k).
 struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - shin - foot
   static constexpr int NL = 4, NDOF = NL + 2, NC = 1, NA = 3;
+  static constexpr bool WARM = false;  // warm-started active sets: measured -4 % here (short, violent episodes)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
 struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin foot) x 2
   static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6;
+  static constexpr bool WARM = true;   // measured +26 % (persistent double-support contacts)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3, 6}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
@@ -300,10 +302,18 @@ __device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const
   }
 }
 
+// Active sets of the previous substep (registers, per lane): contacts and limits persist over the frame_skip substeps,
+// so the pivoting solver usually starts on the right set.  Any start gives the same (unique) LCP solution.
+struct WarmSets {
+  uint32_t sig = 0, up = 0;        // which rows were active / which of them rested on their upper bound
+  uint32_t F1 = 0, U1 = 0;         // final sets of the frictionless stage
+  uint32_t F2 = 0, U2 = 0;         // final sets of the friction stage
+};
+
 // ------------------------------------------------------------------ one World::step (dt) for one env
 template <class Real, class T, class PT>
 __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
-                                           const Real (&tau)[T::NDOF]) {
+                                           const Real (&tau)[T::NDOF], WarmSets& warm) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * T::NC + n_limited<T>();
   Real c[NL], s[NL], px[NL], py[NL], lx[NL], ly[NL], om[NL];
   Real apx[NL], apy[NL];
@@ -499,7 +509,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 
     // initial active set: every row at its finite bound, except rows that x = 0 already violates (w = -b has the
     // wrong sign) -- those start free, which is what the first pivoting iteration would have found
-    uint32_t pinmask = 0, F = 0, U = 0;
+    uint32_t pinmask = 0, F = 0, U = 0, sig = 0, up = 0;
     bool has_contact = false;
     Real bmax0 = Real(0);
     sfor<0, M>([&](auto I) { bmax0 = fmax(bmax0, fabs(b[I])); });
@@ -513,8 +523,14 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       pinmask |= pinned ? (1u << i) : 0u;
       F |= start_free ? (1u << i) : 0u;
       U |= (upper && !start_free) ? (1u << i) : 0u;
+      sig |= act[i] ? (1u << i) : 0u;
+      up |= (act[i] && upper) ? (1u << i) : 0u;
     });
     sfor<0, NC>([&](auto Cc) { has_contact = has_contact || act[2 * Cc]; });
+    // rows that were active on the same side in the previous substep inherit that substep's final set
+    const uint32_t same = T::WARM ? (sig & warm.sig & ~(up ^ warm.up) & ~pinmask) : 0u;
+    F = (F & ~same) | (warm.F1 & same);
+    U = (U & ~same) | (warm.U1 & same);
 
     if (P.solver == 0) blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
     else {
@@ -523,8 +539,10 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters1);
     }
 
+    warm.F1 = F; warm.U1 = U;
     if (__any(has_contact)) {
       // ODE/DART friction bounds: +-mu * (normal impulse of the frictionless solve), then the full problem
+      uint32_t fric = 0;
       sfor<0, NC>([&](auto Cc) {
         constexpr int sn = 2 * Cc, stt = 2 * Cc + 1;
         Real hb = act[sn] ? fabs(P.mu * x[sn]) : Real(0);
@@ -533,14 +551,21 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
         pinmask = pinned ? (pinmask | (1u << stt)) : (pinmask & ~(1u << stt));
         F = pinned ? (F & ~(1u << stt)) : (F | (1u << stt));   // friction rows start free
         U &= ~(1u << stt);
+        fric |= pinned ? 0u : (1u << stt);
       });
+      // ... unless the same contact was sliding/sticking a substep ago: start from that state
+      const uint32_t samef = fric & (same << 1);   // friction row of a contact whose normal row persisted
+      F = (F & ~samef) | (warm.F2 & samef);
+      U = (U & ~samef) | (warm.U2 & samef);
       if (P.solver == 0) blcp_bpp<Real, M, false>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr);
       else {
         bool skip[M];
         sfor<0, M>([&](auto I) { skip[I] = !has_contact; });   // per-env semantics: no contact -> no second stage
         blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters2);
       }
+      warm.F2 = F; warm.U2 = U;
     }
+    warm.sig = sig; warm.up = up;
     // velocity change  H^-1 J^T lambda
     sfor<0, N>([&](auto I) {
       constexpr int i = I;
@@ -633,9 +658,10 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   });
   Real x_before = q[0];
   Real dx = Real(0);
+  WarmSets warm;
 #pragma unroll 1
   for (int f = 0; f < P.frame_skip; ++f) {
-    world_step<Real, T, PT>(P, q, dq, tau);
+    world_step<Real, T, PT>(P, q, dq, tau, warm);
     dx += P.dt * dq[0];
   }
   (void)x_before;

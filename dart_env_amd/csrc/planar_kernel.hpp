@@ -653,7 +653,8 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     constexpr int k = K;
     Real a = (Real)actions[ec * NA + k];
     a2 += a * a;  // control cost uses the unclamped action (hopper.py:55)
-    Real cl = fmin(fmax(a, P.act_lo[k]), P.act_hi[k]);
+    Real cl = (a > P.act_hi[k]) ? P.act_hi[k] : a;   // comparison clamp as hopper.py:25-30: a NaN action stays NaN
+    cl = (cl < P.act_lo[k]) ? P.act_lo[k] : cl;
     tau[N - NA + k] = cl * P.act_scale[k];
   });
   Real x_before = q[0];

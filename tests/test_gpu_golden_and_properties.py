@@ -218,3 +218,31 @@ def test_pgs_solver_converges_to_pivoting_solver():
         s.close()
     dq_err = np.abs(res[0][1] - res[1][1])
     assert np.percentile(dq_err, 99) < 1e-6 and dq_err.max() < 1e-2
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 130])
+def test_ragged_batch_sizes(n):
+    """Batch sizes that do not fill a wavefront: tail lanes shadow the last env and must not write anything."""
+    outs, q, dq, el, ep = _run(n, 6, precision=64)
+    ref, qr, dqr, elr, epr = _run(256, 6, precision=64)
+    assert np.array_equal(q, qr[:n]) and np.array_equal(dq, dqr[:n]) and np.array_equal(ep, epr[:n])
+
+
+def test_non_finite_actions_terminate_instead_of_poisoning_neighbours():
+    """done = not isfinite(state) (hopper.py:60): a NaN/inf action ends that env only."""
+    card = card_for("DartHopper-v1")
+    s = st.HipStepper(card, 128, precision=32)
+    s.configure(st.CFG_SEED, 1)
+    s.reset(None, None, None, want_obs=False)
+    a = np.zeros((128, 3), dtype=np.float32)
+    a[5, 0] = np.nan
+    a[70, 2] = np.inf          # clamps to +1 like any large action (hopper.py:25-30)
+    ob, r, done, trunc = s.step(a)
+    assert done[5] and not done[6] and not done[4]
+    others = np.arange(128) != 5
+    assert np.isfinite(ob[others]).all()
+    assert r[70] == -np.inf            # control cost uses the unclamped action (hopper.py:55), as in the reference
+    assert np.isfinite(r[others & (np.arange(128) != 70)]).all()
+    q, dq = s.get_state()
+    assert np.isfinite(q[70]).all()
+    s.close()

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer boundary (dart_step with numpy arrays, as the gym.vector surface uses it).
+Not the headline number (bench.py's `value` is HBM-resident by contract); recorded in DESIGN.md."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import dart_env_amd
+from dart_env_amd import stepper as st
+from dart_env_amd.model_card import card_for
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+card = card_for("DartHopper-v1")
+s = st.HipStepper(card, n)
+s.configure(st.CFG_AUTORESET, 1)
+s.reset(None, None, None)
+a = np.random.RandomState(0).uniform(-1, 1, (n, 3)).astype(np.float32)
+for _ in range(20):
+    s.step(a)
+t0 = time.perf_counter(); K = 200
+for _ in range(K):
+    s.step(a)
+dt = time.perf_counter() - t0
+print("host-buffer dart_step (H2D actions + kernel + D2H obs/reward/done, philox auto-reset): %.1f us/step, %.3e env-steps/s"
+      % (dt / K * 1e6, n * K / dt))
+venv = dart_env_amd.vector.make("DartHopper-v1", n, noise="philox")
+venv.reset()
+for _ in range(5):
+    venv.step(a)
+t0 = time.perf_counter(); K = 100
+for _ in range(K):
+    venv.step(a)
+dt = time.perf_counter() - t0
+print("DartVectorEnv.step (python surface, philox): %.1f us/step, %.3e env-steps/s" % (dt / K * 1e6, n * K / dt))
+venv2 = dart_env_amd.vector.make("DartHopper-v1", 4096)   # reference-exact MT19937 reset noise drawn on the host
+venv2.seed(0); venv2.reset()
+a2 = a[:4096]
+t0 = time.perf_counter(); K = 20
+for _ in range(K):
+    venv2.step(a2)
+dt = time.perf_counter() - t0
+print("DartVectorEnv.step (mt19937 host noise, 4096 envs): %.1f us/step, %.3e env-steps/s" % (dt / K * 1e6, 4096 * K / dt))

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import json
 import math
+import os
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -220,7 +221,28 @@ _JOINT_TYPES = {"weld": JT_WELD, "prismatic": JT_PRISMATIC, "revolute": JT_REVOL
                 "translational": JT_TRANSLATIONAL, "universal": JT_UNIVERSAL, "free": JT_FREE}
 
 
-def _shape_from_xml(el, body_index: int) -> Optional[Shape]:
+def _mesh_extents(path: str, scale) -> Optional[np.ndarray]:
+    """Full extents of a mesh's axis-aligned bounding box (DART: MeshShape inertia = box inertia of the scaled
+    bounding box).  Only Wavefront .obj is read; a .dae is replaced by the .obj of the same name when present."""
+    import os
+    base, ext = os.path.splitext(path)
+    obj = base + ".obj"
+    if not os.path.exists(obj):
+        return None
+    lo = np.full(3, np.inf)
+    hi = np.full(3, -np.inf)
+    with open(obj) as f:
+        for line in f:
+            if line.startswith("v "):
+                v = np.array([float(t) for t in line.split()[1:4]])
+                lo = np.minimum(lo, v)
+                hi = np.maximum(hi, v)
+    if not np.isfinite(lo).all():
+        return None
+    return (hi - lo) * np.asarray(scale, dtype=np.float64)
+
+
+def _shape_from_xml(el, body_index: int, base_dir: str = "") -> Optional[Shape]:
     pose = np.eye(4)
     t = el.find("transformation")
     if t is not None and t.text:
@@ -242,7 +264,24 @@ def _shape_from_xml(el, body_index: int) -> Optional[Shape]:
         c = g.find("cylinder")
         return Shape(body_index, SH_CYLINDER, pose,
                      np.array([float(c.find("radius").text), float(c.find("height").text), 0.0]))
-    return None  # meshes: no primitive; caller falls back to collision shapes
+    if g.find("multi_sphere") is not None:
+        # DART MultiSphereConvexHullShape: inertia of the bounding box of the spheres; never a collision shape here
+        lo = np.full(3, np.inf)
+        hi = np.full(3, -np.inf)
+        for sp in g.find("multi_sphere").findall("sphere"):
+            r = float(sp.find("radius").text)
+            c = np.array(_floats(sp.find("position").text))
+            lo = np.minimum(lo, c - r)
+            hi = np.maximum(hi, c + r)
+        return Shape(body_index, SH_BOX, pose, hi - lo, collidable=False)
+    if g.find("mesh") is not None:
+        import os
+        m = g.find("mesh")
+        scale = _floats(m.find("scale").text) if m.find("scale") is not None else [1, 1, 1]
+        ext = _mesh_extents(os.path.join(base_dir, m.find("file_name").text.strip()), scale)
+        if ext is not None:
+            return Shape(body_index, SH_BOX, pose, ext, collidable=False)
+    return None  # unreadable mesh: caller falls back to the next shape
 
 
 def shape_inertia(shape: Shape, mass: float) -> np.ndarray:
@@ -289,7 +328,7 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
         for b in sk.findall("body"):
             T_b = T_sk @ pose_from_xyzrpy(_floats(b.find("transformation").text))
             for cs in b.findall("collision_shape"):
-                s = _shape_from_xml(cs, 0)
+                s = _shape_from_xml(cs, 0, os.path.dirname(path))
                 if s is None or s.kind != SH_BOX or s.size[0] < 100.0:
                     continue  # only the big floor slab is the ground plane
                 top = (T_b @ s.pose)[1, 3] + 0.5 * s.size[1]
@@ -392,7 +431,7 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
         body_shapes: List[Shape] = []
         for tag in ("visualization_shape", "collision_shape"):
             for el in bx.findall(tag):
-                s = _shape_from_xml(el, i)
+                s = _shape_from_xml(el, i, os.path.dirname(path))
                 if s is not None:
                     body_shapes.append(s)
         if ine is not None:
@@ -411,7 +450,7 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
                     R = s0.pose[:3, :3]
                     inertia = R @ inertia @ R.T
         for el in bx.findall("collision_shape"):
-            s = _shape_from_xml(el, i)
+            s = _shape_from_xml(el, i, os.path.dirname(path))
             if s is not None:
                 s.collidable = collidable_bodies is None or cname in collidable_bodies
                 shapes.append(s)

@@ -47,7 +47,7 @@
 
 #define MAXL 96  /* internal 1-dof links */
 #define MAXN DART_MAX_DOFS
-#define MAXC DART_MAX_SHAPES
+#define MAXC 64 /* contact points (a box can give 4) */
 #define MAXM (3 * MAXC + MAXN)
 
 typedef struct {
@@ -566,21 +566,52 @@ int oracle_step(OracleWorld* w) {
   int findex[MAXM];
   int m = 0;
   w->ncontacts_last = 0;
-  for (int s = 0; s < c->nshapes; s++) {
+  /* ---- contact points against the ground plane y = ground_y (normal +y) ---- */
+  int ncp = 0;
+  int cp_shape[MAXC];
+  double cp_P[MAXC][3], cp_depth[MAXC];
+  for (int s = 0; s < c->nshapes && ncp < MAXC - 4; s++) {
     if (!c->shape_collidable[s] || !isfinite(c->ground_y)) continue;
-    if (c->shape_type[s] != DART_SH_CAPSULE) continue; /* planar configs: capsules only */
     int li = w->body_link[c->shape_body[s]];
     double Ts[16];
     mat4_mul(w->W[li], c->shape_pose[s], Ts);
-    double r = c->shape_size[s][0], hl = 0.5 * c->shape_size[s][1];
-    double p1[3], p2[3];
-    for (int a = 0; a < 3; a++) { p1[a] = Ts[4 * a + 3] + hl * Ts[4 * a + 2]; p2[a] = Ts[4 * a + 3] - hl * Ts[4 * a + 2]; }
-    const double* pe = (p2[1] < p1[1]) ? p2 : p1; /* lowest endpoint; exact tie -> +axis end (ODE t=0) */
-    double d = pe[1] - c->ground_y;
-    if (d > r) continue;
-    double depth = r - d;
-    /* ODE dCollideSpheres(pl, r, pb, 0): pos = pl - n (r + d)/2 */
-    double P[3] = {pe[0], pe[1] - 0.5 * (r + d), pe[2]};
+    if (c->shape_type[s] == DART_SH_CAPSULE) {
+      double r = c->shape_size[s][0], hl = 0.5 * c->shape_size[s][1];
+      double p1[3], p2[3];
+      for (int a = 0; a < 3; a++) { p1[a] = Ts[4 * a + 3] + hl * Ts[4 * a + 2]; p2[a] = Ts[4 * a + 3] - hl * Ts[4 * a + 2]; }
+      const double* pe = (p2[1] < p1[1]) ? p2 : p1; /* lowest endpoint; exact tie -> +axis end (ODE t=0) */
+      double d = pe[1] - c->ground_y;
+      if (d > r) continue;
+      /* ODE dCollideSpheres(pl, r, pb, 0): pos = pl - n (r + d)/2 */
+      cp_P[ncp][0] = pe[0]; cp_P[ncp][1] = pe[1] - 0.5 * (r + d); cp_P[ncp][2] = pe[2];
+      cp_depth[ncp] = r - d; cp_shape[ncp] = s; ncp++;
+    } else if (c->shape_type[s] == DART_SH_BOX) {
+      /* box vs. the (huge) ground box, ODE/DART dBoxBox face case with the ground's +y face as reference: the
+       * incident face is the box face most anti-parallel to the normal; its vertices that lie below the ground
+       * surface are the contact points (position = the vertex, depth = distance below the surface). */
+      int k = 0;
+      double best = -1;
+      for (int a = 0; a < 3; a++) if (fabs(Ts[4 * 1 + a]) > best) { best = fabs(Ts[4 * 1 + a]); k = a; }
+      double sgn = Ts[4 * 1 + k] > 0 ? -1.0 : 1.0; /* face whose outward normal points down */
+      int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
+      double hk = 0.5 * c->shape_size[s][k], h1 = 0.5 * c->shape_size[s][a1], h2 = 0.5 * c->shape_size[s][a2];
+      static const double sg[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
+      for (int v = 0; v < 4; v++) {
+        double P[3];
+        for (int a = 0; a < 3; a++)
+          P[a] = Ts[4 * a + 3] + sgn * hk * Ts[4 * a + k] + sg[v][0] * h1 * Ts[4 * a + a1] + sg[v][1] * h2 * Ts[4 * a + a2];
+        double depth = c->ground_y - P[1];
+        if (depth < 0) continue;
+        memcpy(cp_P[ncp], P, sizeof P);
+        cp_depth[ncp] = depth; cp_shape[ncp] = s; ncp++;
+      }
+    }
+  }
+  for (int ci = 0; ci < ncp; ci++) {
+    int s = cp_shape[ci];
+    int li = w->body_link[c->shape_body[s]];
+    const double* P = cp_P[ci];
+    double depth = cp_depth[ci];
     double nrm[3] = {0, 1, 0}, t1[3] = {-1, 0, 0}, t2[3] = {0, 0, 1}; /* t1 = normalize(z x n), t2 = n x t1 */
     int base = m;
     point_jacobian(w, li, P, nrm, J[m]); lo[m] = 0; hi[m] = INFINITY; findex[m] = -1;

@@ -145,14 +145,14 @@ class OracleWorld:
         return c
 
     def last_lcp(self):
-        m = 3 * 32 + 32
+        m = 3 * 64 + 32
         lam, w, lo, hi = (np.zeros(m) for _ in range(4))
         res = C.c_double(0)
         k = self.L.oracle_last_lcp(self.h, _p(lam), _p(w), _p(lo), _p(hi), C.byref(res))
         return lam[:k], w[:k], lo[:k], hi[:k], res.value
 
     def last_contacts(self):
-        buf = np.zeros((32, 8))
+        buf = np.zeros((64, 8))
         k = self.L.oracle_last_contacts(self.h, _p(buf))
         return buf[:k]
 

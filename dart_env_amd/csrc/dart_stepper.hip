@@ -144,7 +144,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   P.alive = (Real)c.alive_bonus; P.ctrl_cost = (Real)c.ctrl_cost; P.pen_each = (Real)(c.limit_penalty * 1.5);
   P.pen_margin = (Real)c.penalty_margin; P.h_lo = (Real)c.height_lo; P.h_hi = (Real)c.height_hi;
   P.ang_max = (Real)c.angle_max; P.s_max = (Real)c.state_abs_max; P.v_clip = (Real)c.obs_vel_clip;
-  P.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip)); P.noise = (Real)c.reset_noise;
+  P.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip)); P.noise = (Real)c.reset_noise; P.noise_v = (Real)c.reset_noise_vel;
   P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task;
   P.penalty_link = c.penalty_dof >= 2 ? c.penalty_dof - 2 : -1;
   if (c.task != DART_TASK_NONE && c.height_body != 2) return "height body must be the root link";

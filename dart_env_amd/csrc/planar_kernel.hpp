@@ -100,7 +100,7 @@ struct Params {
   Real damp[T::NDOF], q0[T::NDOF], dq0[T::NDOF];  // joint damping; world.reset() state
   Real e1x[T::NC], e1y[T::NC], e2x[T::NC], e2y[T::NC], rad[T::NC];
   Real act_scale[T::NA], act_lo[T::NA], act_hi[T::NA];
-  Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise;
+  Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise, noise_v;
   int frame_skip, max_steps, penalty_link, task;
   int solver, iters1, iters2;  // solver 0: block principal pivoting (exact); 1: PGS sweeps
   unsigned long long* stats;   // optional [2][32] histogram of wave-level pivoting iterations per stage (debug), or null
@@ -596,7 +596,8 @@ __device__ __host__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // reset noise for env `gid`, episode `ep`: q_i = -r + 2r*u(2i block...), same stream on host and device
 template <class Real, int N>
-__device__ __host__ inline void reset_noise(uint64_t seed, uint64_t gid, uint32_t ep, Real r, Real (&q)[N], Real (&dq)[N]) {
+__device__ __host__ inline void reset_noise(uint64_t seed, uint64_t gid, uint32_t ep, Real r, Real rv, Real (&q)[N],
+                                            Real (&dq)[N]) {
   constexpr int NW = 2 * N;
   Real u[(NW + 3) / 4 * 4];
   for (int blk = 0; blk < (NW + 3) / 4; ++blk) {
@@ -604,7 +605,7 @@ __device__ __host__ inline void reset_noise(uint64_t seed, uint64_t gid, uint32_
     philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), ep, (uint32_t)blk, (uint32_t)seed, (uint32_t)(seed >> 32), o);
     for (int j = 0; j < 4; ++j) u[4 * blk + j] = Real(o[j] >> 8) * Real(1.0 / 16777216.0);
   }
-  for (int i = 0; i < N; ++i) { q[i] = -r + Real(2) * r * u[i]; dq[i] = -r + Real(2) * r * u[N + i]; }
+  for (int i = 0; i < N; ++i) { q[i] = -r + Real(2) * r * u[i]; dq[i] = -rv + Real(2) * rv * u[N + i]; }
 }
 
 // ------------------------------------------------------------------ observation (hopper.py:67-74, walker2d.py:67-74)
@@ -692,7 +693,7 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   bool dn = task_done || trunc;
   if (autoreset && dn) {
     uint32_t ep = episode[ec] + 1;
-    reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, q, dq);
+    reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, P.noise_v, q, dq);
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
     el = 0;
     height = root_height<Real, T, PT>(P, q);
@@ -725,7 +726,7 @@ __global__ void __launch_bounds__(256) reset_kernel(PT P, int64_t n_envs, Real* 
       sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = (Real)qnoise[e * N + i]; dq[i] = (Real)vnoise[e * N + i]; });
     } else {
       uint32_t ep = episode[e] + 1;
-      reset_noise<Real, N>(seed, env_offset + (uint64_t)e, ep, P.noise, q, dq);
+      reset_noise<Real, N>(seed, env_offset + (uint64_t)e, ep, P.noise, P.noise_v, q, dq);
       sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
       episode[e] = ep;
     }

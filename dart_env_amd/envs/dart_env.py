@@ -108,14 +108,14 @@ class BatchedDartEnv:
         return self._rngs[i]
 
     def _draw_noise(self, mask):
-        r = self.card.reset_noise
+        r, rv = self.card.reset_noise, self.card.reset_noise_vel
         qn = np.zeros((self.num_envs, self.ndofs))
         vn = np.zeros((self.num_envs, self.ndofs))
         idx = range(self.num_envs) if mask is None else np.flatnonzero(mask)
         for i in idx:
             rng = self._rng(i)
             qn[i] = rng.uniform(low=-r, high=r, size=self.ndofs)   # qpos first (hopper.py:78)
-            vn[i] = rng.uniform(low=-r, high=r, size=self.ndofs)   # qvel second (hopper.py:79)
+            vn[i] = rng.uniform(low=-rv, high=rv, size=self.ndofs) # qvel second (hopper.py:79, human_walker.py:154)
         return qn, vn
 
     def reset(self, mask=None):

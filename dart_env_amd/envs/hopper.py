@@ -24,24 +24,20 @@ class _SingleEnv(BatchedDartEnv):
         return [self._seeds[0] if self._seeds[0] is not None else seed]
 
     def reset(self):
-        return super().reset(None)[0].astype(np.float64)
+        self._last_obs = super().reset(None)[0].astype(np.float64)
+        return self._last_obs.copy()
+
+    def _info(self, done):
+        return {}
 
     def step(self, a):
         obs, rew, done, _ = super().step(np.asarray(a, dtype=np.float32).reshape(1, self.act_dim))
-        return obs[0].astype(np.float64), np.float64(rew[0]), bool(done[0]), {}
+        self._last_obs = obs[0].astype(np.float64)
+        return self._last_obs.copy(), np.float64(rew[0]), bool(done[0]), self._info(bool(done[0]))
 
     def _get_obs(self):
-        q, dq = self._stepper.get_state()
-        state = np.concatenate([q[0, 1:], np.clip(dq[0], -self.card.obs_vel_clip, self.card.obs_vel_clip)])
-        state[0] = q[0, 1] + self._root_height0
-        return state
-
-    @property
-    def _root_height0(self):
-        # height of bodynodes[2].com() at q = 0 (pelvis frame origin; COM offset 0 for both planar models)
-        from ..model_card import load_model
-        m = load_model(self.task.model)
-        return float(m.bodies[0].T_pj[1, 3] + m.bodies[2].com[1])
+        """The observation of the current state as the device computed it (hopper.py:67-74)."""
+        return self._last_obs.copy()
 
     def set_state(self, qpos, qvel):
         assert np.shape(qpos) == (self.ndofs,) and np.shape(qvel) == (self.ndofs,)  # dart_env.py:146

@@ -24,7 +24,7 @@ from .skel import MAX_BODIES, MAX_DOFS, MAX_SHAPES, ModelCard, parse_skel
 MAX_ACTIONS = 32
 CARD_VERSION = 1
 
-TASK_NONE, TASK_HOPPER, TASK_WALKER2D = 0, 1, 2
+TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER = 0, 1, 2, 3, 4
 
 
 class DartModelCard(C.Structure):
@@ -54,7 +54,8 @@ class DartModelCard(C.Structure):
         ("alive_bonus", C.c_double), ("ctrl_cost", C.c_double), ("limit_penalty", C.c_double),
         ("penalty_margin", C.c_double), ("height_lo", C.c_double), ("height_hi", C.c_double),
         ("angle_max", C.c_double), ("state_abs_max", C.c_double), ("obs_vel_clip", C.c_double),
-        ("reset_noise", C.c_double),
+        ("reset_noise", C.c_double), ("reset_noise_vel", C.c_double),
+        ("aux_body", C.c_int32 * 4), ("aux_real", C.c_double * 8), ("aux_real2", C.c_double * 4),
     ]
 
 
@@ -84,6 +85,10 @@ class TaskSpec:
     state_abs_max: float = 100.0
     obs_vel_clip: float = 10.0
     reset_noise: float = 0.005
+    reset_noise_vel: float = 0.005
+    aux_body_names: List[str] = field(default_factory=list)
+    aux_real: List[float] = field(default_factory=list)
+    aux_real2: List[float] = field(default_factory=list)
     act_low: float = -1.0
     act_high: float = 1.0
 
@@ -100,7 +105,19 @@ WALKER2D = TaskSpec(
     reward_threshold=None, height_body=2, penalty_dof=-1, height_lo=0.8, height_hi=2.0, angle_max=1.0,
     contact_bodies=["h_foot", "h_foot_left"])
 
-TASKS = {t.env_id: t for t in (HOPPER, WALKER2D)}
+# DartHumanWalker-v1 -- reference gym/envs/dart/human_walker.py:16-30 (23 actions, scale*1.5, obs 57+2, frame_skip 15),
+# :109-128 (reward, done), :150-165 (reset: velocity noise 0.05), gym/envs/__init__.py:284-288 (300 steps)
+HUMANWALKER = TaskSpec(
+    env_id="DartHumanWalker-v1", model="humanwalker", task=TASK_HUMANWALKER, frame_skip=15, act_dim=23, obs_dim=59,
+    act_dof0=6,
+    act_scale=[1.5 * v for v in [120, 120, 120, 100, 60, 60, 120, 120, 120, 100, 60, 60, 100, 100, 100, 80, 80, 80,
+                                 50, 80, 80, 80, 50]],
+    max_episode_steps=300, reward_threshold=None, height_body=10, penalty_dof=-1, height_lo=-0.2, height_hi=1.0,
+    angle_max=2.0, contact_bodies=["l-foot", "r-foot"], alive_bonus=2.0, ctrl_cost=0.5, limit_penalty=0.0,
+    reset_noise=0.005, reset_noise_vel=0.05, aux_body_names=["pelvis", "head", "l-foot", "r-foot"],
+    aux_real=[1.0, 2.0, 0.5, 3.0, -0.2, 1.0, 1.3, 0.4], aux_real2=[0.9])
+
+TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, HUMANWALKER)}
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 
@@ -170,6 +187,14 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         c.limit_penalty, c.penalty_margin = task.limit_penalty, task.penalty_margin
         c.height_lo, c.height_hi, c.angle_max = task.height_lo, task.height_hi, task.angle_max
         c.state_abs_max, c.obs_vel_clip, c.reset_noise = task.state_abs_max, task.obs_vel_clip, task.reset_noise
+        c.reset_noise_vel = task.reset_noise_vel
+        names = [b.name for b in model.bodies]
+        for k, nm in enumerate(task.aux_body_names):
+            c.aux_body[k] = names.index(nm)
+        for k, v in enumerate(task.aux_real):
+            c.aux_real[k] = v
+        for k, v in enumerate(task.aux_real2):
+            c.aux_real2[k] = v
     return c
 
 

@@ -18,8 +18,9 @@ def spec(env_id):
 
 
 def make(env_id, **kwargs):
-    from .envs import DartHopperEnv, DartWalker2dEnv
-    cls = {"DartHopper-v1": DartHopperEnv, "DartWalker2d-v1": DartWalker2dEnv}
+    from .envs import DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv
+    cls = {"DartHopper-v1": DartHopperEnv, "DartWalker2d-v1": DartWalker2dEnv,
+           "DartHumanWalker-v1": DartHumanWalkerEnv}
     s = spec(env_id)
     env = cls[env_id](**kwargs)
     env.spec = s

@@ -43,7 +43,9 @@ enum { DART_SH_CAPSULE = 0, DART_SH_BOX = 1, DART_SH_SPHERE = 2, DART_SH_ELLIPSO
 enum {
   DART_TASK_NONE = 0,      /* physics only: obs = [q, dq], reward 0, done 0 */
   DART_TASK_HOPPER = 1,    /* reference gym/envs/dart/hopper.py:36-74   */
-  DART_TASK_WALKER2D = 2   /* reference gym/envs/dart/walker2d.py:22-74 */
+  DART_TASK_WALKER2D = 2,  /* reference gym/envs/dart/walker2d.py:22-74 */
+  DART_TASK_WALKER3D = 3,  /* reserved: reference gym/envs/dart/walker3d.py:33-113 */
+  DART_TASK_HUMANWALKER = 4 /* reference gym/envs/dart/human_walker.py:60-165 */
 };
 
 typedef struct DartModelCard {
@@ -112,7 +114,15 @@ typedef struct DartModelCard {
   double height_lo, height_hi, angle_max;   /* done thresholds (hopper.py:60-62) */
   double state_abs_max;     /* 100 */
   double obs_vel_clip;      /* 10 */
-  double reset_noise;       /* 0.005 (hopper.py:78-79) */
+  double reset_noise;       /* 0.005 position noise (hopper.py:78) */
+  double reset_noise_vel;   /* velocity noise: 0.005 (hopper.py:79), 0.05 for HumanWalker (human_walker.py:154) */
+  /* task-specific extras.  HumanWalker: aux_body = {progress body (bodynodes[1]), head, l-foot, r-foot},
+   * aux_real = {target_vel, alive_bonus 2.0, action_pen 0.5, deviation_pen 3.0, height band lo -0.2, hi 1.0,
+   *             |q[3]| max 1.3, |q[5]| max 0.4}; angle_max = 2.0 (up/forward), state_abs_max etc. as above;
+   * aux_real2 = {side deviation max 0.9} */
+  int32_t aux_body[4];
+  double aux_real[8];
+  double aux_real2[4];
 } DartModelCard;
 
 #ifdef __cplusplus

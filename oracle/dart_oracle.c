@@ -88,6 +88,7 @@ typedef struct OracleWorld {
   int ncontacts_last;
   double contact_last[MAXC][8]; /* body, px,py,pz, depth, fn, ft1, ft2 */
   double lcp_residual_last;
+  double init_height; /* human_walker.py:163 head COM height right after reset_model's set_state */
 } OracleWorld;
 
 /* ------------------------------------------------------------------ small linear algebra */
@@ -753,8 +754,83 @@ double oracle_energy(OracleWorld* w) {
 
 /* ------------------------------------------------------------------ task epilogue (hopper.py:24-74, walker2d.py:22-74)
  * One env-step for the planar locomotion tasks; actions already float64.  Returns done. */
+/* human_walker.py:157-165: values captured by reset_model after set_state */
+void oracle_env_after_reset(OracleWorld* w) {
+  if (w->card.task == DART_TASK_HUMANWALKER) {
+    double cm[3];
+    oracle_body_com(w, w->card.aux_body[1], cm);
+    w->init_height = cm[1];
+  }
+}
+
+static void humanwalker_obs(OracleWorld* w, const int* contact_info, double* obs) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  for (int i = 1; i < n; i++) obs[i - 1] = w->q[i];
+  for (int i = 0; i < n; i++) {
+    double v = w->dq[i];
+    obs[n - 1 + i] = v < -c->obs_vel_clip ? -c->obs_vel_clip : (v > c->obs_vel_clip ? c->obs_vel_clip : v);
+  }
+  obs[2 * n - 1] = contact_info[0];
+  obs[2 * n] = contact_info[1];
+}
+
+/* DartHumanWalkerEnv.step (human_walker.py:75-138) */
+static int humanwalker_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double tau[MAXN] = {0}, abs_sum = 0;
+  for (int k = 0; k < c->act_dim; k++) {
+    double cl = a[k];
+    if (cl > c->act_high[k]) cl = c->act_high[k];
+    if (cl < c->act_low[k]) cl = c->act_low[k];
+    tau[c->act_dof0 + k] = cl * c->act_scale[k];
+    abs_sum += fabs(a[k]);
+  }
+  double cm[3];
+  oracle_body_com(w, c->aux_body[0], cm);
+  double posbefore = cm[0];
+  for (int f = 0; f < c->frame_skip; f++) { oracle_set_forces(w, tau); oracle_step(w); }
+  oracle_body_com(w, c->aux_body[0], cm);
+  double posafter = cm[0];
+  oracle_body_com(w, c->aux_body[1], cm);
+  double height = cm[1], side = cm[2], angle = w->q[3];
+  const double* Th = w->W[w->body_link[c->aux_body[1]]];
+  /* to_world(e_y) - to_world(0), normalised (a rotation column is already unit) -> arccos of its y / x component */
+  double up[3] = {Th[1], Th[5], Th[9]}, fw[3] = {Th[0], Th[4], Th[8]};
+  double nu = sqrt(dot3(up, up)), nf = sqrt(dot3(fw, fw));
+  double ang_uwd = acos(up[1] / nu), ang_fwd = acos(fw[0] / nf);
+  int info[2] = {0, 0};
+  for (int k = 0; k < w->ncontacts_last; k++) {  /* contacts of the last world step (pydart2 collision_result) */
+    if ((int)w->contact_last[k][0] == c->aux_body[2]) info[0] = 1;
+    if ((int)w->contact_last[k][0] == c->aux_body[3]) info[1] = 1;
+  }
+  double envdt = c->dt * c->frame_skip;
+  double vel = (posafter - posbefore) / envdt;
+  double tv = c->aux_real[0];
+  double vel_rew = 2 * (tv - fabs(tv - vel));
+  double action_pen = c->aux_real[2] * abs_sum;
+  double deviation_pen = c->aux_real[3] * fabs(side);
+  double r = vel_rew + c->aux_real[1] - action_pen - deviation_pen;
+  int ok = 1;
+  for (int i = 0; i < n; i++) {
+    if (!isfinite(w->q[i]) || !isfinite(w->dq[i])) ok = 0;
+    if (i >= 2 && !(fabs(w->q[i]) < c->state_abs_max)) ok = 0;
+    if (!(fabs(w->dq[i]) < c->state_abs_max)) ok = 0;
+  }
+  if (!(height - w->init_height > c->aux_real[4] && height - w->init_height < c->aux_real[5] &&
+        fabs(ang_uwd) < c->angle_max && fabs(ang_fwd) < c->angle_max && fabs(angle) < c->aux_real[6] &&
+        fabs(w->q[5]) < c->aux_real[7] && fabs(side) < c->aux_real2[0]))
+    ok = 0;
+  if (!ok) r = 0;
+  *reward = r;
+  humanwalker_obs(w, info, obs);
+  return !ok;
+}
+
 int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
   const DartModelCard* c = &w->card;
+  if (c->task == DART_TASK_HUMANWALKER) return humanwalker_step(w, a, obs, reward);
   int n = w->n;
   double tau[MAXN] = {0};
   double sq = 0;
@@ -805,6 +881,7 @@ int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward
 }
 void oracle_env_obs(OracleWorld* w, double* obs) {
   const DartModelCard* c = &w->card;
+  if (c->task == DART_TASK_HUMANWALKER) { int z[2] = {0, 0}; humanwalker_obs(w, z, obs); return; } /* reset_model zeroes contact_info */
   int n = w->n;
   double cm[3];
   oracle_body_com(w, c->height_body, cm);
@@ -829,7 +906,7 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-void oracle_philox_noise(uint64_t seed, uint64_t gid, uint32_t ep, double r, int n, double* q, double* dq) {
+void oracle_philox_noise(uint64_t seed, uint64_t gid, uint32_t ep, double r, double rv, int n, double* q, double* dq) {
   double u[2 * MAXN + 4];
   int nw = 2 * n;
   for (int blk = 0; blk < (nw + 3) / 4; ++blk) {
@@ -837,7 +914,7 @@ void oracle_philox_noise(uint64_t seed, uint64_t gid, uint32_t ep, double r, int
     philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), ep, (uint32_t)blk, (uint32_t)seed, (uint32_t)(seed >> 32), o);
     for (int j = 0; j < 4; ++j) u[4 * blk + j] = (double)(o[j] >> 8) * (1.0 / 16777216.0);
   }
-  for (int i = 0; i < n; i++) { q[i] = -r + 2.0 * r * u[i]; dq[i] = -r + 2.0 * r * u[n + i]; }
+  for (int i = 0; i < n; i++) { q[i] = -r + 2.0 * r * u[i]; dq[i] = -rv + 2.0 * rv * u[n + i]; }
 }
 
 /* Rollout of `n_envs` independent envs for `steps` env-steps with auto-reset (Philox noise), used as the timed CPU
@@ -859,8 +936,9 @@ int64_t oracle_rollout(const DartModelCard* card, int solver, int64_t n_envs, in
     int elapsed = 0;
     double qn[MAXN], vn[MAXN], rs = 0;
     oracle_reset(w);
-    oracle_philox_noise(seed, env_offset + (uint64_t)e, ep, card->reset_noise, n, qn, vn);
+    oracle_philox_noise(seed, env_offset + (uint64_t)e, ep, card->reset_noise, card->reset_noise_vel, n, qn, vn);
     for (int i = 0; i < n; i++) { w->q[i] += qn[i]; w->dq[i] += vn[i]; }
+    oracle_env_after_reset(w);
     for (int t = 0; t < steps; t++) {
       const float* at = actions + ((size_t)t * n_envs + e) * na;
       for (int k = 0; k < na; k++) a[k] = (double)at[k];
@@ -873,8 +951,9 @@ int64_t oracle_rollout(const DartModelCard* card, int solver, int64_t n_envs, in
       if (done) {
         ep++;
         oracle_reset(w);
-        oracle_philox_noise(seed, env_offset + (uint64_t)e, ep, card->reset_noise, n, qn, vn);
+        oracle_philox_noise(seed, env_offset + (uint64_t)e, ep, card->reset_noise, card->reset_noise_vel, n, qn, vn);
         for (int i = 0; i < n; i++) { w->q[i] += qn[i]; w->dq[i] += vn[i]; }
+        oracle_env_after_reset(w);
         elapsed = 0;
       }
     }

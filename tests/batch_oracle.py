@@ -16,6 +16,7 @@ class OracleBatch:
                 w.reset()
                 q, dq = w.get_state()
                 w.set_state(q + qn[i], dq + vn[i])
+                w.env_after_reset()
                 self.elapsed[i] = 0
 
     def obs(self):

@@ -28,7 +28,7 @@ class OracleStepper:
     def _philox(self, i):
         self.episode[i] += 1
         return ol.philox_noise(int(self.cfg[st.CFG_SEED]), int(self.cfg[st.CFG_ENV_OFFSET]) + i, int(self.episode[i]),
-                               self.card.reset_noise, self.ndofs)
+                               self.card.reset_noise, self.card.reset_noise_vel, self.ndofs)
 
     def reset(self, mask=None, qpos_noise=None, qvel_noise=None, want_obs=True):
         n = self.num_envs

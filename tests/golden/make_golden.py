@@ -106,6 +106,10 @@ class StubBody:
 
     C = property(lambda self: self.com())
 
+    def to_world(self, p):
+        T = self.world.oracle.body_pose(self.index)
+        return T[:3, :3] @ np.asarray(p, dtype=np.float64) + T[:3, 3]
+
 
 class StubSkeleton:
     def __init__(self, world, model):
@@ -115,6 +119,10 @@ class StubSkeleton:
         self.q_upper = np.array(model.upper)
         self.joints = [StubJoint([model.limited[b.dof_offset + k] for k in range(b.ndof)]) for b in model.bodies]
         self.bodynodes = [StubBody(world, i) for i in range(model.nbodies)]
+        self._by_name = {b.name: self.bodynodes[i] for i, b in enumerate(model.bodies)}
+
+    def bodynode(self, name):
+        return self._by_name[name]
 
     q = property(lambda self: SkelVector(self.world.oracle.get_state()[0]))
     dq = property(lambda self: SkelVector(self.world.oracle.get_state()[1]))
@@ -135,8 +143,16 @@ class StubSkeleton:
         pass
 
 
+class StubContact:
+    def __init__(self, ground, body, force):
+        self.skel_id1, self.skel_id2 = 0, 1
+        self.bodynode1, self.bodynode2 = ground, body
+        self.force = force
+
+
 class StubCollisionResult:
-    contacts = []
+    def __init__(self):
+        self.contacts = []
 
 
 class StubWorld:
@@ -144,7 +160,8 @@ class StubWorld:
 
     def __init__(self, dt, skel_path=None):
         name = os.path.basename(skel_path)
-        contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"]}[name]
+        contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"],
+                   "kima_human_edited.skel": ["l-foot", "r-foot"]}[name]
         model = parse_skel(skel_path, dt=dt, collidable_bodies=contact)
         self.model = model
         self.dt = dt
@@ -155,6 +172,11 @@ class StubWorld:
     def step(self):
         StubWorld.n_steps += 1
         self.oracle.step()
+        # pydart2 refreshes collision_result after every world step
+        robot = self.skeletons[1]
+        self.collision_result.contacts = [
+            StubContact(self.skeletons[0], robot.bodynodes[int(c[0])], np.array([c[6], c[5], c[7]]) / self.dt)
+            for c in self.oracle.last_contacts()]
 
     def reset(self):
         self.oracle.reset()
@@ -191,6 +213,8 @@ def install_stubs():
 def rollout_single(gym, env_id, seed, steps, act_scale=1.0, limit=None):
     if limit is None:
         env = gym.make(env_id)
+        if "Human" in env_id:
+            assert env.unwrapped.robot_skeleton.ndofs == 29
     else:  # the reference's TimeLimit wrapper with a short horizon, so truncation is actually exercised
         from gym.wrappers import TimeLimit
         from gym.envs.dart import DartHopperEnv, DartWalker2dEnv
@@ -206,6 +230,8 @@ def rollout_single(gym, env_id, seed, steps, act_scale=1.0, limit=None):
         ob, r, d, info = env.step(a)
         rec["actions"].append(a32); rec["obs"].append(ob); rec["reward"].append(r); rec["done"].append(d)
         rec["truncated"].append(bool(info.get("TimeLimit.truncated", False)))
+        if "broke_sim" in info:
+            rec.setdefault("broke_sim", []).append(bool(info["broke_sim"]))
         sv = env.unwrapped.state_vector()
         n = len(sv) // 2
         rec["q"].append(sv[:n]); rec["dq"].append(sv[n:])
@@ -262,6 +288,10 @@ def main():
                             **rollout_single(gym, env_id, 2, 100, act_scale=0.02, limit=20))
         # (5) SyncVectorEnv semantics: seed fan-out s+i, auto-reset with post-reset obs, dtypes
         np.savez_compressed(os.path.join(out, "%s_vector4_seed3.npz" % tag), **rollout_vector(gym, env_id, 4, 3, 120))
+    # (6) DartHumanWalker-v1 (29 dof, box feet, springs, contact flags in the observation), 300-step TimeLimit
+    np.savez_compressed(os.path.join(out, "humanwalker_single_seed0.npz"), **rollout_single(gym, "DartHumanWalker-v1", 0, 120))
+    np.savez_compressed(os.path.join(out, "humanwalker_single_seed4_small.npz"),
+                        **rollout_single(gym, "DartHumanWalker-v1", 4, 150, act_scale=0.05))
     print("world.step() calls issued by the reference code:", StubWorld.n_steps)
 
 

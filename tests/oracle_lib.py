@@ -53,10 +53,11 @@ def lib():
         L.oracle_env_step.argtypes = [C.c_void_p, dp, dp, dp]
         L.oracle_env_step.restype = C.c_int
         L.oracle_env_obs.argtypes = [C.c_void_p, dp]
+        L.oracle_env_after_reset.argtypes = [C.c_void_p]
         L.oracle_rollout.restype = C.c_int64
         L.oracle_rollout.argtypes = [C.POINTER(DartModelCard), C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float),
                                      C.c_uint64, C.c_uint64, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), dp]
-        L.oracle_philox_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_int, dp, dp]
+        L.oracle_philox_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_int, dp, dp]
         _lib = L
     return _lib
 
@@ -166,6 +167,9 @@ class OracleWorld:
         done = self.L.oracle_env_step(self.h, _p(a), _p(obs), C.byref(rew))
         return obs, rew.value, bool(done)
 
+    def env_after_reset(self):
+        self.L.oracle_env_after_reset(self.h)
+
     def env_obs(self):
         obs = np.zeros(self.card.obs_dim)
         self.L.oracle_env_obs(self.h, _p(obs))
@@ -186,7 +190,7 @@ def rollout(card, actions, seed=0, env_offset=0, solver=0):
     return dict(q=q, dq=dq, episode=ep, elapsed=el, reward_sum=rs, env_steps=cnt)
 
 
-def philox_noise(seed, gid, ep, r, n):
+def philox_noise(seed, gid, ep, r, rv, n):
     q = np.zeros(n); dq = np.zeros(n)
-    lib().oracle_philox_noise(seed, gid, ep, r, n, _p(q), _p(dq))
+    lib().oracle_philox_noise(seed, gid, ep, r, rv, n, _p(q), _p(dq))
     return q, dq

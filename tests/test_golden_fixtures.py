@@ -9,14 +9,14 @@ import pytest
 import dart_env_amd
 from dart_env_amd import seeding, spaces
 from dart_env_amd.model_card import card_for
-from dart_env_amd.envs import DartHopperEnv, DartWalker2dEnv
+from dart_env_amd.envs import DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv
 from dart_env_amd.wrappers import TimeLimit
 from tests.fake_stepper import OracleStepper
 from tests.oracle_lib import OracleWorld
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-IDS = {"hopper": "DartHopper-v1", "walker2d": "DartWalker2d-v1"}
-CLS = {"hopper": DartHopperEnv, "walker2d": DartWalker2dEnv}
+IDS = {"hopper": "DartHopper-v1", "walker2d": "DartWalker2d-v1", "humanwalker": "DartHumanWalker-v1"}
+CLS = {"hopper": DartHopperEnv, "walker2d": DartWalker2dEnv, "humanwalker": DartHumanWalkerEnv}
 
 
 def test_seeding_and_reset_noise_stream():
@@ -45,31 +45,35 @@ def test_box_action_stream():
 
 
 @pytest.mark.parametrize("tag,fix", [("hopper", "single_seed0"), ("walker2d", "single_seed0"),
-                                     ("hopper", "single_seed5_small"), ("walker2d", "single_seed5_small")])
+                                     ("hopper", "single_seed5_small"), ("walker2d", "single_seed5_small"),
+                                     ("humanwalker", "single_seed0"), ("humanwalker", "single_seed4_small")])
 def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
     """C restatement of hopper.py:36-74 / walker2d.py:22-74 == the reference's numpy code, fp64 bit-for-bit."""
     d = np.load(os.path.join(G, "%s_%s.npz" % (tag, fix)))
     w = OracleWorld(card_for(IDS[tag]))
-    seed = 0 if "seed0" in fix else 5
+    seed = int(fix.split("seed")[1].split("_")[0])
     rng, _ = seeding.np_random(seed)
     n = w.n
+    rv = w.card.reset_noise_vel
+    rtol = 1e-12 if tag == "humanwalker" else 0.0   # numpy sums the 23 |a_k| pairwise, the C loop sequentially
 
     def do_reset():
         w.reset()
-        w.set_state(w.q + rng.uniform(-.005, .005, n), w.dq + rng.uniform(-.005, .005, n))
+        w.set_state(w.q + rng.uniform(-.005, .005, n), w.dq + rng.uniform(-rv, rv, n))
+        w.env_after_reset()
         return w.env_obs()
     assert np.array_equal(do_reset(), d["obs0"])
     steps = min(len(d["done"]), 400)
     for t in range(steps):
         ob, r, done = w.env_step(d["actions"][t].astype(np.float64))
         assert np.array_equal(ob, d["obs"][t]), t
-        assert r == d["reward"][t] and done == bool(d["done"][t])
+        assert abs(r - d["reward"][t]) <= rtol * max(1.0, abs(r)) and done == bool(d["done"][t])
         assert np.array_equal(w.q, d["q"][t]) and np.array_equal(w.dq, d["dq"][t])
         if done:
             assert np.array_equal(do_reset(), d["reset_obs"][t])
 
 
-@pytest.mark.parametrize("tag", ["hopper", "walker2d"])
+@pytest.mark.parametrize("tag", ["hopper", "walker2d", "humanwalker"])
 def test_single_env_facade_vs_reference(tag):
     """make(id): seed -> reset -> step loop reproduces the reference's obs/reward/done (obs cross the ABI as float32)."""
     d = np.load(os.path.join(G, "%s_single_seed0.npz" % tag))
@@ -77,14 +81,18 @@ def test_single_env_facade_vs_reference(tag):
     env.seed(0)
     ob = env.reset()
     assert ob.dtype == np.float64 and np.allclose(ob, d["obs0"], atol=1e-7)
-    for t in range(150):
+    for t in range(min(150, len(d["done"]))):
         ob, r, done, info = env.step(d["actions"][t])
         assert np.allclose(ob, d["obs"][t], rtol=0, atol=2e-6), t
-        assert r == d["reward"][t] and isinstance(done, bool) and done == bool(d["done"][t]) and info == {}
+        assert abs(r - d["reward"][t]) < 1e-12 and isinstance(done, bool) and done == bool(d["done"][t])
+        if tag == "humanwalker":
+            assert info["broke_sim"] == bool(d["broke_sim"][t]) and info["done_return"] == done
+        else:
+            assert info == {}
         assert np.allclose(env.state_vector(), np.concatenate([d["q"][t], d["dq"][t]]), atol=0)
         if done:
             assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-7)
-    assert env.dt == pytest.approx(0.008)
+    assert env.dt == pytest.approx(0.03 if tag == "humanwalker" else 0.008)
     env.close()
 
 

@@ -15,6 +15,7 @@
 #include "../../include/dart_stepper.h"
 #include "planar_kernel.hpp"
 #include "static_models.hpp"
+#include "spatial_kernel.hpp"
 
 using namespace dartk;
 
@@ -32,6 +33,9 @@ struct Impl {
   virtual hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) = 0;
   virtual void set_solver(int solver, int it1, int it2) = 0;
   virtual void set_stats(unsigned long long* p) = 0;
+  virtual hipError_t prepare(int64_t) { return hipSuccess; }   // per-handle device allocations of the implementation
+  virtual void release() {}
+  virtual hipError_t debug_dump(double*) { return hipErrorInvalidValue; }
   virtual int slots() const = 0;
   int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
   bool is_static = false;  // true: model constants are compile-time immediates (static_models.hpp)
@@ -59,7 +63,9 @@ struct ImplT : Impl {
     hipLaunchKernelGGL((state_io_kernel<Real, T::NDOF>), grid, block, 0, s, n, (Real*)q, (Real*)dq, qh, dqh, to_device);
     return hipGetLastError();
   }
-  void set_solver(int solver, int it1, int it2) override { P.solver = solver; P.iters1 = it1; P.iters2 = it2; }
+  void set_solver(int solver, int it1, int it2) override {   // 0 = default cap
+    P.solver = solver; P.iters1 = it1 > 0 ? it1 : 24; P.iters2 = it2 > 0 ? it2 : 24;
+  }
   void set_stats(unsigned long long* p) override { P.stats = p; }
   int slots() const override { return 2 * T::NC + n_limited<T>(); }
 };
@@ -79,6 +85,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   if (c.act_dim != T::NA || c.act_dof0 != T::NDOF - T::NA) return "action layout";
   if (c.obs_dim != 2 * T::NDOF - 1 && c.task != DART_TASK_NONE) return "obs_dim";
   if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
+  if (c.contact_cfm != c.cfm) return "contact_cfm differs from cfm";
   // floating base: prismatic x, prismatic y, revolute +-z
   if (c.jtype[0] != DART_JT_PRISMATIC || c.jtype[1] != DART_JT_PRISMATIC || c.parent[0] != -1 || c.parent[1] != 0)
     return "root carriers";
@@ -152,6 +159,163 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   return "";
 }
 
+// ------------------------------------------------------------------ general 3-D skeletons (spatial_kernel.hpp)
+void mat4_to_Rp(const double* T, double* R, double* p) {
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[3 * i + j] = T[4 * i + j]; p[i] = T[4 * i + 3]; }
+}
+void inv_Rp(const double* R, const double* p, double* Ri, double* pi) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ri[3 * i + j] = R[3 * j + i];
+  for (int i = 0; i < 3; i++) pi[i] = -(Ri[3 * i] * p[0] + Ri[3 * i + 1] * p[1] + Ri[3 * i + 2] * p[2]);
+}
+
+// Expand every multi-dof joint of the card into a chain of 1-dof links (massless carriers in between).
+template <class Real>
+std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
+  memset(&M, 0, sizeof(M));
+  if (c.ndofs > SP_MAXN) return "too many dofs";
+  int body_link[DART_MAX_BODIES];
+  int nl = 0;
+  static const double EX[3] = {1, 0, 0}, EY[3] = {0, 1, 0}, EZ[3] = {0, 0, 1}, I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};
+  auto add = [&](int parent, int jtype, int dof, const double* axis, const double* Rpre, const double* ppre,
+                 const double* Rpost, const double* ppost) -> int {
+    if (nl >= SP_MAXL) return -1;
+    int i = nl++;
+    M.parent[i] = parent; M.jtype[i] = jtype; M.dof[i] = dof;
+    for (int k = 0; k < 3; k++) { M.axis[i][k] = (Real)(axis ? axis[k] : 0.0); M.ppre[i][k] = (Real)ppre[k]; M.ppost[i][k] = (Real)ppost[k]; }
+    for (int k = 0; k < 9; k++) { M.Rpre[i][k] = (Real)Rpre[k]; M.Rpost[i][k] = (Real)Rpost[k]; }
+    if (dof >= 0) M.dof_link[dof] = i;
+    bool anc_root = parent < 0 || M.root_trans[parent];
+    M.root_trans[i] = (jtype == 1 && anc_root) ? 1 : 0;
+    return i;
+  };
+  for (int b = 0; b < c.nbodies; b++) {
+    int pl = c.parent[b] < 0 ? -1 : body_link[c.parent[b]];
+    int d0 = c.dof_offset[b];
+    double Rpj[9], ppj[3], Rcj[9], pcj[3], Rpo[9], ppo[3];
+    mat4_to_Rp(c.T_pj[b], Rpj, ppj);
+    mat4_to_Rp(c.T_cj[b], Rcj, pcj);
+    inv_Rp(Rcj, pcj, Rpo, ppo);   // child link frame expressed in the joint frame
+    const double* ax = c.axes[b];
+    int last = -1;
+    switch (c.jtype[b]) {
+      case DART_JT_WELD: last = add(pl, 0, -1, nullptr, Rpj, ppj, Rpo, ppo); break;
+      case DART_JT_PRISMATIC: last = add(pl, 1, d0, ax, Rpj, ppj, Rpo, ppo); break;
+      case DART_JT_REVOLUTE: last = add(pl, 2, d0, ax, Rpj, ppj, Rpo, ppo); break;
+      case DART_JT_TRANSLATIONAL: {
+        int a = add(pl, 1, d0, EX, Rpj, ppj, I3, Z3); int bb = add(a, 1, d0 + 1, EY, I3, Z3, I3, Z3);
+        last = add(bb, 1, d0 + 2, EZ, I3, Z3, Rpo, ppo);
+      } break;
+      case DART_JT_EULER_XYZ: {
+        int a = add(pl, 2, d0, EX, Rpj, ppj, I3, Z3); int bb = add(a, 2, d0 + 1, EY, I3, Z3, I3, Z3);
+        last = add(bb, 2, d0 + 2, EZ, I3, Z3, Rpo, ppo);
+      } break;
+      case DART_JT_EULER_ZYX: {
+        int a = add(pl, 2, d0, EZ, Rpj, ppj, I3, Z3); int bb = add(a, 2, d0 + 1, EY, I3, Z3, I3, Z3);
+        last = add(bb, 2, d0 + 2, EX, I3, Z3, Rpo, ppo);
+      } break;
+      case DART_JT_UNIVERSAL: {
+        int a = add(pl, 2, d0, ax, Rpj, ppj, I3, Z3);
+        last = add(a, 2, d0 + 1, ax + 3, I3, Z3, Rpo, ppo);
+      } break;
+      default: return "unsupported joint type";
+    }
+    if (last < 0) return "too many links";
+    body_link[b] = last;
+    M.mass[last] = (Real)c.mass[b];
+    for (int k = 0; k < 3; k++) M.com[last][k] = (Real)c.com[b][k];
+    for (int k = 0; k < 9; k++) M.inertia[last][k] = (Real)(c.mass[b] > 0 ? c.inertia[b][k] : 0.0);
+  }
+  M.nl = nl; M.n = c.ndofs;
+  for (int d = 0; d < c.ndofs; d++) {
+    M.limited[d] = c.limited[d]; M.lower[d] = (Real)c.lower[d]; M.upper[d] = (Real)c.upper[d];
+    M.damp[d] = (Real)c.damping[d]; M.stiff[d] = (Real)c.stiffness[d]; M.rest[d] = (Real)c.rest[d];
+    M.q0[d] = (Real)c.init_pos[d]; M.dq0[d] = (Real)c.init_vel[d];
+  }
+  int ns = 0;
+  for (int s = 0; s < c.nshapes; s++) {
+    if (!c.shape_collidable[s]) continue;
+    if (c.shape_type[s] != DART_SH_CAPSULE && c.shape_type[s] != DART_SH_BOX) return "collidable shape must be a capsule or a box";
+    if (ns >= SP_MAXS) return "too many collidable shapes";
+    M.sh_link[ns] = body_link[c.shape_body[s]];
+    M.sh_type[ns] = c.shape_type[s] == DART_SH_CAPSULE ? 0 : 1;
+    double R[9], pp[3];
+    mat4_to_Rp(c.shape_pose[s], R, pp);
+    for (int k = 0; k < 9; k++) M.sh_R[ns][k] = (Real)R[k];
+    for (int k = 0; k < 3; k++) { M.sh_p[ns][k] = (Real)pp[k]; M.sh_size[ns][k] = (Real)c.shape_size[s][k]; }
+    ns++;
+  }
+  M.nshapes = ns;
+  M.dt = (Real)c.dt; for (int k = 0; k < 3; k++) M.g[k] = (Real)c.gravity[k];
+  M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;
+  M.limit_erp_dt = (Real)(c.limit_erp / c.dt); M.cfm1 = (Real)(1.0 + c.cfm); M.ccfm1 = (Real)(1.0 + c.contact_cfm);
+  if (c.task != DART_TASK_NONE && c.task != DART_TASK_HUMANWALKER) return "task not served by the spatial kernel";
+  M.task = c.task; M.frame_skip = c.frame_skip; M.act_dim = c.act_dim; M.obs_dim = c.obs_dim; M.act_dof0 = c.act_dof0;
+  M.max_steps = c.max_episode_steps;
+  if (c.act_dim > 32 || c.act_dof0 + c.act_dim > c.ndofs) return "action layout";
+  for (int k = 0; k < c.act_dim; k++) { M.act_scale[k] = (Real)c.act_scale[k]; M.act_lo[k] = (Real)c.act_low[k]; M.act_hi[k] = (Real)c.act_high[k]; }
+  for (int k = 0; k < 4; k++) M.aux_link[k] = (c.task == DART_TASK_HUMANWALKER) ? body_link[c.aux_body[k]] : 0;
+  for (int k = 0; k < 8; k++) M.aux_real[k] = (Real)c.aux_real[k];
+  for (int k = 0; k < 4; k++) M.aux_real2[k] = (Real)c.aux_real2[k];
+  M.aux_real2[1] = (Real)c.angle_max;   // up / forward angle threshold (human_walker.py:124)
+  M.s_max = (Real)c.state_abs_max; M.v_clip = (Real)c.obs_vel_clip; M.noise = (Real)c.reset_noise; M.noise_v = (Real)c.reset_noise_vel;
+  M.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip));
+  M.solver_iters = 200; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.dbg = nullptr;
+  if (c.task == DART_TASK_NONE && c.obs_dim != 2 * c.ndofs) return "physics-only obs must be [q, dq]";
+  return "";
+}
+
+template <class Real>
+struct SpatialImplT : Impl {
+  SpatialModel<Real> M;
+  SpatialModel<Real>* dM = nullptr;
+  Real* init_h = nullptr;
+  size_t lds = 0;
+  hipError_t prepare(int64_t n) override {
+    hipError_t e;
+    nenv = n;
+    if ((e = hipMalloc((void**)&dM, sizeof(M))) != hipSuccess) return e;
+    if ((e = hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&init_h, sizeof(Real) * (size_t)n)) != hipSuccess) return e;
+    if ((e = hipMemset(init_h, 0, sizeof(Real) * (size_t)n)) != hipSuccess) return e;
+    lds = sp_lds_bytes(M.nl, M.n, sizeof(Real));
+    if ((e = hipFuncSetAttribute((const void*)sp_step_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    return hipSuccess;
+  }
+  void release() override { if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); dM = nullptr; init_h = nullptr; }
+  void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
+  hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
+                  float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
+    hipLaunchKernelGGL((sp_step_kernel<Real>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep,
+                       act, obs, rew, done, trunc, autoreset, seed, off);
+    return hipGetLastError();
+  }
+  hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
+                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off) override {
+    hipLaunchKernelGGL((sp_reset_kernel<Real>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep,
+                       mask, qn, vn, obs, seed, off);
+    return hipGetLastError();
+  }
+  hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) override {
+    int64_t count = n * M.n;
+    hipLaunchKernelGGL((sp_state_io_kernel<Real>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, count, (Real*)q,
+                       (Real*)dq, qh, dqh, to_device);
+    return hipGetLastError();
+  }
+  void set_solver(int solver, int it1, int it2) override {   // one wavefront per env: a high cap only costs the hard envs
+    (void)solver; (void)it2; M.solver_iters = it1 > 0 ? it1 : 200; upload();
+  }
+  double* dbg = nullptr; int64_t nenv = 0;
+  void set_stats(unsigned long long* p) override {
+    M.stats = p;
+    if (p && !dbg) { (void)hipMalloc((void**)&dbg, sizeof(double) * 160 * (size_t)nenv); (void)hipMemset(dbg, 0, sizeof(double) * 160 * (size_t)nenv); }
+    M.dbg = p ? dbg : nullptr;
+    upload();
+  }
+  hipError_t debug_dump(double* out) override { return dbg ? hipMemcpy(out, dbg, sizeof(double) * 160 * (size_t)nenv, hipMemcpyDeviceToHost) : hipErrorInvalidValue; }
+  int slots() const override { return SP_MAXM; }
+};
+
 // generic (runtime-parameter) kernel, or the compile-time specialisation when the card is bit-identical to a baked one
 template <class Real, class T, class Static>
 std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why, bool allow_static) {
@@ -172,10 +336,21 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
 
 template <class Real>
 std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why, bool allow_static) {
+  const char* fs = getenv("DART_FORCE_SPATIAL");   // testing aid: run planar models through the general kernel
+  const bool force_spatial = fs && fs[0] == '1';
   why = "hopper-chain: ";
+  if (!force_spatial)
   if (auto p = make_for_topology<Real, HopperTopo, HopperStatic<Real>>(c, why, allow_static)) return p;
   why += "; walker2d-tree: ";
+  if (!force_spatial)
   if (auto p = make_for_topology<Real, Walker2dTopo, Walker2dStatic<Real>>(c, why, allow_static)) return p;
+  why += "; spatial: ";
+  {
+    auto p = std::make_unique<SpatialImplT<Real>>();
+    std::string w = fill_spatial<Real>(c, p->M);
+    if (w.empty()) return p;
+    why += w;
+  }
   return nullptr;
 }
 
@@ -197,7 +372,7 @@ struct DartStepper {
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
   double *h_qn = nullptr, *h_vn = nullptr;
-  int solver = 0, it1 = 24, it2 = 24, autoreset = 0;
+  int solver = 0, it1 = 0, it2 = 0, autoreset = 0;   // it1/it2 = 0: the implementation's default iteration cap
   uint64_t seed = 0, env_offset = 0;
   bool pending = false;
   std::string err;
@@ -241,6 +416,7 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
   int rc = [&]() -> int {
     CHK(h, hipSetDevice(device));
     CHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CHK(h, h->impl->prepare(num_envs));
     size_t rs = precision == 32 ? 4 : 8, nd = (size_t)card->ndofs, N = (size_t)num_envs;
     CHK(h, hipMalloc(&h->q, rs * nd * N));
     CHK(h, hipMalloc(&h->dq, rs * nd * N));
@@ -282,6 +458,7 @@ int dart_destroy(DartStepper* h) {
   if (!h) return DART_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->impl) h->impl->release();
   void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
@@ -464,6 +641,14 @@ int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear) {
   CHK(h, hipStreamSynchronize(h->stream));
   CHK(h, hipMemcpy(hist64, h->d_stats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   if (clear) CHK(h, hipMemset(h->d_stats, 0, 64 * sizeof(unsigned long long)));
+  return DART_OK;
+}
+
+int dart_debug_dump(DartStepper* h, double* out160) {
+  if (!h || !out160) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  CHK(h, h->impl->debug_dump(out160));
   return DART_OK;
 }
 

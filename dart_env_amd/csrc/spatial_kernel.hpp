@@ -1,0 +1,810 @@
+// spatial_kernel.hpp -- gfx950 device code for general (3-D, branching) skeletons: DartHumanWalker-v1 class models.
+//
+// Replaces for one env per WAVEFRONT what the reference does per env through pydart2/DART
+// (reference gym/envs/dart/human_walker.py:60-165, dart_env.py:158-175).
+//
+// Design: the 21/29-dof models do not fit one lane's registers (H is 29x29, the contact/limit LCP has up to 40 rows),
+// so one 64-lane wavefront owns one environment and the per-skeleton block lives in LDS (~35 KB fp32):
+// link frames / velocities / composite inertias, H and its Cholesky factor, the constraint Jacobian (overwritten by
+// W = L^-1 J^T), the Delassus matrix A = W W^T and the pivoting solver's LDL^T workspace.  Tree recursions run on lane 0
+// (they are a dependent chain), everything dense is spread over the lanes: one lane per dof for the mass-matrix
+// rows, one lane per constraint row for Jacobians / triangular solves / A, row-owner right-looking factorisations,
+// and the LCP active-set logic is wave-uniform (row infeasibility flags are gathered with __ballot).
+// Strides of the LDS matrices are odd so that row-per-lane access is bank-conflict free.
+//
+// Dynamics formulation: world-aligned recursive Newton-Euler + composite bodies taken about each joint origin
+// (coordinates relative to the floating base translation so fp32 does not see the travelled distance) -- again a
+// different derivation from the oracle's body-frame spatial algebra.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "planar_kernel.hpp"  // philox, sincos_, rcp_, tol_
+
+namespace dartk {
+
+constexpr int SP_MAXL = 48;   // expanded 1-dof links
+constexpr int SP_MAXN = 32;   // dofs
+constexpr int SP_MAXS = 8;    // collidable shapes
+constexpr int SP_MAXCP = 12;  // contact points (a box face gives up to 4)
+constexpr int SP_MAXM = 40;   // LCP rows
+constexpr int SP_SA = 41;     // row stride of A / LDL workspace (odd: conflict-free row-per-lane access)
+constexpr int SP_LINKF = 49;  // Reals stored per link in LDS
+
+template <class Real>
+struct SpatialModel {
+  int nl, n, nshapes;
+  int parent[SP_MAXL], jtype[SP_MAXL], dof[SP_MAXL], root_trans[SP_MAXL];
+  Real axis[SP_MAXL][3];
+  Real Rpre[SP_MAXL][9], ppre[SP_MAXL][3];    // joint frame in the parent link frame
+  Real Rpost[SP_MAXL][9], ppost[SP_MAXL][3];  // child link frame in the (moved) joint frame
+  Real mass[SP_MAXL], com[SP_MAXL][3], inertia[SP_MAXL][9];
+  int dof_link[SP_MAXN], limited[SP_MAXN];
+  Real lower[SP_MAXN], upper[SP_MAXN], damp[SP_MAXN], stiff[SP_MAXN], rest[SP_MAXN], q0[SP_MAXN], dq0[SP_MAXN];
+  int sh_link[SP_MAXS], sh_type[SP_MAXS];
+  Real sh_R[SP_MAXS][9], sh_p[SP_MAXS][3], sh_size[SP_MAXS][3];
+  Real dt, g[3], ground_y, mu, erp_dt, max_erv, limit_erp_dt, cfm1, ccfm1;   // ccfm1 = 1 + contact_cfm
+  // task
+  int task, frame_skip, act_dim, obs_dim, act_dof0, max_steps;
+  Real act_scale[32], act_lo[32], act_hi[32];
+  int aux_link[4];
+  Real aux_real[8], aux_real2[4];
+  Real s_max, v_clip, noise, noise_v, inv_envdt;
+  int solver_iters, pgs_fallback_sweeps;
+  double* dbg;                 // optional [n_envs][160] dump of the last LCP (debug builds of the tests only)
+  unsigned long long* stats;   // optional [64]: [0..31] pivoting iterations per solve, [32] PGS fallbacks, [33] solves
+};
+
+// ---- tiny 3-vector helpers on registers
+template <class Real> struct V3 { Real x, y, z; };
+template <class Real> __device__ __forceinline__ V3<Real> v3(Real x, Real y, Real z) { return {x, y, z}; }
+template <class Real> __device__ __forceinline__ V3<Real> operator+(V3<Real> a, V3<Real> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class Real> __device__ __forceinline__ V3<Real> operator-(V3<Real> a, V3<Real> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class Real> __device__ __forceinline__ V3<Real> operator*(V3<Real> a, Real s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class Real> __device__ __forceinline__ Real dot(V3<Real> a, V3<Real> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class Real> __device__ __forceinline__ V3<Real> cross(V3<Real> a, V3<Real> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class Real> __device__ __forceinline__ V3<Real> ld3(const Real* p) { return {p[0], p[1], p[2]}; }
+template <class Real> __device__ __forceinline__ void st3(Real* p, V3<Real> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+// y = R x, R row-major 3x3
+template <class Real> __device__ __forceinline__ V3<Real> mulR(const Real* R, V3<Real> x) {
+  return {R[0] * x.x + R[1] * x.y + R[2] * x.z, R[3] * x.x + R[4] * x.y + R[5] * x.z, R[6] * x.x + R[7] * x.y + R[8] * x.z};
+}
+template <class Real> __device__ __forceinline__ void mulRR(const Real* A, const Real* B, Real* C) {  // C = A B
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// LDS layout of one link (offsets in Reals)
+enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_OM = 18, LK_AL = 21, LK_VO = 24, LK_AO = 27, LK_C = 30, LK_F = 33,
+       LK_N = 36, LK_MC = 39, LK_H = 40, LK_IC = 43 };
+
+template <class Real>
+struct SpLds {
+  Real* link;    // [nl][SP_LINKF]
+  Real* q; Real* dq; Real* tau; Real* rhs; Real* vs;   // [n]
+  Real* H;       // [n][n] row-major, lower triangle -> Cholesky factor
+  Real* W;       // [SP_MAXM+1][n]: constraint Jacobian rows, then W = L^-1 J^T
+  Real* A;       // [SP_MAXM][SP_SA]
+  Real* Lw;      // [SP_MAXM][SP_SA]
+  Real* b; Real* lo; Real* hi; Real* x; Real* r; Real* x0;   // [SP_MAXM]
+  int* rdof;     // [SP_MAXM] limit rows: dof index, contact rows: -1
+  int* rfidx;    // [SP_MAXM] friction rows: index of their normal row, else -1
+  Real* cpP;     // [SP_MAXCP][4]: contact point (relative coords) + depth
+  int* cplink;   // [SP_MAXCP]
+  Real* misc;    // [16]: roff(3), scalars
+  int* imisc;    // [8]: ncp, m, contact flags
+};
+
+template <class Real>
+__device__ __forceinline__ size_t sp_lds_reals(int nl, int n) {
+  return (size_t)nl * SP_LINKF + 5 * n + n * n + (SP_MAXM + 1) * n + 2 * SP_MAXM * SP_SA + 6 * SP_MAXM + SP_MAXCP * 4 + 16;
+}
+
+template <class Real>
+__device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n) {
+  SpLds<Real> S;
+  Real* p = base;
+  S.link = p; p += nl * SP_LINKF;
+  S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n; S.vs = p; p += n;
+  S.H = p; p += n * n;
+  S.W = p; p += (SP_MAXM + 1) * n;
+  S.A = p; p += SP_MAXM * SP_SA;
+  S.Lw = p; p += SP_MAXM * SP_SA;
+  S.b = p; p += SP_MAXM; S.lo = p; p += SP_MAXM; S.hi = p; p += SP_MAXM; S.x = p; p += SP_MAXM; S.r = p; p += SP_MAXM; S.x0 = p; p += SP_MAXM;
+  S.cpP = p; p += SP_MAXCP * 4;
+  S.misc = p; p += 16;
+  S.rdof = (int*)p; p += SP_MAXM * sizeof(int) / sizeof(Real) + 1;
+  S.rfidx = (int*)p; p += SP_MAXM * sizeof(int) / sizeof(Real) + 1;
+  S.cplink = (int*)p; p += SP_MAXCP * sizeof(int) / sizeof(Real) + 1;
+  S.imisc = (int*)p;
+  return S;
+}
+__host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes) {
+  size_t reals = (size_t)nl * SP_LINKF + 5 * n + (size_t)n * n + (size_t)(SP_MAXM + 1) * n + 2 * SP_MAXM * SP_SA + 6 * SP_MAXM +
+                 SP_MAXCP * 4 + 16;
+  return reals * real_bytes + (2 * SP_MAXM + SP_MAXCP + 8) * sizeof(int) + 3 * real_bytes + 64;
+}
+
+// ------------------------------------------------------------------ lane-0 recursions
+// forward kinematics (positions relative to the floating-base translation `roff`)
+template <class Real>
+__device__ __forceinline__ void sp_kinematics(const SpatialModel<Real>& Md, SpLds<Real>& S) {
+  V3<Real> roff = v3<Real>(0, 0, 0);
+  for (int i = 0; i < Md.nl; i++) {
+    Real* L = S.link + i * SP_LINKF;
+    const int p = Md.parent[i];
+    Real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    V3<Real> pp = v3<Real>(0, 0, 0);
+    if (p >= 0) {
+      const Real* Lp = S.link + p * SP_LINKF;
+      for (int k = 0; k < 9; k++) Rp[k] = Lp[LK_R + k];
+      pp = ld3(Lp + LK_P);
+    }
+    Real Rj[9];
+    mulRR(Rp, Md.Rpre[i], Rj);
+    V3<Real> pj = pp + mulR(Rp, ld3(Md.ppre[i]));
+    V3<Real> ax = ld3(Md.axis[i]);
+    V3<Real> a = mulR(Rj, ax);
+    Real Rm[9];
+    V3<Real> pm = pj;
+    const int d = Md.dof[i];
+    if (Md.jtype[i] == 2) {  // revolute: Rm = Rj * Rot(axis, q)
+      Real sn, cs;
+      sincos_<Real>(S.q[d], sn, cs);
+      const Real v = Real(1) - cs;
+      Real Rq[9] = {ax.x * ax.x * v + cs,        ax.x * ax.y * v - ax.z * sn, ax.x * ax.z * v + ax.y * sn,
+                    ax.y * ax.x * v + ax.z * sn, ax.y * ax.y * v + cs,        ax.y * ax.z * v - ax.x * sn,
+                    ax.z * ax.x * v - ax.y * sn, ax.z * ax.y * v + ax.x * sn, ax.z * ax.z * v + cs};
+      mulRR(Rj, Rq, Rm);
+    } else {
+      for (int k = 0; k < 9; k++) Rm[k] = Rj[k];
+      if (Md.jtype[i] == 1) {
+        if (Md.root_trans[i]) roff = roff + a * S.q[d];
+        else pm = pj + a * S.q[d];
+      }
+    }
+    Real Ri[9];
+    mulRR(Rm, Md.Rpost[i], Ri);
+    V3<Real> pi = pm + mulR(Rm, ld3(Md.ppost[i]));
+    for (int k = 0; k < 9; k++) L[LK_R + k] = Ri[k];
+    st3(L + LK_P, pi);
+    st3(L + LK_JO, pj);
+    st3(L + LK_A, a);
+    st3(L + LK_C, pi + mulR(Ri, ld3(Md.com[i])));
+  }
+  st3(S.misc, roff);
+}
+
+// velocities, velocity-product accelerations, per-link wrench and composite bodies (all about the joint origins)
+template <class Real>
+__device__ __forceinline__ void sp_dynamics_recursions(const SpatialModel<Real>& Md, SpLds<Real>& S) {
+  const V3<Real> grav = ld3(Md.g);
+  for (int i = 0; i < Md.nl; i++) {
+    Real* L = S.link + i * SP_LINKF;
+    const int p = Md.parent[i];
+    V3<Real> omp = v3<Real>(0, 0, 0), alp = omp, vop = omp, aop = omp, pp = omp;
+    if (p >= 0) {
+      const Real* Lp = S.link + p * SP_LINKF;
+      omp = ld3(Lp + LK_OM); alp = ld3(Lp + LK_AL); vop = ld3(Lp + LK_VO); aop = ld3(Lp + LK_AO); pp = ld3(Lp + LK_P);
+    }
+    const V3<Real> pj = ld3(L + LK_JO), a = ld3(L + LK_A), pi = ld3(L + LK_P), c = ld3(L + LK_C);
+    const V3<Real> r = pj - pp;
+    const V3<Real> vj = vop + cross(omp, r);
+    const V3<Real> aj = aop + cross(alp, r) + cross(omp, cross(omp, r));
+    const int d = Md.dof[i];
+    const Real qd = d >= 0 ? S.dq[d] : Real(0);
+    V3<Real> om = omp, al = alp;
+    const V3<Real> s = pi - pj;
+    V3<Real> vo, ao;
+    if (Md.jtype[i] == 2) {
+      om = omp + a * qd;
+      al = alp + cross(omp, a * qd);
+      vo = vj + cross(om, s);
+      ao = aj + cross(al, s) + cross(om, cross(om, s));
+    } else {
+      vo = vj + cross(omp, s) + a * qd;
+      ao = aj + cross(alp, s) + cross(omp, cross(omp, s)) + cross(omp, a * qd) * Real(2);
+    }
+    st3(L + LK_OM, om); st3(L + LK_AL, al); st3(L + LK_VO, vo); st3(L + LK_AO, ao);
+    // inertia in world axes Iw = R I R^T (symmetric, 6 numbers xx xy xz yy yz zz)
+    const Real* R = L + LK_R;
+    Real RI[9], Iw[9];
+    mulRR(R, Md.inertia[i], RI);
+    for (int x = 0; x < 3; x++)
+      for (int y = 0; y < 3; y++) Iw[3 * x + y] = RI[3 * x] * R[3 * y] + RI[3 * x + 1] * R[3 * y + 1] + RI[3 * x + 2] * R[3 * y + 2];
+    const Real m = Md.mass[i];
+    const V3<Real> dc = c - pi;
+    const V3<Real> ac = ao + cross(al, dc) + cross(om, cross(om, dc));
+    const V3<Real> f = (ac - grav) * m;
+    const V3<Real> nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
+    const V3<Real> dj = c - pj;
+    st3(L + LK_F, f);
+    st3(L + LK_N, nrm + cross(dj, f));
+    L[LK_MC] = m;
+    st3(L + LK_H, dj * m);
+    const Real d2 = dot(dj, dj);
+    L[LK_IC + 0] = Iw[0] + m * (d2 - dj.x * dj.x);
+    L[LK_IC + 1] = Iw[1] - m * dj.x * dj.y;
+    L[LK_IC + 2] = Iw[2] - m * dj.x * dj.z;
+    L[LK_IC + 3] = Iw[4] + m * (d2 - dj.y * dj.y);
+    L[LK_IC + 4] = Iw[5] - m * dj.y * dj.z;
+    L[LK_IC + 5] = Iw[8] + m * (d2 - dj.z * dj.z);
+  }
+  for (int i = Md.nl - 1; i >= 0; i--) {
+    Real* L = S.link + i * SP_LINKF;
+    const int p = Md.parent[i];
+    // generalized bias force of this link's dof
+    const int d = Md.dof[i];
+    const V3<Real> a = ld3(L + LK_A), F = ld3(L + LK_F), N = ld3(L + LK_N);
+    if (d >= 0) {
+      const Real Cb = (Md.jtype[i] == 2) ? dot(a, N) : dot(a, F);
+      S.rhs[d] = S.tau[d] - Cb - Md.damp[d] * S.dq[d] - Md.stiff[d] * (S.q[d] + Md.dt * S.dq[d] - Md.rest[d]);
+    }
+    if (p >= 0) {
+      Real* Lp = S.link + p * SP_LINKF;
+      const V3<Real> o = ld3(L + LK_JO) - ld3(Lp + LK_JO);
+      st3(Lp + LK_F, ld3(Lp + LK_F) + F);
+      st3(Lp + LK_N, ld3(Lp + LK_N) + N + cross(o, F));
+      const Real mc = L[LK_MC];
+      const V3<Real> h = ld3(L + LK_H);
+      const Real oh = dot(o, h), o2 = dot(o, o);
+      const Real diag = Real(2) * oh + mc * o2;
+      Lp[LK_IC + 0] += L[LK_IC + 0] + diag - Real(2) * h.x * o.x - mc * o.x * o.x;
+      Lp[LK_IC + 1] += L[LK_IC + 1] - (h.x * o.y + o.x * h.y) - mc * o.x * o.y;
+      Lp[LK_IC + 2] += L[LK_IC + 2] - (h.x * o.z + o.x * h.z) - mc * o.x * o.z;
+      Lp[LK_IC + 3] += L[LK_IC + 3] + diag - Real(2) * h.y * o.y - mc * o.y * o.y;
+      Lp[LK_IC + 4] += L[LK_IC + 4] - (h.y * o.z + o.y * h.z) - mc * o.y * o.z;
+      Lp[LK_IC + 5] += L[LK_IC + 5] + diag - Real(2) * h.z * o.z - mc * o.z * o.z;
+      st3(Lp + LK_H, ld3(Lp + LK_H) + h + o * mc);
+      Lp[LK_MC] += mc;
+    }
+  }
+}
+
+// row `d` of the mass matrix (lower part): one lane per dof walks its ancestor chain
+template <class Real>
+__device__ __forceinline__ void sp_mass_row(const SpatialModel<Real>& Md, SpLds<Real>& S, int d) {
+  const int n = Md.n;
+  const int i = Md.dof_link[d];
+  const Real* L = S.link + i * SP_LINKF;
+  const V3<Real> a = ld3(L + LK_A), h = ld3(L + LK_H), jo = ld3(L + LK_JO);
+  V3<Real> Lm, K;
+  if (Md.jtype[i] == 2) {
+    Lm = cross(a, h);
+    const Real* I = L + LK_IC;
+    K = v3<Real>(I[0] * a.x + I[1] * a.y + I[2] * a.z, I[1] * a.x + I[3] * a.y + I[4] * a.z, I[2] * a.x + I[4] * a.y + I[5] * a.z);
+  } else {
+    Lm = a * L[LK_MC];
+    K = cross(h, a);
+  }
+  for (int k = 0; k < d; k++) S.H[d * n + k] = Real(0);
+  for (int j = i; j >= 0; j = Md.parent[j]) {
+    const int dj = Md.dof[j];
+    if (dj < 0) continue;
+    const Real* Lj = S.link + j * SP_LINKF;
+    const V3<Real> aj = ld3(Lj + LK_A);
+    Real v;
+    if (Md.jtype[j] == 2) v = dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm));
+    else v = dot(aj, Lm);
+    if (dj == d) v += Md.dt * Md.damp[d] + Md.dt * Md.dt * Md.stiff[d];
+    S.H[d * n + dj] = v;   // dj <= d because parents come first
+  }
+}
+
+// ------------------------------------------------------------------ wave-parallel dense kernels (row-owner scheme)
+// in-place Cholesky of the lower triangle of the n x n matrix M (stride ld); lane r owns row r
+template <class Real>
+__device__ __forceinline__ void sp_cholesky(Real* M, int n, int ld, int lane) {
+  for (int j = 0; j < n; j++) {
+    __syncthreads();
+    const Real djj = sqrt(M[j * ld + j]);
+    const Real inv = Real(1) / djj;
+    __syncthreads();
+    if (lane == j) M[j * ld + j] = djj;
+    Real lij = Real(0);
+    if (lane > j && lane < n) { lij = M[lane * ld + j] * inv; M[lane * ld + j] = lij; }
+    __syncthreads();
+    if (lane > j && lane < n)
+      for (int k = j + 1; k <= lane; k++) M[lane * ld + k] -= lij * M[k * ld + j];
+  }
+  __syncthreads();
+}
+// x <- (L L^T)^-1 x for one vector in LDS, column-oriented, lanes own entries
+template <class Real>
+__device__ __forceinline__ void sp_chol_solve(const Real* Lf, int n, int ld, Real* x, int lane, bool forward, bool backward) {
+  if (forward)
+    for (int j = 0; j < n; j++) {
+      __syncthreads();
+      const Real xj = x[j] / Lf[j * ld + j];
+      __syncthreads();
+      if (lane == j) x[j] = xj;
+      if (lane > j && lane < n) x[lane] -= Lf[lane * ld + j] * xj;
+    }
+  if (backward)
+    for (int j = n - 1; j >= 0; j--) {
+      __syncthreads();
+      const Real xj = x[j] / Lf[j * ld + j];
+      __syncthreads();
+      if (lane == j) x[j] = xj;
+      if (lane < j) x[lane] -= Lf[j * ld + lane] * xj;
+    }
+  __syncthreads();
+}
+
+// Boxed LCP by block principal pivoting, one wavefront per problem (rows = lanes).  F/U are wave-uniform bit masks.
+template <class Real, bool ZERO_BOUNDS>
+__device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask, uint64_t& F, uint64_t& U, int max_iter,
+                                       int pgs_sweeps, unsigned long long* stats, int lane) {
+  if (lane < m) S.x0[lane] = S.x[lane];   // solution of the previous stage (zeros before the first): PGS fallback start
+  Real bmax = Real(0);
+  for (int i = 0; i < m; i++) bmax = fmax(bmax, fabs(S.b[i]));
+  const Real tol = tol_<Real>() * (Real(1) + bmax);
+  int best = m + 1, patience = 3;
+  const bool row = lane < m;
+  bool converged = false;
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    const bool fi = row && ((F >> lane) & 1ull), ui = row && ((U >> lane) & 1ull);
+    __syncthreads();
+    if (row) S.x[lane] = fi ? Real(0) : (ui ? S.hi[lane] : S.lo[lane]);   // xb
+    __syncthreads();
+    // rhs and masked copy of A
+    if (row) {
+      Real t = S.b[lane];
+      if (!ZERO_BOUNDS) for (int j = 0; j < m; j++) t -= S.A[lane * SP_SA + j] * S.x[j];
+      S.r[lane] = fi ? t : S.x[lane];
+      for (int j = 0; j <= lane; j++) {
+        const bool fj = (F >> j) & 1ull;
+        S.Lw[lane * SP_SA + j] = (fi && fj) ? S.A[lane * SP_SA + j] : (j == lane ? Real(1) : Real(0));
+      }
+    }
+    __syncthreads();
+    // LDL^T restricted to the free columns (non-free columns are identity: nothing to eliminate)
+    for (int j = 0; j < m; j++) {
+      if (!((F >> j) & 1ull)) continue;
+      __syncthreads();
+      const Real dj = S.Lw[j * SP_SA + j];
+      const Real inv = Real(1) / dj;
+      Real lij = Real(0);
+      if (row && lane > j && fi) { lij = S.Lw[lane * SP_SA + j] * inv; }
+      __syncthreads();
+      if (row && lane > j && fi) {
+        for (int k = j + 1; k <= lane; k++)
+          if ((F >> k) & 1ull) S.Lw[lane * SP_SA + k] -= lij * S.Lw[k * SP_SA + j];
+        S.Lw[lane * SP_SA + j] = lij;
+      }
+    }
+    __syncthreads();
+    // solve L D L^T x = r over the free rows (column oriented)
+    for (int j = 0; j < m; j++) {
+      if (!((F >> j) & 1ull)) continue;
+      __syncthreads();
+      const Real xj = S.r[j];
+      if (row && lane > j && fi) S.r[lane] -= S.Lw[lane * SP_SA + j] * xj;
+    }
+    __syncthreads();
+    if (fi) S.r[lane] /= S.Lw[lane * SP_SA + lane];
+    for (int j = m - 1; j >= 0; j--) {
+      if (!((F >> j) & 1ull)) continue;
+      __syncthreads();
+      const Real xj = S.r[j];
+      if (row && lane < j && fi) S.r[lane] -= S.Lw[j * SP_SA + lane] * xj;
+    }
+    __syncthreads();
+    // feasibility of every row
+    bool inf = false, gt = false;
+    if (row) {
+      Real w = -S.b[lane];
+      for (int j = 0; j < m; j++) w += S.A[(lane >= j ? lane * SP_SA + j : j * SP_SA + lane)] * S.r[j];
+      const Real ri = S.r[lane], lo = S.lo[lane], hi = S.hi[lane];
+      const bool pinned = (pinmask >> lane) & 1ull;
+      const bool over = ri > hi + tol * (Real(1) + fabs(hi)), under = ri < lo - tol * (Real(1) + fabs(lo));
+      const bool wbad = ui ? (w > tol) : (w < -tol);
+      inf = fi ? (over || under) : (wbad && !pinned);
+      gt = ri > hi;
+    }
+    const uint64_t B = __ballot(inf), GT = __ballot(gt);
+    if (B == 0ull) { converged = true; break; }
+    const int ninf = __popcll(B);
+    const bool improved = ninf < best;
+    const bool single = !improved && patience == 0;
+    best = improved ? ninf : best;
+    patience = improved ? 3 : (patience > 0 ? patience - 1 : 0);
+    const uint64_t Bs = single ? (1ull << (63 - __clzll((long long)B))) : B;
+    const uint64_t toBound = Bs & F, toFree = Bs & ~F;
+    F = (F & ~toBound) | toFree;
+    U = (U & ~(toFree | toBound)) | (toBound & GT);
+  }
+  __syncthreads();
+  if (stats && lane == 0) { atomicAdd(&stats[it < 31 ? it : 31], 1ull); atomicAdd(&stats[33], 1ull); }
+  if (converged) {
+    if (row) S.x[lane] = fmin(fmax(S.r[lane], S.lo[lane]), S.hi[lane]);
+  } else {
+    // The pivoting loop did not settle (degenerate, redundant-contact LCP): projected Gauss-Seidel from the previous
+    // stage's impulses -- always in the box, monotone in the QP energy.  Row dot products are spread over the lanes.
+    if (stats && lane == 0) atomicAdd(&stats[32], 1ull);
+    if (row) S.x[lane] = fmin(fmax(S.x0[lane], S.lo[lane]), S.hi[lane]);
+    __syncthreads();
+    for (int sw = 0; sw < pgs_sweeps; ++sw)
+      for (int i = 0; i < m; i++) {
+        if ((pinmask >> i) & 1ull) continue;
+        Real part = row ? S.A[i * SP_SA + lane] * S.x[lane] : Real(0);
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) {
+          const Real xn = S.x[i] + (S.b[i] - part) / S.A[i * SP_SA + i];
+          S.x[i] = fmin(fmax(xn, S.lo[i]), S.hi[i]);
+        }
+        __syncthreads();
+      }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ one world step for the env owned by this wavefront
+template <class Real>
+__device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLds<Real>& S, int lane, int* contact_flags) {
+  const int n = Md.n, nl = Md.nl;
+  if (lane == 0) {
+    sp_kinematics<Real>(Md, S);
+    sp_dynamics_recursions<Real>(Md, S);
+  }
+  __syncthreads();
+  if (lane < n) sp_mass_row<Real>(Md, S, lane);
+  __syncthreads();
+  sp_cholesky<Real>(S.H, n, n, lane);
+  // vs = dq + dt * H^-1 rhs
+  sp_chol_solve<Real>(S.H, n, n, S.rhs, lane, true, true);
+  if (lane < n) S.vs[lane] = S.dq[lane] + Md.dt * S.rhs[lane];
+  __syncthreads();
+
+  // ---- contact points and active limits (lane 0 builds the compact row list)
+  const V3<Real> roff = ld3(S.misc);
+  if (lane == 0) {
+    int ncp = 0;
+    for (int s = 0; s < Md.nshapes; s++) {
+      const Real* L = S.link + Md.sh_link[s] * SP_LINKF;
+      Real Ts[9];
+      mulRR(L + LK_R, Md.sh_R[s], Ts);
+      const V3<Real> pc = ld3(L + LK_P) + mulR(L + LK_R, ld3(Md.sh_p[s]));
+      if (Md.sh_type[s] == 0) {   // capsule: lowest segment endpoint, ODE sphere-sphere contact position
+        const Real rad = Md.sh_size[s][0], hl = Real(0.5) * Md.sh_size[s][1];
+        const V3<Real> zc = v3<Real>(Ts[2], Ts[5], Ts[8]);
+        const V3<Real> p1 = pc + zc * hl, p2 = pc - zc * hl;
+        const V3<Real> pe = (p2.y < p1.y) ? p2 : p1;
+        const Real d = pe.y + roff.y - Md.ground_y;
+        if (d <= rad && ncp < SP_MAXCP) {
+          S.cpP[4 * ncp + 0] = pe.x; S.cpP[4 * ncp + 1] = pe.y - Real(0.5) * (rad + d); S.cpP[4 * ncp + 2] = pe.z;
+          S.cpP[4 * ncp + 3] = rad - d; S.cplink[ncp] = Md.sh_link[s]; ncp++;
+        }
+      } else {                    // box: vertices of the face that looks down, the ones below the floor
+        int k = 0;
+        Real bestv = Real(-1);
+        for (int a = 0; a < 3; a++) if (fabs(Ts[3 + a]) > bestv) { bestv = fabs(Ts[3 + a]); k = a; }
+        const Real sgn = Ts[3 + k] > Real(0) ? Real(-1) : Real(1);
+        const int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
+        const Real hk = Real(0.5) * Md.sh_size[s][k], h1 = Real(0.5) * Md.sh_size[s][a1], h2 = Real(0.5) * Md.sh_size[s][a2];
+        const V3<Real> ek = v3<Real>(Ts[k], Ts[3 + k], Ts[6 + k]), e1 = v3<Real>(Ts[a1], Ts[3 + a1], Ts[6 + a1]),
+                       e2 = v3<Real>(Ts[a2], Ts[3 + a2], Ts[6 + a2]);
+        const Real sg1[4] = {1, -1, -1, 1}, sg2[4] = {1, 1, -1, -1};
+        for (int v = 0; v < 4; v++) {
+          const V3<Real> P = pc + ek * (sgn * hk) + e1 * (sg1[v] * h1) + e2 * (sg2[v] * h2);
+          const Real depth = Md.ground_y - (P.y + roff.y);
+          if (depth >= Real(0) && ncp < SP_MAXCP) {
+            S.cpP[4 * ncp + 0] = P.x; S.cpP[4 * ncp + 1] = P.y; S.cpP[4 * ncp + 2] = P.z; S.cpP[4 * ncp + 3] = depth;
+            S.cplink[ncp] = Md.sh_link[s]; ncp++;
+          }
+        }
+      }
+    }
+    int m = 3 * ncp;
+    for (int r = 0; r < m; r++) { S.rdof[r] = -1; S.rfidx[r] = (r % 3 == 0) ? -1 : (r - r % 3); }
+    for (int d = 0; d < n && m < SP_MAXM; d++) {
+      if (!Md.limited[d]) continue;
+      const Real qd = S.q[d];
+      const bool low = qd <= Md.lower[d], up = !low && qd >= Md.upper[d];
+      if (!(low || up)) continue;
+      const Real viol = low ? qd - Md.lower[d] : qd - Md.upper[d];
+      const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
+      S.rdof[m] = d; S.rfidx[m] = -1;
+      S.b[m] = bounce - S.vs[d];
+      S.lo[m] = low ? Real(0) : -inf_<Real>();
+      S.hi[m] = low ? inf_<Real>() : Real(0);
+      m++;
+    }
+    S.imisc[0] = ncp;
+    S.imisc[1] = m;
+    for (int f = 0; f < 2; f++) contact_flags[f] = 0;
+    for (int cidx = 0; cidx < ncp; cidx++)
+      for (int f = 0; f < 2; f++) if (S.cplink[cidx] == Md.aux_link[2 + f]) contact_flags[f] = 1;
+  }
+  __syncthreads();
+  const int ncp = S.imisc[0], m = S.imisc[1];
+  if (m > 0) {
+    // ---- Jacobian rows (lane per row), b for contact rows
+    if (lane < m) {
+      Real* Jr = S.W + lane * n;
+      for (int k = 0; k < n; k++) Jr[k] = Real(0);
+      const int d = S.rdof[lane];
+      if (d >= 0) {
+        Jr[d] = Real(1);
+      } else {
+        const int cidx = lane / 3, kind = lane % 3;
+        const V3<Real> dir = kind == 0 ? v3<Real>(0, 1, 0) : (kind == 1 ? v3<Real>(-1, 0, 0) : v3<Real>(0, 0, 1));
+        const V3<Real> P = ld3(S.cpP + 4 * cidx);
+        Real rel = Real(0);
+        for (int j = S.cplink[cidx]; j >= 0; j = Md.parent[j]) {
+          const int dj = Md.dof[j];
+          if (dj < 0) continue;
+          const Real* Lj = S.link + j * SP_LINKF;
+          const V3<Real> aj = ld3(Lj + LK_A);
+          const Real v = (Md.jtype[j] == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj);
+          Jr[dj] = v;
+          rel += v * S.vs[dj];
+        }
+        const Real depth = S.cpP[4 * cidx + 3];
+        S.b[lane] = (kind == 0 ? fmin(depth * Md.erp_dt, Md.max_erv) : Real(0)) - rel;
+        S.lo[lane] = Real(0);
+        S.hi[lane] = kind == 0 ? inf_<Real>() : Real(0);   // friction rows pinned during the frictionless stage
+      }
+    }
+    __syncthreads();
+    // ---- W = L^-1 J^T : every lane forward-substitutes its own row
+    if (lane < m) {
+      Real* y = S.W + lane * n;
+      for (int k = 0; k < n; k++) {
+        Real t = y[k];
+        for (int j = 0; j < k; j++) t -= S.H[k * n + j] * y[j];
+        y[k] = t / S.H[k * n + k];
+      }
+    }
+    __syncthreads();
+    // ---- A = W W^T (lower), cfm on the diagonal
+    if (lane < m) {
+      const Real* wi = S.W + lane * n;
+      for (int k = 0; k <= lane; k++) {
+        const Real* wk = S.W + k * n;
+        Real t = Real(0);
+        for (int j = 0; j < n; j++) t += wi[j] * wk[j];
+        if (k == lane) t *= (S.rdof[lane] >= 0) ? Md.cfm1 : Md.ccfm1;
+        S.A[lane * SP_SA + k] = t;
+      }
+    }
+    __syncthreads();
+    if (lane < m) for (int k = lane + 1; k < m; k++) S.A[lane * SP_SA + k] = S.A[k * SP_SA + lane];   // mirror for row reads
+    __syncthreads();
+    // ---- stage 1 (frictionless), stage 2 (friction bounds from the stage-1 normal impulses)
+    uint64_t pinmask = 0, F = 0, U = 0;
+    {
+      Real bm = Real(0);
+      for (int i = 0; i < m; i++) bm = fmax(bm, fabs(S.b[i]));
+      const Real tol0 = tol_<Real>() * (Real(1) + bm);
+      bool pinned = false, upper = false, startf = false;
+      if (lane < m) {
+        pinned = !(S.lo[lane] < S.hi[lane]);
+        upper = !(S.lo[lane] == Real(0));
+        startf = !pinned && (upper ? (S.b[lane] < -tol0) : (S.b[lane] > tol0));
+      }
+      pinmask = __ballot(pinned); F = __ballot(startf); U = __ballot(upper && !startf);
+    }
+    if (lane < m) S.x[lane] = Real(0);
+    __syncthreads();
+    sp_blcp<Real, true>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane);
+    if (ncp > 0) {
+      bool isf = false, pinned = false;
+      if (lane < m && S.rfidx[lane] >= 0) {
+        const Real hb = fabs(Md.mu * S.x[S.rfidx[lane]]);
+        // a direction the skeleton cannot move in (planar model, z tangent) has A_ii = 0: keep that row out
+        isf = true; pinned = !(hb > Real(0)) || !(S.A[lane * SP_SA + lane] > Real(1e-12));
+        S.hi[lane] = hb; S.lo[lane] = -hb;
+      }
+      __syncthreads();
+      const uint64_t fr = __ballot(isf), pf = __ballot(isf && pinned);
+      pinmask = (pinmask & ~fr) | pf;
+      F = (F & ~fr) | (fr & ~pf);
+      U &= ~fr;
+      sp_blcp<Real, false>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane);
+    }
+    if (Md.dbg) {
+      double* D = Md.dbg + (size_t)blockIdx.x * 160;
+      if (lane == 0) { D[0] = m; D[1] = ncp; }
+      if (lane < m) { D[2 + lane] = (double)S.x[lane]; D[42 + lane] = (double)S.b[lane]; D[82 + lane] = (double)S.hi[lane]; D[122 + lane] = (double)S.A[lane * SP_SA + lane]; }
+    }
+    // ---- velocity change: dv = L^-T (W^T lambda)
+    if (lane < n) {
+      Real u = Real(0);
+      for (int i = 0; i < m; i++) u += S.W[i * n + lane] * S.x[i];
+      S.rhs[lane] = u;
+    }
+    __syncthreads();
+    sp_chol_solve<Real>(S.H, n, n, S.rhs, lane, false, true);
+    if (lane < n) S.vs[lane] += S.rhs[lane];
+  }
+  __syncthreads();
+  if (lane < n) { S.dq[lane] = S.vs[lane]; S.q[lane] += Md.dt * S.vs[lane]; }
+  __syncthreads();
+  (void)nl;
+}
+
+// ------------------------------------------------------------------ task epilogues (lane 0, after a fresh kinematics pass)
+// HumanWalker: reward / done / obs (human_walker.py:75-149).  Returns done.
+template <class Real>
+__device__ __forceinline__ bool sp_humanwalker_epilogue(const SpatialModel<Real>& Md, SpLds<Real>& S, Real pos_before,
+                                                        Real abs_a_sum, Real init_height, const int* cflags,
+                                                        Real& reward_out) {
+  const V3<Real> roff = ld3(S.misc);
+  const Real* Lb = S.link + Md.aux_link[0] * SP_LINKF;
+  const Real* Lh = S.link + Md.aux_link[1] * SP_LINKF;
+  const Real pos_after = Lb[LK_C] + roff.x;
+  const Real height = Lh[LK_C + 1] + roff.y, side = Lh[LK_C + 2] + roff.z;
+  const Real* R = Lh + LK_R;
+  const V3<Real> up = v3<Real>(R[1], R[4], R[7]), fw = v3<Real>(R[0], R[3], R[6]);
+  const Real ang_u = acos(fmin(fmax(up.y / sqrt(dot(up, up)), Real(-1)), Real(1)));
+  const Real ang_f = acos(fmin(fmax(fw.x / sqrt(dot(fw, fw)), Real(-1)), Real(1)));
+  const Real vel = (pos_after - pos_before) * Md.inv_envdt;
+  const Real tv = Md.aux_real[0];
+  Real rew = Real(2) * (tv - fabs(tv - vel)) + Md.aux_real[1] - Md.aux_real[2] * abs_a_sum - Md.aux_real[3] * fabs(side);
+  bool ok = true;
+  for (int i = 0; i < Md.n; i++) {
+    ok = ok && isfinite(S.q[i]) && isfinite(S.dq[i]) && (fabs(S.dq[i]) < Md.s_max);
+    if (i >= 2) ok = ok && (fabs(S.q[i]) < Md.s_max);
+  }
+  const Real dh = height - init_height;
+  ok = ok && (dh > Md.aux_real[4]) && (dh < Md.aux_real[5]) && (fabs(ang_u) < Md.aux_real2[1]) && (fabs(ang_f) < Md.aux_real2[1]) &&
+       (fabs(S.q[3]) < Md.aux_real[6]) && (fabs(S.q[5]) < Md.aux_real[7]) && (fabs(side) < Md.aux_real2[0]);
+  if (!ok) rew = Real(0);
+  reward_out = rew;
+  (void)cflags;
+  return !ok;
+}
+
+template <class Real>
+__device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds<Real>& S, const int* cflags, float* __restrict__ o, int lane) {
+  const int n = Md.n;
+  if (Md.task == 0) {   // physics only: [q, dq]
+    if (lane < n) { o[lane] = (float)S.q[lane]; o[n + lane] = (float)S.dq[lane]; }
+    return;
+  }
+  if (lane >= 1 && lane < n) o[lane - 1] = (float)S.q[lane];
+  if (lane < n) o[n - 1 + lane] = (float)fmin(fmax(S.dq[lane], -Md.v_clip), Md.v_clip);
+  if (lane < 2) o[2 * n - 1 + lane] = (float)cflags[lane];
+}
+
+// ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
+template <class Real>
+__global__ void __launch_bounds__(64) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
+                                                      Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ init_h,
+                                                      int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
+                                                      const float* __restrict__ actions, float* __restrict__ obs,
+                                                      float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                      uint8_t* __restrict__ truncated, int autoreset, uint64_t seed,
+                                                      uint64_t env_offset) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  const SpatialModel<Real>& Md = *Mp;
+  const int lane = threadIdx.x;
+  const int64_t e = blockIdx.x;
+  if (e >= n_envs) return;
+  const int n = Md.n;
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n);
+  int* cflags = S.imisc + 2;
+  Real* sh_scal = S.misc + 8;
+  if (lane < n) { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; S.tau[lane] = Real(0); }
+  __syncthreads();
+  Real abs_sum = Real(0);
+  if (lane == 0) {
+    for (int k = 0; k < Md.act_dim; k++) {
+      const Real a = (Real)actions[e * Md.act_dim + k];
+      abs_sum += fabs(a);
+      Real cl = (a > Md.act_hi[k]) ? Md.act_hi[k] : a;
+      cl = (cl < Md.act_lo[k]) ? Md.act_lo[k] : cl;
+      S.tau[Md.act_dof0 + k] = cl * Md.act_scale[k];
+    }
+    sp_kinematics<Real>(Md, S);
+    sh_scal[0] = (Md.task == 4) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : Real(0);   // posbefore
+    cflags[0] = 0; cflags[1] = 0;
+  }
+  __syncthreads();
+  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real>(Md, S, lane, cflags);
+  bool dn = false, tr = false;
+  if (lane == 0) {
+    sp_kinematics<Real>(Md, S);
+    Real rew = Real(0);
+    bool task_done = false;
+    if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, init_h[e], cflags, rew);
+    int el = elapsed[e] + 1;
+    const bool trunc = (Md.max_steps > 0) && (el >= Md.max_steps);
+    dn = task_done || trunc; tr = trunc && !task_done;
+    reward[e] = (float)rew;
+    done[e] = dn ? 1 : 0;
+    truncated[e] = tr ? 1 : 0;
+    elapsed[e] = (autoreset && dn) ? 0 : el;
+    sh_scal[1] = dn ? Real(1) : Real(0);
+  }
+  __syncthreads();
+  dn = sh_scal[1] != Real(0);
+  if (autoreset && dn) {
+    const uint32_t ep = episode[e] + 1;
+    // Philox reset noise, same stream as the planar kernels / the oracle: u[0..n) positions, u[n..2n) velocities
+    if (lane < n) {
+      const int iq = lane, iv = n + lane;
+      uint32_t o[4];
+      philox4x32_10((uint32_t)(env_offset + e), (uint32_t)((env_offset + e) >> 32), ep, (uint32_t)(iq / 4), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+      const Real uq = Real(o[iq % 4] >> 8) * Real(1.0 / 16777216.0);
+      philox4x32_10((uint32_t)(env_offset + e), (uint32_t)((env_offset + e) >> 32), ep, (uint32_t)(iv / 4), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+      const Real uv = Real(o[iv % 4] >> 8) * Real(1.0 / 16777216.0);
+      S.q[lane] = Md.q0[lane] + (-Md.noise + Real(2) * Md.noise * uq);
+      S.dq[lane] = Md.dq0[lane] + (-Md.noise_v + Real(2) * Md.noise_v * uv);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      episode[e] = ep;
+      sp_kinematics<Real>(Md, S);
+      if (Md.task == 4) init_h[e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
+      cflags[0] = 0; cflags[1] = 0;
+    }
+    __syncthreads();
+  }
+  if (lane < n) { qs[e * n + lane] = S.q[lane]; dqs[e * n + lane] = S.dq[lane]; }
+  sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
+}
+
+// masked reset: q = init + noise (host rows or Philox), elapsed = 0, init height, obs
+template <class Real>
+__global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
+                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ init_h,
+                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
+                                                       const uint8_t* __restrict__ mask, const double* __restrict__ qnoise,
+                                                       const double* __restrict__ vnoise, float* __restrict__ obs,
+                                                       uint64_t seed, uint64_t env_offset) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  const SpatialModel<Real>& Md = *Mp;
+  const int lane = threadIdx.x;
+  const int64_t e = blockIdx.x;
+  if (e >= n_envs) return;
+  const int n = Md.n;
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n);
+  int* cflags = S.imisc + 2;
+  const bool m = (mask == nullptr) || mask[e];
+  if (lane < n) {
+    if (m) {
+      if (qnoise) { S.q[lane] = (Real)qnoise[e * n + lane]; S.dq[lane] = (Real)vnoise[e * n + lane]; }
+      else {
+        const uint32_t ep = episode[e] + 1;
+        const int iq = lane, iv = n + lane;
+        uint32_t o[4];
+        philox4x32_10((uint32_t)(env_offset + e), (uint32_t)((env_offset + e) >> 32), ep, (uint32_t)(iq / 4), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        const Real uq = Real(o[iq % 4] >> 8) * Real(1.0 / 16777216.0);
+        philox4x32_10((uint32_t)(env_offset + e), (uint32_t)((env_offset + e) >> 32), ep, (uint32_t)(iv / 4), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        const Real uv = Real(o[iv % 4] >> 8) * Real(1.0 / 16777216.0);
+        S.q[lane] = Md.q0[lane] + (-Md.noise + Real(2) * Md.noise * uq);
+        S.dq[lane] = Md.dq0[lane] + (-Md.noise_v + Real(2) * Md.noise_v * uv);
+      }
+    } else { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    cflags[0] = 0; cflags[1] = 0;
+    if (m) {
+      if (!qnoise) episode[e] = episode[e] + 1;
+      elapsed[e] = 0;
+      sp_kinematics<Real>(Md, S);
+      if (Md.task == 4) init_h[e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
+    }
+  }
+  __syncthreads();
+  if (m && lane < n) { qs[e * n + lane] = S.q[lane]; dqs[e * n + lane] = S.dq[lane]; }
+  if (obs) sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
+}
+
+// (N, n) doubles <-> the kernel's AoS state
+template <class Real>
+__global__ void sp_state_io_kernel(int64_t count, Real* __restrict__ qs, Real* __restrict__ dqs, double* __restrict__ qh,
+                                   double* __restrict__ dqh, int to_device) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  if (to_device) { qs[i] = (Real)qh[i]; dqs[i] = (Real)dqh[i]; }
+  else { qh[i] = (double)qs[i]; dqh[i] = (double)dqs[i]; }
+}
+
+}  // namespace dartk

@@ -56,6 +56,7 @@ class DartModelCard(C.Structure):
         ("angle_max", C.c_double), ("state_abs_max", C.c_double), ("obs_vel_clip", C.c_double),
         ("reset_noise", C.c_double), ("reset_noise_vel", C.c_double),
         ("aux_body", C.c_int32 * 4), ("aux_real", C.c_double * 8), ("aux_real2", C.c_double * 4),
+        ("contact_cfm", C.c_double),
     ]
 
 
@@ -89,6 +90,7 @@ class TaskSpec:
     aux_body_names: List[str] = field(default_factory=list)
     aux_real: List[float] = field(default_factory=list)
     aux_real2: List[float] = field(default_factory=list)
+    contact_cfm: Optional[float] = None   # None -> the model's DART cfm (1e-9)
     act_low: float = -1.0
     act_high: float = 1.0
 
@@ -115,7 +117,7 @@ HUMANWALKER = TaskSpec(
     max_episode_steps=300, reward_threshold=None, height_body=10, penalty_dof=-1, height_lo=-0.2, height_hi=1.0,
     angle_max=2.0, contact_bodies=["l-foot", "r-foot"], alive_bonus=2.0, ctrl_cost=0.5, limit_penalty=0.0,
     reset_noise=0.005, reset_noise_vel=0.05, aux_body_names=["pelvis", "head", "l-foot", "r-foot"],
-    aux_real=[1.0, 2.0, 0.5, 3.0, -0.2, 1.0, 1.3, 0.4], aux_real2=[0.9])
+    aux_real=[1.0, 2.0, 0.5, 3.0, -0.2, 1.0, 1.3, 0.4], aux_real2=[0.9], contact_cfm=1e-4)
 
 TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, HUMANWALKER)}
 
@@ -159,6 +161,7 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         c.limited[i] = int(model.limited[i])
         c.damping[i], c.stiffness[i], c.rest[i] = model.damping[i], model.stiffness[i], model.rest[i]
         c.init_pos[i], c.init_vel[i] = model.init_pos[i], model.init_vel[i]
+    c.contact_cfm = model.cfm
     c.nshapes = len(model.shapes)
     for i, s in enumerate(model.shapes):
         c.shape_body[i], c.shape_type[i], c.shape_collidable[i] = s.body, s.kind, int(s.collidable)
@@ -188,6 +191,8 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         c.height_lo, c.height_hi, c.angle_max = task.height_lo, task.height_hi, task.angle_max
         c.state_abs_max, c.obs_vel_clip, c.reset_noise = task.state_abs_max, task.obs_vel_clip, task.reset_noise
         c.reset_noise_vel = task.reset_noise_vel
+        if task.contact_cfm is not None:
+            c.contact_cfm = task.contact_cfm
         names = [b.name for b in model.bodies]
         for k, nm in enumerate(task.aux_body_names):
             c.aux_body[k] = names.index(nm)

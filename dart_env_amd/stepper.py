@@ -27,7 +27,7 @@ SOLVER_BPP, SOLVER_PGS = 0, 1
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump",
 ]
 
 
@@ -74,6 +74,7 @@ def load_library(path: Optional[str] = None):
     L.dart_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.dart_reset_device.argtypes = [vp, vp, vp, vp]
     L.dart_sync.argtypes = [vp]
+    L.dart_debug_dump.argtypes = [vp, dp]
     L.dart_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.dart_get_counters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
     L.dart_time_steps.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, dp]
@@ -198,6 +199,11 @@ class HipStepper:
         h = np.zeros(64, dtype=np.uint64)
         self._check(self.L.dart_get_stats(self.h, _ptr(h, C.c_uint64), int(clear)))
         return h[:32], h[32:]
+
+    def debug_dump(self):
+        out = np.zeros((self.num_envs, 160))
+        self._check(self.L.dart_debug_dump(self.h, _ptr(out, C.c_double)))
+        return out
 
     def sync(self):
         self._check(self.L.dart_sync(self.h))

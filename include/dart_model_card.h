@@ -123,6 +123,11 @@ typedef struct DartModelCard {
   int32_t aux_body[4];
   double aux_real[8];
   double aux_real2[4];
+  /* Regularisation of CONTACT rows (normal + friction): diag(A) *= 1 + contact_cfm.  DART's value is `cfm` (1e-9);
+   * models whose feet are boxes produce up to 4 coplanar, redundant contact points per rigid foot, which makes the
+   * Delassus matrix singular up to that 1e-9 -- the split of the normal impulse (and with it the friction bounds) is
+   * then decided by rounding / pivoting order, in DART as much as here.  A larger value makes the LCP well posed. */
+  double contact_cfm;
 } DartModelCard;
 
 #ifdef __cplusplus

@@ -113,6 +113,10 @@ int dart_get_counters(DartStepper* h, int32_t* elapsed, uint32_t* episode);
  * hist64[32..63] the same for the friction stage.  Needs DART_CFG_STATS = 1. */
 int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear);
 
+/* Debugging aid of the spatial kernel (needs DART_CFG_STATS): per env 160 doubles = {m, ncp, x[40], b[40], hi[40], diagA[40]}
+ * of the last LCP solved. */
+int dart_debug_dump(DartStepper* h, double* out160);
+
 /* Wait for everything enqueued on the handle's stream. */
 int dart_sync(DartStepper* h);
 

@@ -88,6 +88,7 @@ typedef struct OracleWorld {
   int ncontacts_last;
   double contact_last[MAXC][8]; /* body, px,py,pz, depth, fn, ft1, ft2 */
   double lcp_residual_last;
+  double A_last[MAXM * MAXM], b_last[MAXM]; /* debug copies of the last LCP */
   double init_height; /* human_walker.py:163 head COM height right after reset_model's set_state */
 } OracleWorld;
 
@@ -636,6 +637,7 @@ int oracle_step(OracleWorld* w) {
     double* cl = w->contact_last[w->ncontacts_last++];
     cl[0] = c->shape_body[s]; cl[1] = P[0]; cl[2] = P[1]; cl[3] = P[2]; cl[4] = depth; cl[5] = base;
   }
+  const int contact_rows = m; /* rows [0, contact_rows) belong to contacts, the rest to joint limits */
   for (int i = 0; i < n; i++) {
     if (!c->limited[i]) continue;
     int side = 0;
@@ -666,7 +668,8 @@ int oracle_step(OracleWorld* w) {
         for (int k = 0; k < n; k++) s += J[i][k] * Y[j][k];
         A[i * m + j] = s;
       }
-    for (int i = 0; i < m; i++) A[i * m + i] *= (1.0 + c->cfm);
+    for (int i = 0; i < m; i++) A[i * m + i] *= (1.0 + (i < contact_rows ? c->contact_cfm : c->cfm));
+    memcpy(w->A_last, A, (size_t)m * m * sizeof(double)); memcpy(w->b_last, b, m * sizeof(double));
     /* stage 1: rows without findex */
     int idx1[MAXM], m1 = 0, idx2[MAXM];
     for (int i = 0; i < m; i++) { x[i] = 0; idx2[i] = i; if (findex[i] < 0) idx1[m1++] = i; }
@@ -731,6 +734,10 @@ void oracle_body_com(OracleWorld* w, int body, double* out3) {
 int oracle_last_lcp(const OracleWorld* w, double* lambda, double* wv, double* lo, double* hi, double* residual) {
   for (int i = 0; i < w->m_last; i++) { lambda[i] = w->lambda_last[i]; wv[i] = w->w_last[i]; lo[i] = w->lo_last[i]; hi[i] = w->hi_last[i]; }
   *residual = w->lcp_residual_last;
+  return w->m_last;
+}
+int oracle_last_Ab(const OracleWorld* w, double* A, double* b) {
+  memcpy(A, w->A_last, (size_t)w->m_last * w->m_last * sizeof(double)); memcpy(b, w->b_last, w->m_last * sizeof(double));
   return w->m_last;
 }
 int oracle_last_contacts(const OracleWorld* w, double* out8) {

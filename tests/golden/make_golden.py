@@ -165,7 +165,13 @@ class StubWorld:
         model = parse_skel(skel_path, dt=dt, collidable_bodies=contact)
         self.model = model
         self.dt = dt
-        self.oracle = OracleWorld(build_card(model, None))
+        card = build_card(model, None)
+        from dart_env_amd.model_card import TASKS
+        spec = {"hopper_capsule.skel": "DartHopper-v1", "walker2d.skel": "DartWalker2d-v1",
+                "kima_human_edited.skel": "DartHumanWalker-v1"}[name]
+        if TASKS[spec].contact_cfm is not None:   # same contact regularisation as the shipped task card
+            card.contact_cfm = TASKS[spec].contact_cfm
+        self.oracle = OracleWorld(card)
         self.skeletons = [Anything(), StubSkeleton(self, model)]
         self.collision_result = StubCollisionResult()
 

@@ -54,6 +54,8 @@ def lib():
         L.oracle_env_step.restype = C.c_int
         L.oracle_env_obs.argtypes = [C.c_void_p, dp]
         L.oracle_env_after_reset.argtypes = [C.c_void_p]
+        L.oracle_last_Ab.argtypes = [C.c_void_p, dp, dp]
+        L.oracle_last_Ab.restype = C.c_int
         L.oracle_rollout.restype = C.c_int64
         L.oracle_rollout.argtypes = [C.POINTER(DartModelCard), C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float),
                                      C.c_uint64, C.c_uint64, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), dp]
@@ -151,6 +153,11 @@ class OracleWorld:
         res = C.c_double(0)
         k = self.L.oracle_last_lcp(self.h, _p(lam), _p(w), _p(lo), _p(hi), C.byref(res))
         return lam[:k], w[:k], lo[:k], hi[:k], res.value
+
+    def last_Ab(self):
+        A = np.zeros(224 * 224); b = np.zeros(224)
+        m = self.L.oracle_last_Ab(self.h, _p(A), _p(b))
+        return A[:m * m].reshape(m, m), b[:m]
 
     def last_contacts(self):
         buf = np.zeros((64, 8))

@@ -1,0 +1,141 @@
+"""GPU parity of the general (wave-per-env, LDS-resident) kernel against the fp64 oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from dart_env_amd.model_card import build_card, card_for, load_model
+from tests.batch_oracle import OracleBatch
+from tests.oracle_lib import OracleWorld
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture
+def force_spatial(monkeypatch):
+    monkeypatch.setenv("DART_FORCE_SPATIAL", "1")
+
+
+def _physics_card(model_name, contact_bodies):
+    m = load_model(model_name)
+    for s in m.shapes:
+        s.collidable = m.bodies[s.body].name in contact_bodies
+    card = build_card(m, None)
+    if model_name == "humanwalker":
+        card.contact_cfm = 1e-4     # box feet: redundant coplanar contacts need the regularisation (see dart_model_card.h)
+    return card, m
+
+
+@pytest.mark.parametrize("name,bodies", [("hopper", ["h_foot"]), ("walker2d", ["h_foot", "h_foot_left"]),
+                                         ("humanwalker", ["l-foot", "r-foot"])])
+def test_spatial_physics_only_fp64_matches_oracle(force_spatial, name, bodies):
+    """Physics-only cards (task NONE: action = generalized force, obs = [q, dq]) through the spatial kernel, fp64."""
+    from dart_env_amd.stepper import HipStepper
+    card, m = _physics_card(name, bodies)
+    n, nd = 48, card.ndofs
+    rng = np.random.RandomState(0)
+    gpu = HipStepper(card, n, precision=64)
+    worlds = [OracleWorld(card) for _ in range(n)]
+    q0 = rng.uniform(-.05, .05, (n, nd)); v0 = rng.uniform(-.3, .3, (n, nd))
+    if name == "humanwalker":
+        q0[:, 1] -= 0.045           # start with the feet just above the floor so contacts begin within a few steps
+    gpu.set_state(q0, v0)
+    for i, w in enumerate(worlds):
+        w.set_state(q0[i], v0[i])
+    scale = 5.0 if name != "humanwalker" else 20.0
+    worst_q = worst_dq = 0.0
+    saw_rows = 0
+    bad_env_steps = 0
+    for t in range(60):
+        tau = (rng.uniform(-1, 1, (n, nd)) * scale).astype(np.float32)
+        tau[:, :3 if nd < 20 else 6] = 0
+        obs, rew, done, trunc = gpu.step(tau)
+        for i, w in enumerate(worlds):
+            w.set_forces(tau[i].astype(np.float64)); w.step()
+            saw_rows += len(w.last_lcp()[0]) > 0
+        qg, dqg = gpu.get_state()
+        qo = np.stack([w.q for w in worlds]); dqo = np.stack([w.dq for w in worlds])
+        eq = np.abs(qg - qo).max(axis=1); edq = np.abs(dqg - dqo).max(axis=1)
+        # An env whose pivoting loop hit its cap finishes with PGS sweeps (residual ~1e-4): re-synchronise it to the
+        # oracle and count it, so one hard LCP does not mask everything after it.
+        bad = (eq > 1e-8) | (edq > 1e-6)
+        bad_env_steps += int(bad.sum())
+        worst_q = max(worst_q, eq[~bad].max()); worst_dq = max(worst_dq, edq[~bad].max())
+        assert eq.max() < 1e-4 and edq.max() < 0.05, (t, eq.max(), edq.max())     # the PGS fallback stays close
+        if bad.any():
+            gpu.set_state(qo, dqo)
+        assert np.allclose(obs[:, :nd], qg, atol=1e-5)
+    print(name, "max|dq|", worst_q, "max|ddq|", worst_dq, "steps with constraints", saw_rows, "fallback env-steps", bad_env_steps)
+    assert saw_rows > 100
+    assert worst_q < 1e-8 and worst_dq < 1e-6
+    # hopper / walker2d never need the fallback; redundant box-foot contacts under 20 Nm random torques do in < 1 %
+    assert bad_env_steps <= (0.01 * n * 60 if name == "humanwalker" else 0)
+    gpu.close()
+
+
+def test_humanwalker_env_fp64_matches_oracle():
+    from dart_env_amd.stepper import HipStepper
+    card = card_for("DartHumanWalker-v1")
+    n, nd, na = 64, card.ndofs, card.act_dim
+    rng = np.random.RandomState(1)
+    gpu = HipStepper(card, n, precision=64)
+    ora = OracleBatch(card, n)
+    qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.05, .05, (n, nd))
+    og = gpu.reset(None, qn, vn); ora.reset(None, qn, vn)
+    assert np.allclose(og, ora.obs(), atol=1e-6)
+    mism = 0
+    for t in range(25):
+        a = rng.uniform(-1, 1, (n, na)).astype(np.float32) * (0.3 if t % 2 else 1.0)
+        og, rg, dg, tg = gpu.step(a)
+        oo, ro, do, to = ora.step(a)
+        qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+        assert np.abs(qg - qo).max() < 1e-7 and np.abs(dqg - dqo).max() < 1e-5, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        mism += int((dg != do).sum())
+        same = dg == do
+        assert np.allclose(og[same], oo[same], atol=2e-5) and np.allclose(rg[same], ro[same], atol=1e-4)
+        if do.any():
+            qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.05, .05, (n, nd))
+            gpu.reset(do.astype(np.uint8), qn, vn, want_obs=False); ora.reset(do, qn, vn)
+    assert mism == 0
+    gpu.close()
+
+
+def test_humanwalker_golden_fixture_fp64():
+    from dart_env_amd.envs import DartHumanWalkerEnv
+    d = np.load(os.path.join(G, "humanwalker_single_seed0.npz"))
+    env = DartHumanWalkerEnv(precision=64)
+    env.seed(0)
+    assert np.allclose(env.reset(), d["obs0"], atol=1e-6)
+    for t in range(60):
+        ob, r, done, info = env.step(d["actions"][t])
+        assert done == bool(d["done"][t]), t
+        assert np.allclose(ob, d["obs"][t], rtol=0, atol=2e-5), (t, np.abs(ob - d["obs"][t]).max())
+        assert abs(r - d["reward"][t]) < 1e-4
+        assert np.allclose(env.state_vector(), np.concatenate([d["q"][t], d["dq"][t]]), rtol=0, atol=1e-6)
+        if done:
+            assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-6)
+    env.close()
+
+
+def test_humanwalker_fp32_and_device_autoreset():
+    from dart_env_amd import stepper as st
+    from tests import oracle_lib as ol
+    card = card_for("DartHumanWalker-v1")
+    n, steps = 256, 12
+    acts = np.random.RandomState(4).uniform(-1, 1, (steps, n, card.act_dim)).astype(np.float32)
+    ref = ol.rollout(card, acts, seed=3, env_offset=0)
+    for prec, tol in ((64, 1e-6), (32, 2e-3)):
+        s = st.HipStepper(card, n, precision=prec)
+        s.configure(st.CFG_AUTORESET, 1); s.configure(st.CFG_SEED, 3)
+        s.reset(None, None, None, want_obs=False)
+        for t in range(steps):
+            s.step(acts[t])
+        q, dq = s.get_state()
+        el, ep = s.counters()
+        same = (ep == ref["episode"]) & (el == ref["elapsed"])
+        assert same.mean() > (0.999 if prec == 64 else 0.95)
+        err = np.abs(q - ref["q"])[same].max(axis=1)
+        print("precision", prec, "same-history", same.mean(), "median err", np.median(err), "p95", np.percentile(err, 95))
+        assert np.percentile(err, 95) < tol
+        s.close()

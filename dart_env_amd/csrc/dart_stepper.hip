@@ -184,6 +184,11 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
     for (int k = 0; k < 3; k++) { M.axis[i][k] = (Real)(axis ? axis[k] : 0.0); M.ppre[i][k] = (Real)ppre[k]; M.ppost[i][k] = (Real)ppost[k]; }
     for (int k = 0; k < 9; k++) { M.Rpre[i][k] = (Real)Rpre[k]; M.Rpost[i][k] = (Real)Rpost[k]; }
     if (dof >= 0) M.dof_link[dof] = i;
+    auto ident = [](const double* R, const double* p) {
+      for (int k = 0; k < 9; k++) if (R[k] != ((k % 4 == 0) ? 1.0 : 0.0)) return 0;
+      return (p[0] == 0 && p[1] == 0 && p[2] == 0) ? 1 : 0;
+    };
+    M.pre_ident[i] = ident(Rpre, ppre); M.post_ident[i] = ident(Rpost, ppost);
     bool anc_root = parent < 0 || M.root_trans[parent];
     M.root_trans[i] = (jtype == 1 && anc_root) ? 1 : 0;
     return i;
@@ -226,6 +231,38 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
     for (int k = 0; k < 9; k++) M.inertia[last][k] = (Real)(c.mass[b] > 0 ? c.inertia[b][k] : 0.0);
   }
   M.nl = nl; M.n = c.ndofs;
+  {  // depth levels, children lists, constant world axes of the root-chain prismatic links
+    int depth[SP_MAXL], maxd = 0;
+    double Rw[SP_MAXL][9];   // world rotation of each link's JOINT frame at q = 0 (valid for root-chain links)
+    for (int i = 0; i < nl; i++) {
+      depth[i] = M.parent[i] < 0 ? 0 : depth[M.parent[i]] + 1;
+      if (depth[i] > maxd) maxd = depth[i];
+    }
+    M.nlevels = maxd + 1;
+    for (int i = 0; i < nl; i++) M.link_level[i] = depth[i];
+    int k = 0;
+    for (int lv = 0; lv <= maxd; lv++) { M.level_start[lv] = k; for (int i = 0; i < nl; i++) if (depth[i] == lv) M.level_link[k++] = i; }
+    M.level_start[maxd + 1] = k;
+    k = 0;
+    for (int i = 0; i < nl; i++) { M.child_start[i] = k; for (int j = 0; j < nl; j++) if (M.parent[j] == i) M.child_list[k++] = j; }
+    M.child_start[nl] = k;
+    for (int i = 0; i < nl; i++) {
+      double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      if (M.parent[i] >= 0) {   // parent link frame = parent joint frame * Rpost(parent) (prismatic parents do not rotate)
+        int p = M.parent[i];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+          double s2 = 0; for (int t = 0; t < 3; t++) s2 += Rw[p][3 * a + t] * (double)M.Rpost[p][3 * t + b];
+          Rp[3 * a + b] = s2;
+        }
+      }
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+        double s2 = 0; for (int t = 0; t < 3; t++) s2 += Rp[3 * a + t] * (double)M.Rpre[i][3 * t + b];
+        Rw[i][3 * a + b] = s2;
+      }
+      for (int a = 0; a < 3; a++)
+        M.root_axis_world[i][a] = (Real)(Rw[i][3 * a] * (double)M.axis[i][0] + Rw[i][3 * a + 1] * (double)M.axis[i][1] + Rw[i][3 * a + 2] * (double)M.axis[i][2]);
+    }
+  }
   for (int d = 0; d < c.ndofs; d++) {
     M.limited[d] = c.limited[d]; M.lower[d] = (Real)c.lower[d]; M.upper[d] = (Real)c.upper[d];
     M.damp[d] = (Real)c.damping[d]; M.stiff[d] = (Real)c.stiffness[d]; M.rest[d] = (Real)c.rest[d];

@@ -27,15 +27,21 @@ constexpr int SP_MAXL = 48;   // expanded 1-dof links
 constexpr int SP_MAXN = 32;   // dofs
 constexpr int SP_MAXS = 8;    // collidable shapes
 constexpr int SP_MAXCP = 12;  // contact points (a box face gives up to 4)
-constexpr int SP_MAXM = 40;   // LCP rows
-constexpr int SP_SA = 41;     // row stride of A / LDL workspace (odd: conflict-free row-per-lane access)
+constexpr int SP_MAXM = 36;   // LCP rows (12 contact points x 3; HumanWalker peaks at ~31 active rows)
+constexpr int SP_TRI = SP_MAXM * (SP_MAXM + 1) / 2;   // packed lower triangle of A / of the LDL workspace
+__device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 constexpr int SP_LINKF = 49;  // Reals stored per link in LDS
 
 template <class Real>
 struct SpatialModel {
   int nl, n, nshapes;
   int parent[SP_MAXL], jtype[SP_MAXL], dof[SP_MAXL], root_trans[SP_MAXL];
+  int pre_ident[SP_MAXL], post_ident[SP_MAXL];   // 1: the fixed transform is the identity (carriers of expanded joints)
+  int link_level[SP_MAXL];
+  int nlevels, level_start[SP_MAXL + 1], level_link[SP_MAXL];   // links grouped by tree depth (independent within a level)
+  int child_start[SP_MAXL + 1], child_list[SP_MAXL];            // children of every link
   Real axis[SP_MAXL][3];
+  Real root_axis_world[SP_MAXL][3];   // world axis of the root-chain prismatic links (constant)
   Real Rpre[SP_MAXL][9], ppre[SP_MAXL][3];    // joint frame in the parent link frame
   Real Rpost[SP_MAXL][9], ppost[SP_MAXL][3];  // child link frame in the (moved) joint frame
   Real mass[SP_MAXL], com[SP_MAXL][3], inertia[SP_MAXL][9];
@@ -84,10 +90,10 @@ template <class Real>
 struct SpLds {
   Real* link;    // [nl][SP_LINKF]
   Real* q; Real* dq; Real* tau; Real* rhs; Real* vs;   // [n]
-  Real* H;       // [n][n] row-major, lower triangle -> Cholesky factor
+  Real* H;       // [n(n+1)/2] packed lower triangle -> Cholesky factor
   Real* W;       // [SP_MAXM+1][n]: constraint Jacobian rows, then W = L^-1 J^T
-  Real* A;       // [SP_MAXM][SP_SA]
-  Real* Lw;      // [SP_MAXM][SP_SA]
+  Real* A;       // [SP_TRI] packed symmetric
+  Real* Lw;      // [SP_TRI] packed lower
   Real* b; Real* lo; Real* hi; Real* x; Real* r; Real* x0;   // [SP_MAXM]
   int* rdof;     // [SP_MAXM] limit rows: dof index, contact rows: -1
   int* rfidx;    // [SP_MAXM] friction rows: index of their normal row, else -1
@@ -99,7 +105,7 @@ struct SpLds {
 
 template <class Real>
 __device__ __forceinline__ size_t sp_lds_reals(int nl, int n) {
-  return (size_t)nl * SP_LINKF + 5 * n + n * n + (SP_MAXM + 1) * n + 2 * SP_MAXM * SP_SA + 6 * SP_MAXM + SP_MAXCP * 4 + 16;
+  return (size_t)nl * SP_LINKF + 5 * n + n * (n + 1) / 2 + (SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM + SP_MAXCP * 4 + 16;
 }
 
 template <class Real>
@@ -108,10 +114,10 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n) {
   Real* p = base;
   S.link = p; p += nl * SP_LINKF;
   S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n; S.vs = p; p += n;
-  S.H = p; p += n * n;
+  S.H = p; p += n * (n + 1) / 2;
   S.W = p; p += (SP_MAXM + 1) * n;
-  S.A = p; p += SP_MAXM * SP_SA;
-  S.Lw = p; p += SP_MAXM * SP_SA;
+  S.A = p; p += SP_TRI;
+  S.Lw = p; p += SP_TRI;
   S.b = p; p += SP_MAXM; S.lo = p; p += SP_MAXM; S.hi = p; p += SP_MAXM; S.x = p; p += SP_MAXM; S.r = p; p += SP_MAXM; S.x0 = p; p += SP_MAXM;
   S.cpP = p; p += SP_MAXCP * 4;
   S.misc = p; p += 16;
@@ -122,7 +128,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n) {
   return S;
 }
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes) {
-  size_t reals = (size_t)nl * SP_LINKF + 5 * n + (size_t)n * n + (size_t)(SP_MAXM + 1) * n + 2 * SP_MAXM * SP_SA + 6 * SP_MAXM +
+  size_t reals = (size_t)nl * SP_LINKF + 5 * n + (size_t)n * (n + 1) / 2 + (size_t)(SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM +
                  SP_MAXCP * 4 + 16;
   return reals * real_bytes + (2 * SP_MAXM + SP_MAXCP + 8) * sizeof(int) + 3 * real_bytes + 64;
 }
@@ -130,9 +136,9 @@ __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes)
 // ------------------------------------------------------------------ lane-0 recursions
 // forward kinematics (positions relative to the floating-base translation `roff`)
 template <class Real>
-__device__ __forceinline__ void sp_kinematics(const SpatialModel<Real>& Md, SpLds<Real>& S) {
+__device__ __forceinline__ void sp_kinematics(const SpatialModel<Real>& Md, SpLds<Real>& S, int only_link = -1) {
   V3<Real> roff = v3<Real>(0, 0, 0);
-  for (int i = 0; i < Md.nl; i++) {
+  for (int i = (only_link >= 0 ? only_link : 0); i < (only_link >= 0 ? only_link + 1 : Md.nl); i++) {
     Real* L = S.link + i * SP_LINKF;
     const int p = Md.parent[i];
     Real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -143,8 +149,9 @@ __device__ __forceinline__ void sp_kinematics(const SpatialModel<Real>& Md, SpLd
       pp = ld3(Lp + LK_P);
     }
     Real Rj[9];
-    mulRR(Rp, Md.Rpre[i], Rj);
-    V3<Real> pj = pp + mulR(Rp, ld3(Md.ppre[i]));
+    V3<Real> pj = pp;
+    if (Md.pre_ident[i]) { for (int k = 0; k < 9; k++) Rj[k] = Rp[k]; }
+    else { mulRR(Rp, Md.Rpre[i], Rj); pj = pp + mulR(Rp, ld3(Md.ppre[i])); }
     V3<Real> ax = ld3(Md.axis[i]);
     V3<Real> a = mulR(Rj, ax);
     Real Rm[9];
@@ -161,27 +168,137 @@ __device__ __forceinline__ void sp_kinematics(const SpatialModel<Real>& Md, SpLd
     } else {
       for (int k = 0; k < 9; k++) Rm[k] = Rj[k];
       if (Md.jtype[i] == 1) {
-        if (Md.root_trans[i]) roff = roff + a * S.q[d];
-        else pm = pj + a * S.q[d];
+        if (!Md.root_trans[i]) pm = pj + a * S.q[d];
+        else if (only_link < 0) roff = roff + a * S.q[d];
       }
     }
     Real Ri[9];
-    mulRR(Rm, Md.Rpost[i], Ri);
-    V3<Real> pi = pm + mulR(Rm, ld3(Md.ppost[i]));
+    V3<Real> pi = pm;
+    if (Md.post_ident[i]) { for (int k = 0; k < 9; k++) Ri[k] = Rm[k]; }
+    else { mulRR(Rm, Md.Rpost[i], Ri); pi = pm + mulR(Rm, ld3(Md.ppost[i])); }
     for (int k = 0; k < 9; k++) L[LK_R + k] = Ri[k];
     st3(L + LK_P, pi);
     st3(L + LK_JO, pj);
     st3(L + LK_A, a);
     st3(L + LK_C, pi + mulR(Ri, ld3(Md.com[i])));
   }
+  if (only_link < 0) st3(S.misc, roff);
+}
+
+// per-link model constants, held in the registers of the lane that owns the link for the whole kernel
+template <class Real>
+struct LinkConst {
+  int parent, jtype, dof, root_trans, pre_ident, post_ident, level;
+  Real axis[3], Rpre[9], ppre[3], Rpost[9], ppost[3], mass, com[3], inertia[9];
+};
+template <class Real>
+__device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md, int i, LinkConst<Real>& c) {
+  c.parent = Md.parent[i]; c.jtype = Md.jtype[i]; c.dof = Md.dof[i]; c.root_trans = Md.root_trans[i];
+  c.pre_ident = Md.pre_ident[i]; c.post_ident = Md.post_ident[i]; c.level = Md.link_level[i];
+  for (int k = 0; k < 3; k++) { c.axis[k] = Md.axis[i][k]; c.ppre[k] = Md.ppre[i][k]; c.ppost[k] = Md.ppost[i][k]; c.com[k] = Md.com[i][k]; }
+  for (int k = 0; k < 9; k++) { c.Rpre[k] = Md.Rpre[i][k]; c.Rpost[k] = Md.Rpost[i][k]; c.inertia[k] = Md.inertia[i][k]; }
+  c.mass = Md.mass[i];
+}
+
+// kinematics + velocity chain + wrench / composite seeds of link i (its parent is complete), constants from registers
+template <class Real>
+__device__ __forceinline__ void sp_link_forward(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
+  Real* L = S.link + i * SP_LINKF;
+  Real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  V3<Real> pp = v3<Real>(0, 0, 0), omp = pp, alp = pp, vop = pp, aop = pp;
+  if (lc.parent >= 0) {
+    const Real* Lp = S.link + lc.parent * SP_LINKF;
+    for (int k = 0; k < 9; k++) Rp[k] = Lp[LK_R + k];
+    pp = ld3(Lp + LK_P); omp = ld3(Lp + LK_OM); alp = ld3(Lp + LK_AL); vop = ld3(Lp + LK_VO); aop = ld3(Lp + LK_AO);
+  }
+  Real Rj[9];
+  V3<Real> pj = pp;
+  if (lc.pre_ident) { for (int k = 0; k < 9; k++) Rj[k] = Rp[k]; }
+  else { mulRR(Rp, lc.Rpre, Rj); pj = pp + mulR(Rp, ld3(lc.ppre)); }
+  const V3<Real> ax = ld3(lc.axis);
+  const V3<Real> a = mulR(Rj, ax);
+  Real Rm[9];
+  V3<Real> pm = pj;
+  const Real qv = lc.dof >= 0 ? S.q[lc.dof] : Real(0), qd = lc.dof >= 0 ? S.dq[lc.dof] : Real(0);
+  if (lc.jtype == 2) {
+    Real sn, cs;
+    sincos_<Real>(qv, sn, cs);
+    const Real v = Real(1) - cs;
+    Real Rq[9] = {ax.x * ax.x * v + cs,        ax.x * ax.y * v - ax.z * sn, ax.x * ax.z * v + ax.y * sn,
+                  ax.y * ax.x * v + ax.z * sn, ax.y * ax.y * v + cs,        ax.y * ax.z * v - ax.x * sn,
+                  ax.z * ax.x * v - ax.y * sn, ax.z * ax.y * v + ax.x * sn, ax.z * ax.z * v + cs};
+    mulRR(Rj, Rq, Rm);
+  } else {
+    for (int k = 0; k < 9; k++) Rm[k] = Rj[k];
+    if (lc.jtype == 1 && !lc.root_trans) pm = pj + a * qv;
+  }
+  Real Ri[9];
+  V3<Real> pi = pm;
+  if (lc.post_ident) { for (int k = 0; k < 9; k++) Ri[k] = Rm[k]; }
+  else { mulRR(Rm, lc.Rpost, Ri); pi = pm + mulR(Rm, ld3(lc.ppost)); }
+  const V3<Real> c = pi + mulR(Ri, ld3(lc.com));
+  // velocities / velocity-product accelerations
+  const V3<Real> r = pj - pp;
+  const V3<Real> vj = vop + cross(omp, r);
+  const V3<Real> aj = aop + cross(alp, r) + cross(omp, cross(omp, r));
+  V3<Real> om = omp, al = alp, vo, ao;
+  const V3<Real> sv = pi - pj;
+  if (lc.jtype == 2) {
+    om = omp + a * qd;
+    al = alp + cross(omp, a * qd);
+    vo = vj + cross(om, sv);
+    ao = aj + cross(al, sv) + cross(om, cross(om, sv));
+  } else {
+    vo = vj + cross(omp, sv) + a * qd;
+    ao = aj + cross(alp, sv) + cross(omp, cross(omp, sv)) + cross(omp, a * qd) * Real(2);
+  }
+  for (int k = 0; k < 9; k++) L[LK_R + k] = Ri[k];
+  st3(L + LK_P, pi); st3(L + LK_JO, pj); st3(L + LK_A, a); st3(L + LK_C, c);
+  st3(L + LK_OM, om); st3(L + LK_AL, al); st3(L + LK_VO, vo); st3(L + LK_AO, ao);
+  // wrench and composite seeds about the joint origin
+  const Real m = lc.mass;
+  const V3<Real> dj = c - pj;
+  V3<Real> f = v3<Real>(0, 0, 0), nrm = f;
+  Real Iw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (m > Real(0)) {
+    Real RI[9];
+    mulRR(Ri, lc.inertia, RI);
+    for (int x = 0; x < 3; x++)
+      for (int y = 0; y < 3; y++) Iw[3 * x + y] = RI[3 * x] * Ri[3 * y] + RI[3 * x + 1] * Ri[3 * y + 1] + RI[3 * x + 2] * Ri[3 * y + 2];
+    const V3<Real> dc = c - pi;
+    const V3<Real> ac = ao + cross(al, dc) + cross(om, cross(om, dc));
+    f = (ac - ld3(Md.g)) * m;
+    nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
+  }
+  st3(L + LK_F, f);
+  st3(L + LK_N, nrm + cross(dj, f));
+  L[LK_MC] = m;
+  st3(L + LK_H, dj * m);
+  const Real d2 = dot(dj, dj);
+  L[LK_IC + 0] = Iw[0] + m * (d2 - dj.x * dj.x);
+  L[LK_IC + 1] = Iw[1] - m * dj.x * dj.y;
+  L[LK_IC + 2] = Iw[2] - m * dj.x * dj.z;
+  L[LK_IC + 3] = Iw[4] + m * (d2 - dj.y * dj.y);
+  L[LK_IC + 4] = Iw[5] - m * dj.y * dj.z;
+  L[LK_IC + 5] = Iw[8] + m * (d2 - dj.z * dj.z);
+}
+
+// floating-base translation: root-chain prismatic joints have fixed world axes (their ancestors never rotate)
+template <class Real>
+__device__ __forceinline__ void sp_root_offset(const SpatialModel<Real>& Md, SpLds<Real>& S) {
+  V3<Real> roff = v3<Real>(0, 0, 0);
+  for (int i = 0; i < Md.nl; i++) {
+    if (!Md.root_trans[i]) continue;
+    // axis in world = (product of the constant pre/post rotations up to here) * axis; stored by the host
+    roff = roff + ld3(Md.root_axis_world[i]) * S.q[Md.dof[i]];
+  }
   st3(S.misc, roff);
 }
 
-// velocities, velocity-product accelerations, per-link wrench and composite bodies (all about the joint origins)
+// serial chain (lane 0): angular / linear velocities and velocity-product accelerations of every link origin
 template <class Real>
-__device__ __forceinline__ void sp_dynamics_recursions(const SpatialModel<Real>& Md, SpLds<Real>& S) {
-  const V3<Real> grav = ld3(Md.g);
-  for (int i = 0; i < Md.nl; i++) {
+__device__ __forceinline__ void sp_velocity_chain(const SpatialModel<Real>& Md, SpLds<Real>& S, int only_link = -1) {
+  for (int i = (only_link >= 0 ? only_link : 0); i < (only_link >= 0 ? only_link + 1 : Md.nl); i++) {
     Real* L = S.link + i * SP_LINKF;
     const int p = Md.parent[i];
     V3<Real> omp = v3<Real>(0, 0, 0), alp = omp, vop = omp, aop = omp, pp = omp;
@@ -189,7 +306,7 @@ __device__ __forceinline__ void sp_dynamics_recursions(const SpatialModel<Real>&
       const Real* Lp = S.link + p * SP_LINKF;
       omp = ld3(Lp + LK_OM); alp = ld3(Lp + LK_AL); vop = ld3(Lp + LK_VO); aop = ld3(Lp + LK_AO); pp = ld3(Lp + LK_P);
     }
-    const V3<Real> pj = ld3(L + LK_JO), a = ld3(L + LK_A), pi = ld3(L + LK_P), c = ld3(L + LK_C);
+    const V3<Real> pj = ld3(L + LK_JO), a = ld3(L + LK_A), pi = ld3(L + LK_P);
     const V3<Real> r = pj - pp;
     const V3<Real> vj = vop + cross(omp, r);
     const V3<Real> aj = aop + cross(alp, r) + cross(omp, cross(omp, r));
@@ -208,34 +325,87 @@ __device__ __forceinline__ void sp_dynamics_recursions(const SpatialModel<Real>&
       ao = aj + cross(alp, s) + cross(omp, cross(omp, s)) + cross(omp, a * qd) * Real(2);
     }
     st3(L + LK_OM, om); st3(L + LK_AL, al); st3(L + LK_VO, vo); st3(L + LK_AO, ao);
-    // inertia in world axes Iw = R I R^T (symmetric, 6 numbers xx xy xz yy yz zz)
+  }
+}
+
+// per-link (lane = link, independent): wrench and composite-body seeds about the link's own joint origin
+template <class Real>
+__device__ __forceinline__ void sp_link_dynamics(const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
+  Real* L = S.link + i * SP_LINKF;
+  const V3<Real> grav = ld3(Md.g);
+  const V3<Real> pj = ld3(L + LK_JO), pi = ld3(L + LK_P), c = ld3(L + LK_C);
+  const V3<Real> om = ld3(L + LK_OM), al = ld3(L + LK_AL), ao = ld3(L + LK_AO);
+  const Real m = Md.mass[i];
+  const V3<Real> dj = c - pj;
+  V3<Real> f = v3<Real>(0, 0, 0), nrm = f;
+  Real Iw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (m > Real(0)) {
     const Real* R = L + LK_R;
-    Real RI[9], Iw[9];
+    Real RI[9];
     mulRR(R, Md.inertia[i], RI);
     for (int x = 0; x < 3; x++)
       for (int y = 0; y < 3; y++) Iw[3 * x + y] = RI[3 * x] * R[3 * y] + RI[3 * x + 1] * R[3 * y + 1] + RI[3 * x + 2] * R[3 * y + 2];
-    const Real m = Md.mass[i];
     const V3<Real> dc = c - pi;
     const V3<Real> ac = ao + cross(al, dc) + cross(om, cross(om, dc));
-    const V3<Real> f = (ac - grav) * m;
-    const V3<Real> nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
-    const V3<Real> dj = c - pj;
-    st3(L + LK_F, f);
-    st3(L + LK_N, nrm + cross(dj, f));
-    L[LK_MC] = m;
-    st3(L + LK_H, dj * m);
-    const Real d2 = dot(dj, dj);
-    L[LK_IC + 0] = Iw[0] + m * (d2 - dj.x * dj.x);
-    L[LK_IC + 1] = Iw[1] - m * dj.x * dj.y;
-    L[LK_IC + 2] = Iw[2] - m * dj.x * dj.z;
-    L[LK_IC + 3] = Iw[4] + m * (d2 - dj.y * dj.y);
-    L[LK_IC + 4] = Iw[5] - m * dj.y * dj.z;
-    L[LK_IC + 5] = Iw[8] + m * (d2 - dj.z * dj.z);
+    f = (ac - grav) * m;
+    nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
   }
+  st3(L + LK_F, f);
+  st3(L + LK_N, nrm + cross(dj, f));
+  L[LK_MC] = m;
+  st3(L + LK_H, dj * m);
+  const Real d2 = dot(dj, dj);
+  L[LK_IC + 0] = Iw[0] + m * (d2 - dj.x * dj.x);
+  L[LK_IC + 1] = Iw[1] - m * dj.x * dj.y;
+  L[LK_IC + 2] = Iw[2] - m * dj.x * dj.z;
+  L[LK_IC + 3] = Iw[4] + m * (d2 - dj.y * dj.y);
+  L[LK_IC + 4] = Iw[5] - m * dj.y * dj.z;
+  L[LK_IC + 5] = Iw[8] + m * (d2 - dj.z * dj.z);
+}
+
+// parent-centric backward step for link i (all its children are already complete): gather their wrenches and
+// composite bodies, then emit this link's rhs entry
+template <class Real>
+__device__ __forceinline__ void sp_gather_children(const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
+  Real* Lp = S.link + i * SP_LINKF;
+  V3<Real> F = ld3(Lp + LK_F), N = ld3(Lp + LK_N), H = ld3(Lp + LK_H);
+  Real mcp = Lp[LK_MC];
+  Real I0 = Lp[LK_IC + 0], I1 = Lp[LK_IC + 1], I2 = Lp[LK_IC + 2], I3 = Lp[LK_IC + 3], I4 = Lp[LK_IC + 4], I5 = Lp[LK_IC + 5];
+  const V3<Real> jop = ld3(Lp + LK_JO);
+  for (int ci = Md.child_start[i]; ci < Md.child_start[i + 1]; ci++) {
+    const Real* L = S.link + Md.child_list[ci] * SP_LINKF;
+    const V3<Real> o = ld3(L + LK_JO) - jop, Fc = ld3(L + LK_F);
+    F = F + Fc;
+    N = N + ld3(L + LK_N) + cross(o, Fc);
+    const Real mc = L[LK_MC];
+    const V3<Real> h = ld3(L + LK_H);
+    const Real diag = Real(2) * dot(o, h) + mc * dot(o, o);
+    I0 += L[LK_IC + 0] + diag - Real(2) * h.x * o.x - mc * o.x * o.x;
+    I1 += L[LK_IC + 1] - (h.x * o.y + o.x * h.y) - mc * o.x * o.y;
+    I2 += L[LK_IC + 2] - (h.x * o.z + o.x * h.z) - mc * o.x * o.z;
+    I3 += L[LK_IC + 3] + diag - Real(2) * h.y * o.y - mc * o.y * o.y;
+    I4 += L[LK_IC + 4] - (h.y * o.z + o.y * h.z) - mc * o.y * o.z;
+    I5 += L[LK_IC + 5] + diag - Real(2) * h.z * o.z - mc * o.z * o.z;
+    H = H + h + o * mc;
+    mcp += mc;
+  }
+  st3(Lp + LK_F, F); st3(Lp + LK_N, N); st3(Lp + LK_H, H);
+  Lp[LK_MC] = mcp;
+  Lp[LK_IC + 0] = I0; Lp[LK_IC + 1] = I1; Lp[LK_IC + 2] = I2; Lp[LK_IC + 3] = I3; Lp[LK_IC + 4] = I4; Lp[LK_IC + 5] = I5;
+  const int d = Md.dof[i];
+  if (d >= 0) {
+    const V3<Real> a = ld3(Lp + LK_A);
+    const Real Cb = (Md.jtype[i] == 2) ? dot(a, N) : dot(a, F);
+    S.rhs[d] = S.tau[d] - Cb - Md.damp[d] * S.dq[d] - Md.stiff[d] * (S.q[d] + Md.dt * S.dq[d] - Md.rest[d]);
+  }
+}
+
+// serial leaves-to-root pass (lane 0): fold wrenches and composite bodies into the parents, emit the rhs
+template <class Real>
+__device__ __forceinline__ void sp_backward_pass(const SpatialModel<Real>& Md, SpLds<Real>& S) {
   for (int i = Md.nl - 1; i >= 0; i--) {
     Real* L = S.link + i * SP_LINKF;
     const int p = Md.parent[i];
-    // generalized bias force of this link's dof
     const int d = Md.dof[i];
     const V3<Real> a = ld3(L + LK_A), F = ld3(L + LK_F), N = ld3(L + LK_N);
     if (d >= 0) {
@@ -248,17 +418,19 @@ __device__ __forceinline__ void sp_dynamics_recursions(const SpatialModel<Real>&
       st3(Lp + LK_F, ld3(Lp + LK_F) + F);
       st3(Lp + LK_N, ld3(Lp + LK_N) + N + cross(o, F));
       const Real mc = L[LK_MC];
-      const V3<Real> h = ld3(L + LK_H);
-      const Real oh = dot(o, h), o2 = dot(o, o);
-      const Real diag = Real(2) * oh + mc * o2;
-      Lp[LK_IC + 0] += L[LK_IC + 0] + diag - Real(2) * h.x * o.x - mc * o.x * o.x;
-      Lp[LK_IC + 1] += L[LK_IC + 1] - (h.x * o.y + o.x * h.y) - mc * o.x * o.y;
-      Lp[LK_IC + 2] += L[LK_IC + 2] - (h.x * o.z + o.x * h.z) - mc * o.x * o.z;
-      Lp[LK_IC + 3] += L[LK_IC + 3] + diag - Real(2) * h.y * o.y - mc * o.y * o.y;
-      Lp[LK_IC + 4] += L[LK_IC + 4] - (h.y * o.z + o.y * h.z) - mc * o.y * o.z;
-      Lp[LK_IC + 5] += L[LK_IC + 5] + diag - Real(2) * h.z * o.z - mc * o.z * o.z;
-      st3(Lp + LK_H, ld3(Lp + LK_H) + h + o * mc);
-      Lp[LK_MC] += mc;
+      if (mc > Real(0)) {
+        const V3<Real> h = ld3(L + LK_H);
+        const Real oh = dot(o, h), o2 = dot(o, o);
+        const Real diag = Real(2) * oh + mc * o2;
+        Lp[LK_IC + 0] += L[LK_IC + 0] + diag - Real(2) * h.x * o.x - mc * o.x * o.x;
+        Lp[LK_IC + 1] += L[LK_IC + 1] - (h.x * o.y + o.x * h.y) - mc * o.x * o.y;
+        Lp[LK_IC + 2] += L[LK_IC + 2] - (h.x * o.z + o.x * h.z) - mc * o.x * o.z;
+        Lp[LK_IC + 3] += L[LK_IC + 3] + diag - Real(2) * h.y * o.y - mc * o.y * o.y;
+        Lp[LK_IC + 4] += L[LK_IC + 4] - (h.y * o.z + o.y * h.z) - mc * o.y * o.z;
+        Lp[LK_IC + 5] += L[LK_IC + 5] + diag - Real(2) * h.z * o.z - mc * o.z * o.z;
+        st3(Lp + LK_H, ld3(Lp + LK_H) + h + o * mc);
+        Lp[LK_MC] += mc;
+      }
     }
   }
 }
@@ -279,7 +451,7 @@ __device__ __forceinline__ void sp_mass_row(const SpatialModel<Real>& Md, SpLds<
     Lm = a * L[LK_MC];
     K = cross(h, a);
   }
-  for (int k = 0; k < d; k++) S.H[d * n + k] = Real(0);
+  for (int k = 0; k < d; k++) S.H[TI(d, k)] = Real(0);
   for (int j = i; j >= 0; j = Md.parent[j]) {
     const int dj = Md.dof[j];
     if (dj < 0) continue;
@@ -289,25 +461,30 @@ __device__ __forceinline__ void sp_mass_row(const SpatialModel<Real>& Md, SpLds<
     if (Md.jtype[j] == 2) v = dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm));
     else v = dot(aj, Lm);
     if (dj == d) v += Md.dt * Md.damp[d] + Md.dt * Md.dt * Md.stiff[d];
-    S.H[d * n + dj] = v;   // dj <= d because parents come first
+    S.H[TI(d, dj)] = v;   // dj <= d because parents come first
   }
 }
 
 // ------------------------------------------------------------------ wave-parallel dense kernels (row-owner scheme)
-// in-place Cholesky of the lower triangle of the n x n matrix M (stride ld); lane r owns row r
+// in-place Cholesky of the lower triangle of the n x n matrix M (stride ld, n <= 32): row r is owned by the lane pair
+// (r, r + 32), each taking half of the trailing-update range
 template <class Real>
 __device__ __forceinline__ void sp_cholesky(Real* M, int n, int ld, int lane) {
+  const int r = lane & 31, half = lane >> 5;
   for (int j = 0; j < n; j++) {
     __syncthreads();
-    const Real djj = sqrt(M[j * ld + j]);
+    const Real djj = sqrt(M[TI(j, j)]);
     const Real inv = Real(1) / djj;
     __syncthreads();
-    if (lane == j) M[j * ld + j] = djj;
-    Real lij = Real(0);
-    if (lane > j && lane < n) { lij = M[lane * ld + j] * inv; M[lane * ld + j] = lij; }
+    if (lane == j) M[TI(j, j)] = djj;
+    if (half == 0 && r > j && r < n) M[TI(r, j)] *= inv;
     __syncthreads();
-    if (lane > j && lane < n)
-      for (int k = j + 1; k <= lane; k++) M[lane * ld + k] -= lij * M[k * ld + j];
+    if (r > j && r < n) {
+      const Real lij = M[TI(r, j)];
+      const int lo = j + 1, hi = r + 1, mid = (lo + hi) >> 1;
+      const int k0 = half ? mid : lo, k1 = half ? hi : mid;
+      for (int k = k0; k < k1; k++) M[TI(r, k)] -= lij * M[TI(k, j)];
+    }
   }
   __syncthreads();
 }
@@ -317,18 +494,18 @@ __device__ __forceinline__ void sp_chol_solve(const Real* Lf, int n, int ld, Rea
   if (forward)
     for (int j = 0; j < n; j++) {
       __syncthreads();
-      const Real xj = x[j] / Lf[j * ld + j];
+      const Real xj = x[j] / Lf[TI(j, j)];
       __syncthreads();
       if (lane == j) x[j] = xj;
-      if (lane > j && lane < n) x[lane] -= Lf[lane * ld + j] * xj;
+      if (lane > j && lane < n) x[lane] -= Lf[TI(lane, j)] * xj;
     }
   if (backward)
     for (int j = n - 1; j >= 0; j--) {
       __syncthreads();
-      const Real xj = x[j] / Lf[j * ld + j];
+      const Real xj = x[j] / Lf[TI(j, j)];
       __syncthreads();
       if (lane == j) x[j] = xj;
-      if (lane < j) x[lane] -= Lf[j * ld + lane] * xj;
+      if (lane < j) x[lane] -= Lf[TI(j, lane)] * xj;
     }
   __syncthreads();
 }
@@ -353,11 +530,11 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
     // rhs and masked copy of A
     if (row) {
       Real t = S.b[lane];
-      if (!ZERO_BOUNDS) for (int j = 0; j < m; j++) t -= S.A[lane * SP_SA + j] * S.x[j];
+      if (!ZERO_BOUNDS) for (int j = 0; j < m; j++) t -= S.A[TI(lane, j)] * S.x[j];
       S.r[lane] = fi ? t : S.x[lane];
       for (int j = 0; j <= lane; j++) {
         const bool fj = (F >> j) & 1ull;
-        S.Lw[lane * SP_SA + j] = (fi && fj) ? S.A[lane * SP_SA + j] : (j == lane ? Real(1) : Real(0));
+        S.Lw[TI(lane, j)] = (fi && fj) ? S.A[TI(lane, j)] : (j == lane ? Real(1) : Real(0));
       }
     }
     __syncthreads();
@@ -365,15 +542,15 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
     for (int j = 0; j < m; j++) {
       if (!((F >> j) & 1ull)) continue;
       __syncthreads();
-      const Real dj = S.Lw[j * SP_SA + j];
+      const Real dj = S.Lw[TI(j, j)];
       const Real inv = Real(1) / dj;
       Real lij = Real(0);
-      if (row && lane > j && fi) { lij = S.Lw[lane * SP_SA + j] * inv; }
+      if (row && lane > j && fi) { lij = S.Lw[TI(lane, j)] * inv; }
       __syncthreads();
       if (row && lane > j && fi) {
         for (int k = j + 1; k <= lane; k++)
-          if ((F >> k) & 1ull) S.Lw[lane * SP_SA + k] -= lij * S.Lw[k * SP_SA + j];
-        S.Lw[lane * SP_SA + j] = lij;
+          if ((F >> k) & 1ull) S.Lw[TI(lane, k)] -= lij * S.Lw[TI(k, j)];
+        S.Lw[TI(lane, j)] = lij;
       }
     }
     __syncthreads();
@@ -382,22 +559,22 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
       if (!((F >> j) & 1ull)) continue;
       __syncthreads();
       const Real xj = S.r[j];
-      if (row && lane > j && fi) S.r[lane] -= S.Lw[lane * SP_SA + j] * xj;
+      if (row && lane > j && fi) S.r[lane] -= S.Lw[TI(lane, j)] * xj;
     }
     __syncthreads();
-    if (fi) S.r[lane] /= S.Lw[lane * SP_SA + lane];
+    if (fi) S.r[lane] /= S.Lw[TI(lane, lane)];
     for (int j = m - 1; j >= 0; j--) {
       if (!((F >> j) & 1ull)) continue;
       __syncthreads();
       const Real xj = S.r[j];
-      if (row && lane < j && fi) S.r[lane] -= S.Lw[j * SP_SA + lane] * xj;
+      if (row && lane < j && fi) S.r[lane] -= S.Lw[TI(j, lane)] * xj;
     }
     __syncthreads();
     // feasibility of every row
     bool inf = false, gt = false;
     if (row) {
       Real w = -S.b[lane];
-      for (int j = 0; j < m; j++) w += S.A[(lane >= j ? lane * SP_SA + j : j * SP_SA + lane)] * S.r[j];
+      for (int j = 0; j < m; j++) w += S.A[TI(lane, j)] * S.r[j];
       const Real ri = S.r[lane], lo = S.lo[lane], hi = S.hi[lane];
       const bool pinned = (pinmask >> lane) & 1ull;
       const bool over = ri > hi + tol * (Real(1) + fabs(hi)), under = ri < lo - tol * (Real(1) + fabs(lo));
@@ -430,10 +607,10 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
     for (int sw = 0; sw < pgs_sweeps; ++sw)
       for (int i = 0; i < m; i++) {
         if ((pinmask >> i) & 1ull) continue;
-        Real part = row ? S.A[i * SP_SA + lane] * S.x[lane] : Real(0);
+        Real part = row ? S.A[TI(i, lane)] * S.x[lane] : Real(0);
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0) {
-          const Real xn = S.x[i] + (S.b[i] - part) / S.A[i * SP_SA + i];
+          const Real xn = S.x[i] + (S.b[i] - part) / S.A[TI(i, i)];
           S.x[i] = fmin(fmax(xn, S.lo[i]), S.hi[i]);
         }
         __syncthreads();
@@ -443,21 +620,37 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
 }
 
 // ------------------------------------------------------------------ one world step for the env owned by this wavefront
+#define SP_TICK(ph)                                                                              \
+  do {                                                                                            \
+    if (Md.stats && lane == 0) {                                                                  \
+      const unsigned long long t1_ = __builtin_readcyclecounter();                                \
+      atomicAdd(&Md.stats[40 + (ph)], t1_ - t0_);                                                 \
+      t0_ = t1_;                                                                                  \
+    }                                                                                             \
+  } while (0)
+
 template <class Real>
-__device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLds<Real>& S, int lane, int* contact_flags) {
+__device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, const LinkConst<Real>& lc, SpLds<Real>& S, int lane,
+                                              int* contact_flags) {
   const int n = Md.n, nl = Md.nl;
-  if (lane == 0) {
-    sp_kinematics<Real>(Md, S);
-    sp_dynamics_recursions<Real>(Md, S);
+  unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
+  // tree recursions level by level: links of equal depth are independent, one lane each
+  if (lane == 0) sp_root_offset<Real>(Md, S);
+  const int nlev = Md.nlevels;
+  for (int lv = 0; lv < nlev; lv++) {
+    if (lane < nl && lc.level == lv) sp_link_forward<Real>(lc, Md, S, lane);   // lane i owns link i
+    __syncthreads();
   }
-  __syncthreads();
+  for (int lv = nlev - 1; lv >= 0; lv--) {
+    if (lane < nl && lc.level == lv) sp_gather_children<Real>(Md, S, lane);
+    __syncthreads();
+  }
+  SP_TICK(0);
   if (lane < n) sp_mass_row<Real>(Md, S, lane);
   __syncthreads();
+  SP_TICK(1);
   sp_cholesky<Real>(S.H, n, n, lane);
-  // vs = dq + dt * H^-1 rhs
-  sp_chol_solve<Real>(S.H, n, n, S.rhs, lane, true, true);
-  if (lane < n) S.vs[lane] = S.dq[lane] + Md.dt * S.rhs[lane];
-  __syncthreads();
+  SP_TICK(2);
 
   // ---- contact points and active limits (lane 0 builds the compact row list)
   const V3<Real> roff = ld3(S.misc);
@@ -508,7 +701,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLd
       const Real viol = low ? qd - Md.lower[d] : qd - Md.upper[d];
       const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
       S.rdof[m] = d; S.rfidx[m] = -1;
-      S.b[m] = bounce - S.vs[d];
+      S.b[m] = bounce - S.dq[d];   // the dt * W_i . y part (unconstrained acceleration) is added after the W solve
       S.lo[m] = low ? Real(0) : -inf_<Real>();
       S.hi[m] = low ? inf_<Real>() : Real(0);
       m++;
@@ -521,8 +714,10 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLd
   }
   __syncthreads();
   const int ncp = S.imisc[0], m = S.imisc[1];
-  if (m > 0) {
-    // ---- Jacobian rows (lane per row), b for contact rows
+  SP_TICK(3);
+  {
+    // ---- Jacobian rows (lane per row) + the generalized-force row (index m), bias part of b for contact rows
+    if (lane == m) for (int k = 0; k < n; k++) S.W[m * n + k] = S.rhs[k];
     if (lane < m) {
       Real* Jr = S.W + lane * n;
       for (int k = 0; k < n; k++) Jr[k] = Real(0);
@@ -541,7 +736,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLd
           const V3<Real> aj = ld3(Lj + LK_A);
           const Real v = (Md.jtype[j] == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj);
           Jr[dj] = v;
-          rel += v * S.vs[dj];
+          rel += v * S.dq[dj];
         }
         const Real depth = S.cpP[4 * cidx + 3];
         S.b[lane] = (kind == 0 ? fmin(depth * Md.erp_dt, Md.max_erv) : Real(0)) - rel;
@@ -550,16 +745,29 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLd
       }
     }
     __syncthreads();
-    // ---- W = L^-1 J^T : every lane forward-substitutes its own row
-    if (lane < m) {
+    SP_TICK(4);
+    // ---- W = L^-1 [J^T | rhs] : every lane forward-substitutes its own row; row m becomes y = L^-1 rhs
+    if (lane <= m) {
       Real* y = S.W + lane * n;
       for (int k = 0; k < n; k++) {
         Real t = y[k];
-        for (int j = 0; j < k; j++) t -= S.H[k * n + j] * y[j];
-        y[k] = t / S.H[k * n + k];
+        for (int j = 0; j < k; j++) t -= S.H[TI(k, j)] * y[j];
+        y[k] = t / S.H[TI(k, k)];
       }
     }
     __syncthreads();
+    // b_i = bounce_i - J_i (dq + dt H^-1 rhs) = bias_i - dt W_i . y
+    if (lane < m) {
+      const Real* wi = S.W + lane * n;
+      const Real* y = S.W + m * n;
+      Real t = Real(0);
+      for (int k = 0; k < n; k++) t += wi[k] * y[k];
+      S.b[lane] -= Md.dt * t;
+    }
+    __syncthreads();
+    SP_TICK(5);
+  }
+  if (m > 0) {
     // ---- A = W W^T (lower), cfm on the diagonal
     if (lane < m) {
       const Real* wi = S.W + lane * n;
@@ -568,12 +776,11 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLd
         Real t = Real(0);
         for (int j = 0; j < n; j++) t += wi[j] * wk[j];
         if (k == lane) t *= (S.rdof[lane] >= 0) ? Md.cfm1 : Md.ccfm1;
-        S.A[lane * SP_SA + k] = t;
+        S.A[TI(lane, k)] = t;
       }
     }
     __syncthreads();
-    if (lane < m) for (int k = lane + 1; k < m; k++) S.A[lane * SP_SA + k] = S.A[k * SP_SA + lane];   // mirror for row reads
-    __syncthreads();
+    SP_TICK(6);
     // ---- stage 1 (frictionless), stage 2 (friction bounds from the stage-1 normal impulses)
     uint64_t pinmask = 0, F = 0, U = 0;
     {
@@ -591,12 +798,13 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLd
     if (lane < m) S.x[lane] = Real(0);
     __syncthreads();
     sp_blcp<Real, true>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane);
+    SP_TICK(7);
     if (ncp > 0) {
       bool isf = false, pinned = false;
       if (lane < m && S.rfidx[lane] >= 0) {
         const Real hb = fabs(Md.mu * S.x[S.rfidx[lane]]);
         // a direction the skeleton cannot move in (planar model, z tangent) has A_ii = 0: keep that row out
-        isf = true; pinned = !(hb > Real(0)) || !(S.A[lane * SP_SA + lane] > Real(1e-12));
+        isf = true; pinned = !(hb > Real(0)) || !(S.A[TI(lane, lane)] > Real(1e-12));
         S.hi[lane] = hb; S.lo[lane] = -hb;
       }
       __syncthreads();
@@ -606,21 +814,23 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, SpLd
       U &= ~fr;
       sp_blcp<Real, false>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane);
     }
+    SP_TICK(8);
     if (Md.dbg) {
       double* D = Md.dbg + (size_t)blockIdx.x * 160;
       if (lane == 0) { D[0] = m; D[1] = ncp; }
-      if (lane < m) { D[2 + lane] = (double)S.x[lane]; D[42 + lane] = (double)S.b[lane]; D[82 + lane] = (double)S.hi[lane]; D[122 + lane] = (double)S.A[lane * SP_SA + lane]; }
+      if (lane < m) { D[2 + lane] = (double)S.x[lane]; D[42 + lane] = (double)S.b[lane]; D[82 + lane] = (double)S.hi[lane]; D[122 + lane] = (double)S.A[TI(lane, lane)]; }
     }
-    // ---- velocity change: dv = L^-T (W^T lambda)
-    if (lane < n) {
-      Real u = Real(0);
-      for (int i = 0; i < m; i++) u += S.W[i * n + lane] * S.x[i];
-      S.rhs[lane] = u;
-    }
-    __syncthreads();
-    sp_chol_solve<Real>(S.H, n, n, S.rhs, lane, false, true);
-    if (lane < n) S.vs[lane] += S.rhs[lane];
   }
+  // ---- new velocity: vs = dq + L^-T (dt y + W^T lambda)
+  if (lane < n) {
+    Real u = Md.dt * S.W[m * n + lane];
+    for (int i = 0; i < m; i++) u += S.W[i * n + lane] * S.x[i];
+    S.rhs[lane] = u;
+  }
+  __syncthreads();
+  sp_chol_solve<Real>(S.H, n, n, S.rhs, lane, false, true);
+  if (lane < n) S.vs[lane] = S.dq[lane] + S.rhs[lane];
+  SP_TICK(9);
   __syncthreads();
   if (lane < n) { S.dq[lane] = S.vs[lane]; S.q[lane] += Md.dt * S.vs[lane]; }
   __syncthreads();
@@ -673,7 +883,7 @@ __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds
 
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
 template <class Real>
-__global__ void __launch_bounds__(64) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
+__global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ init_h,
                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
                                                       const float* __restrict__ actions, float* __restrict__ obs,
@@ -705,7 +915,9 @@ __global__ void __launch_bounds__(64) sp_step_kernel(const SpatialModel<Real>* _
     cflags[0] = 0; cflags[1] = 0;
   }
   __syncthreads();
-  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real>(Md, S, lane, cflags);
+  LinkConst<Real> lc;
+  sp_load_link_const<Real>(Md, lane < Md.nl ? lane : 0, lc);
+  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real>(Md, lc, S, lane, cflags);
   bool dn = false, tr = false;
   if (lane == 0) {
     sp_kinematics<Real>(Md, S);

@@ -15,5 +15,8 @@ for t in range(20):
     s.step(rng.uniform(-1, 1, (n, 23)).astype(np.float32) * (0.3 if t % 2 else 1.0))
 s.sync(); dt = time.time() - t0
 h1, h2 = s.solver_stats()
+names=["kin+dyn(lane0)","mass rows","chol+qdd","contacts/rows","J rows","W fwd","A=WWt","BPP stage1","BPP stage2","dv update"]
+tot=h2[8:18].sum()
+print("phase cycles %:", {nm: round(100*float(c)/float(tot),1) for nm,c in zip(names,h2[8:18])})
 print("contact_cfm", card.contact_cfm, "iters hist", h1.tolist(), "fallbacks", int(h2[0]), "solves", int(h2[1]), "time/step ms", dt / 20 * 1e3)
 q, dq = s.get_state(); print("finite", np.isfinite(q).all(), "max|dq|", np.abs(dq).max())

@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (0: 65536, or 16384 for DartHumanWalker-v1 = BASELINE config 4)")
     ap.add_argument("--env-id", default="DartHopper-v1")
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--solver", default="bpp", choices=["bpp", "pgs"])
@@ -76,7 +76,7 @@ def main():
     from dart_env_amd import stepper as st
 
     card = card_for(args.env_id)
-    n = args.envs
+    n = args.envs or (16384 if args.env_id == "DartHumanWalker-v1" else 65536)
     env = st.HipStepper(card, n, device=local_rank, precision=args.precision)
     env.configure(st.CFG_AUTORESET, 1)
     env.configure(st.CFG_SEED, 0)

@@ -16,6 +16,7 @@
 #include "planar_kernel.hpp"
 #include "static_models.hpp"
 #include "spatial_kernel.hpp"
+#include "mt19937_kernels.hpp"
 
 using namespace dartk;
 
@@ -29,7 +30,8 @@ struct Impl {
                           float* obs, float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed,
                           uint64_t off) = 0;
   virtual hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
-                           const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off) = 0;
+                           const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off,
+                           int obs_masked_only = 0) = 0;
   virtual hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) = 0;
   virtual void set_solver(int solver, int it1, int it2) = 0;
   virtual void set_stats(unsigned long long* p) = 0;
@@ -52,10 +54,10 @@ struct ImplT : Impl {
     return hipGetLastError();
   }
   hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
-                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off) override {
+                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off, int obs_masked_only) override {
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL((reset_kernel<Real, T, PT>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, mask, qn, vn, obs,
-                       seed, off);
+                       seed, off, obs_masked_only);
     return hipGetLastError();
   }
   hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) override {
@@ -328,9 +330,9 @@ struct SpatialImplT : Impl {
     return hipGetLastError();
   }
   hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
-                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off) override {
+                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off, int obs_masked_only) override {
     hipLaunchKernelGGL((sp_reset_kernel<Real>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep,
-                       mask, qn, vn, obs, seed, off);
+                       mask, qn, vn, obs, seed, off, obs_masked_only);
     return hipGetLastError();
   }
   hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) override {
@@ -406,6 +408,10 @@ struct DartStepper {
   uint8_t *d_done = nullptr, *d_trunc = nullptr, *d_mask = nullptr;
   double *d_qn = nullptr, *d_vn = nullptr;
   unsigned long long* d_stats = nullptr;
+  uint32_t* mt = nullptr;        // MT19937 bank [624][N] (dart_seed_mt19937)
+  int32_t* mt_pos = nullptr;
+  double *d_init_pos = nullptr, *d_init_vel = nullptr;
+  int noise_mode = 0;            // 0: Philox / host-supplied noise, 1: device MT19937 bank (reference-exact)
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
   double *h_qn = nullptr, *h_vn = nullptr;
@@ -496,7 +502,7 @@ int dart_destroy(DartStepper* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->impl) h->impl->release();
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -548,6 +554,42 @@ int dart_configure(DartStepper* h, int key, double value) {
   return DART_OK;
 }
 
+// MT19937 mode: draw reference-exact reset noise on the device for the masked envs into d_qn / d_vn
+static int mt_draw(DartStepper* h, hipStream_t s, const uint8_t* d_mask) {
+  const double r = h->card.reset_noise, rv = h->card.reset_noise_vel;
+  dim3 grid((unsigned)((h->n + 127) / 128)), block(128);
+  hipLaunchKernelGGL(mt_draw_kernel, grid, block, 0, s, h->n, (int)h->card.ndofs, h->mt, h->mt_pos, d_mask, -r, r - (-r), -rv,
+                     rv - (-rv), h->d_init_pos, h->d_init_vel, h->d_qn, h->d_vn);
+  CHK(h, hipGetLastError());
+  return DART_OK;
+}
+
+int dart_seed_mt19937(DartStepper* h, const uint32_t* keys, const int32_t* key_len) {
+  if (!h || !keys || !key_len) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  const size_t N = (size_t)h->n, nd = (size_t)h->card.ndofs;
+  if (!h->mt) {
+    CHK(h, hipMalloc((void**)&h->mt, sizeof(uint32_t) * 624 * N));
+    CHK(h, hipMalloc((void**)&h->mt_pos, sizeof(int32_t) * N));
+    CHK(h, hipMalloc((void**)&h->d_init_pos, sizeof(double) * nd));
+    CHK(h, hipMalloc((void**)&h->d_init_vel, sizeof(double) * nd));
+    CHK(h, hipMemcpy(h->d_init_pos, h->card.init_pos, sizeof(double) * nd, hipMemcpyHostToDevice));
+    CHK(h, hipMemcpy(h->d_init_vel, h->card.init_vel, sizeof(double) * nd, hipMemcpyHostToDevice));
+  }
+  uint32_t* dk = nullptr; int32_t* dl = nullptr;
+  CHK(h, hipMalloc((void**)&dk, sizeof(uint32_t) * 2 * N));
+  CHK(h, hipMalloc((void**)&dl, sizeof(int32_t) * N));
+  CHK(h, hipMemcpy(dk, keys, sizeof(uint32_t) * 2 * N, hipMemcpyHostToDevice));
+  CHK(h, hipMemcpy(dl, key_len, sizeof(int32_t) * N, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(mt_seed_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, h->stream, h->n, h->mt, h->mt_pos, dk, dl);
+  CHK(h, hipGetLastError());
+  CHK(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(dk); (void)hipFree(dl);
+  h->noise_mode = 1;
+  return DART_OK;
+}
+
 int dart_reset(DartStepper* h, const uint8_t* mask, const double* qpos_noise, const double* qvel_noise, float* obs_out) {
   if (!h) return DART_E_INVALID;
   if ((qpos_noise == nullptr) != (qvel_noise == nullptr)) { h->err = "give both noise arrays or neither"; return DART_E_INVALID; }
@@ -573,6 +615,10 @@ int dart_reset(DartStepper* h, const uint8_t* mask, const double* qpos_noise, co
     CHK(h, hipMemcpyAsync(h->d_qn, h->h_qn, 8 * N * nd, hipMemcpyHostToDevice, h->stream));
     CHK(h, hipMemcpyAsync(h->d_vn, h->h_vn, 8 * N * nd, hipMemcpyHostToDevice, h->stream));
     dqn = h->d_qn; dvn = h->d_vn;
+  } else if (h->noise_mode == 1) {
+    int rc = mt_draw(h, h->stream, dmask);
+    if (rc != DART_OK) return rc;
+    dqn = h->d_qn; dvn = h->d_vn;
   }
   CHK(h, h->impl->reset(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, dmask, dqn, dvn,
                         obs_out ? h->d_obs : nullptr, h->seed, h->env_offset));
@@ -586,7 +632,13 @@ int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void*
   if (!h) return DART_E_INVALID;
   CHK(h, hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
-  CHK(h, h->impl->reset(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_mask, nullptr, nullptr, d_obs, h->seed, h->env_offset));
+  const double *dqn = nullptr, *dvn = nullptr;
+  if (h->noise_mode == 1) {
+    int rc = mt_draw(h, s, d_mask);
+    if (rc != DART_OK) return rc;
+    dqn = h->d_qn; dvn = h->d_vn;
+  }
+  CHK(h, h->impl->reset(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_mask, dqn, dvn, d_obs, h->seed, h->env_offset));
   return DART_OK;
 }
 
@@ -620,8 +672,15 @@ int dart_step_async(DartStepper* h, const float* actions) {
   size_t N = (size_t)h->n;
   memcpy(h->h_act, actions, 4 * N * h->card.act_dim);
   CHK(h, hipMemcpyAsync(h->d_act, h->h_act, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
+  const bool mt_reset = h->autoreset && h->noise_mode == 1;
   CHK(h, h->impl->step(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done,
-                       h->d_trunc, h->autoreset, h->seed, h->env_offset));
+                       h->d_trunc, mt_reset ? 0 : h->autoreset, h->seed, h->env_offset));
+  if (mt_reset) {   // done envs: MT19937 noise, reset, post-reset observation (sync_vector_env.py:77-78)
+    int rc = mt_draw(h, h->stream, h->d_done);
+    if (rc != DART_OK) return rc;
+    CHK(h, h->impl->reset(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_done, h->d_qn, h->d_vn, h->d_obs, h->seed,
+                          h->env_offset, 1));
+  }
   CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
   CHK(h, hipMemcpyAsync(h->h_rew, h->d_rew, 4 * N, hipMemcpyDeviceToHost, h->stream));
   CHK(h, hipMemcpyAsync(h->h_done, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
@@ -656,9 +715,16 @@ int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float
   if (!h || !d_actions) return DART_E_INVALID;
   CHK(h, hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
-  CHK(h, h->impl->step(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_actions, d_obs ? d_obs : h->d_obs,
-                       d_reward ? d_reward : h->d_rew, d_done ? d_done : h->d_done,
-                       d_truncated ? d_truncated : h->d_trunc, h->autoreset, h->seed, h->env_offset));
+  const bool mt_reset = h->autoreset && h->noise_mode == 1;
+  float* o = d_obs ? d_obs : h->d_obs;
+  uint8_t* dn = d_done ? d_done : h->d_done;
+  CHK(h, h->impl->step(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_actions, o, d_reward ? d_reward : h->d_rew, dn,
+                       d_truncated ? d_truncated : h->d_trunc, mt_reset ? 0 : h->autoreset, h->seed, h->env_offset));
+  if (mt_reset) {
+    int rc = mt_draw(h, s, dn);
+    if (rc != DART_OK) return rc;
+    CHK(h, h->impl->reset(s, h->n, h->q, h->dq, h->elapsed, h->episode, dn, h->d_qn, h->d_vn, o, h->seed, h->env_offset, 1));
+  }
   return DART_OK;
 }
 

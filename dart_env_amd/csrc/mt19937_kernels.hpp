@@ -1,0 +1,107 @@
+// mt19937_kernels.hpp -- a bank of per-env MT19937 generators in HBM, so that reset noise is BIT-EXACT with the
+// reference at any batch size without a host loop.
+//
+// The reference seeds each env with `seeding.np_random(seed)` (reference gym/utils/seeding.py:11-19: seed -> SHA-512 ->
+// uint32 words -> numpy RandomState.seed(list) = MT19937 init_by_array) and draws
+// `np_random.uniform(-r, r, ndofs)` for qpos, then for qvel (reference gym/envs/dart/hopper.py:78-79).  numpy's legacy
+// uniform is  low + (high - low) * ((a >> 5) * 2^26 + (b >> 6)) / 2^53  with two successive 32-bit outputs a, b.
+// State layout: mt[624][N] (env fastest -> coalesced when one lane serves one env), pos[N] = slot of the next word.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dartk {
+
+// init_by_array(key[0..len)) for every env; keys: [N][2], len[N] in {1, 2}
+__global__ void mt_seed_kernel(int64_t n_envs, uint32_t* __restrict__ mt, int32_t* __restrict__ pos,
+                               const uint32_t* __restrict__ keys, const int32_t* __restrict__ key_len) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_envs) return;
+  auto M = [&](int i) -> uint32_t& { return mt[(int64_t)i * n_envs + e]; };
+  uint32_t prev = 19650218u;
+  M(0) = prev;
+  for (int i = 1; i < 624; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; M(i) = prev; }
+  const int len = key_len[e];
+  const uint32_t k0 = keys[2 * e], k1 = keys[2 * e + 1];
+  int i = 1, j = 0;
+  for (int k = 624; k; k--) {
+    const uint32_t p = M(i - 1);
+    M(i) = (M(i) ^ ((p ^ (p >> 30)) * 1664525u)) + (j == 0 ? k0 : k1) + (uint32_t)j;
+    i++; j++;
+    if (i >= 624) { M(0) = M(623); i = 1; }
+    if (j >= len) j = 0;
+  }
+  for (int k = 623; k; k--) {
+    const uint32_t p = M(i - 1);
+    M(i) = (M(i) ^ ((p ^ (p >> 30)) * 1566083941u)) - (uint32_t)i;
+    i++;
+    if (i >= 624) { M(0) = M(623); i = 1; }
+  }
+  M(0) = 0x80000000u;
+  pos[e] = 0;     // numpy regenerates before its first draw: the first output is x[624], produced over slot 0
+}
+
+// For every env with mask[e] != 0 (mask == nullptr: all): draw 2*ndofs doubles and emit
+//   qn[e][d] = init_pos[d] + U(-r, r),  vn[e][d] = init_vel[d] + U(-rv, rv)     (row-major doubles, as dart_reset takes them)
+//
+// The generator runs in its incremental form: output k is the tempered  x[k+624] = x[k+397] ^ twist(x[k], x[k+1]),
+// written over x[k]'s slot -- the same in-place order numpy's block regeneration uses, so the streams are identical, but
+// a reset costs a fixed 4*ndofs word updates instead of an occasional 624-word loop that would stall the whole launch
+// on the few lanes that hit it.  Words are produced 8 at a time so that the 17 loads of a chunk are in flight together
+// (lanes of a wave are sparse here -- only the envs that just finished -- so this kernel is latency-, not bandwidth-bound).
+__global__ void mt_draw_kernel(int64_t n_envs, int ndofs, uint32_t* __restrict__ mt, int32_t* __restrict__ pos,
+                               const uint8_t* __restrict__ mask, double low_q, double range_q, double low_v,
+                               double range_v, const double* __restrict__ init_pos, const double* __restrict__ init_vel,
+                               double* __restrict__ qn, double* __restrict__ vn) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_envs) return;
+  if (mask && !mask[e]) return;
+  auto M = [&](int i) -> uint32_t& { return mt[(int64_t)(i >= 624 ? i - 624 : i) * n_envs + e]; };
+  // numpy rounds the product and the sum separately (no fma); the reference then adds the noise to q / dq.
+  // (HIP's __dmul_rn is a plain `*` and still contracts, hence the pragma.)
+  auto affine = [](double base, double low, double range, double u) -> double {
+#pragma clang fp contract(off)
+    const double prod = range * u;
+    const double noise = low + prod;
+    return base + noise;
+  };
+  auto temper = [](uint32_t y) -> uint32_t {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  };
+  int p = pos[e];                       // slot of the next word to produce, 0..623
+  const int n_doubles = 2 * ndofs;
+  for (int d0 = 0; d0 < n_doubles; d0 += 4) {
+    uint32_t lo[9], hi[8], out[8];
+#pragma unroll
+    for (int j = 0; j < 9; j++) lo[j] = M(p + j);
+#pragma unroll
+    for (int j = 0; j < 8; j++) hi[j] = M(p + 397 + j);   // never a slot this chunk overwrites (397 + j - i != 0, 624)
+    const int cnt = n_doubles - d0 < 4 ? n_doubles - d0 : 4;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t y = (lo[j] & 0x80000000u) | (lo[j + 1] & 0x7fffffffu);
+      const uint32_t x = hi[j] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      out[j] = temper(x);
+      if (j < 2 * cnt) M(p + j) = x;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (t < cnt) {
+        const uint32_t a = out[2 * t] >> 5, b = out[2 * t + 1] >> 6;
+        const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+        const int d = d0 + t;
+        if (d < ndofs) qn[e * ndofs + d] = affine(init_pos[d], low_q, range_q, u);
+        else vn[e * ndofs + d - ndofs] = affine(init_vel[d - ndofs], low_v, range_v, u);
+      }
+    }
+    p += 2 * cnt;
+    if (p >= 624) p -= 624;
+  }
+  pos[e] = p;
+}
+
+}  // namespace dartk

@@ -715,7 +715,8 @@ __global__ void __launch_bounds__(256) reset_kernel(PT P, int64_t n_envs, Real* 
                                                      Real* __restrict__ dqs, int32_t* __restrict__ elapsed,
                                                      uint32_t* __restrict__ episode, const uint8_t* __restrict__ mask,
                                                      const double* __restrict__ qnoise, const double* __restrict__ vnoise,
-                                                     float* __restrict__ obs, uint64_t seed, uint64_t env_offset) {
+                                                     float* __restrict__ obs, uint64_t seed, uint64_t env_offset,
+                                                     int obs_masked_only) {
   constexpr int N = T::NDOF;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_envs) return;
@@ -735,7 +736,7 @@ __global__ void __launch_bounds__(256) reset_kernel(PT P, int64_t n_envs, Real* 
   } else {
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + e]; dq[i] = dqs[(int64_t)i * n_envs + e]; });
   }
-  if (obs) write_obs<Real, T, PT>(P, q, dq, root_height<Real, T, PT>(P, q), obs + e * (2 * N - 1));
+  if (obs && (m || !obs_masked_only)) write_obs<Real, T, PT>(P, q, dq, root_height<Real, T, PT>(P, q), obs + e * (2 * N - 1));
 }
 
 // (N, n) row-major doubles  <->  SoA state, for set_state / get_state (dart_env.py:145-148, 211-215)

@@ -968,7 +968,7 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
                                                        int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
                                                        const uint8_t* __restrict__ mask, const double* __restrict__ qnoise,
                                                        const double* __restrict__ vnoise, float* __restrict__ obs,
-                                                       uint64_t seed, uint64_t env_offset) {
+                                                       uint64_t seed, uint64_t env_offset, int obs_masked_only) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
   const SpatialModel<Real>& Md = *Mp;
   const int lane = threadIdx.x;
@@ -1006,7 +1006,7 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
   }
   __syncthreads();
   if (m && lane < n) { qs[e * n + lane] = S.q[lane]; dqs[e * n + lane] = S.dq[lane]; }
-  if (obs) sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
+  if (obs && (m || !obs_masked_only)) sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
 }
 
 // (N, n) doubles <-> the kernel's AoS state

@@ -7,9 +7,11 @@ What stays on the host is what the reference also keeps there: seeding and reset
 ``np_random`` (MT19937, reference hopper.py:78-79), spaces, and the auto-reset policy of the vector wrapper.
 
 Reset noise modes
-  * ``noise="mt19937"`` (default): bit-exact with the reference -- env i owns ``seeding.np_random(seed_i)`` and a reset
-    draws ``uniform(-r, r, ndofs)`` for qpos then for qvel (hopper.py:78-79).
-  * ``noise="philox"``: counter-based noise generated on the device (throughput mode, used by bench.py).
+  * ``noise="mt19937"`` (default): bit-exact with the reference -- env i owns the MT19937 stream of
+    ``seeding.np_random(seed_i)`` and a reset draws ``uniform(-r, r, ndofs)`` for qpos then for qvel (hopper.py:78-79).
+    The generators live in HBM (``dart_seed_mt19937``), so this costs no host loop at any batch size.
+  * ``noise="mt19937-host"``: the same streams drawn by numpy on the host and uploaded (cross-check / CPU tests).
+  * ``noise="philox"``: counter-based noise generated inside the step kernel (bench.py).
 """
 from __future__ import annotations
 
@@ -59,8 +61,8 @@ class BatchedDartEnv:
     def __init__(self, env_id: str, num_envs: int = 1, device: int = 0, precision: int = 32, noise: str = "mt19937",
                  max_episode_steps: Optional[int] = None, card: Optional[DartModelCard] = None,
                  stepper_factory: Optional[Callable] = None):
-        if noise not in ("mt19937", "philox"):
-            raise ValueError("noise must be 'mt19937' or 'philox'")
+        if noise not in ("mt19937", "mt19937-host", "philox"):
+            raise ValueError("noise must be 'mt19937', 'mt19937-host' or 'philox'")
         self.env_id = env_id
         self.task = TASKS[env_id]
         self.card = card if card is not None else card_for(env_id)
@@ -72,6 +74,9 @@ class BatchedDartEnv:
         self.noise = noise
         factory = stepper_factory or _st.HipStepper  # no CPU fallback: HipStepper raises without lib/GPU
         self._stepper = factory(self.card, self.num_envs, device, precision)
+        if noise == "mt19937" and not hasattr(self._stepper, "seed_mt19937"):
+            noise = self.noise = "mt19937-host"     # injected test stepper without a device bank
+        self.device_noise = noise in ("mt19937", "philox")
         # spaces exactly as DartEnv.__init__ builds them (dart_env.py:85-86, 97-100)
         hi = np.array([self.card.act_high[k] for k in range(self.act_dim)])
         lo = np.array([self.card.act_low[k] for k in range(self.act_dim)])
@@ -100,6 +105,21 @@ class BatchedDartEnv:
         if self.noise == "philox":
             s0 = seeding.create_seed(seeds[0])
             self._stepper.configure(_st.CFG_SEED, float(s0 % (1 << 53)))
+        elif self.noise == "mt19937":
+            # the words numpy's RandomState.seed(list) receives in seeding.np_random (gym/utils/seeding.py:17-18)
+            keys = np.zeros((self.num_envs, 2), dtype=np.uint32)
+            klen = np.zeros(self.num_envs, dtype=np.int32)
+            used = []
+            for i, sd in enumerate(seeds):
+                if sd is not None and not (isinstance(sd, (int, np.integer)) and 0 <= sd):
+                    raise seeding.SeedError("Seed must be a non-negative integer or omitted, not %r" % (sd,))
+                sd = seeding.create_seed(sd)
+                words = seeding.int_list_from_bigint(seeding.hash_seed(sd))
+                klen[i] = len(words)
+                keys[i, :len(words)] = words
+                used.append(sd)
+            self._stepper.seed_mt19937(keys, klen)
+            self._seeds = used
         return list(seeds)
 
     def _rng(self, i):
@@ -121,7 +141,7 @@ class BatchedDartEnv:
     def reset(self, mask=None):
         """reset_model() for the masked envs (all when None); returns the (num_envs, obs_dim) float32 observations."""
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        if self.noise == "philox":
+        if self.device_noise:
             return self._stepper.reset(m, None, None)
         qn, vn = self._draw_noise(m)
         return self._stepper.reset(m, qn, vn)

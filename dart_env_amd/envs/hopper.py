@@ -11,7 +11,7 @@ class _SingleEnv(BatchedDartEnv):
     ENV_ID = None
 
     def __init__(self, device=0, precision=32, stepper_factory=None):
-        super().__init__(self.ENV_ID, num_envs=1, device=device, precision=precision, noise="mt19937",
+        super().__init__(self.ENV_ID, num_envs=1, device=device, precision=precision, noise="mt19937-host",
                          max_episode_steps=0, stepper_factory=stepper_factory)
         self.control_bounds = np.array([[self.card.act_high[k] for k in range(self.act_dim)],
                                         [self.card.act_low[k] for k in range(self.act_dim)]])

@@ -53,7 +53,7 @@ class DartVectorEnv:
         self.viewer = None
         self.spec_id = env_id
         self._pending = False
-        if noise == "philox":
+        if self.env.device_noise:   # resets happen on the device, inside / right after the step kernel
             self.env._stepper.configure(_st.CFG_AUTORESET, 1)
             self.env._stepper.configure(_st.CFG_ENV_OFFSET, env_offset)
 
@@ -91,7 +91,7 @@ class DartVectorEnv:
             raise NoAsyncCallError(_st.E_NOT_PENDING, "Calling `step_wait` without any prior call to `step_async`.")
         self._pending = False
         obs, rew, done, trunc = self.env.step_wait()
-        if self.env.noise == "mt19937" and done.any():
+        if not self.env.device_noise and done.any():
             obs = self.env.reset(done)      # post-reset observation for done envs (sync_vector_env.py:77-78)
         return obs, rew, done, InfoList(trunc)
 

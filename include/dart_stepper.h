@@ -78,6 +78,14 @@ int dart_configure(DartStepper* h, int key, double value);
 int dart_reset(DartStepper* h, const uint8_t* mask, const double* qpos_noise, const double* qvel_noise,
                float* obs_out);
 
+/* Replaces DartEnv.seed for the whole batch (reference dart_env.py:117-119, gym/utils/seeding.py:11-19, and the
+ * `s + i` fan-out of gym/vector/sync_vector_env.py:50-58): builds one MT19937 generator per env in HBM from
+ * keys[i][0..key_len[i]) -- the uint32 words the reference hands to numpy's RandomState.seed(list) -- and switches the
+ * handle to "MT19937 noise": dart_reset(mask, NULL, NULL, ..) and the auto-reset of dart_step then draw
+ * uniform(-reset_noise, reset_noise, ndofs) for qpos and qvel from env i's own stream, bit-exact with the reference.
+ * keys: (N, 2) uint32, key_len: (N,) int32 in {1, 2}. */
+int dart_seed_mt19937(DartStepper* h, const uint32_t* keys, const int32_t* key_len);
+
 /* Replaces DartEnv.set_state / state_vector (dart_env.py:145-148, 211-215) for the whole batch.
  * q, dq: (N, ndofs) float64. */
 int dart_set_state(DartStepper* h, const double* q, const double* dq);

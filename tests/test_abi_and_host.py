@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "dart_stepper.h")).read()
-    declared = sorted(set(re.findall(r"\b(dart_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(dart_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 15
     assert sorted(st.EXPORTS) == declared, (sorted(st.EXPORTS), declared)
     L = st.load_library()

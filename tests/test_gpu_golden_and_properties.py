@@ -246,3 +246,89 @@ def test_non_finite_actions_terminate_instead_of_poisoning_neighbours():
     q, dq = s.get_state()
     assert np.isfinite(q[70]).all()
     s.close()
+
+
+def test_device_mt19937_bank_is_bit_exact_with_numpy_streams():
+    """dart_seed_mt19937 + device draws == seeding.np_random(seed).uniform(...) for qpos then qvel, through 60 resets
+    of every env (crosses the 624-word regeneration several times), for 1- and 2-word keys."""
+    from dart_env_amd import seeding
+    card = card_for("DartHopper-v1")
+    n = 300
+    seeds = list(range(7, 7 + n))
+    s = st.HipStepper(card, n, precision=64)
+    keys = np.zeros((n, 2), dtype=np.uint32); klen = np.zeros(n, dtype=np.int32)
+    rngs = []
+    for i, sd in enumerate(seeds):
+        w = seeding.int_list_from_bigint(seeding.hash_seed(sd))
+        if i == 5:
+            w = [w[0]]                      # exercise the single-word key path with a hand-made generator
+            r = np.random.RandomState(); r.seed(w)
+        else:
+            r, _ = seeding.np_random(sd)
+        klen[i] = len(w); keys[i, :len(w)] = w
+        rngs.append(r)
+    s.seed_mt19937(keys, klen)
+    rs = np.random.RandomState(0)
+    for it in range(60):
+        mask = (rs.rand(n) < 0.7).astype(np.uint8) if it else None
+        s.reset(mask, None, None, want_obs=False)
+        q, dq = s.get_state()
+        for i in range(n):
+            if mask is None or mask[i]:
+                eq = rngs[i].uniform(low=-.005, high=.005, size=6); ev = rngs[i].uniform(low=-.005, high=.005, size=6)
+                assert np.array_equal(q[i], eq) and np.array_equal(dq[i], ev), (it, i, q[i] - eq, dq[i] - ev)
+    s.close()
+
+
+@pytest.mark.parametrize("tag", ["hopper", "walker2d"])
+def test_vector_env_device_mt19937_matches_reference_fixture(tag):
+    """Default noise mode: generators in HBM, resets inside dart_step -- still the reference's SyncVectorEnv stream."""
+    d = np.load(os.path.join(G, "%s_vector4_seed3.npz" % tag))
+    venv = dart_env_amd.vector.make(IDS[tag], 4, precision=64)
+    assert venv.env.noise == "mt19937" and venv.env.device_noise
+    venv.seed(3)
+    ob = venv.reset()
+    assert np.allclose(ob, d["obs0"], atol=1e-7)
+    for t in range(len(d["done"])):
+        ob, r, done, infos = venv.step(d["actions"][t])
+        assert np.array_equal(done, d["done"][t]), t
+        assert np.allclose(ob, d["obs"][t], rtol=0, atol=5e-6) and np.allclose(r, d["reward"][t], atol=1e-4)
+    venv.close()
+
+
+def test_device_resident_step_with_mt19937_resets_equals_host_buffer_step():
+    """dart_step_device (learner-owned HBM buffers, caller's stream) and dart_step (host arrays) run the same three
+    launches in MT19937 auto-reset mode: identical states, observations and done flags after 120 steps."""
+    import torch
+    from dart_env_amd import seeding
+    card = card_for("DartWalker2d-v1")
+    n = 512
+    keys = np.zeros((n, 2), dtype=np.uint32); klen = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        w = seeding.int_list_from_bigint(seeding.hash_seed(100 + i))
+        klen[i] = len(w); keys[i, :len(w)] = w
+    a_host = st.HipStepper(card, n, precision=64); b_dev = st.HipStepper(card, n, precision=64)
+    for s in (a_host, b_dev):
+        s.configure(st.CFG_AUTORESET, 1); s.seed_mt19937(keys, klen)
+    ob_a = a_host.reset(None, None, None)
+    d_obs = torch.empty((n, card.obs_dim), dtype=torch.float32, device="cuda")
+    d_rew = torch.empty(n, dtype=torch.float32, device="cuda")
+    d_done = torch.empty(n, dtype=torch.uint8, device="cuda"); d_tr = torch.empty(n, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    b_dev.reset_device(0, d_obs.data_ptr(), stream.cuda_stream); stream.synchronize()
+    assert np.array_equal(d_obs.cpu().numpy(), ob_a)
+    rs = np.random.RandomState(5)
+    n_done = 0
+    for t in range(120):
+        act = rs.uniform(-1, 1, (n, card.act_dim)).astype(np.float32)
+        oa, ra, da, ta = a_host.step(act)
+        d_act = torch.from_numpy(act).cuda()
+        b_dev.step_device(d_act.data_ptr(), d_obs.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), d_tr.data_ptr(),
+                          stream.cuda_stream)
+        stream.synchronize()
+        assert np.array_equal(d_done.cpu().numpy().astype(bool), da) and np.array_equal(d_obs.cpu().numpy(), oa), t
+        n_done += int(da.sum())
+    assert n_done > n            # every env went through resets on the device
+    qa, va = a_host.get_state(); qb, vb = b_dev.get_state()
+    assert np.array_equal(qa, qb) and np.array_equal(va, vb)
+    a_host.close(); b_dev.close()

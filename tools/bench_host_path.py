@@ -31,11 +31,24 @@ for _ in range(K):
     venv.step(a)
 dt = time.perf_counter() - t0
 print("DartVectorEnv.step (python surface, philox): %.1f us/step, %.3e env-steps/s" % (dt / K * 1e6, n * K / dt))
-venv2 = dart_env_amd.vector.make("DartHopper-v1", 4096)   # reference-exact MT19937 reset noise drawn on the host
+t0 = time.perf_counter()
+venv2 = dart_env_amd.vector.make("DartHopper-v1", n)   # default: reference-exact MT19937 reset noise, bank in HBM
 venv2.seed(0); venv2.reset()
+print("seed(0) + reset() of %d MT19937 envs: %.2f s" % (n, time.perf_counter() - t0))
+for _ in range(5):
+    venv2.step(a)
+t0 = time.perf_counter(); K = 100
+for _ in range(K):
+    venv2.step(a)
+dt = time.perf_counter() - t0
+print("DartVectorEnv.step (python surface, device mt19937): %.1f us/step, %.3e env-steps/s" % (dt / K * 1e6, n * K / dt))
+venv3 = dart_env_amd.vector.make("DartHopper-v1", 4096, noise="mt19937-host")   # numpy draws on the host
+venv3.seed(0); venv3.reset()
 a2 = a[:4096]
+for _ in range(3):
+    venv3.step(a2)
 t0 = time.perf_counter(); K = 20
 for _ in range(K):
-    venv2.step(a2)
+    venv3.step(a2)
 dt = time.perf_counter() - t0
-print("DartVectorEnv.step (mt19937 host noise, 4096 envs): %.1f us/step, %.3e env-steps/s" % (dt / K * 1e6, 4096 * K / dt))
+print("DartVectorEnv.step (mt19937-host noise, 4096 envs): %.1f us/step, %.3e env-steps/s" % (dt / K * 1e6, 4096 * K / dt))

@@ -869,6 +869,40 @@ __device__ __forceinline__ bool sp_humanwalker_epilogue(const SpatialModel<Real>
   return !ok;
 }
 
+// Walker3d: reward / done (walker3d.py:44-97).  Progress, height, side deviation and the up / forward angles are those
+// of bodynodes[0] (aux_link[0]); aux_link[1..2] are the two penalised dofs; aux_real = {alive, ctrl_cost, limit_penalty,
+// deviation_pen, height_lo, height_hi, penalty_margin}.  Returns done.
+template <class Real>
+__device__ __forceinline__ bool sp_walker3d_epilogue(const SpatialModel<Real>& Md, SpLds<Real>& S, Real pos_before,
+                                                     Real sq_a_sum, Real& reward_out) {
+  const V3<Real> roff = ld3(S.misc);
+  const Real* Lb = S.link + Md.aux_link[0] * SP_LINKF;
+  const Real pos_after = Lb[LK_C] + roff.x, height = Lb[LK_C + 1] + roff.y, side = Lb[LK_C + 2] + roff.z;
+  const Real* R = Lb + LK_R;
+  const V3<Real> up = v3<Real>(R[1], R[4], R[7]), fw = v3<Real>(R[0], R[3], R[6]);
+  const Real ang_u = acos(fmin(fmax(up.y / sqrt(dot(up, up)), Real(-1)), Real(1)));
+  const Real ang_f = acos(fmin(fmax(fw.x / sqrt(dot(fw, fw)), Real(-1)), Real(1)));
+  Real pen = Real(0);
+  for (int k = 1; k <= 2; k++) {
+    const int j = Md.aux_link[k];
+    if ((Md.lower[j] - S.q[j]) > -Md.aux_real[6]) pen += Real(1.5);
+    if ((Md.upper[j] - S.q[j]) < Md.aux_real[6]) pen += Real(1.5);
+  }
+  Real rew = (pos_after - pos_before) * Md.inv_envdt + Md.aux_real[0];
+  rew -= Md.aux_real[1] * sq_a_sum;
+  rew -= Md.aux_real[2] * pen;
+  rew -= Md.aux_real[3] * fabs(side);
+  bool ok = true;
+  for (int i = 0; i < Md.n; i++) {
+    ok = ok && isfinite(S.q[i]) && isfinite(S.dq[i]) && (fabs(S.dq[i]) < Md.s_max);
+    if (i >= 2) ok = ok && (fabs(S.q[i]) < Md.s_max);
+  }
+  ok = ok && (height > Md.aux_real[4]) && (height < Md.aux_real[5]) && (fabs(ang_u) < Md.aux_real2[1]) && (fabs(ang_f) < Md.aux_real2[1]);
+  if (!ok) rew = Real(0);
+  reward_out = rew;
+  return !ok;
+}
+
 template <class Real>
 __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds<Real>& S, const int* cflags, float* __restrict__ o, int lane) {
   const int n = Md.n;
@@ -878,7 +912,7 @@ __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds
   }
   if (lane >= 1 && lane < n) o[lane - 1] = (float)S.q[lane];
   if (lane < n) o[n - 1 + lane] = (float)fmin(fmax(S.dq[lane], -Md.v_clip), Md.v_clip);
-  if (lane < 2) o[2 * n - 1 + lane] = (float)cflags[lane];
+  if (Md.task == 4 && lane < 2) o[2 * n - 1 + lane] = (float)cflags[lane];   // foot-contact flags (human_walker.py:146)
 }
 
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
@@ -901,17 +935,17 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
   Real* sh_scal = S.misc + 8;
   if (lane < n) { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; S.tau[lane] = Real(0); }
   __syncthreads();
-  Real abs_sum = Real(0);
+  Real abs_sum = Real(0), sq_sum = Real(0);
   if (lane == 0) {
     for (int k = 0; k < Md.act_dim; k++) {
       const Real a = (Real)actions[e * Md.act_dim + k];
-      abs_sum += fabs(a);
+      abs_sum += fabs(a); sq_sum += a * a;
       Real cl = (a > Md.act_hi[k]) ? Md.act_hi[k] : a;
       cl = (cl < Md.act_lo[k]) ? Md.act_lo[k] : cl;
       S.tau[Md.act_dof0 + k] = cl * Md.act_scale[k];
     }
     sp_kinematics<Real>(Md, S);
-    sh_scal[0] = (Md.task == 4) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : Real(0);   // posbefore
+    sh_scal[0] = (Md.task != 0) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : Real(0);   // posbefore
     cflags[0] = 0; cflags[1] = 0;
   }
   __syncthreads();
@@ -924,6 +958,7 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
     Real rew = Real(0);
     bool task_done = false;
     if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, init_h[e], cflags, rew);
+    else if (Md.task == 3) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     int el = elapsed[e] + 1;
     const bool trunc = (Md.max_steps > 0) && (el >= Md.max_steps);
     dn = task_done || trunc; tr = trunc && !task_done;

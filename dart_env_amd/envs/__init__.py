@@ -2,3 +2,4 @@ from .dart_env import BatchedDartEnv  # noqa: F401
 from .hopper import DartHopperEnv  # noqa: F401
 from .walker2d import DartWalker2dEnv  # noqa: F401
 from .human_walker import DartHumanWalkerEnv  # noqa: F401
+from .walker3d import DartWalker3dEnv  # noqa: F401

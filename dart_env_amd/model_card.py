@@ -88,6 +88,7 @@ class TaskSpec:
     reset_noise: float = 0.005
     reset_noise_vel: float = 0.005
     aux_body_names: List[str] = field(default_factory=list)
+    aux_ints: List[int] = field(default_factory=list)   # stored in aux_body[] after the named bodies
     aux_real: List[float] = field(default_factory=list)
     aux_real2: List[float] = field(default_factory=list)
     contact_cfm: Optional[float] = None   # None -> the model's DART cfm (1e-9)
@@ -119,7 +120,17 @@ HUMANWALKER = TaskSpec(
     reset_noise=0.005, reset_noise_vel=0.05, aux_body_names=["pelvis", "head", "l-foot", "r-foot"],
     aux_real=[1.0, 2.0, 0.5, 3.0, -0.2, 1.0, 1.3, 0.4], aux_real2=[0.9], contact_cfm=1e-4)
 
-TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, HUMANWALKER)}
+# DartWalker3d-v1 -- reference gym/envs/dart/walker3d.py:10-15 (15 actions, scale 100 / 150 for the waist / 20 for the
+# ankles, obs 41, frame_skip 4), :45-92 (reward, done; quantities of bodynodes[0] = the translational carrier body),
+# :68 (limit penalty on q[-3], q[-9] = the two knees), gym/envs/__init__.py:272-276 (1000 steps)
+WALKER3D = TaskSpec(
+    env_id="DartWalker3d-v1", model="walker3d", task=TASK_WALKER3D, frame_skip=4, act_dim=15, obs_dim=41, act_dof0=6,
+    act_scale=[150.0] * 3 + [100.0] * 4 + [20.0] * 2 + [100.0] * 4 + [20.0] * 2,
+    max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1, height_lo=1.05, height_hi=2.0,
+    angle_max=0.84, contact_bodies=["h_foot", "h_foot_left"], alive_bonus=1.0, ctrl_cost=1e-3, limit_penalty=0.2,
+    aux_body_names=["h_torso_aux"], aux_ints=[18, 12], aux_real=[1e-3], contact_cfm=1e-4)
+
+TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER)}
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 
@@ -196,6 +207,8 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         names = [b.name for b in model.bodies]
         for k, nm in enumerate(task.aux_body_names):
             c.aux_body[k] = names.index(nm)
+        for k, v in enumerate(task.aux_ints):
+            c.aux_body[len(task.aux_body_names) + k] = v
         for k, v in enumerate(task.aux_real):
             c.aux_real[k] = v
         for k, v in enumerate(task.aux_real2):

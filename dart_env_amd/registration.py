@@ -1,4 +1,4 @@
-"""``gym.make`` for the Dart ids this package serves (reference gym/envs/__init__.py:206-211, 265-270;
+"""``gym.make`` for the Dart ids this package serves (reference gym/envs/__init__.py:206-211, 265-276, 284-288;
 gym/envs/registration.py:81-97: the registry wraps the env in TimeLimit(max_episode_steps))."""
 from .model_card import TASKS
 from .wrappers import TimeLimit
@@ -18,9 +18,9 @@ def spec(env_id):
 
 
 def make(env_id, **kwargs):
-    from .envs import DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv
+    from .envs import DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv, DartWalker3dEnv
     cls = {"DartHopper-v1": DartHopperEnv, "DartWalker2d-v1": DartWalker2dEnv,
-           "DartHumanWalker-v1": DartHumanWalkerEnv}
+           "DartWalker3d-v1": DartWalker3dEnv, "DartHumanWalker-v1": DartHumanWalkerEnv}
     s = spec(env_id)
     env = cls[env_id](**kwargs)
     env.spec = s

@@ -44,7 +44,7 @@ enum {
   DART_TASK_NONE = 0,      /* physics only: obs = [q, dq], reward 0, done 0 */
   DART_TASK_HOPPER = 1,    /* reference gym/envs/dart/hopper.py:36-74   */
   DART_TASK_WALKER2D = 2,  /* reference gym/envs/dart/walker2d.py:22-74 */
-  DART_TASK_WALKER3D = 3,  /* reserved: reference gym/envs/dart/walker3d.py:33-113 */
+  DART_TASK_WALKER3D = 3,  /* reference gym/envs/dart/walker3d.py:33-113 */
   DART_TASK_HUMANWALKER = 4 /* reference gym/envs/dart/human_walker.py:60-165 */
 };
 
@@ -119,7 +119,10 @@ typedef struct DartModelCard {
   /* task-specific extras.  HumanWalker: aux_body = {progress body (bodynodes[1]), head, l-foot, r-foot},
    * aux_real = {target_vel, alive_bonus 2.0, action_pen 0.5, deviation_pen 3.0, height band lo -0.2, hi 1.0,
    *             |q[3]| max 1.3, |q[5]| max 0.4}; angle_max = 2.0 (up/forward), state_abs_max etc. as above;
-   * aux_real2 = {side deviation max 0.9} */
+   * aux_real2 = {side deviation max 0.9}.
+   * Walker3d: aux_body = {bodynodes[0] (progress / height / side / up-forward angles), penalty dof a, penalty dof b}
+   * (walker3d.py:68 `for j in [-3, -9]` resolved to dof indices), limit_penalty = 0.2 * 1.5 per side,
+   * aux_real = {deviation_pen 1e-3}; reward is zeroed when done (walker3d.py:91-92). */
   int32_t aux_body[4];
   double aux_real[8];
   double aux_real2[4];

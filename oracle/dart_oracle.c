@@ -835,9 +835,64 @@ static int humanwalker_step(OracleWorld* w, const double* a, double* obs, double
   return !ok;
 }
 
+/* DartWalker3dEnv.step (walker3d.py:44-97).  All body quantities are those of bodynodes[0] (aux_body[0]). */
+static void walker3d_obs(OracleWorld* w, double* obs) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  for (int i = 1; i < n; i++) obs[i - 1] = w->q[i];
+  for (int i = 0; i < n; i++) {
+    double v = w->dq[i];
+    obs[n - 1 + i] = v < -c->obs_vel_clip ? -c->obs_vel_clip : (v > c->obs_vel_clip ? c->obs_vel_clip : v);
+  }
+}
+static int walker3d_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double tau[MAXN] = {0}, sq = 0;
+  for (int k = 0; k < c->act_dim; k++) {
+    double cl = a[k];
+    if (cl > c->act_high[k]) cl = c->act_high[k];
+    if (cl < c->act_low[k]) cl = c->act_low[k];
+    tau[c->act_dof0 + k] = cl * c->act_scale[k];
+    sq += a[k] * a[k];
+  }
+  double cm[3];
+  oracle_body_com(w, c->aux_body[0], cm);
+  double posbefore = cm[0];
+  for (int f = 0; f < c->frame_skip; f++) { oracle_set_forces(w, tau); oracle_step(w); }
+  oracle_body_com(w, c->aux_body[0], cm);
+  double posafter = cm[0], height = cm[1], side = cm[2];
+  const double* Tb = w->W[w->body_link[c->aux_body[0]]];
+  double up[3] = {Tb[1], Tb[5], Tb[9]}, fw[3] = {Tb[0], Tb[4], Tb[8]};
+  double ang_uwd = acos(up[1] / sqrt(dot3(up, up))), ang_fwd = acos(fw[0] / sqrt(dot3(fw, fw)));
+  double pen = 0;
+  for (int k = 1; k <= 2; k++) {
+    int j = c->aux_body[k];
+    if ((c->lower[j] - w->q[j]) > -c->penalty_margin) pen += 1.5;
+    if ((c->upper[j] - w->q[j]) < c->penalty_margin) pen += 1.5;
+  }
+  double envdt = c->dt * c->frame_skip;
+  double r = (posafter - posbefore) / envdt + c->alive_bonus;
+  r -= c->ctrl_cost * sq;
+  r -= c->limit_penalty * pen;
+  r -= c->aux_real[0] * fabs(side);
+  int ok = 1;
+  for (int i = 0; i < n; i++) {
+    if (!isfinite(w->q[i]) || !isfinite(w->dq[i])) ok = 0;
+    if (i >= 2 && !(fabs(w->q[i]) < c->state_abs_max)) ok = 0;
+    if (!(fabs(w->dq[i]) < c->state_abs_max)) ok = 0;
+  }
+  if (!(height > c->height_lo && height < c->height_hi && fabs(ang_uwd) < c->angle_max && fabs(ang_fwd) < c->angle_max)) ok = 0;
+  if (!ok) r = 0;
+  *reward = r;
+  walker3d_obs(w, obs);
+  return !ok;
+}
+
 int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
   const DartModelCard* c = &w->card;
   if (c->task == DART_TASK_HUMANWALKER) return humanwalker_step(w, a, obs, reward);
+  if (c->task == DART_TASK_WALKER3D) return walker3d_step(w, a, obs, reward);
   int n = w->n;
   double tau[MAXN] = {0};
   double sq = 0;
@@ -889,6 +944,7 @@ int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward
 void oracle_env_obs(OracleWorld* w, double* obs) {
   const DartModelCard* c = &w->card;
   if (c->task == DART_TASK_HUMANWALKER) { int z[2] = {0, 0}; humanwalker_obs(w, z, obs); return; } /* reset_model zeroes contact_info */
+  if (c->task == DART_TASK_WALKER3D) { walker3d_obs(w, obs); return; }
   int n = w->n;
   double cm[3];
   oracle_body_com(w, c->height_body, cm);

@@ -9,14 +9,16 @@ import pytest
 import dart_env_amd
 from dart_env_amd import seeding, spaces
 from dart_env_amd.model_card import card_for
-from dart_env_amd.envs import DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv
+from dart_env_amd.envs import DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv, DartWalker3dEnv
 from dart_env_amd.wrappers import TimeLimit
 from tests.fake_stepper import OracleStepper
 from tests.oracle_lib import OracleWorld
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-IDS = {"hopper": "DartHopper-v1", "walker2d": "DartWalker2d-v1", "humanwalker": "DartHumanWalker-v1"}
-CLS = {"hopper": DartHopperEnv, "walker2d": DartWalker2dEnv, "humanwalker": DartHumanWalkerEnv}
+IDS = {"hopper": "DartHopper-v1", "walker2d": "DartWalker2d-v1", "humanwalker": "DartHumanWalker-v1",
+       "walker3d": "DartWalker3d-v1"}
+CLS = {"hopper": DartHopperEnv, "walker2d": DartWalker2dEnv, "humanwalker": DartHumanWalkerEnv,
+       "walker3d": DartWalker3dEnv}
 
 
 def test_seeding_and_reset_noise_stream():
@@ -46,7 +48,8 @@ def test_box_action_stream():
 
 @pytest.mark.parametrize("tag,fix", [("hopper", "single_seed0"), ("walker2d", "single_seed0"),
                                      ("hopper", "single_seed5_small"), ("walker2d", "single_seed5_small"),
-                                     ("humanwalker", "single_seed0"), ("humanwalker", "single_seed4_small")])
+                                     ("humanwalker", "single_seed0"), ("humanwalker", "single_seed4_small"),
+                                     ("walker3d", "single_seed0"), ("walker3d", "single_seed6_small")])
 def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
     """C restatement of hopper.py:36-74 / walker2d.py:22-74 == the reference's numpy code, fp64 bit-for-bit."""
     d = np.load(os.path.join(G, "%s_%s.npz" % (tag, fix)))
@@ -55,7 +58,7 @@ def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
     rng, _ = seeding.np_random(seed)
     n = w.n
     rv = w.card.reset_noise_vel
-    rtol = 1e-12 if tag == "humanwalker" else 0.0   # numpy sums the 23 |a_k| pairwise, the C loop sequentially
+    rtol = 1e-12 if tag in ("humanwalker", "walker3d") else 0.0   # numpy sums >= 8 terms pairwise, the C loop sequentially
 
     def do_reset():
         w.reset()
@@ -73,7 +76,7 @@ def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
             assert np.array_equal(do_reset(), d["reset_obs"][t])
 
 
-@pytest.mark.parametrize("tag", ["hopper", "walker2d", "humanwalker"])
+@pytest.mark.parametrize("tag", ["hopper", "walker2d", "humanwalker", "walker3d"])
 def test_single_env_facade_vs_reference(tag):
     """make(id): seed -> reset -> step loop reproduces the reference's obs/reward/done (obs cross the ABI as float32)."""
     d = np.load(os.path.join(G, "%s_single_seed0.npz" % tag))

@@ -248,6 +248,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
     k = 0;
     for (int i = 0; i < nl; i++) { M.child_start[i] = k; for (int j = 0; j < nl; j++) if (M.parent[j] == i) M.child_list[k++] = j; }
     M.child_start[nl] = k;
+    for (int i = 0; i < nl; i++) if (M.child_start[i + 1] - M.child_start[i] > 8) return "more than 8 child links on one link";
     for (int i = 0; i < nl; i++) {
       double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       if (M.parent[i] >= 0) {   // parent link frame = parent joint frame * Rpost(parent) (prismatic parents do not rotate)

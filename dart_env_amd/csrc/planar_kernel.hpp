@@ -142,6 +142,13 @@ template <> __device__ __forceinline__ float rcp_<float>(float x) {
   return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
 template <> __device__ __forceinline__ double rcp_<double>(double x) { return 1.0 / x; }
+// reciprocal square root: v_rsq_f32 + one Newton step in fp32; IEEE in fp64
+template <class Real> __device__ __forceinline__ Real rsqrt_(Real x);
+template <> __device__ __forceinline__ float rsqrt_<float>(float x) {
+  const float r = __builtin_amdgcn_rsqf(x);
+  return r * fmaf(-0.5f * x * r, r, 1.5f);
+}
+template <> __device__ __forceinline__ double rsqrt_<double>(double x) { return 1.0 / sqrt(x); }
 template <class Real> __device__ __forceinline__ Real inf_() { return Real(__builtin_huge_valf()); }
 template <class Real> __device__ __forceinline__ Real tol_() { return sizeof(Real) == 4 ? Real(2e-6) : Real(1e-12); }
 

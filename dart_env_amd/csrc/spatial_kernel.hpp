@@ -30,6 +30,7 @@ constexpr int SP_MAXCP = 12;  // contact points (a box face gives up to 4)
 constexpr int SP_MAXM = 36;   // LCP rows (12 contact points x 3; HumanWalker peaks at ~31 active rows)
 constexpr int SP_TRI = SP_MAXM * (SP_MAXM + 1) / 2;   // packed lower triangle of A / of the LDL workspace
 __device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+__device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
 constexpr int SP_LINKF = 49;  // Reals stored per link in LDS
 
 template <class Real>
@@ -99,13 +100,18 @@ struct SpLds {
   int* rfidx;    // [SP_MAXM] friction rows: index of their normal row, else -1
   Real* cpP;     // [SP_MAXCP][4]: contact point (relative coords) + depth
   int* cplink;   // [SP_MAXCP]
+  Real* sinv;    // [n]: 1 / L_jj of the mass-matrix Cholesky factor
   Real* misc;    // [16]: roff(3), scalars
   int* imisc;    // [8]: ncp, m, contact flags
+  int* topo;     // [nl]: (parent + 1) | (dof + 1) << 8 | jtype << 16 -- ancestor walks read this instead of global memory
 };
+__device__ __forceinline__ int topo_parent(int w) { return (w & 0xff) - 1; }
+__device__ __forceinline__ int topo_dof(int w) { return ((w >> 8) & 0xff) - 1; }
+__device__ __forceinline__ int topo_jtype(int w) { return (w >> 16) & 0xff; }
 
 template <class Real>
 __device__ __forceinline__ size_t sp_lds_reals(int nl, int n) {
-  return (size_t)nl * SP_LINKF + 5 * n + n * (n + 1) / 2 + (SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM + SP_MAXCP * 4 + 16;
+  return (size_t)nl * SP_LINKF + 6 * n + n * (n + 1) / 2 + (SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM + SP_MAXCP * 4 + 16;
 }
 
 template <class Real>
@@ -121,16 +127,18 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n) {
   S.b = p; p += SP_MAXM; S.lo = p; p += SP_MAXM; S.hi = p; p += SP_MAXM; S.x = p; p += SP_MAXM; S.r = p; p += SP_MAXM; S.x0 = p; p += SP_MAXM;
   S.cpP = p; p += SP_MAXCP * 4;
   S.misc = p; p += 16;
+  S.sinv = p; p += n;
   S.rdof = (int*)p; p += SP_MAXM * sizeof(int) / sizeof(Real) + 1;
   S.rfidx = (int*)p; p += SP_MAXM * sizeof(int) / sizeof(Real) + 1;
   S.cplink = (int*)p; p += SP_MAXCP * sizeof(int) / sizeof(Real) + 1;
   S.imisc = (int*)p;
+  S.topo = S.imisc + 8;
   return S;
 }
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes) {
-  size_t reals = (size_t)nl * SP_LINKF + 5 * n + (size_t)n * (n + 1) / 2 + (size_t)(SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM +
+  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)n * (n + 1) / 2 + (size_t)(SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM +
                  SP_MAXCP * 4 + 16;
-  return reals * real_bytes + (2 * SP_MAXM + SP_MAXCP + 8) * sizeof(int) + 3 * real_bytes + 64;
+  return reals * real_bytes + (2 * SP_MAXM + SP_MAXCP + 8 + nl) * sizeof(int) + 3 * real_bytes + 64;
 }
 
 // ------------------------------------------------------------------ lane-0 recursions
@@ -189,7 +197,11 @@ __device__ __forceinline__ void sp_kinematics(const SpatialModel<Real>& Md, SpLd
 template <class Real>
 struct LinkConst {
   int parent, jtype, dof, root_trans, pre_ident, post_ident, level;
+  int nchild; unsigned long long children;   // up to 8 child links, one byte each
   Real axis[3], Rpre[9], ppre[3], Rpost[9], ppost[3], mass, com[3], inertia[9];
+  Real damp, stiff, rest;                    // of this link's dof
+  // the same lane also owns dof `lane` (mass-matrix row, limits)
+  int d_link; Real d_diag;                   // link of dof `lane`; dt*damping + dt^2*stiffness
 };
 template <class Real>
 __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md, int i, LinkConst<Real>& c) {
@@ -198,6 +210,14 @@ __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md,
   for (int k = 0; k < 3; k++) { c.axis[k] = Md.axis[i][k]; c.ppre[k] = Md.ppre[i][k]; c.ppost[k] = Md.ppost[i][k]; c.com[k] = Md.com[i][k]; }
   for (int k = 0; k < 9; k++) { c.Rpre[k] = Md.Rpre[i][k]; c.Rpost[k] = Md.Rpost[i][k]; c.inertia[k] = Md.inertia[i][k]; }
   c.mass = Md.mass[i];
+  c.nchild = Md.child_start[i + 1] - Md.child_start[i];
+  c.children = 0ull;
+  for (int k = 0; k < c.nchild && k < 8; k++) c.children |= (unsigned long long)(Md.child_list[Md.child_start[i] + k] & 0xff) << (8 * k);
+  const int d = c.dof >= 0 ? c.dof : 0;
+  c.damp = Md.damp[d]; c.stiff = Md.stiff[d]; c.rest = Md.rest[d];
+  const int dl = i < Md.n ? i : 0;
+  c.d_link = Md.dof_link[dl];
+  c.d_diag = Md.dt * Md.damp[dl] + Md.dt * Md.dt * Md.stiff[dl];
 }
 
 // kinematics + velocity chain + wrench / composite seeds of link i (its parent is complete), constants from registers
@@ -366,14 +386,14 @@ __device__ __forceinline__ void sp_link_dynamics(const SpatialModel<Real>& Md, S
 // parent-centric backward step for link i (all its children are already complete): gather their wrenches and
 // composite bodies, then emit this link's rhs entry
 template <class Real>
-__device__ __forceinline__ void sp_gather_children(const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
+__device__ __forceinline__ void sp_gather_children(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
   Real* Lp = S.link + i * SP_LINKF;
   V3<Real> F = ld3(Lp + LK_F), N = ld3(Lp + LK_N), H = ld3(Lp + LK_H);
   Real mcp = Lp[LK_MC];
   Real I0 = Lp[LK_IC + 0], I1 = Lp[LK_IC + 1], I2 = Lp[LK_IC + 2], I3 = Lp[LK_IC + 3], I4 = Lp[LK_IC + 4], I5 = Lp[LK_IC + 5];
   const V3<Real> jop = ld3(Lp + LK_JO);
-  for (int ci = Md.child_start[i]; ci < Md.child_start[i + 1]; ci++) {
-    const Real* L = S.link + Md.child_list[ci] * SP_LINKF;
+  for (int ci = 0; ci < lc.nchild; ci++) {
+    const Real* L = S.link + (int)((lc.children >> (8 * ci)) & 0xffull) * SP_LINKF;
     const V3<Real> o = ld3(L + LK_JO) - jop, Fc = ld3(L + LK_F);
     F = F + Fc;
     N = N + ld3(L + LK_N) + cross(o, Fc);
@@ -392,11 +412,11 @@ __device__ __forceinline__ void sp_gather_children(const SpatialModel<Real>& Md,
   st3(Lp + LK_F, F); st3(Lp + LK_N, N); st3(Lp + LK_H, H);
   Lp[LK_MC] = mcp;
   Lp[LK_IC + 0] = I0; Lp[LK_IC + 1] = I1; Lp[LK_IC + 2] = I2; Lp[LK_IC + 3] = I3; Lp[LK_IC + 4] = I4; Lp[LK_IC + 5] = I5;
-  const int d = Md.dof[i];
+  const int d = lc.dof;
   if (d >= 0) {
     const V3<Real> a = ld3(Lp + LK_A);
-    const Real Cb = (Md.jtype[i] == 2) ? dot(a, N) : dot(a, F);
-    S.rhs[d] = S.tau[d] - Cb - Md.damp[d] * S.dq[d] - Md.stiff[d] * (S.q[d] + Md.dt * S.dq[d] - Md.rest[d]);
+    const Real Cb = (lc.jtype == 2) ? dot(a, N) : dot(a, F);
+    S.rhs[d] = S.tau[d] - Cb - lc.damp * S.dq[d] - lc.stiff * (S.q[d] + Md.dt * S.dq[d] - lc.rest);
   }
 }
 
@@ -437,13 +457,12 @@ __device__ __forceinline__ void sp_backward_pass(const SpatialModel<Real>& Md, S
 
 // row `d` of the mass matrix (lower part): one lane per dof walks its ancestor chain
 template <class Real>
-__device__ __forceinline__ void sp_mass_row(const SpatialModel<Real>& Md, SpLds<Real>& S, int d) {
-  const int n = Md.n;
-  const int i = Md.dof_link[d];
+__device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int d) {
+  const int i = lc.d_link;
   const Real* L = S.link + i * SP_LINKF;
   const V3<Real> a = ld3(L + LK_A), h = ld3(L + LK_H), jo = ld3(L + LK_JO);
   V3<Real> Lm, K;
-  if (Md.jtype[i] == 2) {
+  if (topo_jtype(S.topo[i]) == 2) {
     Lm = cross(a, h);
     const Real* I = L + LK_IC;
     K = v3<Real>(I[0] * a.x + I[1] * a.y + I[2] * a.z, I[1] * a.x + I[3] * a.y + I[4] * a.z, I[2] * a.x + I[4] * a.y + I[5] * a.z);
@@ -452,61 +471,59 @@ __device__ __forceinline__ void sp_mass_row(const SpatialModel<Real>& Md, SpLds<
     K = cross(h, a);
   }
   for (int k = 0; k < d; k++) S.H[TI(d, k)] = Real(0);
-  for (int j = i; j >= 0; j = Md.parent[j]) {
-    const int dj = Md.dof[j];
+  for (int j = i; j >= 0;) {
+    const int w = S.topo[j];
+    const int dj = topo_dof(w), jcur = j;
+    j = topo_parent(w);
     if (dj < 0) continue;
-    const Real* Lj = S.link + j * SP_LINKF;
+    const Real* Lj = S.link + jcur * SP_LINKF;
     const V3<Real> aj = ld3(Lj + LK_A);
     Real v;
-    if (Md.jtype[j] == 2) v = dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm));
+    if (topo_jtype(w) == 2) v = dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm));
     else v = dot(aj, Lm);
-    if (dj == d) v += Md.dt * Md.damp[d] + Md.dt * Md.dt * Md.stiff[d];
+    if (dj == d) v += lc.d_diag;
     S.H[TI(d, dj)] = v;   // dj <= d because parents come first
   }
 }
 
 // ------------------------------------------------------------------ wave-parallel dense kernels (row-owner scheme)
-// in-place Cholesky of the lower triangle of the n x n matrix M (stride ld, n <= 32): row r is owned by the lane pair
-// (r, r + 32), each taking half of the trailing-update range
+// in-place Cholesky of the packed lower triangle M (n <= 32): row r is owned by the lane pair (r, r + 32), each taking
+// half of the trailing-update range.  Right-looking on the UNSCALED column (u_kj = l_kj d_j): column j is read-only while
+// it is eliminated, so one barrier per column is enough; a final pass scales column j by 1/sqrt(d_j), which leaves the
+// ordinary Cholesky factor below the diagonal, sqrt(d_j) on it and sinv[j] = 1/sqrt(d_j) for the substitutions.
 template <class Real>
-__device__ __forceinline__ void sp_cholesky(Real* M, int n, int ld, int lane) {
+__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane) {
   const int r = lane & 31, half = lane >> 5;
+  const int rbase = TL(r, 0);
   for (int j = 0; j < n; j++) {
     __syncthreads();
-    const Real djj = sqrt(M[TI(j, j)]);
-    const Real inv = Real(1) / djj;
-    __syncthreads();
-    if (lane == j) M[TI(j, j)] = djj;
-    if (half == 0 && r > j && r < n) M[TI(r, j)] *= inv;
-    __syncthreads();
     if (r > j && r < n) {
-      const Real lij = M[TI(r, j)];
+      const Real inv = rcp_<Real>(M[TL(j, j)]);
+      const Real lij = M[rbase + j] * inv;
       const int lo = j + 1, hi = r + 1, mid = (lo + hi) >> 1;
       const int k0 = half ? mid : lo, k1 = half ? hi : mid;
-      for (int k = k0; k < k1; k++) M[TI(r, k)] -= lij * M[TI(k, j)];
+      int kj = TL(k0, j);
+      for (int k = k0; k < k1; k++) { M[rbase + k] -= lij * M[kj]; kj += k + 1; }
     }
   }
   __syncthreads();
+  if (lane < n) sinv[lane] = rsqrt_<Real>(M[TL(lane, lane)]);
+  __syncthreads();
+  if (half == 0 && r < n) {
+    for (int j = 0; j < r; j++) M[rbase + j] *= sinv[j];
+    M[rbase + r] = M[rbase + r] * sinv[r];   // = sqrt(d_r)
+  }
+  __syncthreads();
 }
-// x <- (L L^T)^-1 x for one vector in LDS, column-oriented, lanes own entries
+// x <- L^-T x (backward) for one vector in LDS, column-oriented, lanes own entries
 template <class Real>
-__device__ __forceinline__ void sp_chol_solve(const Real* Lf, int n, int ld, Real* x, int lane, bool forward, bool backward) {
-  if (forward)
-    for (int j = 0; j < n; j++) {
-      __syncthreads();
-      const Real xj = x[j] / Lf[TI(j, j)];
-      __syncthreads();
-      if (lane == j) x[j] = xj;
-      if (lane > j && lane < n) x[lane] -= Lf[TI(lane, j)] * xj;
-    }
-  if (backward)
-    for (int j = n - 1; j >= 0; j--) {
-      __syncthreads();
-      const Real xj = x[j] / Lf[TI(j, j)];
-      __syncthreads();
-      if (lane == j) x[j] = xj;
-      if (lane < j) x[lane] -= Lf[TI(j, lane)] * xj;
-    }
+__device__ __forceinline__ void sp_chol_backsolve(const Real* Lf, const Real* sinv, int n, Real* x, int lane) {
+  for (int j = n - 1; j >= 0; j--) {
+    __syncthreads();
+    const Real xj = x[j] * sinv[j];
+    if (lane == j) x[j] = xj;
+    if (lane < j) x[lane] -= Lf[TL(j, lane)] * xj;
+  }
   __syncthreads();
 }
 
@@ -522,6 +539,7 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
   const bool row = lane < m;
   bool converged = false;
   int it = 0;
+  const int rbase = TL(lane, 0);
   for (; it < max_iter; ++it) {
     const bool fi = row && ((F >> lane) & 1ull), ui = row && ((U >> lane) & 1ull);
     __syncthreads();
@@ -530,51 +548,67 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
     // rhs and masked copy of A
     if (row) {
       Real t = S.b[lane];
-      if (!ZERO_BOUNDS) for (int j = 0; j < m; j++) t -= S.A[TI(lane, j)] * S.x[j];
+      if (!ZERO_BOUNDS) {
+        for (int j = 0; j <= lane; j++) t -= S.A[rbase + j] * S.x[j];
+        int jl = TL(lane + 1, lane);
+        for (int j = lane + 1; j < m; j++) { t -= S.A[jl] * S.x[j]; jl += j + 1; }
+      }
       S.r[lane] = fi ? t : S.x[lane];
-      for (int j = 0; j <= lane; j++) {
+      for (int j = 0; j < lane; j++) {
         const bool fj = (F >> j) & 1ull;
-        S.Lw[TI(lane, j)] = (fi && fj) ? S.A[TI(lane, j)] : (j == lane ? Real(1) : Real(0));
+        S.Lw[rbase + j] = (fi && fj) ? S.A[rbase + j] : Real(0);
+      }
+      S.Lw[rbase + lane] = fi ? S.A[rbase + lane] : Real(1);
+    }
+    __syncthreads();
+    // LDL^T restricted to the free columns (non-free columns are identity: nothing to eliminate); column j is
+    // read-only while it is eliminated (unscaled entries u_kj = l_kj d_j), so one barrier per column
+    {
+      uint64_t Fr = F;
+      while (Fr) {
+        const int j = __builtin_ctzll(Fr);
+        Fr &= Fr - 1;
+        __syncthreads();
+        if (row && lane > j && fi) {
+          const Real lij = S.Lw[rbase + j] * rcp_<Real>(S.Lw[TL(j, j)]);
+          int kj = TL(j + 1, j);
+          for (int k = j + 1; k <= lane; k++) { S.Lw[rbase + k] -= lij * S.Lw[kj]; kj += k + 1; }
+        }
       }
     }
     __syncthreads();
-    // LDL^T restricted to the free columns (non-free columns are identity: nothing to eliminate)
-    for (int j = 0; j < m; j++) {
-      if (!((F >> j) & 1ull)) continue;
-      __syncthreads();
-      const Real dj = S.Lw[TI(j, j)];
-      const Real inv = Real(1) / dj;
-      Real lij = Real(0);
-      if (row && lane > j && fi) { lij = S.Lw[TI(lane, j)] * inv; }
-      __syncthreads();
-      if (row && lane > j && fi) {
-        for (int k = j + 1; k <= lane; k++)
-          if ((F >> k) & 1ull) S.Lw[TI(lane, k)] -= lij * S.Lw[TI(k, j)];
-        S.Lw[TI(lane, j)] = lij;
+    // 1/d_j, then solve L D L^T x = r over the free rows (column oriented; l_ij = u_ij / d_j)
+    const Real invd_own = row ? rcp_<Real>(S.Lw[rbase + lane]) : Real(1);
+    {
+      uint64_t Fr = F;
+      while (Fr) {
+        const int j = __builtin_ctzll(Fr);
+        Fr &= Fr - 1;
+        __syncthreads();
+        const Real xj = S.r[j] * rcp_<Real>(S.Lw[TL(j, j)]);
+        if (row && lane > j && fi) S.r[lane] -= S.Lw[rbase + j] * xj;
       }
     }
     __syncthreads();
-    // solve L D L^T x = r over the free rows (column oriented)
-    for (int j = 0; j < m; j++) {
-      if (!((F >> j) & 1ull)) continue;
-      __syncthreads();
-      const Real xj = S.r[j];
-      if (row && lane > j && fi) S.r[lane] -= S.Lw[TI(lane, j)] * xj;
-    }
-    __syncthreads();
-    if (fi) S.r[lane] /= S.Lw[TI(lane, lane)];
-    for (int j = m - 1; j >= 0; j--) {
-      if (!((F >> j) & 1ull)) continue;
-      __syncthreads();
-      const Real xj = S.r[j];
-      if (row && lane < j && fi) S.r[lane] -= S.Lw[TI(j, lane)] * xj;
+    if (fi) S.r[lane] *= invd_own;
+    {
+      uint64_t Fr = F;
+      while (Fr) {
+        const int j = 63 - __builtin_clzll(Fr);
+        Fr &= ~(1ull << j);
+        __syncthreads();
+        const Real xj = S.r[j];
+        if (row && lane < j && fi) S.r[lane] -= S.Lw[TL(j, lane)] * invd_own * xj;
+      }
     }
     __syncthreads();
     // feasibility of every row
     bool inf = false, gt = false;
     if (row) {
       Real w = -S.b[lane];
-      for (int j = 0; j < m; j++) w += S.A[TI(lane, j)] * S.r[j];
+      for (int j = 0; j <= lane; j++) w += S.A[rbase + j] * S.r[j];
+      int jl = TL(lane + 1, lane);
+      for (int j = lane + 1; j < m; j++) { w += S.A[jl] * S.r[j]; jl += j + 1; }
       const Real ri = S.r[lane], lo = S.lo[lane], hi = S.hi[lane];
       const bool pinned = (pinmask >> lane) & 1ull;
       const bool over = ri > hi + tol * (Real(1) + fabs(hi)), under = ri < lo - tol * (Real(1) + fabs(lo));
@@ -642,14 +676,14 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     __syncthreads();
   }
   for (int lv = nlev - 1; lv >= 0; lv--) {
-    if (lane < nl && lc.level == lv) sp_gather_children<Real>(Md, S, lane);
+    if (lane < nl && lc.level == lv) sp_gather_children<Real>(lc, Md, S, lane);
     __syncthreads();
   }
   SP_TICK(0);
-  if (lane < n) sp_mass_row<Real>(Md, S, lane);
+  if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
   __syncthreads();
   SP_TICK(1);
-  sp_cholesky<Real>(S.H, n, n, lane);
+  sp_cholesky<Real>(S.H, S.sinv, n, lane);
   SP_TICK(2);
 
   // ---- contact points and active limits (lane 0 builds the compact row list)
@@ -729,12 +763,14 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         const V3<Real> dir = kind == 0 ? v3<Real>(0, 1, 0) : (kind == 1 ? v3<Real>(-1, 0, 0) : v3<Real>(0, 0, 1));
         const V3<Real> P = ld3(S.cpP + 4 * cidx);
         Real rel = Real(0);
-        for (int j = S.cplink[cidx]; j >= 0; j = Md.parent[j]) {
-          const int dj = Md.dof[j];
+        for (int j = S.cplink[cidx]; j >= 0;) {
+          const int w = S.topo[j];
+          const int dj = topo_dof(w), jcur = j;
+          j = topo_parent(w);
           if (dj < 0) continue;
-          const Real* Lj = S.link + j * SP_LINKF;
+          const Real* Lj = S.link + jcur * SP_LINKF;
           const V3<Real> aj = ld3(Lj + LK_A);
-          const Real v = (Md.jtype[j] == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj);
+          const Real v = (topo_jtype(w) == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj);
           Jr[dj] = v;
           rel += v * S.dq[dj];
         }
@@ -749,10 +785,12 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     // ---- W = L^-1 [J^T | rhs] : every lane forward-substitutes its own row; row m becomes y = L^-1 rhs
     if (lane <= m) {
       Real* y = S.W + lane * n;
+      const Real* Hk = S.H;            // row k of the packed factor starts at TL(k, 0)
       for (int k = 0; k < n; k++) {
         Real t = y[k];
-        for (int j = 0; j < k; j++) t -= S.H[TI(k, j)] * y[j];
-        y[k] = t / S.H[TI(k, k)];
+        for (int j = 0; j < k; j++) t -= Hk[j] * y[j];
+        y[k] = t * S.sinv[k];
+        Hk += k + 1;
       }
     }
     __syncthreads();
@@ -768,15 +806,21 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     SP_TICK(5);
   }
   if (m > 0) {
-    // ---- A = W W^T (lower), cfm on the diagonal
-    if (lane < m) {
-      const Real* wi = S.W + lane * n;
-      for (int k = 0; k <= lane; k++) {
+    // ---- A = W W^T (lower), cfm on the diagonal.  The m(m+1)/2 entries are dealt round-robin to the 64 lanes
+    // (row-per-lane would leave the last lane with m dot products and the first with one).
+    {
+      const int ntri = m * (m + 1) / 2;
+      const Real cfm1 = Md.cfm1, ccfm1 = Md.ccfm1;
+      int i = 0, base = 0;   // entry e = base + k with base = i(i+1)/2
+      for (int e = lane; e < ntri; e += 64) {
+        while (base + i + 1 <= e) { base += i + 1; i++; }
+        const int k = e - base;
+        const Real* wi = S.W + i * n;
         const Real* wk = S.W + k * n;
         Real t = Real(0);
         for (int j = 0; j < n; j++) t += wi[j] * wk[j];
-        if (k == lane) t *= (S.rdof[lane] >= 0) ? Md.cfm1 : Md.ccfm1;
-        S.A[TI(lane, k)] = t;
+        if (k == i) t *= (S.rdof[i] >= 0) ? cfm1 : ccfm1;
+        S.A[e] = t;   // TI(i, k) == e for k <= i
       }
     }
     __syncthreads();
@@ -828,7 +872,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     S.rhs[lane] = u;
   }
   __syncthreads();
-  sp_chol_solve<Real>(S.H, n, n, S.rhs, lane, false, true);
+  sp_chol_backsolve<Real>(S.H, S.sinv, n, S.rhs, lane);
   if (lane < n) S.vs[lane] = S.dq[lane] + S.rhs[lane];
   SP_TICK(9);
   __syncthreads();
@@ -934,6 +978,7 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
   int* cflags = S.imisc + 2;
   Real* sh_scal = S.misc + 8;
   if (lane < n) { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; S.tau[lane] = Real(0); }
+  if (lane < Md.nl) S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16);
   __syncthreads();
   Real abs_sum = Real(0), sq_sum = Real(0);
   if (lane == 0) {

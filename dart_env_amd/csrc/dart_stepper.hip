@@ -240,15 +240,35 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
       depth[i] = M.parent[i] < 0 ? 0 : depth[M.parent[i]] + 1;
       if (depth[i] > maxd) maxd = depth[i];
     }
-    M.nlevels = maxd + 1;
-    for (int i = 0; i < nl; i++) M.link_level[i] = depth[i];
+    M.nrounds = 0;
+    while ((1 << M.nrounds) < maxd + 1) M.nrounds++;
+    if (M.nrounds > SP_ROUNDS) return "tree deeper than 64 links";
+    for (int i = 0; i < nl; i++) {
+      M.anc[i][0] = M.parent[i];
+      for (int r = 1; r < SP_ROUNDS; r++) M.anc[i][r] = M.anc[i][r - 1] < 0 ? -1 : M.anc[M.anc[i][r - 1]][r - 1];
+    }
     int k = 0;
-    for (int lv = 0; lv <= maxd; lv++) { M.level_start[lv] = k; for (int i = 0; i < nl; i++) if (depth[i] == lv) M.level_link[k++] = i; }
-    M.level_start[maxd + 1] = k;
-    k = 0;
     for (int i = 0; i < nl; i++) { M.child_start[i] = k; for (int j = 0; j < nl; j++) if (M.parent[j] == i) M.child_list[k++] = j; }
     M.child_start[nl] = k;
     for (int i = 0; i < nl; i++) if (M.child_start[i + 1] - M.child_start[i] > 8) return "more than 8 child links on one link";
+    // groups: parent p and its only child i share their joint origin for every q when p is a massless carrier whose
+    // own motion does not move the child's joint frame origin (revolute, weld, or a root translation folded into roff)
+    for (int i = 0; i < nl; i++) M.group_leader[i] = i;
+    for (int i = nl - 1; i > 0; i--) {
+      const int p = M.parent[i];
+      if (p < 0) continue;
+      const bool still = M.jtype[p] == 2 || M.jtype[p] == 0 || (M.jtype[p] == 1 && M.root_trans[p]);
+      if (M.mass[p] == (Real)0 && M.child_start[p + 1] - M.child_start[p] == 1 && M.pre_ident[i] && M.post_ident[p] && still)
+        M.group_leader[p] = M.group_leader[i];
+    }
+    int gd[SP_MAXL], maxg = 0;
+    for (int i = 0; i < nl; i++) {
+      const int p = M.parent[i];
+      gd[i] = p < 0 ? 0 : (M.group_leader[p] == M.group_leader[i] ? gd[p] : gd[p] + 1);
+      if (gd[i] > maxg) maxg = gd[i];
+    }
+    for (int i = 0; i < nl; i++) M.group_level[i] = M.group_leader[i] == i ? gd[i] : -1;
+    M.n_group_levels = maxg + 1;
     for (int i = 0; i < nl; i++) {
       double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       if (M.parent[i] >= 0) {   // parent link frame = parent joint frame * Rpost(parent) (prismatic parents do not rotate)

@@ -31,15 +31,20 @@ constexpr int SP_MAXM = 36;   // LCP rows (12 contact points x 3; HumanWalker pe
 constexpr int SP_TRI = SP_MAXM * (SP_MAXM + 1) / 2;   // packed lower triangle of A / of the LDL workspace
 __device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 __device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
-constexpr int SP_LINKF = 49;  // Reals stored per link in LDS
+constexpr int SP_LINKF = 37;  // Reals stored per link in LDS
+constexpr int SP_ROUNDS = 6;  // pointer-jumping rounds: trees up to 64 links deep
 
 template <class Real>
 struct SpatialModel {
   int nl, n, nshapes;
   int parent[SP_MAXL], jtype[SP_MAXL], dof[SP_MAXL], root_trans[SP_MAXL];
   int pre_ident[SP_MAXL], post_ident[SP_MAXL];   // 1: the fixed transform is the identity (carriers of expanded joints)
-  int link_level[SP_MAXL];
-  int nlevels, level_start[SP_MAXL + 1], level_link[SP_MAXL];   // links grouped by tree depth (independent within a level)
+  int nrounds;                       // ceil(log2(tree depth)): pointer-jumping rounds of the forward pass
+  int anc[SP_MAXL][SP_ROUNDS];       // anc[i][k] = 2^k-th ancestor of link i, -1 beyond the root
+  // backward pass: links of one expanded joint share their joint origin, so their composite bodies are identical;
+  // only the group's last link (the leader, the one that carries the mass) gathers, level by level over GROUPS
+  int group_leader[SP_MAXL], group_level[SP_MAXL];   // group_level: depth of the group for leaders, -1 for the others
+  int n_group_levels;
   int child_start[SP_MAXL + 1], child_list[SP_MAXL];            // children of every link
   Real axis[SP_MAXL][3];
   Real root_axis_world[SP_MAXL][3];   // world axis of the root-chain prismatic links (constant)
@@ -84,8 +89,7 @@ template <class Real> __device__ __forceinline__ void mulRR(const Real* A, const
 }
 
 // LDS layout of one link (offsets in Reals)
-enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_OM = 18, LK_AL = 21, LK_VO = 24, LK_AO = 27, LK_C = 30, LK_F = 33,
-       LK_N = 36, LK_MC = 39, LK_H = 40, LK_IC = 43 };
+enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_C = 18, LK_F = 21, LK_N = 24, LK_MC = 27, LK_H = 28, LK_IC = 31 };
 
 template <class Real>
 struct SpLds {
@@ -103,6 +107,7 @@ struct SpLds {
   Real* sinv;    // [n]: 1 / L_jj of the mass-matrix Cholesky factor
   Real* misc;    // [16]: roff(3), scalars
   int* imisc;    // [8]: ncp, m, contact flags
+  unsigned long long* ticks;   // [10] phase cycle counters of this env-step (diagnostics, only touched when stats are on)
   int* topo;     // [nl]: (parent + 1) | (dof + 1) << 8 | jtype << 16 -- ancestor walks read this instead of global memory
 };
 __device__ __forceinline__ int topo_parent(int w) { return (w & 0xff) - 1; }
@@ -133,12 +138,13 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n) {
   S.cplink = (int*)p; p += SP_MAXCP * sizeof(int) / sizeof(Real) + 1;
   S.imisc = (int*)p;
   S.topo = S.imisc + 8;
+  S.ticks = (unsigned long long*)(((size_t)(S.topo + nl) + 7) & ~(size_t)7);
   return S;
 }
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes) {
   size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)n * (n + 1) / 2 + (size_t)(SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM +
                  SP_MAXCP * 4 + 16;
-  return reals * real_bytes + (2 * SP_MAXM + SP_MAXCP + 8 + nl) * sizeof(int) + 3 * real_bytes + 64;
+  return reals * real_bytes + (2 * SP_MAXM + SP_MAXCP + 8 + nl) * sizeof(int) + 3 * real_bytes + 64 + 10 * sizeof(unsigned long long);
 }
 
 // ------------------------------------------------------------------ lane-0 recursions
@@ -196,9 +202,12 @@ __device__ __forceinline__ void sp_kinematics(const SpatialModel<Real>& Md, SpLd
 // per-link model constants, held in the registers of the lane that owns the link for the whole kernel
 template <class Real>
 struct LinkConst {
-  int parent, jtype, dof, root_trans, pre_ident, post_ident, level;
-  int nchild; unsigned long long children;   // up to 8 child links, one byte each
+  int parent, jtype, dof, root_trans;
+  int anc[SP_ROUNDS];
+  int group_leader, group_level;
+  int nchild; unsigned long long children;   // leaders: the leaders of up to 8 child groups, one byte each
   Real axis[3], Rpre[9], ppre[3], Rpost[9], ppost[3], mass, com[3], inertia[9];
+  Real axr[3], cpost[3];                     // Rpost^T axis, Rpost^T ppost: world axis / joint origin from the link frame
   Real damp, stiff, rest;                    // of this link's dof
   // the same lane also owns dof `lane` (mass-matrix row, limits)
   int d_link; Real d_diag;                   // link of dof `lane`; dt*damping + dt^2*stiffness
@@ -206,13 +215,19 @@ struct LinkConst {
 template <class Real>
 __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md, int i, LinkConst<Real>& c) {
   c.parent = Md.parent[i]; c.jtype = Md.jtype[i]; c.dof = Md.dof[i]; c.root_trans = Md.root_trans[i];
-  c.pre_ident = Md.pre_ident[i]; c.post_ident = Md.post_ident[i]; c.level = Md.link_level[i];
+  for (int k = 0; k < SP_ROUNDS; k++) c.anc[k] = Md.anc[i][k];
+  c.group_leader = Md.group_leader[i]; c.group_level = Md.group_level[i];
   for (int k = 0; k < 3; k++) { c.axis[k] = Md.axis[i][k]; c.ppre[k] = Md.ppre[i][k]; c.ppost[k] = Md.ppost[i][k]; c.com[k] = Md.com[i][k]; }
   for (int k = 0; k < 9; k++) { c.Rpre[k] = Md.Rpre[i][k]; c.Rpost[k] = Md.Rpost[i][k]; c.inertia[k] = Md.inertia[i][k]; }
+  for (int k = 0; k < 3; k++) {
+    c.axr[k] = c.Rpost[k] * c.axis[0] + c.Rpost[3 + k] * c.axis[1] + c.Rpost[6 + k] * c.axis[2];
+    c.cpost[k] = c.Rpost[k] * c.ppost[0] + c.Rpost[3 + k] * c.ppost[1] + c.Rpost[6 + k] * c.ppost[2];
+  }
   c.mass = Md.mass[i];
   c.nchild = Md.child_start[i + 1] - Md.child_start[i];
   c.children = 0ull;
-  for (int k = 0; k < c.nchild && k < 8; k++) c.children |= (unsigned long long)(Md.child_list[Md.child_start[i] + k] & 0xff) << (8 * k);
+  for (int k = 0; k < c.nchild && k < 8; k++)
+    c.children |= (unsigned long long)(Md.group_leader[Md.child_list[Md.child_start[i] + k]] & 0xff) << (8 * k);
   const int d = c.dof >= 0 ? c.dof : 0;
   c.damp = Md.damp[d]; c.stiff = Md.stiff[d]; c.rest = Md.rest[d];
   const int dl = i < Md.n ? i : 0;
@@ -220,61 +235,103 @@ __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md,
   c.d_diag = Md.dt * Md.damp[dl] + Md.dt * Md.dt * Md.stiff[dl];
 }
 
-// kinematics + velocity chain + wrench / composite seeds of link i (its parent is complete), constants from registers
+template <class Real> __device__ __forceinline__ V3<Real> shfl3(V3<Real> v, int src) {
+  return {__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src)};
+}
+
+// Forward pass of the whole tree in O(log depth) wave steps (all 64 lanes call; lane i owns link i).
+//   1. every lane builds its link's transform relative to the parent link,
+//   2. pointer jumping composes them into world transforms: round k folds in the 2^k-th ancestor's partial product,
+//      fetched from that lane's registers with ds_bpermute (__shfl) -- no LDS traffic, no level-by-level serialisation,
+//   3. angular velocity, velocity-product angular and linear accelerations are path sums of per-link terms
+//      (w_i = a_i qd_i;  t_i = om_parent x w_i;  b_i = the centripetal / Coriolis increment): three more prefix sums,
+//   4. the link's wrench and composite-body seeds about its own joint origin go to LDS.
 template <class Real>
-__device__ __forceinline__ void sp_link_forward(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
-  Real* L = S.link + i * SP_LINKF;
-  Real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  V3<Real> pp = v3<Real>(0, 0, 0), omp = pp, alp = pp, vop = pp, aop = pp;
-  if (lc.parent >= 0) {
-    const Real* Lp = S.link + lc.parent * SP_LINKF;
-    for (int k = 0; k < 9; k++) Rp[k] = Lp[LK_R + k];
-    pp = ld3(Lp + LK_P); omp = ld3(Lp + LK_OM); alp = ld3(Lp + LK_AL); vop = ld3(Lp + LK_VO); aop = ld3(Lp + LK_AO);
-  }
-  Real Rj[9];
-  V3<Real> pj = pp;
-  if (lc.pre_ident) { for (int k = 0; k < 9; k++) Rj[k] = Rp[k]; }
-  else { mulRR(Rp, lc.Rpre, Rj); pj = pp + mulR(Rp, ld3(lc.ppre)); }
+__device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane) {
+  const bool live = lane < Md.nl;
+  const bool rev = lc.jtype == 2, slide = lc.jtype == 1 && !lc.root_trans;
+  const Real qv = (live && lc.dof >= 0) ? S.q[lc.dof] : Real(0), qd = (live && lc.dof >= 0) ? S.dq[lc.dof] : Real(0);
   const V3<Real> ax = ld3(lc.axis);
-  const V3<Real> a = mulR(Rj, ax);
-  Real Rm[9];
-  V3<Real> pm = pj;
-  const Real qv = lc.dof >= 0 ? S.q[lc.dof] : Real(0), qd = lc.dof >= 0 ? S.dq[lc.dof] : Real(0);
-  if (lc.jtype == 2) {
-    Real sn, cs;
-    sincos_<Real>(qv, sn, cs);
+  Real R[9];
+  V3<Real> p;
+  {
+    Real sn = Real(0), cs = Real(1);
+    if (rev) sincos_<Real>(qv, sn, cs);
     const Real v = Real(1) - cs;
-    Real Rq[9] = {ax.x * ax.x * v + cs,        ax.x * ax.y * v - ax.z * sn, ax.x * ax.z * v + ax.y * sn,
-                  ax.y * ax.x * v + ax.z * sn, ax.y * ax.y * v + cs,        ax.y * ax.z * v - ax.x * sn,
-                  ax.z * ax.x * v - ax.y * sn, ax.z * ax.y * v + ax.x * sn, ax.z * ax.z * v + cs};
-    mulRR(Rj, Rq, Rm);
-  } else {
-    for (int k = 0; k < 9; k++) Rm[k] = Rj[k];
-    if (lc.jtype == 1 && !lc.root_trans) pm = pj + a * qv;
+    const Real Rq[9] = {ax.x * ax.x * v + cs,        ax.x * ax.y * v - ax.z * sn, ax.x * ax.z * v + ax.y * sn,
+                        ax.y * ax.x * v + ax.z * sn, ax.y * ax.y * v + cs,        ax.y * ax.z * v - ax.x * sn,
+                        ax.z * ax.x * v - ax.y * sn, ax.z * ax.y * v + ax.x * sn, ax.z * ax.z * v + cs};
+    Real T[9];
+    mulRR(Rq, lc.Rpost, T);
+    V3<Real> t = mulR(Rq, ld3(lc.ppost));
+    if (slide) t = t + ax * qv;
+    mulRR(lc.Rpre, T, R);
+    p = ld3(lc.ppre) + mulR(lc.Rpre, t);
+    if (!live) { for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? Real(1) : Real(0); p = v3<Real>(0, 0, 0); }
   }
-  Real Ri[9];
-  V3<Real> pi = pm;
-  if (lc.post_ident) { for (int k = 0; k < 9; k++) Ri[k] = Rm[k]; }
-  else { mulRR(Rm, lc.Rpost, Ri); pi = pm + mulR(Rm, ld3(lc.ppost)); }
-  const V3<Real> c = pi + mulR(Ri, ld3(lc.com));
-  // velocities / velocity-product accelerations
-  const V3<Real> r = pj - pp;
-  const V3<Real> vj = vop + cross(omp, r);
-  const V3<Real> aj = aop + cross(alp, r) + cross(omp, cross(omp, r));
-  V3<Real> om = omp, al = alp, vo, ao;
-  const V3<Real> sv = pi - pj;
-  if (lc.jtype == 2) {
-    om = omp + a * qd;
-    al = alp + cross(omp, a * qd);
-    vo = vj + cross(om, sv);
-    ao = aj + cross(al, sv) + cross(om, cross(om, sv));
-  } else {
-    vo = vj + cross(omp, sv) + a * qd;
-    ao = aj + cross(alp, sv) + cross(omp, cross(omp, sv)) + cross(omp, a * qd) * Real(2);
+  const int nr = Md.nrounds;
+#pragma unroll
+  for (int k = 0; k < SP_ROUNDS; k++) {
+    if (k < nr) {
+      const int hop = lc.anc[k], src = hop >= 0 ? hop : lane;
+      Real Rh[9];
+      for (int c = 0; c < 9; c++) Rh[c] = __shfl(R[c], src);
+      const V3<Real> ph = shfl3(p, src);
+      if (hop >= 0) {
+        Real Rn[9];
+        mulRR(Rh, R, Rn);
+        p = ph + mulR(Rh, p);
+        for (int c = 0; c < 9; c++) R[c] = Rn[c];
+      }
+    }
   }
-  for (int k = 0; k < 9; k++) L[LK_R + k] = Ri[k];
-  st3(L + LK_P, pi); st3(L + LK_JO, pj); st3(L + LK_A, a); st3(L + LK_C, c);
-  st3(L + LK_OM, om); st3(L + LK_AL, al); st3(L + LK_VO, vo); st3(L + LK_AO, ao);
+  const V3<Real> a = mulR(R, ld3(lc.axr));
+  V3<Real> pj = p - mulR(R, ld3(lc.cpost));
+  if (slide) pj = pj - a * qv;
+  const V3<Real> c = p + mulR(R, ld3(lc.com));
+  // angular velocity
+  const V3<Real> w = rev ? a * qd : v3<Real>(0, 0, 0);
+  V3<Real> om = w;
+#pragma unroll
+  for (int k = 0; k < SP_ROUNDS; k++) {
+    if (k < nr) {
+      const int hop = lc.anc[k];
+      const V3<Real> t = shfl3(om, hop >= 0 ? hop : lane);
+      if (hop >= 0) om = om + t;
+    }
+  }
+  const V3<Real> omp = om - w;
+  // velocity-product angular acceleration
+  const V3<Real> ta = rev ? cross(omp, w) : v3<Real>(0, 0, 0);
+  V3<Real> al = ta;
+#pragma unroll
+  for (int k = 0; k < SP_ROUNDS; k++) {
+    if (k < nr) {
+      const int hop = lc.anc[k];
+      const V3<Real> t = shfl3(al, hop >= 0 ? hop : lane);
+      if (hop >= 0) al = al + t;
+    }
+  }
+  const V3<Real> alp = al - ta;
+  // velocity-product linear acceleration of the link origin
+  V3<Real> pp = shfl3(p, lc.parent >= 0 ? lc.parent : lane);
+  if (lc.parent < 0) pp = v3<Real>(0, 0, 0);
+  const V3<Real> r = pj - pp, sv = p - pj;
+  V3<Real> ao = cross(alp, r) + cross(omp, cross(omp, r));
+  if (rev) ao = ao + cross(al, sv) + cross(om, cross(om, sv));
+  else ao = ao + cross(alp, sv) + cross(omp, cross(omp, sv)) + cross(omp, a * qd) * Real(2);
+#pragma unroll
+  for (int k = 0; k < SP_ROUNDS; k++) {
+    if (k < nr) {
+      const int hop = lc.anc[k];
+      const V3<Real> t = shfl3(ao, hop >= 0 ? hop : lane);
+      if (hop >= 0) ao = ao + t;
+    }
+  }
+  if (!live) return;
+  Real* L = S.link + lane * SP_LINKF;
+  for (int k = 0; k < 9; k++) L[LK_R + k] = R[k];
+  st3(L + LK_P, p); st3(L + LK_JO, pj); st3(L + LK_A, a); st3(L + LK_C, c);
   // wrench and composite seeds about the joint origin
   const Real m = lc.mass;
   const V3<Real> dj = c - pj;
@@ -282,10 +339,10 @@ __device__ __forceinline__ void sp_link_forward(const LinkConst<Real>& lc, const
   Real Iw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (m > Real(0)) {
     Real RI[9];
-    mulRR(Ri, lc.inertia, RI);
+    mulRR(R, lc.inertia, RI);
     for (int x = 0; x < 3; x++)
-      for (int y = 0; y < 3; y++) Iw[3 * x + y] = RI[3 * x] * Ri[3 * y] + RI[3 * x + 1] * Ri[3 * y + 1] + RI[3 * x + 2] * Ri[3 * y + 2];
-    const V3<Real> dc = c - pi;
+      for (int y = 0; y < 3; y++) Iw[3 * x + y] = RI[3 * x] * R[3 * y] + RI[3 * x + 1] * R[3 * y + 1] + RI[3 * x + 2] * R[3 * y + 2];
+    const V3<Real> dc = c - p;
     const V3<Real> ac = ao + cross(al, dc) + cross(om, cross(om, dc));
     f = (ac - ld3(Md.g)) * m;
     nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
@@ -315,76 +372,8 @@ __device__ __forceinline__ void sp_root_offset(const SpatialModel<Real>& Md, SpL
   st3(S.misc, roff);
 }
 
-// serial chain (lane 0): angular / linear velocities and velocity-product accelerations of every link origin
-template <class Real>
-__device__ __forceinline__ void sp_velocity_chain(const SpatialModel<Real>& Md, SpLds<Real>& S, int only_link = -1) {
-  for (int i = (only_link >= 0 ? only_link : 0); i < (only_link >= 0 ? only_link + 1 : Md.nl); i++) {
-    Real* L = S.link + i * SP_LINKF;
-    const int p = Md.parent[i];
-    V3<Real> omp = v3<Real>(0, 0, 0), alp = omp, vop = omp, aop = omp, pp = omp;
-    if (p >= 0) {
-      const Real* Lp = S.link + p * SP_LINKF;
-      omp = ld3(Lp + LK_OM); alp = ld3(Lp + LK_AL); vop = ld3(Lp + LK_VO); aop = ld3(Lp + LK_AO); pp = ld3(Lp + LK_P);
-    }
-    const V3<Real> pj = ld3(L + LK_JO), a = ld3(L + LK_A), pi = ld3(L + LK_P);
-    const V3<Real> r = pj - pp;
-    const V3<Real> vj = vop + cross(omp, r);
-    const V3<Real> aj = aop + cross(alp, r) + cross(omp, cross(omp, r));
-    const int d = Md.dof[i];
-    const Real qd = d >= 0 ? S.dq[d] : Real(0);
-    V3<Real> om = omp, al = alp;
-    const V3<Real> s = pi - pj;
-    V3<Real> vo, ao;
-    if (Md.jtype[i] == 2) {
-      om = omp + a * qd;
-      al = alp + cross(omp, a * qd);
-      vo = vj + cross(om, s);
-      ao = aj + cross(al, s) + cross(om, cross(om, s));
-    } else {
-      vo = vj + cross(omp, s) + a * qd;
-      ao = aj + cross(alp, s) + cross(omp, cross(omp, s)) + cross(omp, a * qd) * Real(2);
-    }
-    st3(L + LK_OM, om); st3(L + LK_AL, al); st3(L + LK_VO, vo); st3(L + LK_AO, ao);
-  }
-}
-
-// per-link (lane = link, independent): wrench and composite-body seeds about the link's own joint origin
-template <class Real>
-__device__ __forceinline__ void sp_link_dynamics(const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
-  Real* L = S.link + i * SP_LINKF;
-  const V3<Real> grav = ld3(Md.g);
-  const V3<Real> pj = ld3(L + LK_JO), pi = ld3(L + LK_P), c = ld3(L + LK_C);
-  const V3<Real> om = ld3(L + LK_OM), al = ld3(L + LK_AL), ao = ld3(L + LK_AO);
-  const Real m = Md.mass[i];
-  const V3<Real> dj = c - pj;
-  V3<Real> f = v3<Real>(0, 0, 0), nrm = f;
-  Real Iw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (m > Real(0)) {
-    const Real* R = L + LK_R;
-    Real RI[9];
-    mulRR(R, Md.inertia[i], RI);
-    for (int x = 0; x < 3; x++)
-      for (int y = 0; y < 3; y++) Iw[3 * x + y] = RI[3 * x] * R[3 * y] + RI[3 * x + 1] * R[3 * y + 1] + RI[3 * x + 2] * R[3 * y + 2];
-    const V3<Real> dc = c - pi;
-    const V3<Real> ac = ao + cross(al, dc) + cross(om, cross(om, dc));
-    f = (ac - grav) * m;
-    nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
-  }
-  st3(L + LK_F, f);
-  st3(L + LK_N, nrm + cross(dj, f));
-  L[LK_MC] = m;
-  st3(L + LK_H, dj * m);
-  const Real d2 = dot(dj, dj);
-  L[LK_IC + 0] = Iw[0] + m * (d2 - dj.x * dj.x);
-  L[LK_IC + 1] = Iw[1] - m * dj.x * dj.y;
-  L[LK_IC + 2] = Iw[2] - m * dj.x * dj.z;
-  L[LK_IC + 3] = Iw[4] + m * (d2 - dj.y * dj.y);
-  L[LK_IC + 4] = Iw[5] - m * dj.y * dj.z;
-  L[LK_IC + 5] = Iw[8] + m * (d2 - dj.z * dj.z);
-}
-
-// parent-centric backward step for link i (all its children are already complete): gather their wrenches and
-// composite bodies, then emit this link's rhs entry
+// parent-centric backward step for group leader i (all child groups are complete): gather their wrenches and composite
+// bodies (lc.children holds the child groups' leaders)
 template <class Real>
 __device__ __forceinline__ void sp_gather_children(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
   Real* Lp = S.link + i * SP_LINKF;
@@ -412,46 +401,20 @@ __device__ __forceinline__ void sp_gather_children(const LinkConst<Real>& lc, co
   st3(Lp + LK_F, F); st3(Lp + LK_N, N); st3(Lp + LK_H, H);
   Lp[LK_MC] = mcp;
   Lp[LK_IC + 0] = I0; Lp[LK_IC + 1] = I1; Lp[LK_IC + 2] = I2; Lp[LK_IC + 3] = I3; Lp[LK_IC + 4] = I4; Lp[LK_IC + 5] = I5;
+}
+// every link of a group takes the leader's composite (same joint origin, massless carriers), then emits its rhs entry
+template <class Real>
+__device__ __forceinline__ void sp_link_rhs(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
+  Real* L = S.link + i * SP_LINKF;
+  if (lc.group_leader != i) {
+    const Real* G = S.link + lc.group_leader * SP_LINKF;
+    for (int k = LK_F; k < SP_LINKF; k++) L[k] = G[k];
+  }
   const int d = lc.dof;
   if (d >= 0) {
-    const V3<Real> a = ld3(Lp + LK_A);
-    const Real Cb = (lc.jtype == 2) ? dot(a, N) : dot(a, F);
+    const V3<Real> a = ld3(L + LK_A);
+    const Real Cb = (lc.jtype == 2) ? dot(a, ld3(L + LK_N)) : dot(a, ld3(L + LK_F));
     S.rhs[d] = S.tau[d] - Cb - lc.damp * S.dq[d] - lc.stiff * (S.q[d] + Md.dt * S.dq[d] - lc.rest);
-  }
-}
-
-// serial leaves-to-root pass (lane 0): fold wrenches and composite bodies into the parents, emit the rhs
-template <class Real>
-__device__ __forceinline__ void sp_backward_pass(const SpatialModel<Real>& Md, SpLds<Real>& S) {
-  for (int i = Md.nl - 1; i >= 0; i--) {
-    Real* L = S.link + i * SP_LINKF;
-    const int p = Md.parent[i];
-    const int d = Md.dof[i];
-    const V3<Real> a = ld3(L + LK_A), F = ld3(L + LK_F), N = ld3(L + LK_N);
-    if (d >= 0) {
-      const Real Cb = (Md.jtype[i] == 2) ? dot(a, N) : dot(a, F);
-      S.rhs[d] = S.tau[d] - Cb - Md.damp[d] * S.dq[d] - Md.stiff[d] * (S.q[d] + Md.dt * S.dq[d] - Md.rest[d]);
-    }
-    if (p >= 0) {
-      Real* Lp = S.link + p * SP_LINKF;
-      const V3<Real> o = ld3(L + LK_JO) - ld3(Lp + LK_JO);
-      st3(Lp + LK_F, ld3(Lp + LK_F) + F);
-      st3(Lp + LK_N, ld3(Lp + LK_N) + N + cross(o, F));
-      const Real mc = L[LK_MC];
-      if (mc > Real(0)) {
-        const V3<Real> h = ld3(L + LK_H);
-        const Real oh = dot(o, h), o2 = dot(o, o);
-        const Real diag = Real(2) * oh + mc * o2;
-        Lp[LK_IC + 0] += L[LK_IC + 0] + diag - Real(2) * h.x * o.x - mc * o.x * o.x;
-        Lp[LK_IC + 1] += L[LK_IC + 1] - (h.x * o.y + o.x * h.y) - mc * o.x * o.y;
-        Lp[LK_IC + 2] += L[LK_IC + 2] - (h.x * o.z + o.x * h.z) - mc * o.x * o.z;
-        Lp[LK_IC + 3] += L[LK_IC + 3] + diag - Real(2) * h.y * o.y - mc * o.y * o.y;
-        Lp[LK_IC + 4] += L[LK_IC + 4] - (h.y * o.z + o.y * h.z) - mc * o.y * o.z;
-        Lp[LK_IC + 5] += L[LK_IC + 5] + diag - Real(2) * h.z * o.z - mc * o.z * o.z;
-        st3(Lp + LK_H, ld3(Lp + LK_H) + h + o * mc);
-        Lp[LK_MC] += mc;
-      }
-    }
   }
 }
 
@@ -658,7 +621,7 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
   do {                                                                                            \
     if (Md.stats && lane == 0) {                                                                  \
       const unsigned long long t1_ = __builtin_readcyclecounter();                                \
-      atomicAdd(&Md.stats[40 + (ph)], t1_ - t0_);                                                 \
+      S.ticks[ph] += t1_ - t0_;                                                                   \
       t0_ = t1_;                                                                                  \
     }                                                                                             \
   } while (0)
@@ -670,15 +633,14 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
   // tree recursions level by level: links of equal depth are independent, one lane each
   if (lane == 0) sp_root_offset<Real>(Md, S);
-  const int nlev = Md.nlevels;
-  for (int lv = 0; lv < nlev; lv++) {
-    if (lane < nl && lc.level == lv) sp_link_forward<Real>(lc, Md, S, lane);   // lane i owns link i
+  sp_forward<Real>(lc, Md, S, lane);   // lane i owns link i
+  __syncthreads();
+  for (int lv = Md.n_group_levels - 1; lv >= 0; lv--) {
+    if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);
     __syncthreads();
   }
-  for (int lv = nlev - 1; lv >= 0; lv--) {
-    if (lane < nl && lc.level == lv) sp_gather_children<Real>(lc, Md, S, lane);
-    __syncthreads();
-  }
+  if (lane < nl) sp_link_rhs<Real>(lc, Md, S, lane);
+  __syncthreads();
   SP_TICK(0);
   if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
   __syncthreads();
@@ -979,6 +941,7 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
   Real* sh_scal = S.misc + 8;
   if (lane < n) { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; S.tau[lane] = Real(0); }
   if (lane < Md.nl) S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16);
+  if (Md.stats && lane < 10) S.ticks[lane] = 0ull;
   __syncthreads();
   Real abs_sum = Real(0), sq_sum = Real(0);
   if (lane == 0) {
@@ -997,6 +960,7 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
   LinkConst<Real> lc;
   sp_load_link_const<Real>(Md, lane < Md.nl ? lane : 0, lc);
   for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real>(Md, lc, S, lane, cflags);
+  if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
   if (lane == 0) {
     sp_kinematics<Real>(Md, S);

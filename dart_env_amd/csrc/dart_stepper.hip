@@ -269,6 +269,18 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
     }
     for (int i = 0; i < nl; i++) M.group_level[i] = M.group_leader[i] == i ? gd[i] : -1;
     M.n_group_levels = maxg + 1;
+    M.n_root_trans = 0;
+    for (int i = 0; i < nl; i++) if (M.root_trans[i]) { if (M.n_root_trans >= 8) return "more than 8 root translation links"; M.root_trans_link[M.n_root_trans++] = i; }
+    for (int i = 0; i < nl; i++) {
+      Real* g = M.lconst[i];
+      for (int t = 0; t < 9; t++) { g[LC_RPRE + t] = M.Rpre[i][t]; g[LC_RPOST + t] = M.Rpost[i][t]; g[LC_INERTIA + t] = M.inertia[i][t]; }
+      for (int t = 0; t < 3; t++) {
+        g[LC_PPRE + t] = M.ppre[i][t]; g[LC_PPOST + t] = M.ppost[i][t]; g[LC_AXIS + t] = M.axis[i][t]; g[LC_COM + t] = M.com[i][t];
+        // Rpost^T axis, Rpost^T ppost: world axis and joint origin follow from the link frame alone
+        g[LC_AXR + t] = M.Rpost[i][t] * M.axis[i][0] + M.Rpost[i][3 + t] * M.axis[i][1] + M.Rpost[i][6 + t] * M.axis[i][2];
+        g[LC_CPOST + t] = M.Rpost[i][t] * M.ppost[i][0] + M.Rpost[i][3 + t] * M.ppost[i][1] + M.Rpost[i][6 + t] * M.ppost[i][2];
+      }
+    }
     for (int i = 0; i < nl; i++) {
       double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       if (M.parent[i] >= 0) {   // parent link frame = parent joint frame * Rpost(parent) (prismatic parents do not rotate)

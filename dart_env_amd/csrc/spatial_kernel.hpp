@@ -30,8 +30,11 @@ constexpr int SP_MAXCP = 12;  // contact points (a box face gives up to 4)
 constexpr int SP_MAXM = 36;   // LCP rows (12 contact points x 3; HumanWalker peaks at ~31 active rows)
 constexpr int SP_TRI = SP_MAXM * (SP_MAXM + 1) / 2;   // packed lower triangle of A / of the LDL workspace
 __device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+__device__ __host__ constexpr int sp_npad(int n) { return (n + 7) & ~7; }   // H is stored padded with identity rows to a multiple of 8
 __device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
 constexpr int SP_LINKF = 37;  // Reals stored per link in LDS
+constexpr int SP_LCONST = 48;   // Rpre 9, ppre 3, Rpost 9, ppost 3, axis 3, com 3, inertia 9, axr 3, cpost 3 (+3 pad)
+enum { LC_RPRE = 0, LC_PPRE = 9, LC_RPOST = 12, LC_PPOST = 21, LC_AXIS = 24, LC_COM = 27, LC_INERTIA = 30, LC_AXR = 39, LC_CPOST = 42 };
 constexpr int SP_ROUNDS = 6;  // pointer-jumping rounds: trees up to 64 links deep
 
 template <class Real>
@@ -39,12 +42,16 @@ struct SpatialModel {
   int nl, n, nshapes;
   int parent[SP_MAXL], jtype[SP_MAXL], dof[SP_MAXL], root_trans[SP_MAXL];
   int pre_ident[SP_MAXL], post_ident[SP_MAXL];   // 1: the fixed transform is the identity (carriers of expanded joints)
+  int n_root_trans, root_trans_link[8];   // the root-chain prismatic links (floating-base translation)
   int nrounds;                       // ceil(log2(tree depth)): pointer-jumping rounds of the forward pass
   int anc[SP_MAXL][SP_ROUNDS];       // anc[i][k] = 2^k-th ancestor of link i, -1 beyond the root
   // backward pass: links of one expanded joint share their joint origin, so their composite bodies are identical;
   // only the group's last link (the leader, the one that carries the mass) gathers, level by level over GROUPS
   int group_leader[SP_MAXL], group_level[SP_MAXL];   // group_level: depth of the group for leaders, -1 for the others
   int n_group_levels;
+  // the forward pass re-reads its link's geometry from here every substep (48 contiguous Reals per link, 12 x 16-byte
+  // loads issued together: one L1/L2-resident latency per substep instead of ~45 VGPRs held for the whole kernel)
+  Real lconst[SP_MAXL][SP_LCONST];
   int child_start[SP_MAXL + 1], child_list[SP_MAXL];            // children of every link
   Real axis[SP_MAXL][3];
   Real root_axis_world[SP_MAXL][3];   // world axis of the root-chain prismatic links (constant)
@@ -116,7 +123,7 @@ __device__ __forceinline__ int topo_jtype(int w) { return (w >> 16) & 0xff; }
 
 template <class Real>
 __device__ __forceinline__ size_t sp_lds_reals(int nl, int n) {
-  return (size_t)nl * SP_LINKF + 6 * n + n * (n + 1) / 2 + (SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM + SP_MAXCP * 4 + 16;
+  return (size_t)nl * SP_LINKF + 6 * n + sp_npad(n) * (sp_npad(n) + 1) / 2 + (SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM + SP_MAXCP * 4 + 16;
 }
 
 template <class Real>
@@ -125,7 +132,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n) {
   Real* p = base;
   S.link = p; p += nl * SP_LINKF;
   S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n; S.vs = p; p += n;
-  S.H = p; p += n * (n + 1) / 2;
+  S.H = p; p += sp_npad(n) * (sp_npad(n) + 1) / 2;
   S.W = p; p += (SP_MAXM + 1) * n;
   S.A = p; p += SP_TRI;
   S.Lw = p; p += SP_TRI;
@@ -142,7 +149,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n) {
   return S;
 }
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes) {
-  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)n * (n + 1) / 2 + (size_t)(SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM +
+  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM +
                  SP_MAXCP * 4 + 16;
   return reals * real_bytes + (2 * SP_MAXM + SP_MAXCP + 8 + nl) * sizeof(int) + 3 * real_bytes + 64 + 10 * sizeof(unsigned long long);
 }
@@ -206,23 +213,17 @@ struct LinkConst {
   int anc[SP_ROUNDS];
   int group_leader, group_level;
   int nchild; unsigned long long children;   // leaders: the leaders of up to 8 child groups, one byte each
-  Real axis[3], Rpre[9], ppre[3], Rpost[9], ppost[3], mass, com[3], inertia[9];
-  Real axr[3], cpost[3];                     // Rpost^T axis, Rpost^T ppost: world axis / joint origin from the link frame
+  Real mass;
   Real damp, stiff, rest;                    // of this link's dof
   // the same lane also owns dof `lane` (mass-matrix row, limits)
   int d_link; Real d_diag;                   // link of dof `lane`; dt*damping + dt^2*stiffness
+  int d_limited; Real d_lower, d_upper;
 };
 template <class Real>
 __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md, int i, LinkConst<Real>& c) {
   c.parent = Md.parent[i]; c.jtype = Md.jtype[i]; c.dof = Md.dof[i]; c.root_trans = Md.root_trans[i];
   for (int k = 0; k < SP_ROUNDS; k++) c.anc[k] = Md.anc[i][k];
   c.group_leader = Md.group_leader[i]; c.group_level = Md.group_level[i];
-  for (int k = 0; k < 3; k++) { c.axis[k] = Md.axis[i][k]; c.ppre[k] = Md.ppre[i][k]; c.ppost[k] = Md.ppost[i][k]; c.com[k] = Md.com[i][k]; }
-  for (int k = 0; k < 9; k++) { c.Rpre[k] = Md.Rpre[i][k]; c.Rpost[k] = Md.Rpost[i][k]; c.inertia[k] = Md.inertia[i][k]; }
-  for (int k = 0; k < 3; k++) {
-    c.axr[k] = c.Rpost[k] * c.axis[0] + c.Rpost[3 + k] * c.axis[1] + c.Rpost[6 + k] * c.axis[2];
-    c.cpost[k] = c.Rpost[k] * c.ppost[0] + c.Rpost[3 + k] * c.ppost[1] + c.Rpost[6 + k] * c.ppost[2];
-  }
   c.mass = Md.mass[i];
   c.nchild = Md.child_start[i + 1] - Md.child_start[i];
   c.children = 0ull;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md,
   const int dl = i < Md.n ? i : 0;
   c.d_link = Md.dof_link[dl];
   c.d_diag = Md.dt * Md.damp[dl] + Md.dt * Md.dt * Md.stiff[dl];
+  c.d_limited = (i < Md.n) ? Md.limited[dl] : 0; c.d_lower = Md.lower[dl]; c.d_upper = Md.upper[dl];
 }
 
 template <class Real> __device__ __forceinline__ V3<Real> shfl3(V3<Real> v, int src) {
@@ -251,7 +253,13 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
   const bool live = lane < Md.nl;
   const bool rev = lc.jtype == 2, slide = lc.jtype == 1 && !lc.root_trans;
   const Real qv = (live && lc.dof >= 0) ? S.q[lc.dof] : Real(0), qd = (live && lc.dof >= 0) ? S.dq[lc.dof] : Real(0);
-  const V3<Real> ax = ld3(lc.axis);
+  Real G[SP_LCONST];   // this link's geometry block
+  {
+    const Real* g = Md.lconst[live ? lane : 0];
+#pragma unroll
+    for (int k = 0; k < SP_LCONST; k++) G[k] = g[k];
+  }
+  const V3<Real> ax = ld3(G + LC_AXIS);
   Real R[9];
   V3<Real> p;
   {
@@ -262,11 +270,11 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
                         ax.y * ax.x * v + ax.z * sn, ax.y * ax.y * v + cs,        ax.y * ax.z * v - ax.x * sn,
                         ax.z * ax.x * v - ax.y * sn, ax.z * ax.y * v + ax.x * sn, ax.z * ax.z * v + cs};
     Real T[9];
-    mulRR(Rq, lc.Rpost, T);
-    V3<Real> t = mulR(Rq, ld3(lc.ppost));
+    mulRR(Rq, G + LC_RPOST, T);
+    V3<Real> t = mulR(Rq, ld3(G + LC_PPOST));
     if (slide) t = t + ax * qv;
-    mulRR(lc.Rpre, T, R);
-    p = ld3(lc.ppre) + mulR(lc.Rpre, t);
+    mulRR(G + LC_RPRE, T, R);
+    p = ld3(G + LC_PPRE) + mulR(G + LC_RPRE, t);
     if (!live) { for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? Real(1) : Real(0); p = v3<Real>(0, 0, 0); }
   }
   const int nr = Md.nrounds;
@@ -285,10 +293,10 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
       }
     }
   }
-  const V3<Real> a = mulR(R, ld3(lc.axr));
-  V3<Real> pj = p - mulR(R, ld3(lc.cpost));
+  const V3<Real> a = mulR(R, ld3(G + LC_AXR));
+  V3<Real> pj = p - mulR(R, ld3(G + LC_CPOST));
   if (slide) pj = pj - a * qv;
-  const V3<Real> c = p + mulR(R, ld3(lc.com));
+  const V3<Real> c = p + mulR(R, ld3(G + LC_COM));
   // angular velocity
   const V3<Real> w = rev ? a * qd : v3<Real>(0, 0, 0);
   V3<Real> om = w;
@@ -339,7 +347,7 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
   Real Iw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (m > Real(0)) {
     Real RI[9];
-    mulRR(R, lc.inertia, RI);
+    mulRR(R, G + LC_INERTIA, RI);
     for (int x = 0; x < 3; x++)
       for (int y = 0; y < 3; y++) Iw[3 * x + y] = RI[3 * x] * R[3 * y] + RI[3 * x + 1] * R[3 * y + 1] + RI[3 * x + 2] * R[3 * y + 2];
     const V3<Real> dc = c - p;
@@ -364,8 +372,8 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
 template <class Real>
 __device__ __forceinline__ void sp_root_offset(const SpatialModel<Real>& Md, SpLds<Real>& S) {
   V3<Real> roff = v3<Real>(0, 0, 0);
-  for (int i = 0; i < Md.nl; i++) {
-    if (!Md.root_trans[i]) continue;
+  for (int k = 0; k < Md.n_root_trans; k++) {
+    const int i = Md.root_trans_link[k];
     // axis in world = (product of the constant pre/post rotations up to here) * axis; stored by the host
     roff = roff + ld3(Md.root_axis_world[i]) * S.q[Md.dof[i]];
   }
@@ -450,31 +458,46 @@ __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const Spa
 }
 
 // ------------------------------------------------------------------ wave-parallel dense kernels (row-owner scheme)
-// in-place Cholesky of the packed lower triangle M (n <= 32): row r is owned by the lane pair (r, r + 32), each taking
-// half of the trailing-update range.  Right-looking on the UNSCALED column (u_kj = l_kj d_j): column j is read-only while
-// it is eliminated, so one barrier per column is enough; a final pass scales column j by 1/sqrt(d_j), which leaves the
-// ordinary Cholesky factor below the diagonal, sqrt(d_j) on it and sinv[j] = 1/sqrt(d_j) for the substitutions.
+template <class Real> __device__ __forceinline__ Real readlane_(Real x, int l);
+template <> __device__ __forceinline__ float readlane_<float>(float x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+template <> __device__ __forceinline__ double readlane_<double>(double x, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Cholesky of the packed lower triangle M (n <= 32, stored padded to sp_npad(n) with identity rows), run as a
+// systolic array over the wave: lane r holds row r in REGISTERS, both loops are fully unrolled, and the finished
+// column entry L_kj travels from lane k to everybody through v_readlane (an SGPR operand of the FMA) -- no LDS traffic
+// and no barrier inside the factorisation.  Per column j: d_j = readlane(row[j], j); L_rj = row[j] / sqrt(d_j);
+// row[k] -= L_rj L_kj for k > j.  Updates beyond a lane's diagonal are garbage that nothing reads (kept finite by the
+// identity padding).  The factor is written back to LDS once at the end, with sinv[j] = 1 / L_jj.
 template <class Real>
 __device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane) {
-  const int r = lane & 31, half = lane >> 5;
-  const int rbase = TL(r, 0);
-  for (int j = 0; j < n; j++) {
-    __syncthreads();
-    if (r > j && r < n) {
-      const Real inv = rcp_<Real>(M[TL(j, j)]);
-      const Real lij = M[rbase + j] * inv;
-      const int lo = j + 1, hi = r + 1, mid = (lo + hi) >> 1;
-      const int k0 = half ? mid : lo, k1 = half ? hi : mid;
-      int kj = TL(k0, j);
-      for (int k = k0; k < k1; k++) { M[rbase + k] -= lij * M[kj]; kj += k + 1; }
+  const int np = sp_npad(n);
+  const int r = lane < np ? lane : 0;   // spare lanes shadow lane 0 (convergent code, results discarded)
+  const int rb = TL(r, 0);
+  Real row[SP_MAXN];
+#pragma unroll
+  for (int k = 0; k < SP_MAXN; k++) row[k] = (k <= r) ? M[rb + k] : (k < np ? Real(0) : Real(0));
+#pragma unroll
+  for (int j = 0; j < SP_MAXN; j++) {
+    if (j < np) {
+      const Real dj = readlane_<Real>(row[j], j);
+      const Real sj = rsqrt_<Real>(dj);
+      const Real lrj = (r >= j) ? row[j] * sj : Real(0);   // lanes above the diagonal contribute nothing
+      row[j] = lrj;
+      if (lane == j) sinv[j] = sj;
+#pragma unroll
+      for (int k = j + 1; k < SP_MAXN; k++)
+        if (k < np) row[k] -= lrj * readlane_<Real>(lrj, k);
     }
   }
-  __syncthreads();
-  if (lane < n) sinv[lane] = rsqrt_<Real>(M[TL(lane, lane)]);
-  __syncthreads();
-  if (half == 0 && r < n) {
-    for (int j = 0; j < r; j++) M[rbase + j] *= sinv[j];
-    M[rbase + r] = M[rbase + r] * sinv[r];   // = sqrt(d_r)
+  if (lane < n) {
+#pragma unroll
+    for (int k = 0; k < SP_MAXN; k++) if (k <= lane) M[rb + k] = row[k];
   }
   __syncthreads();
 }
@@ -643,73 +666,93 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   __syncthreads();
   SP_TICK(0);
   if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
+  else if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[TL(lane, k)] = Real(0); S.H[TL(lane, lane)] = Real(1); }
   __syncthreads();
   SP_TICK(1);
   sp_cholesky<Real>(S.H, S.sinv, n, lane);
   SP_TICK(2);
 
-  // ---- contact points and active limits (lane 0 builds the compact row list)
+  // ---- contact points and active limits, in parallel: lane s tests collision shape s, lane d tests the limits of
+  // dof d; ballots give every hit its slot (shape order, then vertex order -- the serial order of the oracle)
   const V3<Real> roff = ld3(S.misc);
-  if (lane == 0) {
-    int ncp = 0;
-    for (int s = 0; s < Md.nshapes; s++) {
-      const Real* L = S.link + Md.sh_link[s] * SP_LINKF;
-      Real Ts[9];
-      mulRR(L + LK_R, Md.sh_R[s], Ts);
-      const V3<Real> pc = ld3(L + LK_P) + mulR(L + LK_R, ld3(Md.sh_p[s]));
-      if (Md.sh_type[s] == 0) {   // capsule: lowest segment endpoint, ODE sphere-sphere contact position
-        const Real rad = Md.sh_size[s][0], hl = Real(0.5) * Md.sh_size[s][1];
-        const V3<Real> zc = v3<Real>(Ts[2], Ts[5], Ts[8]);
-        const V3<Real> p1 = pc + zc * hl, p2 = pc - zc * hl;
-        const V3<Real> pe = (p2.y < p1.y) ? p2 : p1;
-        const Real d = pe.y + roff.y - Md.ground_y;
-        if (d <= rad && ncp < SP_MAXCP) {
-          S.cpP[4 * ncp + 0] = pe.x; S.cpP[4 * ncp + 1] = pe.y - Real(0.5) * (rad + d); S.cpP[4 * ncp + 2] = pe.z;
-          S.cpP[4 * ncp + 3] = rad - d; S.cplink[ncp] = Md.sh_link[s]; ncp++;
-        }
-      } else {                    // box: vertices of the face that looks down, the ones below the floor
-        int k = 0;
-        Real bestv = Real(-1);
-        for (int a = 0; a < 3; a++) if (fabs(Ts[3 + a]) > bestv) { bestv = fabs(Ts[3 + a]); k = a; }
-        const Real sgn = Ts[3 + k] > Real(0) ? Real(-1) : Real(1);
-        const int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
-        const Real hk = Real(0.5) * Md.sh_size[s][k], h1 = Real(0.5) * Md.sh_size[s][a1], h2 = Real(0.5) * Md.sh_size[s][a2];
-        const V3<Real> ek = v3<Real>(Ts[k], Ts[3 + k], Ts[6 + k]), e1 = v3<Real>(Ts[a1], Ts[3 + a1], Ts[6 + a1]),
-                       e2 = v3<Real>(Ts[a2], Ts[3 + a2], Ts[6 + a2]);
-        const Real sg1[4] = {1, -1, -1, 1}, sg2[4] = {1, 1, -1, -1};
-        for (int v = 0; v < 4; v++) {
-          const V3<Real> P = pc + ek * (sgn * hk) + e1 * (sg1[v] * h1) + e2 * (sg2[v] * h2);
-          const Real depth = Md.ground_y - (P.y + roff.y);
-          if (depth >= Real(0) && ncp < SP_MAXCP) {
-            S.cpP[4 * ncp + 0] = P.x; S.cpP[4 * ncp + 1] = P.y; S.cpP[4 * ncp + 2] = P.z; S.cpP[4 * ncp + 3] = depth;
-            S.cplink[ncp] = Md.sh_link[s]; ncp++;
-          }
-        }
+  int ncp, m;
+  {
+    const bool has_shape = lane < Md.nshapes;
+    const int s = has_shape ? lane : 0;
+    const int slink = Md.sh_link[s], stype = Md.sh_type[s];
+    Real sR[9];
+    for (int k = 0; k < 9; k++) sR[k] = Md.sh_R[s][k];
+    const V3<Real> sp = ld3(Md.sh_p[s]), ssz = ld3(Md.sh_size[s]);
+    const Real* L = S.link + slink * SP_LINKF;
+    Real Ts[9];
+    mulRR(L + LK_R, sR, Ts);
+    const V3<Real> pc = ld3(L + LK_P) + mulR(L + LK_R, sp);
+    V3<Real> P[4];
+    Real dep[4];
+    bool hit[4] = {false, false, false, false};
+    if (stype == 0) {   // capsule: lowest segment endpoint, ODE sphere-sphere contact position
+      const Real rad = ssz.x, hl = Real(0.5) * ssz.y;
+      const V3<Real> zc = v3<Real>(Ts[2], Ts[5], Ts[8]);
+      const V3<Real> p1 = pc + zc * hl, p2 = pc - zc * hl;
+      const V3<Real> pe = (p2.y < p1.y) ? p2 : p1;
+      const Real d = pe.y + roff.y - Md.ground_y;
+      hit[0] = has_shape && d <= rad;
+      P[0] = v3<Real>(pe.x, pe.y - Real(0.5) * (rad + d), pe.z); dep[0] = rad - d;
+      for (int v = 1; v < 4; v++) { P[v] = P[0]; dep[v] = Real(0); }
+    } else {            // box: vertices of the face that looks down, the ones below the floor
+      const V3<Real> c0 = v3<Real>(Ts[0], Ts[3], Ts[6]), c1 = v3<Real>(Ts[1], Ts[4], Ts[7]), c2 = v3<Real>(Ts[2], Ts[5], Ts[8]);
+      int k = 0;
+      Real bestv = fabs(c0.y);
+      if (fabs(c1.y) > bestv) { bestv = fabs(c1.y); k = 1; }
+      if (fabs(c2.y) > bestv) k = 2;
+      const V3<Real> ek = k == 0 ? c0 : (k == 1 ? c1 : c2), e1 = k == 0 ? c1 : (k == 1 ? c2 : c0), e2 = k == 0 ? c2 : (k == 1 ? c0 : c1);
+      const Real hk = Real(0.5) * (k == 0 ? ssz.x : (k == 1 ? ssz.y : ssz.z)), h1 = Real(0.5) * (k == 0 ? ssz.y : (k == 1 ? ssz.z : ssz.x)),
+                 h2 = Real(0.5) * (k == 0 ? ssz.z : (k == 1 ? ssz.x : ssz.y));
+      const Real sgn = ek.y > Real(0) ? Real(-1) : Real(1);
+      const V3<Real> base = pc + ek * (sgn * hk);
+      const Real sg1[4] = {1, -1, -1, 1}, sg2[4] = {1, 1, -1, -1};
+      for (int v = 0; v < 4; v++) {
+        P[v] = base + e1 * (sg1[v] * h1) + e2 * (sg2[v] * h2);
+        dep[v] = Md.ground_y - (P[v].y + roff.y);
+        hit[v] = has_shape && dep[v] >= Real(0);
       }
     }
-    int m = 3 * ncp;
-    for (int r = 0; r < m; r++) { S.rdof[r] = -1; S.rfidx[r] = (r % 3 == 0) ? -1 : (r - r % 3); }
-    for (int d = 0; d < n && m < SP_MAXM; d++) {
-      if (!Md.limited[d]) continue;
-      const Real qd = S.q[d];
-      const bool low = qd <= Md.lower[d], up = !low && qd >= Md.upper[d];
-      if (!(low || up)) continue;
-      const Real viol = low ? qd - Md.lower[d] : qd - Md.upper[d];
-      const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
-      S.rdof[m] = d; S.rfidx[m] = -1;
-      S.b[m] = bounce - S.dq[d];   // the dt * W_i . y part (unconstrained acceleration) is added after the W solve
-      S.lo[m] = low ? Real(0) : -inf_<Real>();
-      S.hi[m] = low ? inf_<Real>() : Real(0);
-      m++;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint64_t hm[4];
+    int before = 0, total = 0;
+    for (int v = 0; v < 4; v++) { hm[v] = __ballot(hit[v]); before += __popcll(hm[v] & lt); total += __popcll(hm[v]); }
+    int idx = before;
+    for (int v = 0; v < 4; v++) {
+      if (hit[v]) {
+        if (idx < SP_MAXCP) { S.cpP[4 * idx + 0] = P[v].x; S.cpP[4 * idx + 1] = P[v].y; S.cpP[4 * idx + 2] = P[v].z; S.cpP[4 * idx + 3] = dep[v]; S.cplink[idx] = slink; }
+        idx++;
+      }
     }
-    S.imisc[0] = ncp;
-    S.imisc[1] = m;
-    for (int f = 0; f < 2; f++) contact_flags[f] = 0;
-    for (int cidx = 0; cidx < ncp; cidx++)
-      for (int f = 0; f < 2; f++) if (S.cplink[cidx] == Md.aux_link[2 + f]) contact_flags[f] = 1;
+    ncp = total < SP_MAXCP ? total : SP_MAXCP;
+    // foot-contact flags of the observation (human_walker.py:97-106): any contact on aux_link[2], aux_link[3]
+    const bool anyhit = hit[0] || hit[1] || hit[2] || hit[3];
+    const uint64_t f0 = __ballot(anyhit && slink == Md.aux_link[2]), f1 = __ballot(anyhit && slink == Md.aux_link[3]);
+    if (lane == 0) { contact_flags[0] = f0 != 0ull; contact_flags[1] = f1 != 0ull; }
+    // contact rows: normal, two tangents
+    if (lane < 3 * ncp) { S.rdof[lane] = -1; S.rfidx[lane] = (lane % 3 == 0) ? -1 : (lane - lane % 3); }
+    // joint-limit rows
+    const Real qd = lane < n ? S.q[lane] : Real(0);
+    const bool low = lane < n && lc.d_limited && qd <= lc.d_lower;
+    const bool up = lane < n && lc.d_limited && !low && qd >= lc.d_upper;
+    const uint64_t lm = __ballot(low || up);
+    const int row = 3 * ncp + __popcll(lm & lt);
+    if ((low || up) && row < SP_MAXM) {
+      const Real viol = low ? qd - lc.d_lower : qd - lc.d_upper;
+      const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
+      S.rdof[row] = lane; S.rfidx[row] = -1;
+      S.b[row] = bounce - S.dq[lane];   // the dt * W_i . y part (unconstrained acceleration) is added after the W solve
+      S.lo[row] = low ? Real(0) : -inf_<Real>();
+      S.hi[row] = low ? inf_<Real>() : Real(0);
+    }
+    m = 3 * ncp + __popcll(lm);
+    m = m < SP_MAXM ? m : SP_MAXM;
   }
   __syncthreads();
-  const int ncp = S.imisc[0], m = S.imisc[1];
   SP_TICK(3);
   {
     // ---- Jacobian rows (lane per row) + the generalized-force row (index m), bias part of b for contact rows
@@ -745,15 +788,24 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     __syncthreads();
     SP_TICK(4);
     // ---- W = L^-1 [J^T | rhs] : every lane forward-substitutes its own row; row m becomes y = L^-1 rhs
+    // The row lives in registers and both loops are fully unrolled (SP_MAXN x SP_MAXN / 2 predicated steps, uniform
+    // `k < n` branches): every factor entry is one LDS read at an immediate offset, no index arithmetic.
     if (lane <= m) {
-      Real* y = S.W + lane * n;
-      const Real* Hk = S.H;            // row k of the packed factor starts at TL(k, 0)
-      for (int k = 0; k < n; k++) {
-        Real t = y[k];
-        for (int j = 0; j < k; j++) t -= Hk[j] * y[j];
-        y[k] = t * S.sinv[k];
-        Hk += k + 1;
+      Real* yrow = S.W + lane * n;
+      Real y[SP_MAXN];
+#pragma unroll
+      for (int k = 0; k < SP_MAXN; k++) y[k] = (k < n) ? yrow[k] : Real(0);
+#pragma unroll
+      for (int k = 0; k < SP_MAXN; k++) {
+        if (k < n) {
+          Real t = y[k];
+#pragma unroll
+          for (int j = 0; j < k; j++) t -= S.H[TL(k, j)] * y[j];
+          y[k] = t * S.sinv[k];
+        }
       }
+#pragma unroll
+      for (int k = 0; k < SP_MAXN; k++) if (k < n) yrow[k] = y[k];
     }
     __syncthreads();
     // b_i = bounce_i - J_i (dq + dt H^-1 rhs) = bias_i - dt W_i . y

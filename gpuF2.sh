@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3

@@ -474,32 +474,37 @@ template <> __device__ __forceinline__ double readlane_<double>(double x, int l)
 // and no barrier inside the factorisation.  Per column j: d_j = readlane(row[j], j); L_rj = row[j] / sqrt(d_j);
 // row[k] -= L_rj L_kj for k > j.  Updates beyond a lane's diagonal are garbage that nothing reads (kept finite by the
 // identity padding).  The factor is written back to LDS once at the end, with sinv[j] = 1 / L_jj.
-template <class Real>
-__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane) {
-  const int np = sp_npad(n);
-  const int r = lane < np ? lane : 0;   // spare lanes shadow lane 0 (convergent code, results discarded)
+template <class Real, int NP>
+__device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int lane) {
+  const int r = lane < NP ? lane : 0;   // spare lanes shadow lane 0 (convergent code, results discarded)
   const int rb = TL(r, 0);
-  Real row[SP_MAXN];
+  Real row[NP];
 #pragma unroll
-  for (int k = 0; k < SP_MAXN; k++) row[k] = (k <= r) ? M[rb + k] : (k < np ? Real(0) : Real(0));
+  for (int k = 0; k < NP; k++) row[k] = (k <= r) ? M[rb + k] : Real(0);
 #pragma unroll
-  for (int j = 0; j < SP_MAXN; j++) {
-    if (j < np) {
-      const Real dj = readlane_<Real>(row[j], j);
-      const Real sj = rsqrt_<Real>(dj);
-      const Real lrj = (r >= j) ? row[j] * sj : Real(0);   // lanes above the diagonal contribute nothing
-      row[j] = lrj;
-      if (lane == j) sinv[j] = sj;
+  for (int j = 0; j < NP; j++) {
+    const Real dj = readlane_<Real>(row[j], j);
+    const Real sj = rsqrt_<Real>(dj);
+    const Real lrj = (r >= j) ? row[j] * sj : Real(0);   // lanes above the diagonal contribute nothing
+    row[j] = lrj;
+    if (lane == j) sinv[j] = sj;
 #pragma unroll
-      for (int k = j + 1; k < SP_MAXN; k++)
-        if (k < np) row[k] -= lrj * readlane_<Real>(lrj, k);
-    }
+    for (int k = j + 1; k < NP; k++) row[k] -= lrj * readlane_<Real>(lrj, k);
   }
   if (lane < n) {
 #pragma unroll
-    for (int k = 0; k < SP_MAXN; k++) if (k <= lane) M[rb + k] = row[k];
+    for (int k = 0; k < NP; k++) if (k <= lane) M[rb + k] = row[k];
   }
   __syncthreads();
+}
+// one straight-line variant per padded size (only the one a model uses ever enters the instruction cache)
+template <class Real>
+__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane) {
+  const int np = sp_npad(n);
+  if (np <= 8) sp_cholesky_t<Real, 8>(M, sinv, n, lane);
+  else if (np <= 16) sp_cholesky_t<Real, 16>(M, sinv, n, lane);
+  else if (np <= 24) sp_cholesky_t<Real, 24>(M, sinv, n, lane);
+  else sp_cholesky_t<Real, 32>(M, sinv, n, lane);
 }
 // x <- L^-T x (backward) for one vector in LDS, column-oriented, lanes own entries
 template <class Real>
@@ -514,9 +519,9 @@ __device__ __forceinline__ void sp_chol_backsolve(const Real* Lf, const Real* si
 }
 
 // Boxed LCP by block principal pivoting, one wavefront per problem (rows = lanes).  F/U are wave-uniform bit masks.
-template <class Real, bool ZERO_BOUNDS>
+template <class Real>
 __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask, uint64_t& F, uint64_t& U, int max_iter,
-                                       int pgs_sweeps, unsigned long long* stats, int lane) {
+                                       int pgs_sweeps, unsigned long long* stats, int lane, const bool ZERO_BOUNDS) {
   if (lane < m) S.x0[lane] = S.x[lane];   // solution of the previous stage (zeros before the first): PGS fallback start
   Real bmax = Real(0);
   for (int i = 0; i < m; i++) bmax = fmax(bmax, fabs(S.b[i]));
@@ -855,22 +860,25 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     }
     if (lane < m) S.x[lane] = Real(0);
     __syncthreads();
-    sp_blcp<Real, true>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane);
-    SP_TICK(7);
-    if (ncp > 0) {
-      bool isf = false, pinned = false;
-      if (lane < m && S.rfidx[lane] >= 0) {
-        const Real hb = fabs(Md.mu * S.x[S.rfidx[lane]]);
-        // a direction the skeleton cannot move in (planar model, z tangent) has A_ii = 0: keep that row out
-        isf = true; pinned = !(hb > Real(0)) || !(S.A[TI(lane, lane)] > Real(1e-12));
-        S.hi[lane] = hb; S.lo[lane] = -hb;
+    // one inlined copy of the solver serves both stages (instruction-cache footprint)
+    for (int stage = 0; stage < 2; stage++) {
+      if (stage == 1) {
+        SP_TICK(7);
+        if (ncp == 0) break;
+        bool isf = false, pinned = false;
+        if (lane < m && S.rfidx[lane] >= 0) {
+          const Real hb = fabs(Md.mu * S.x[S.rfidx[lane]]);
+          // a direction the skeleton cannot move in (planar model, z tangent) has A_ii = 0: keep that row out
+          isf = true; pinned = !(hb > Real(0)) || !(S.A[TI(lane, lane)] > Real(1e-12));
+          S.hi[lane] = hb; S.lo[lane] = -hb;
+        }
+        __syncthreads();
+        const uint64_t fr = __ballot(isf), pf = __ballot(isf && pinned);
+        pinmask = (pinmask & ~fr) | pf;
+        F = (F & ~fr) | (fr & ~pf);
+        U &= ~fr;
       }
-      __syncthreads();
-      const uint64_t fr = __ballot(isf), pf = __ballot(isf && pinned);
-      pinmask = (pinmask & ~fr) | pf;
-      F = (F & ~fr) | (fr & ~pf);
-      U &= ~fr;
-      sp_blcp<Real, false>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane);
+      sp_blcp<Real>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0);
     }
     SP_TICK(8);
     if (Md.dbg) {

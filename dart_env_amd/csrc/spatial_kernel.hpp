@@ -969,10 +969,31 @@ __device__ __forceinline__ bool sp_walker3d_epilogue(const SpatialModel<Real>& M
   return !ok;
 }
 
+// CartPole (cart_pole.py:12-24): reward 1, done when the observation is not finite or |q[1]| > angle_max.
+// HalfCheetah (half_cheetah.py:43-63): aux_real = {alive, ctrl_cost}; reward zeroed when the state broke.
+template <class Real>
+__device__ __forceinline__ bool sp_simple_epilogue(const SpatialModel<Real>& Md, SpLds<Real>& S, Real pos_before, Real sq_a_sum,
+                                                   Real& reward_out) {
+  bool fin = true, bounded = true;
+  for (int i = 0; i < Md.n; i++) {
+    fin = fin && isfinite(S.q[i]) && isfinite(S.dq[i]);
+    bounded = bounded && (fabs(S.dq[i]) < Md.s_max) && (i < 2 || fabs(S.q[i]) < Md.s_max);
+  }
+  if (Md.task == 5) {
+    reward_out = Md.aux_real[0];
+    return !(fin && fabs(S.q[1]) <= Md.aux_real2[1]);
+  }
+  const bool ok = fin && bounded;
+  Real rew = (S.q[0] - pos_before) * Md.inv_envdt + Md.aux_real[0];
+  rew -= Md.aux_real[1] * sq_a_sum;
+  reward_out = ok ? rew : Real(0);
+  return !(ok && fabs(S.q[2]) < Md.aux_real2[1]);
+}
+
 template <class Real>
 __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds<Real>& S, const int* cflags, float* __restrict__ o, int lane) {
   const int n = Md.n;
-  if (Md.task == 0) {   // physics only: [q, dq]
+  if (Md.task == 0 || Md.task == 5) {   // physics only, CartPole: [q, dq]
     if (lane < n) { o[lane] = (float)S.q[lane]; o[n + lane] = (float)S.dq[lane]; }
     return;
   }
@@ -1013,7 +1034,7 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
       S.tau[Md.act_dof0 + k] = cl * Md.act_scale[k];
     }
     sp_kinematics<Real>(Md, S);
-    sh_scal[0] = (Md.task != 0) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : Real(0);   // posbefore
+    sh_scal[0] = (Md.task == 3 || Md.task == 4) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
     cflags[0] = 0; cflags[1] = 0;
   }
   __syncthreads();
@@ -1028,6 +1049,7 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
     bool task_done = false;
     if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, init_h[e], cflags, rew);
     else if (Md.task == 3) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
+    else if (Md.task >= 5) task_done = sp_simple_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     int el = elapsed[e] + 1;
     const bool trunc = (Md.max_steps > 0) && (el >= Md.max_steps);
     dn = task_done || trunc; tr = trunc && !task_done;

@@ -3,3 +3,5 @@ from .hopper import DartHopperEnv  # noqa: F401
 from .walker2d import DartWalker2dEnv  # noqa: F401
 from .human_walker import DartHumanWalkerEnv  # noqa: F401
 from .walker3d import DartWalker3dEnv  # noqa: F401
+from .cart_pole import DartCartPoleEnv  # noqa: F401
+from .half_cheetah import DartHalfCheetahEnv  # noqa: F401

@@ -78,8 +78,9 @@ class BatchedDartEnv:
             noise = self.noise = "mt19937-host"     # injected test stepper without a device bank
         self.device_noise = noise in ("mt19937", "philox")
         # spaces exactly as DartEnv.__init__ builds them (dart_env.py:85-86, 97-100)
-        hi = np.array([self.card.act_high[k] for k in range(self.act_dim)])
-        lo = np.array([self.card.act_low[k] for k in range(self.act_dim)])
+        # control_bounds of the reference env (the card carries +-inf instead when the env does not clamp)
+        hi = np.full(self.act_dim, self.task.act_high, dtype=np.float64)
+        lo = np.full(self.act_dim, self.task.act_low, dtype=np.float64)
         self.action_space = spaces.Box(lo, hi)
         inf = np.inf * np.ones(self.obs_dim)
         self.observation_space = spaces.Box(-inf, inf)

@@ -13,8 +13,7 @@ class _SingleEnv(BatchedDartEnv):
     def __init__(self, device=0, precision=32, stepper_factory=None):
         super().__init__(self.ENV_ID, num_envs=1, device=device, precision=precision, noise="mt19937-host",
                          max_episode_steps=0, stepper_factory=stepper_factory)
-        self.control_bounds = np.array([[self.card.act_high[k] for k in range(self.act_dim)],
-                                        [self.card.act_low[k] for k in range(self.act_dim)]])
+        self.control_bounds = np.array([[self.task.act_high] * self.act_dim, [self.task.act_low] * self.act_dim])
         self.action_scale = np.array([self.card.act_scale[k] for k in range(self.act_dim)])
 
     def seed(self, seed=None):

@@ -24,7 +24,7 @@ from .skel import MAX_BODIES, MAX_DOFS, MAX_SHAPES, ModelCard, parse_skel
 MAX_ACTIONS = 32
 CARD_VERSION = 1
 
-TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER = 0, 1, 2, 3, 4
+TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER, TASK_CARTPOLE, TASK_HALFCHEETAH = 0, 1, 2, 3, 4, 5, 6
 
 
 class DartModelCard(C.Structure):
@@ -94,6 +94,9 @@ class TaskSpec:
     contact_cfm: Optional[float] = None   # None -> the model's DART cfm (1e-9)
     act_low: float = -1.0
     act_high: float = 1.0
+    clamp_actions: bool = True            # False: the env passes a[k] * scale on unclamped (cart_pole.py:16)
+    all_bodies_collide: bool = False      # every collision shape of the robot vs. the ground (half_cheetah)
+    physics_dt: float = 0.002             # DartEnv.__init__'s dt argument (dart_env.py:29)
 
 
 HOPPER = TaskSpec(
@@ -130,7 +133,24 @@ WALKER3D = TaskSpec(
     angle_max=0.84, contact_bodies=["h_foot", "h_foot_left"], alive_bonus=1.0, ctrl_cost=1e-3, limit_penalty=0.2,
     aux_body_names=["h_torso_aux"], aux_ints=[18, 12], aux_real=[1e-3], contact_cfm=1e-4)
 
-TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER)}
+# DartCartPole-v1 -- reference gym/envs/dart/cart_pole.py:6-39 (dt 0.02, frame_skip 2, obs [q, dq], scale 100, no clamp,
+# reward 1, done |q[1]| > 0.2 or non-finite obs, reset noise +-0.01), gym/envs/__init__.py:220-225
+CARTPOLE = TaskSpec(
+    env_id="DartCartPole-v1", model="cartpole", task=TASK_CARTPOLE, frame_skip=2, act_dim=1, obs_dim=4, act_dof0=0,
+    act_scale=[100.0], max_episode_steps=1000, reward_threshold=950.0, height_body=0, penalty_dof=-1,
+    height_lo=-np.inf, height_hi=np.inf, angle_max=0.2, alive_bonus=1.0, ctrl_cost=0.0, limit_penalty=0.0,
+    state_abs_max=np.inf, obs_vel_clip=np.inf, reset_noise=0.01, reset_noise_vel=0.01, clamp_actions=False,
+    physics_dt=0.02)
+
+# DartHalfCheetah-v1 -- reference gym/envs/dart/half_cheetah.py:5-114 (dt 0.01, frame_skip 5, scale [120,90,60,120,60,30],
+# obs q[1:], dq (17), reward dx/dt + 1 - 0.1 sum a^2, done on |s[2:]| >= 100 or |q[2]| >= 1.3), __init__.py:213-218
+HALFCHEETAH = TaskSpec(
+    env_id="DartHalfCheetah-v1", model="halfcheetah", task=TASK_HALFCHEETAH, frame_skip=5, act_dim=6, obs_dim=17,
+    act_dof0=3, act_scale=[120.0, 90.0, 60.0, 120.0, 60.0, 30.0], max_episode_steps=1000, reward_threshold=4800.0,
+    height_body=2, penalty_dof=-1, height_lo=-np.inf, height_hi=np.inf, angle_max=1.3, alive_bonus=1.0, ctrl_cost=0.1,
+    limit_penalty=0.0, obs_vel_clip=np.inf, all_bodies_collide=True, physics_dt=0.01)
+
+TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH)}
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 
@@ -196,7 +216,8 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         c.act_dof0, c.max_episode_steps = task.act_dof0, task.max_episode_steps
         c.height_body, c.penalty_dof = task.height_body, task.penalty_dof
         for k in range(task.act_dim):
-            c.act_scale[k], c.act_low[k], c.act_high[k] = task.act_scale[k], task.act_low, task.act_high
+            c.act_scale[k] = task.act_scale[k]
+            c.act_low[k], c.act_high[k] = (task.act_low, task.act_high) if task.clamp_actions else (-np.inf, np.inf)
         c.alive_bonus, c.ctrl_cost = task.alive_bonus, task.ctrl_cost
         c.limit_penalty, c.penalty_margin = task.limit_penalty, task.penalty_margin
         c.height_lo, c.height_hi, c.angle_max = task.height_lo, task.height_hi, task.angle_max
@@ -221,5 +242,5 @@ def card_for(env_id: str, all_bodies_collide: bool = False) -> DartModelCard:
     task = TASKS[env_id]
     model = load_model(task.model)
     for s in model.shapes:
-        s.collidable = all_bodies_collide or model.bodies[s.body].name in task.contact_bodies
+        s.collidable = all_bodies_collide or task.all_bodies_collide or model.bodies[s.body].name in task.contact_bodies
     return build_card(model, task)

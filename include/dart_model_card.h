@@ -45,7 +45,11 @@ enum {
   DART_TASK_HOPPER = 1,    /* reference gym/envs/dart/hopper.py:36-74   */
   DART_TASK_WALKER2D = 2,  /* reference gym/envs/dart/walker2d.py:22-74 */
   DART_TASK_WALKER3D = 3,  /* reference gym/envs/dart/walker3d.py:33-113 */
-  DART_TASK_HUMANWALKER = 4 /* reference gym/envs/dart/human_walker.py:60-165 */
+  DART_TASK_HUMANWALKER = 4, /* reference gym/envs/dart/human_walker.py:60-165 */
+  DART_TASK_CARTPOLE = 5,    /* reference gym/envs/dart/cart_pole.py:12-39: obs [q, dq], reward 1, done |q[1]| > angle_max,
+                                 action NOT clamped (act_low/high = -/+inf), tau[0] = a[0] * 100 */
+  DART_TASK_HALFCHEETAH = 6  /* reference gym/envs/dart/half_cheetah.py:28-93: reward dx/dt + 1 - 0.1 sum a^2 (0 if the
+                                 state broke), done adds |q[2]| >= angle_max (1.3), obs q[1:], dq (unclipped) */
 };
 
 typedef struct DartModelCard {

@@ -889,8 +889,58 @@ static int walker3d_step(OracleWorld* w, const double* a, double* obs, double* r
   return !ok;
 }
 
+/* DartCartPoleEnv.step (cart_pole.py:12-24) and DartHalfCheetahEnv.step (half_cheetah.py:28-78) */
+static void qdq_obs(OracleWorld* w, int skip_first, double* obs) {
+  int n = w->n, o = 0;
+  for (int i = skip_first; i < n; i++) obs[o++] = w->q[i];
+  for (int i = 0; i < n; i++) obs[o++] = w->dq[i];
+}
+static int cartpole_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  double tau[MAXN] = {0};
+  tau[c->act_dof0] = a[0] * c->act_scale[0];   /* no clamp (cart_pole.py:16) */
+  for (int f = 0; f < c->frame_skip; f++) { oracle_set_forces(w, tau); oracle_step(w); }
+  qdq_obs(w, 0, obs);
+  int ok = 1;
+  for (int i = 0; i < 2 * w->n; i++) if (!isfinite(obs[i])) ok = 0;
+  if (!(fabs(obs[1]) <= c->angle_max)) ok = 0;
+  *reward = c->alive_bonus;
+  return !ok;
+}
+static int halfcheetah_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double tau[MAXN] = {0}, sq = 0;
+  double posbefore = w->q[0];
+  for (int k = 0; k < c->act_dim; k++) {
+    double cl = a[k];
+    if (cl > c->act_high[k]) cl = c->act_high[k];
+    if (cl < c->act_low[k]) cl = c->act_low[k];
+    tau[c->act_dof0 + k] = cl * c->act_scale[k];
+    sq += a[k] * a[k];
+  }
+  for (int f = 0; f < c->frame_skip; f++) { oracle_set_forces(w, tau); oracle_step(w); }
+  double envdt = c->dt * c->frame_skip;
+  double r = (w->q[0] - posbefore) / envdt * 1.0;   /* velrew_weight = 1 (half_cheetah.py:12) */
+  r += c->alive_bonus * 1;
+  r -= c->ctrl_cost * sq;
+  int ok = 1;
+  for (int i = 0; i < n; i++) {
+    if (!isfinite(w->q[i]) || !isfinite(w->dq[i])) ok = 0;
+    if (i >= 2 && !(fabs(w->q[i]) < c->state_abs_max)) ok = 0;
+    if (!(fabs(w->dq[i]) < c->state_abs_max)) ok = 0;
+  }
+  if (!ok) r = 0;
+  *reward = r;
+  int done = !(ok && fabs(w->q[2]) < c->angle_max);
+  qdq_obs(w, 1, obs);
+  return done;
+}
+
 int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
   const DartModelCard* c = &w->card;
+  if (c->task == DART_TASK_CARTPOLE) return cartpole_step(w, a, obs, reward);
+  if (c->task == DART_TASK_HALFCHEETAH) return halfcheetah_step(w, a, obs, reward);
   if (c->task == DART_TASK_HUMANWALKER) return humanwalker_step(w, a, obs, reward);
   if (c->task == DART_TASK_WALKER3D) return walker3d_step(w, a, obs, reward);
   int n = w->n;
@@ -945,6 +995,8 @@ void oracle_env_obs(OracleWorld* w, double* obs) {
   const DartModelCard* c = &w->card;
   if (c->task == DART_TASK_HUMANWALKER) { int z[2] = {0, 0}; humanwalker_obs(w, z, obs); return; } /* reset_model zeroes contact_info */
   if (c->task == DART_TASK_WALKER3D) { walker3d_obs(w, obs); return; }
+  if (c->task == DART_TASK_CARTPOLE) { qdq_obs(w, 0, obs); return; }
+  if (c->task == DART_TASK_HALFCHEETAH) { qdq_obs(w, 1, obs); return; }
   int n = w->n;
   double cm[3];
   oracle_body_com(w, c->height_body, cm);

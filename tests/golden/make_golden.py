@@ -109,7 +109,10 @@ class StubBody:
 
     C = property(lambda self: self.com())
 
-    def to_world(self, p):
+    def local_com(self):
+        return np.array(self.world.model.bodies[self.index].com, dtype=np.float64)
+
+    def to_world(self, p=(0.0, 0.0, 0.0)):
         T = self.world.oracle.body_pose(self.index)
         return T[:3, :3] @ np.asarray(p, dtype=np.float64) + T[:3, 3]
 
@@ -164,14 +167,16 @@ class StubWorld:
     def __init__(self, dt, skel_path=None):
         name = os.path.basename(skel_path)
         contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"],
-                   "kima_human_edited.skel": ["l-foot", "r-foot"], "walker3d_waist.skel": ["h_foot", "h_foot_left"]}[name]
+                   "kima_human_edited.skel": ["l-foot", "r-foot"], "walker3d_waist.skel": ["h_foot", "h_foot_left"],
+                   "cartpole.skel": None, "half_cheetah.skel": None}[name]   # None: every collision shape
         model = parse_skel(skel_path, dt=dt, collidable_bodies=contact)
         self.model = model
         self.dt = dt
         card = build_card(model, None)
         from dart_env_amd.model_card import TASKS
         spec = {"hopper_capsule.skel": "DartHopper-v1", "walker2d.skel": "DartWalker2d-v1",
-                "kima_human_edited.skel": "DartHumanWalker-v1", "walker3d_waist.skel": "DartWalker3d-v1"}[name]
+                "kima_human_edited.skel": "DartHumanWalker-v1", "walker3d_waist.skel": "DartWalker3d-v1",
+                "cartpole.skel": "DartCartPole-v1", "half_cheetah.skel": "DartHalfCheetah-v1"}[name]
         if TASKS[spec].contact_cfm is not None:   # same contact regularisation as the shipped task card
             card.contact_cfm = TASKS[spec].contact_cfm
         self.oracle = OracleWorld(card)
@@ -306,6 +311,12 @@ def main():
     np.savez_compressed(os.path.join(out, "walker3d_single_seed6_small.npz"),
                         **rollout_single(gym, "DartWalker3d-v1", 6, 400, act_scale=0.05))
     np.savez_compressed(os.path.join(out, "walker3d_vector4_seed3.npz"), **rollout_vector(gym, "DartWalker3d-v1", 4, 3, 120))
+    # (8) DartCartPole-v1 (no clamp, obs [q, dq], dt 0.02) and DartHalfCheetah-v1 (all capsules collide, dt 0.01)
+    for env_id, tag in (("DartCartPole-v1", "cartpole"), ("DartHalfCheetah-v1", "halfcheetah")):
+        np.savez_compressed(os.path.join(out, "%s_single_seed0.npz" % tag), **rollout_single(gym, env_id, 0, 300))
+        np.savez_compressed(os.path.join(out, "%s_single_seed1_big.npz" % tag),
+                            **rollout_single(gym, env_id, 1, 200, act_scale=1.5))   # beyond +-1: clamp / no clamp
+        np.savez_compressed(os.path.join(out, "%s_vector4_seed3.npz" % tag), **rollout_vector(gym, env_id, 4, 3, 120))
     print("world.step() calls issued by the reference code:", StubWorld.n_steps)
 
 

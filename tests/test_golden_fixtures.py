@@ -9,16 +9,17 @@ import pytest
 import dart_env_amd
 from dart_env_amd import seeding, spaces
 from dart_env_amd.model_card import card_for
-from dart_env_amd.envs import DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv, DartWalker3dEnv
+from dart_env_amd.envs import (DartCartPoleEnv, DartHalfCheetahEnv, DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv,
+                               DartWalker3dEnv)
 from dart_env_amd.wrappers import TimeLimit
 from tests.fake_stepper import OracleStepper
 from tests.oracle_lib import OracleWorld
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 IDS = {"hopper": "DartHopper-v1", "walker2d": "DartWalker2d-v1", "humanwalker": "DartHumanWalker-v1",
-       "walker3d": "DartWalker3d-v1"}
+       "walker3d": "DartWalker3d-v1", "cartpole": "DartCartPole-v1", "halfcheetah": "DartHalfCheetah-v1"}
 CLS = {"hopper": DartHopperEnv, "walker2d": DartWalker2dEnv, "humanwalker": DartHumanWalkerEnv,
-       "walker3d": DartWalker3dEnv}
+       "walker3d": DartWalker3dEnv, "cartpole": DartCartPoleEnv, "halfcheetah": DartHalfCheetahEnv}
 
 
 def test_seeding_and_reset_noise_stream():
@@ -49,7 +50,9 @@ def test_box_action_stream():
 @pytest.mark.parametrize("tag,fix", [("hopper", "single_seed0"), ("walker2d", "single_seed0"),
                                      ("hopper", "single_seed5_small"), ("walker2d", "single_seed5_small"),
                                      ("humanwalker", "single_seed0"), ("humanwalker", "single_seed4_small"),
-                                     ("walker3d", "single_seed0"), ("walker3d", "single_seed6_small")])
+                                     ("walker3d", "single_seed0"), ("walker3d", "single_seed6_small"),
+                                     ("cartpole", "single_seed0"), ("cartpole", "single_seed1_big"),
+                                     ("halfcheetah", "single_seed0"), ("halfcheetah", "single_seed1_big")])
 def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
     """C restatement of hopper.py:36-74 / walker2d.py:22-74 == the reference's numpy code, fp64 bit-for-bit."""
     d = np.load(os.path.join(G, "%s_%s.npz" % (tag, fix)))
@@ -57,12 +60,12 @@ def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
     seed = int(fix.split("seed")[1].split("_")[0])
     rng, _ = seeding.np_random(seed)
     n = w.n
-    rv = w.card.reset_noise_vel
+    r0, rv = w.card.reset_noise, w.card.reset_noise_vel
     rtol = 1e-12 if tag in ("humanwalker", "walker3d") else 0.0   # numpy sums >= 8 terms pairwise, the C loop sequentially
 
     def do_reset():
         w.reset()
-        w.set_state(w.q + rng.uniform(-.005, .005, n), w.dq + rng.uniform(-rv, rv, n))
+        w.set_state(w.q + rng.uniform(-r0, r0, n), w.dq + rng.uniform(-rv, rv, n))
         w.env_after_reset()
         return w.env_obs()
     assert np.array_equal(do_reset(), d["obs0"])
@@ -76,7 +79,7 @@ def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
             assert np.array_equal(do_reset(), d["reset_obs"][t])
 
 
-@pytest.mark.parametrize("tag", ["hopper", "walker2d", "humanwalker", "walker3d"])
+@pytest.mark.parametrize("tag", ["hopper", "walker2d", "humanwalker", "walker3d", "cartpole", "halfcheetah"])
 def test_single_env_facade_vs_reference(tag):
     """make(id): seed -> reset -> step loop reproduces the reference's obs/reward/done (obs cross the ABI as float32)."""
     d = np.load(os.path.join(G, "%s_single_seed0.npz" % tag))
@@ -95,7 +98,7 @@ def test_single_env_facade_vs_reference(tag):
         assert np.allclose(env.state_vector(), np.concatenate([d["q"][t], d["dq"][t]]), atol=0)
         if done:
             assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-7)
-    assert env.dt == pytest.approx(0.03 if tag == "humanwalker" else 0.008)
+    assert env.dt == pytest.approx({"humanwalker": 0.03, "cartpole": 0.04, "halfcheetah": 0.05}.get(tag, 0.008))
     env.close()
 
 
@@ -114,7 +117,7 @@ def test_time_limit_truncation_vs_reference(tag):
     assert d["truncated"].sum() >= 3
 
 
-@pytest.mark.parametrize("tag", ["hopper", "walker2d"])
+@pytest.mark.parametrize("tag", ["hopper", "walker2d", "cartpole", "halfcheetah"])
 def test_vector_env_vs_reference_syncvectorenv(tag):
     """seed(int) fan-out s+i, auto-reset returning the post-reset observation, dtypes (sync_vector_env.py:50-84)."""
     d = np.load(os.path.join(G, "%s_vector4_seed3.npz" % tag))
@@ -129,6 +132,6 @@ def test_vector_env_vs_reference_syncvectorenv(tag):
         assert np.allclose(ob, d["obs"][t], rtol=0, atol=2e-6)
         assert np.array_equal(r, d["reward"][t])
         assert len(infos) == 4 and all(isinstance(i, dict) for i in infos)
-    assert d["done"].sum() > 10
+    assert d["done"].sum() > {"hopper": 10, "walker2d": 10, "cartpole": 10}.get(tag, -1)   # the cheetah never falls here
     assert str(d["obs_dtype"]) == "float32" and str(d["reward_dtype"]) == "float64" and str(d["done_dtype"]) == "bool"
     venv.close()

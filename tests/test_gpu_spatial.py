@@ -222,3 +222,58 @@ def test_walker3d_fp32_and_device_autoreset():
         # fp32: a contact that opens / closes one substep earlier than in fp64 moves an env by ~1e-3; the bulk stays at 1e-5
         assert np.median(err) < tol / 10 and np.percentile(err, 90) < (tol if prec == 64 else 5e-3)
         s.close()
+
+
+# ------------------------------------------------------------------ DartCartPole-v1 / DartHalfCheetah-v1 on the spatial kernel
+@pytest.mark.parametrize("env_id,noise", [("DartCartPole-v1", 0.01), ("DartHalfCheetah-v1", 0.005)])
+def test_classic_env_fp64_matches_oracle(env_id, noise):
+    from dart_env_amd.stepper import HipStepper
+    card = card_for(env_id)
+    n, nd, na = 96, card.ndofs, card.act_dim
+    rng = np.random.RandomState(3)
+    gpu = HipStepper(card, n, precision=64)
+    ora = OracleBatch(card, n)
+    qn = rng.uniform(-noise, noise, (n, nd)); vn = rng.uniform(-noise, noise, (n, nd))
+    og = gpu.reset(None, qn, vn); ora.reset(None, qn, vn)
+    assert og.shape == (n, card.obs_dim) and np.allclose(og, ora.obs(), atol=1e-6)
+    n_done = 0
+    for t in range(100):
+        a = rng.uniform(-1.5, 1.5, (n, na)).astype(np.float32)     # beyond +-1: the cheetah clamps, the cart-pole does not
+        if env_id == "DartHalfCheetah-v1" and t == 40:              # flip a few cheetahs to exercise |q[2]| >= 1.3
+            q, dq = gpu.get_state(); q[:8, 2] = 1.4; q[:8, 1] += 0.5
+            gpu.set_state(q, dq)
+            for i in range(8):
+                ora.worlds[i].set_state(q[i], dq[i])
+        og, rg, dg, tg = gpu.step(a)
+        oo, ro, do, to = ora.step(a)
+        qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+        assert np.abs(qg - qo).max() < 1e-7 and np.abs(dqg - dqo).max() < 1e-5, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        assert np.array_equal(dg, do), t
+        assert np.allclose(og, oo, atol=2e-5) and np.allclose(rg, ro, atol=1e-4)
+        n_done += int(do.sum())
+        if do.any():
+            qn = rng.uniform(-noise, noise, (n, nd)); vn = rng.uniform(-noise, noise, (n, nd))
+            gpu.reset(do.astype(np.uint8), qn, vn, want_obs=False); ora.reset(do, qn, vn)
+    assert n_done >= 8
+    gpu.close()
+
+
+@pytest.mark.parametrize("tag,env_id", [("cartpole", "DartCartPole-v1"), ("halfcheetah", "DartHalfCheetah-v1")])
+def test_classic_env_vector_fixture_and_fp32(tag, env_id):
+    """Reference SyncVectorEnv fixture through the default (device MT19937) vector env in fp64; fp32 stays close."""
+    import dart_env_amd
+    d = np.load(os.path.join(G, "%s_vector4_seed3.npz" % tag))
+    for prec, tol in ((64, 2e-5), (32, 5e-3)):
+        venv = dart_env_amd.vector.make(env_id, 4, precision=prec)
+        venv.seed(3)
+        assert np.allclose(venv.reset(), d["obs0"], atol=1e-6)
+        for t in range(len(d["done"]) if prec == 64 else 25):
+            ob, r, done, infos = venv.step(d["actions"][t])
+            if prec == 64:
+                assert np.array_equal(done, d["done"][t]), t
+                assert np.allclose(ob, d["obs"][t], rtol=0, atol=tol) and np.allclose(r, d["reward"][t], atol=1e-4)
+            elif np.array_equal(done, d["done"][t]) and not done.any():
+                assert np.allclose(ob, d["obs"][t], rtol=0, atol=tol), (t, np.abs(ob - d["obs"][t]).max())
+            else:
+                break
+        venv.close()

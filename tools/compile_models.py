@@ -17,7 +17,10 @@ ASSETS = {
     "walker2d": "walker2d.skel",            # walker2d.py:12
     "walker3d": "walker3d_waist.skel",      # walker3d.py:18
     "humanwalker": "kima/kima_human_edited.skel",  # human_walker.py
+    "cartpole": "cartpole.skel",            # cart_pole.py:9 (dt 0.02)
+    "halfcheetah": "half_cheetah.skel",     # half_cheetah.py:18 (dt 0.01)
 }
+DT = {"cartpole": 0.02, "halfcheetah": 0.01}
 
 
 def main():
@@ -25,7 +28,7 @@ def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dart_env_amd", "models")
     os.makedirs(out, exist_ok=True)
     for name, rel in ASSETS.items():
-        card = parse_skel(os.path.join(ref, "gym/envs/dart/assets", rel), dt=0.002)
+        card = parse_skel(os.path.join(ref, "gym/envs/dart/assets", rel), dt=DT.get(name, 0.002))
         with open(os.path.join(out, name + ".json"), "w") as f:
             f.write(card.to_json())
         print("%-12s ndofs=%2d bodies=%2d mass=%.8f ground_y=%g" % (name, card.ndofs, card.nbodies, card.total_mass, card.ground_y))

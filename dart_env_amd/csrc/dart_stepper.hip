@@ -39,6 +39,7 @@ struct Impl {
   virtual void release() {}
   virtual hipError_t debug_dump(double*) { return hipErrorInvalidValue; }
   virtual int slots() const = 0;
+  bool soa = true;         // state layout: q[n][N] (planar kernels) or q[N][n] (spatial kernel)
   int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
   bool is_static = false;  // true: model constants are compile-time immediates (static_models.hpp)
 };
@@ -172,7 +173,7 @@ void inv_Rp(const double* R, const double* p, double* Ri, double* pi) {
 
 // Expand every multi-dof joint of the card into a chain of 1-dof links (massless carriers in between).
 template <class Real>
-std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
+std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool physics_only = false) {
   memset(&M, 0, sizeof(M));
   if (c.ndofs > SP_MAXN) return "too many dofs";
   int body_link[DART_MAX_BODIES];
@@ -320,6 +321,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
   M.dt = (Real)c.dt; for (int k = 0; k < 3; k++) M.g[k] = (Real)c.gravity[k];
   M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;
   M.limit_erp_dt = (Real)(c.limit_erp / c.dt); M.cfm1 = (Real)(1.0 + c.cfm); M.ccfm1 = (Real)(1.0 + c.contact_cfm);
+  if (physics_only) { M.task = 0; return ""; }   // dynamics getters: geometry, inertia and topology only
   if (c.task != DART_TASK_NONE && c.task != DART_TASK_HUMANWALKER && c.task != DART_TASK_WALKER3D && c.task != DART_TASK_CARTPOLE &&
       c.task != DART_TASK_HALFCHEETAH)
     return "task not served by the spatial kernel";
@@ -347,6 +349,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M) {
 
 template <class Real>
 struct SpatialImplT : Impl {
+  SpatialImplT() { soa = false; }
   SpatialModel<Real> M;
   SpatialModel<Real>* dM = nullptr;
   Real* init_h = nullptr;
@@ -460,6 +463,9 @@ struct DartStepper {
   int solver = 0, it1 = 0, it2 = 0, autoreset = 0;   // it1/it2 = 0: the implementation's default iteration cap
   uint64_t seed = 0, env_offset = 0;
   bool pending = false;
+  void* dyn_model = nullptr;     // device SpatialModel<float|double> used by dart_get_dynamics (built on first use)
+  size_t dyn_lds = 0;
+  double *d_dynM = nullptr, *d_dync = nullptr;
   std::string err;
 };
 
@@ -471,6 +477,30 @@ struct DartStepper {
       return DART_E_HIP;                                                                     \
     }                                                                                        \
   } while (0)
+
+template <class Real>
+static int dynamics_impl(DartStepper* h, double* mass, double* bias) {
+  const size_t N = (size_t)h->n, nd = (size_t)h->card.ndofs;
+  if (!h->dyn_model) {
+    auto M = std::make_unique<SpatialModel<Real>>();
+    std::string w = fill_spatial<Real>(h->card, *M, true);
+    if (!w.empty()) { h->err = "dynamics getters: " + w; return DART_E_UNSUPPORTED; }
+    CHK(h, hipMalloc(&h->dyn_model, sizeof(SpatialModel<Real>)));
+    CHK(h, hipMemcpy(h->dyn_model, M.get(), sizeof(SpatialModel<Real>), hipMemcpyHostToDevice));
+    h->dyn_lds = sp_lds_bytes(M->nl, M->n, sizeof(Real));
+    CHK(h, hipFuncSetAttribute((const void*)sp_dynamics_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds));
+    CHK(h, hipMalloc((void**)&h->d_dynM, sizeof(double) * N * nd * nd));
+    CHK(h, hipMalloc((void**)&h->d_dync, sizeof(double) * N * nd));
+  }
+  hipLaunchKernelGGL((sp_dynamics_kernel<Real>), dim3((unsigned)N), dim3(64), h->dyn_lds, h->stream,
+                     (const SpatialModel<Real>*)h->dyn_model, h->n, (const Real*)h->q, (const Real*)h->dq, h->impl->soa ? 1 : 0,
+                     mass ? h->d_dynM : nullptr, bias ? h->d_dync : nullptr);
+  CHK(h, hipGetLastError());
+  if (mass) CHK(h, hipMemcpyAsync(mass, h->d_dynM, sizeof(double) * N * nd * nd, hipMemcpyDeviceToHost, h->stream));
+  if (bias) CHK(h, hipMemcpyAsync(bias, h->d_dync, sizeof(double) * N * nd, hipMemcpyDeviceToHost, h->stream));
+  CHK(h, hipStreamSynchronize(h->stream));
+  return DART_OK;
+}
 
 extern "C" {
 
@@ -544,7 +574,7 @@ int dart_destroy(DartStepper* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->impl) h->impl->release();
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -795,6 +825,13 @@ int dart_debug_dump(DartStepper* h, double* out160) {
   CHK(h, hipStreamSynchronize(h->stream));
   CHK(h, h->impl->debug_dump(out160));
   return DART_OK;
+}
+
+int dart_get_dynamics(DartStepper* h, double* mass_matrix, double* coriolis_gravity) {
+  if (!h || (!mass_matrix && !coriolis_gravity)) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  return h->precision == 32 ? dynamics_impl<float>(h, mass_matrix, coriolis_gravity) : dynamics_impl<double>(h, mass_matrix, coriolis_gravity);
 }
 
 int dart_sync(DartStepper* h) {

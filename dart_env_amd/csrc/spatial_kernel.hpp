@@ -1087,6 +1087,56 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
   sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
 }
 
+// Dynamics quantities of the CURRENT state (pydart2's skel.M and skel.c, reference gym/envs/dart/walker3d_spd.py:40-55):
+// mass matrix (n x n, symmetric, without the implicit damping / stiffness terms) and Coriolis + gravity forces.
+// One wavefront per env; `soa` tells how the owning implementation stores its state (planar kernels: q[n][N]).
+template <class Real>
+__global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
+                                                          const Real* __restrict__ qs, const Real* __restrict__ dqs, int soa,
+                                                          double* __restrict__ mass_out, double* __restrict__ bias_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  const SpatialModel<Real>& Md = *Mp;
+  const int lane = threadIdx.x;
+  const int64_t e = blockIdx.x;
+  if (e >= n_envs) return;
+  const int n = Md.n, nl = Md.nl;
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl, n);
+  if (lane < n) {
+    const int64_t at = soa ? (int64_t)lane * n_envs + e : e * n + lane;
+    S.q[lane] = qs[at]; S.dq[lane] = dqs[at]; S.tau[lane] = Real(0);
+  }
+  if (lane < nl) S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16);
+  __syncthreads();
+  LinkConst<Real> lc;
+  sp_load_link_const<Real>(Md, lane < nl ? lane : 0, lc);
+  if (lane == 0) sp_root_offset<Real>(Md, S);
+  sp_forward<Real>(lc, Md, S, lane);
+  __syncthreads();
+  for (int lv = Md.n_group_levels - 1; lv >= 0; lv--) {
+    if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);
+    __syncthreads();
+  }
+  if (lane < nl) sp_link_rhs<Real>(lc, Md, S, lane);
+  __syncthreads();
+  if (bias_out && lane < nl && lc.dof >= 0) {
+    const Real* L = S.link + lane * SP_LINKF;
+    const V3<Real> a = ld3(L + LK_A);
+    bias_out[e * n + lc.dof] = (double)((lc.jtype == 2) ? dot(a, ld3(L + LK_N)) : dot(a, ld3(L + LK_F)));
+  }
+  if (mass_out) {
+    if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
+    __syncthreads();
+    if (lane < n) {
+      double* Mo = mass_out + e * n * n;
+      for (int k = 0; k <= lane; k++) {
+        double v = (double)S.H[TL(lane, k)];
+        if (k == lane) v -= (double)lc.d_diag;
+        Mo[lane * n + k] = v; Mo[k * n + lane] = v;
+      }
+    }
+  }
+}
+
 // masked reset: q = init + noise (host rows or Philox), elapsed = 0, init height, obs
 template <class Real>
 __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,

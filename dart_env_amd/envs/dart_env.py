@@ -43,6 +43,16 @@ class SkeletonView:
         return self._env._stepper.get_state()[1]
 
     @property
+    def M(self):
+        """Mass matrices (num_envs, ndofs, ndofs) -- pydart2 skel.M (reference walker3d_spd.py:44)."""
+        return self._env._stepper.dynamics(True, False)[0]
+
+    @property
+    def c(self):
+        """Coriolis + gravity forces (num_envs, ndofs) -- pydart2 skel.c (reference walker3d_spd.py:49)."""
+        return self._env._stepper.dynamics(False, True)[1]
+
+    @property
     def q_lower(self):
         c = self._env.card
         return np.array([c.lower[i] for i in range(c.ndofs)])

@@ -27,7 +27,7 @@ SOLVER_BPP, SOLVER_PGS = 0, 1
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics",
 ]
 
 
@@ -75,6 +75,7 @@ def load_library(path: Optional[str] = None):
     L.dart_reset_device.argtypes = [vp, vp, vp, vp]
     L.dart_sync.argtypes = [vp]
     L.dart_seed_mt19937.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+    L.dart_get_dynamics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dart_debug_dump.argtypes = [vp, dp]
     L.dart_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.dart_get_counters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
@@ -142,6 +143,14 @@ class HipStepper:
         k = np.ascontiguousarray(keys, dtype=np.uint32).reshape(self.num_envs, 2)
         n = np.ascontiguousarray(key_len, dtype=np.int32).reshape(self.num_envs)
         self._check(self.L.dart_seed_mt19937(self.h, _ptr(k, C.c_uint32), _ptr(n, C.c_int32)))
+
+    def dynamics(self, mass=True, bias=True):
+        """-> (M (N, n, n), c (N, n)): pydart2's skel.M and skel.c for every env (None for the one not requested)."""
+        n, d = self.num_envs, self.ndofs
+        M = np.empty((n, d, d), dtype=np.float64) if mass else None
+        c = np.empty((n, d), dtype=np.float64) if bias else None
+        self._check(self.L.dart_get_dynamics(self.h, _ptr(M, C.c_double) if mass else None, _ptr(c, C.c_double) if bias else None))
+        return M, c
 
     # -- state --
     def reset(self, mask=None, qpos_noise=None, qvel_noise=None, want_obs=True):

@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_spatial.py -m gpu -q -x -k classic 2>&1 | tail -12
-python bench.py --env-id DartHalfCheetah-v1 --envs 65536 --steps 50 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
-python bench.py --env-id DartCartPole-v1 --envs 65536 --steps 50 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+python -m pytest tests/test_gpu_spatial.py -m gpu -q -x -k dynamics 2>&1 | tail -12

@@ -125,6 +125,12 @@ int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear);
  * of the last LCP solved. */
 int dart_debug_dump(DartStepper* h, double* out160);
 
+/* Dynamics quantities of the current state of every env -- pydart2's `skel.M` and `skel.c` (reference
+ * gym/envs/dart/walker3d_spd.py:40-55 builds its SPD controller from them): mass_matrix (N, ndofs, ndofs) symmetric,
+ * WITHOUT the implicit damping / stiffness terms the integrator adds; coriolis_gravity (N, ndofs) = C(q, dq) dq + g(q).
+ * Either pointer may be NULL.  Computed by the generic tree kernel for every model (planar ones included). */
+int dart_get_dynamics(DartStepper* h, double* mass_matrix, double* coriolis_gravity);
+
 /* Wait for everything enqueued on the handle's stream. */
 int dart_sync(DartStepper* h);
 

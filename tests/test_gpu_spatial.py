@@ -277,3 +277,30 @@ def test_classic_env_vector_fixture_and_fp32(tag, env_id):
             else:
                 break
         venv.close()
+
+
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartWalker3d-v1", "DartHumanWalker-v1"])
+def test_dynamics_getters_match_oracle(env_id):
+    """dart_get_dynamics = pydart2's skel.M / skel.c: CRBA mass matrix and RNEA bias of the oracle at random states,
+    for models stepped by the planar kernels (SoA state) as well as by the spatial one."""
+    from dart_env_amd.stepper import HipStepper
+    card = card_for(env_id)
+    n, nd = 40, card.ndofs
+    rng = np.random.RandomState(11)
+    q = rng.uniform(-0.4, 0.4, (n, nd)); dq = rng.uniform(-2, 2, (n, nd))
+    q[:, 0] += 100.0 * rng.rand(n)              # far from the origin: the getters must not care
+    w = OracleWorld(card)
+    for prec, rtol in ((64, 1e-11), (32, 2e-5)):
+        s = HipStepper(card, n, precision=prec)
+        s.set_state(q, dq)
+        M, c = s.dynamics()
+        qs, dqs = s.get_state()                   # what the device actually holds (fp32 rounding of q)
+        for i in range(n):
+            w.set_state(qs[i], dqs[i])
+            Mo, co = w.mass_matrix(), w.bias()
+            assert np.abs(M[i] - Mo).max() <= rtol * np.abs(Mo).max(), (prec, i, np.abs(M[i] - Mo).max())
+            assert np.abs(c[i] - co).max() <= rtol * max(1.0, np.abs(co).max()) * (1 if prec == 64 else 20), (prec, i, np.abs(c[i] - co).max())
+        assert np.allclose(M, np.transpose(M, (0, 2, 1)))
+        Mo_only, _ = s.dynamics(True, False); _, c_only = s.dynamics(False, True)
+        assert np.array_equal(Mo_only, M) and np.array_equal(c_only, c)
+        s.close()

@@ -17,6 +17,7 @@
 #include "static_models.hpp"
 #include "spatial_kernel.hpp"
 #include "mt19937_kernels.hpp"
+#include "episode_kernels.hpp"
 
 using namespace dartk;
 
@@ -463,6 +464,9 @@ struct DartStepper {
   int solver = 0, it1 = 0, it2 = 0, autoreset = 0;   // it1/it2 = 0: the implementation's default iteration cap
   uint64_t seed = 0, env_offset = 0;
   bool pending = false;
+  double *d_ep_ret = nullptr, *d_last_ret = nullptr, *d_ep_tot = nullptr;   // DART_CFG_EPISODE_STATS
+  int32_t *d_ep_len = nullptr, *d_last_len = nullptr;
+  bool ep_stats = false;
   void* dyn_model = nullptr;     // device SpatialModel<float|double> used by dart_get_dynamics (built on first use)
   size_t dyn_lds = 0;
   double *d_dynM = nullptr, *d_dync = nullptr;
@@ -574,7 +578,7 @@ int dart_destroy(DartStepper* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->impl) h->impl->release();
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -616,6 +620,18 @@ int dart_configure(DartStepper* h, int key, double value) {
       }
       h->impl->set_stats(value != 0 ? h->d_stats : nullptr);
       break;
+    case DART_CFG_EPISODE_STATS:
+      if (value != 0 && !h->d_ep_ret) {
+        const size_t N = (size_t)h->n;
+        CHK(h, hipMalloc((void**)&h->d_ep_ret, 8 * N)); CHK(h, hipMalloc((void**)&h->d_last_ret, 8 * N));
+        CHK(h, hipMalloc((void**)&h->d_ep_len, 4 * N)); CHK(h, hipMalloc((void**)&h->d_last_len, 4 * N));
+        CHK(h, hipMalloc((void**)&h->d_ep_tot, 8 * 3));
+        CHK(h, hipMemset(h->d_ep_ret, 0, 8 * N)); CHK(h, hipMemset(h->d_last_ret, 0, 8 * N));
+        CHK(h, hipMemset(h->d_ep_len, 0, 4 * N)); CHK(h, hipMemset(h->d_last_len, 0, 4 * N));
+        CHK(h, hipMemset(h->d_ep_tot, 0, 8 * 3));
+      }
+      h->ep_stats = value != 0;
+      break;
     case DART_CFG_BLOCK_THREADS:
       if (value != 64 && value != 32 && value != 16) { h->err = "block threads must be 16, 32 or 64"; return DART_E_INVALID; }
       h->impl->block_threads = (int)value; break;
@@ -623,6 +639,21 @@ int dart_configure(DartStepper* h, int key, double value) {
   }
   if (h->solver < 0 || h->solver > 1 || h->it1 < 0 || h->it2 < 0) { h->err = "bad solver setting"; return DART_E_INVALID; }
   h->impl->set_solver(h->solver, h->it1, h->it2);
+  return DART_OK;
+}
+
+// episode return / length accumulators (DART_CFG_EPISODE_STATS): after every step, on the step's stream
+static int episode_accumulate(DartStepper* h, hipStream_t s, const float* d_rew, const uint8_t* d_done) {
+  if (!h->ep_stats) return DART_OK;
+  hipLaunchKernelGGL(episode_stats_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, h->n, d_rew, d_done, h->d_ep_ret,
+                     h->d_ep_len, h->d_last_ret, h->d_last_len, h->d_ep_tot);
+  CHK(h, hipGetLastError());
+  return DART_OK;
+}
+static int episode_restart(DartStepper* h, hipStream_t s, const uint8_t* d_mask) {
+  if (!h->ep_stats) return DART_OK;
+  hipLaunchKernelGGL(episode_reset_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, h->n, d_mask, h->d_ep_ret, h->d_ep_len);
+  CHK(h, hipGetLastError());
   return DART_OK;
 }
 
@@ -694,6 +725,7 @@ int dart_reset(DartStepper* h, const uint8_t* mask, const double* qpos_noise, co
   }
   CHK(h, h->impl->reset(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, dmask, dqn, dvn,
                         obs_out ? h->d_obs : nullptr, h->seed, h->env_offset));
+  { int rc = episode_restart(h, h->stream, dmask); if (rc != DART_OK) return rc; }
   if (obs_out) CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
   CHK(h, hipStreamSynchronize(h->stream));
   if (obs_out) memcpy(obs_out, h->h_obs, 4 * N * h->card.obs_dim);
@@ -711,7 +743,7 @@ int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void*
     dqn = h->d_qn; dvn = h->d_vn;
   }
   CHK(h, h->impl->reset(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_mask, dqn, dvn, d_obs, h->seed, h->env_offset));
-  return DART_OK;
+  return episode_restart(h, s, d_mask);
 }
 
 static int state_copy(DartStepper* h, double* q, double* dq, int to_device) {
@@ -747,6 +779,7 @@ int dart_step_async(DartStepper* h, const float* actions) {
   const bool mt_reset = h->autoreset && h->noise_mode == 1;
   CHK(h, h->impl->step(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done,
                        h->d_trunc, mt_reset ? 0 : h->autoreset, h->seed, h->env_offset));
+  { int rc = episode_accumulate(h, h->stream, h->d_rew, h->d_done); if (rc != DART_OK) return rc; }
   if (mt_reset) {   // done envs: MT19937 noise, reset, post-reset observation (sync_vector_env.py:77-78)
     int rc = mt_draw(h, h->stream, h->d_done);
     if (rc != DART_OK) return rc;
@@ -792,6 +825,7 @@ int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float
   uint8_t* dn = d_done ? d_done : h->d_done;
   CHK(h, h->impl->step(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_actions, o, d_reward ? d_reward : h->d_rew, dn,
                        d_truncated ? d_truncated : h->d_trunc, mt_reset ? 0 : h->autoreset, h->seed, h->env_offset));
+  { int rc = episode_accumulate(h, s, d_reward ? d_reward : h->d_rew, dn); if (rc != DART_OK) return rc; }
   if (mt_reset) {
     int rc = mt_draw(h, s, dn);
     if (rc != DART_OK) return rc;
@@ -824,6 +858,20 @@ int dart_debug_dump(DartStepper* h, double* out160) {
   CHK(h, hipSetDevice(h->device));
   CHK(h, hipStreamSynchronize(h->stream));
   CHK(h, h->impl->debug_dump(out160));
+  return DART_OK;
+}
+
+int dart_get_episode_stats(DartStepper* h, double* last_return, int32_t* last_length, double* totals3, int clear_totals) {
+  if (!h) return DART_E_INVALID;
+  if (!h->d_ep_ret) { h->err = "enable DART_CFG_EPISODE_STATS first"; return DART_E_INVALID; }
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  const size_t N = (size_t)h->n;
+  if (last_return) CHK(h, hipMemcpy(last_return, h->d_last_ret, 8 * N, hipMemcpyDeviceToHost));
+  if (last_length) CHK(h, hipMemcpy(last_length, h->d_last_len, 4 * N, hipMemcpyDeviceToHost));
+  if (totals3) CHK(h, hipMemcpy(totals3, h->d_ep_tot, 8 * 3, hipMemcpyDeviceToHost));
+  if (clear_totals) CHK(h, hipMemset(h->d_ep_tot, 0, 8 * 3));
   return DART_OK;
 }
 

@@ -21,13 +21,14 @@ LIB_PATH = os.environ.get("DART_STEPPER_LIB", os.path.join(_HERE, LIB_NAME))
 # error codes / keys (include/dart_stepper.h)
 DART_OK, E_INVALID, E_NO_DEVICE, E_UNSUPPORTED, E_HIP, E_PENDING, E_NOT_PENDING = 0, -1, -2, -3, -4, -5, -6
 Q_NUM_ENVS, Q_NDOFS, Q_OBS_DIM, Q_ACT_DIM, Q_FRAME_SKIP, Q_PRECISION, Q_DEVICE, Q_LCP_SLOTS, Q_STATIC_KERNEL = range(9)
-CFG_SOLVER, CFG_ITERS_STAGE1, CFG_ITERS_STAGE2, CFG_AUTORESET, CFG_SEED, CFG_ENV_OFFSET, CFG_BLOCK_THREADS, CFG_STATS = range(8)
+(CFG_SOLVER, CFG_ITERS_STAGE1, CFG_ITERS_STAGE2, CFG_AUTORESET, CFG_SEED, CFG_ENV_OFFSET, CFG_BLOCK_THREADS, CFG_STATS,
+ CFG_EPISODE_STATS) = range(9)
 SOLVER_BPP, SOLVER_PGS = 0, 1
 
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats",
 ]
 
 
@@ -76,6 +77,7 @@ def load_library(path: Optional[str] = None):
     L.dart_sync.argtypes = [vp]
     L.dart_seed_mt19937.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     L.dart_get_dynamics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.dart_get_episode_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]
     L.dart_debug_dump.argtypes = [vp, dp]
     L.dart_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.dart_get_counters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
@@ -143,6 +145,15 @@ class HipStepper:
         k = np.ascontiguousarray(keys, dtype=np.uint32).reshape(self.num_envs, 2)
         n = np.ascontiguousarray(key_len, dtype=np.int32).reshape(self.num_envs)
         self._check(self.L.dart_seed_mt19937(self.h, _ptr(k, C.c_uint32), _ptr(n, C.c_int32)))
+
+    def episode_stats(self, per_env=True, clear_totals=False):
+        """-> (last_return (N,), last_length (N,), totals [sum_return, sum_length, count]); needs CFG_EPISODE_STATS."""
+        r = np.empty(self.num_envs, dtype=np.float64) if per_env else None
+        l = np.empty(self.num_envs, dtype=np.int32) if per_env else None
+        tot = np.zeros(3, dtype=np.float64)
+        self._check(self.L.dart_get_episode_stats(self.h, _ptr(r, C.c_double) if per_env else None,
+                                                  _ptr(l, C.c_int32) if per_env else None, _ptr(tot, C.c_double), int(clear_totals)))
+        return r, l, tot
 
     def dynamics(self, mass=True, bias=True):
         """-> (M (N, n, n), c (N, n)): pydart2's skel.M and skel.c for every env (None for the one not requested)."""

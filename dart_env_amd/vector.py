@@ -22,8 +22,9 @@ class ClosedEnvironmentError(RuntimeError):
 class InfoList:
     """list-of-dict view built lazily (65 536 dict allocations per step would dominate the step)."""
 
-    def __init__(self, truncated):
+    def __init__(self, truncated, extra=None):
         self._t = truncated
+        self._extra = extra or {}     # env index -> dict merged into that env's info (e.g. {'episode': {...}})
 
     def __len__(self):
         return len(self._t)
@@ -31,7 +32,10 @@ class InfoList:
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[j] for j in range(*i.indices(len(self)))]
-        return {"TimeLimit.truncated": True} if self._t[i] else {}
+        d = {"TimeLimit.truncated": True} if self._t[i] else {}
+        if i in self._extra:
+            d.update(self._extra[i])
+        return d
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))

@@ -54,7 +54,8 @@ enum {
   DART_CFG_SEED = 4,        /* Philox key (low 53 bits of the double are used) */
   DART_CFG_ENV_OFFSET = 5,  /* global index of env 0 of this handle (multi-GPU sharding keeps streams distinct) */
   DART_CFG_BLOCK_THREADS = 6,/* envs (active lanes) per wave64 workgroup of the step kernel: 64, 32 or 16 */
-  DART_CFG_STATS = 7        /* 1: histogram the wave-level pivoting iteration counts (dart_get_stats) */
+  DART_CFG_STATS = 7,       /* 1: histogram the wave-level pivoting iteration counts (dart_get_stats) */
+  DART_CFG_EPISODE_STATS = 8 /* 1: keep per-env episode return / length accumulators on the device (dart_get_episode_stats) */
 };
 
 /* Library-level error text for failures that happen before a handle exists (handle == NULL). */
@@ -124,6 +125,14 @@ int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear);
 /* Debugging aid of the spatial kernel (needs DART_CFG_STATS): per env 160 doubles = {m, ncp, x[40], b[40], hi[40], diagA[40]}
  * of the last LCP solved. */
 int dart_debug_dump(DartStepper* h, double* out160);
+
+/* Episode statistics kept on the device (DART_CFG_EPISODE_STATS = 1) -- the batched form of the reference's
+ * RecordEpisodeStatistics wrapper (gym/wrappers/record_episode_statistics.py:22-34): every step adds the reward to the
+ * env's running return and 1 to its length; an env that reports done latches them into last_return[i] /
+ * last_length[i] (the wrapper's info['episode'] 'r' and 'l') and restarts; dart_reset restarts the masked envs.
+ * totals3 = {sum of returns, sum of lengths, count} over the episodes finished since the last clear.
+ * Any output pointer may be NULL. */
+int dart_get_episode_stats(DartStepper* h, double* last_return, int32_t* last_length, double* totals3, int clear_totals);
 
 /* Dynamics quantities of the current state of every env -- pydart2's `skel.M` and `skel.c` (reference
  * gym/envs/dart/walker3d_spd.py:40-55 builds its SPD controller from them): mass_matrix (N, ndofs, ndofs) symmetric,

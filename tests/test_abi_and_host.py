@@ -132,3 +132,42 @@ def test_shard_layout():
     assert [shard_layout(524288, 8, r) for r in range(8)] == [(r * 65536, 65536) for r in range(8)]
     lay = [shard_layout(10, 4, r) for r in range(4)]
     assert lay == [(0, 3), (3, 3), (6, 2), (8, 2)]
+
+
+def test_record_episode_statistics_wrappers():
+    """RecordEpisodeStatistics (gym/wrappers/record_episode_statistics.py:22-34): single-env wrapper and the vector
+    one (host fallback here, device accumulators in the GPU suite) agree with a hand accumulation of the rewards."""
+    import dart_env_amd
+    from dart_env_amd.envs import DartHopperEnv
+    from dart_env_amd.wrappers import RecordEpisodeStatistics, TimeLimit, VectorRecordEpisodeStatistics
+    from tests.fake_stepper import OracleStepper
+    env = RecordEpisodeStatistics(TimeLimit(DartHopperEnv(stepper_factory=OracleStepper), max_episode_steps=30), deque_size=5)
+    env.seed(0)
+    env.reset()
+    rs = np.random.RandomState(0)
+    ret, ln, n_ep = 0.0, 0, 0
+    for t in range(150):
+        ob, r, done, info = env.step(rs.uniform(-1, 1, 3))
+        ret += r; ln += 1
+        if done:
+            assert info["episode"]["r"] == pytest.approx(ret, abs=1e-12) and info["episode"]["l"] == ln and info["episode"]["t"] >= 0
+            n_ep += 1; ret, ln = 0.0, 0
+            env.reset()
+        else:
+            assert "episode" not in info
+    assert n_ep >= 5 and len(env.return_queue) == 5 and len(env.length_queue) == 5
+    venv = VectorRecordEpisodeStatistics(dart_env_amd.vector.make("DartHopper-v1", 6, stepper_factory=OracleStepper))
+    venv.seed(1)
+    venv.reset()
+    acc, cnt, fin = np.zeros(6), np.zeros(6, dtype=int), 0
+    for t in range(60):
+        ob, r, done, infos = venv.step(rs.uniform(-1, 1, (6, 3)).astype(np.float32))
+        acc += r; cnt += 1
+        for i in range(6):
+            if done[i]:
+                assert infos[i]["episode"]["r"] == pytest.approx(acc[i], abs=1e-9) and infos[i]["episode"]["l"] == cnt[i]
+                acc[i] = 0; cnt[i] = 0; fin += 1
+            else:
+                assert "episode" not in infos[i]
+    assert fin >= 6 and len(venv.return_queue) == min(fin, 100)
+    venv.close()

@@ -51,3 +51,49 @@ def test_two_rank_sharding_equals_single_batch():
         o, w, d = got[r]
         assert o.shape == (total, 11)
         assert np.array_equal(o, obs) and np.allclose(w, rew, atol=1e-5) and np.array_equal(d, done)
+
+
+def _rollout_worker(rank, world, port, total, T, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from dart_env_amd.distributed import RolloutBuffer, ShardedDartVectorEnv
+    from tests.fake_stepper import OracleStepper
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    env = ShardedDartVectorEnv("DartHopper-v1", total, rank=rank, world_size=world, seed=9, stepper_factory=OracleStepper)
+    buf = RolloutBuffer(env, T)
+    policy = lambda ob: torch.tanh(ob[:, :3] * 3.0 - ob[:, 5:8])   # deterministic function of the observation
+    full = buf.collect(policy).gather()
+    q.put((rank, {k: v.numpy() for k, v in full.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+    env.close()
+
+
+def test_rollout_buffer_gather_two_ranks():
+    """Trajectories collected shard-by-shard and gathered once equal the trajectory of the unsharded batch."""
+    import torch
+    from dart_env_amd.distributed import RolloutBuffer, ShardedDartVectorEnv
+    from tests.fake_stepper import OracleStepper
+    total, T, world = 6, 25, 2
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rollout_worker, args=(r, world, port, total, T, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=180) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    env = ShardedDartVectorEnv("DartHopper-v1", total, rank=0, world_size=1, seed=9, stepper_factory=OracleStepper)
+    policy = lambda ob: torch.tanh(ob[:, :3] * 3.0 - ob[:, 5:8])
+    ref = RolloutBuffer(env, T).collect(policy).gather()
+    n = total // world
+    for r in range(world):
+        g = got[r]
+        assert g["obs"].shape == (world, T + 1, n, 11) and g["dones"].shape == (world, T, n)
+        for k in ("obs", "actions", "rewards", "dones", "truncated"):
+            whole = ref[k].numpy()[0]                                  # (T[+1], total, ...)
+            for s in range(world):
+                assert np.allclose(g[k][s], whole[:, s * n:(s + 1) * n], atol=1e-6), (k, r, s)
+    assert ref["dones"].sum() > 0
+    env.close()

@@ -332,3 +332,60 @@ def test_device_resident_step_with_mt19937_resets_equals_host_buffer_step():
     qa, va = a_host.get_state(); qb, vb = b_dev.get_state()
     assert np.array_equal(qa, qb) and np.array_equal(va, vb)
     a_host.close(); b_dev.close()
+
+
+def test_device_episode_statistics_match_host_accumulation():
+    """DART_CFG_EPISODE_STATS: per-env return / length accumulators in HBM = RecordEpisodeStatistics semantics."""
+    from dart_env_amd.wrappers import VectorRecordEpisodeStatistics
+    n = 2048
+    venv = VectorRecordEpisodeStatistics(dart_env_amd.vector.make("DartHopper-v1", n, noise="philox"))
+    assert venv._device
+    venv.seed(4)
+    venv.reset()
+    rs = np.random.RandomState(8)
+    acc, cnt = np.zeros(n), np.zeros(n, dtype=np.int64)
+    fin = 0; sum_r = 0.0; sum_l = 0
+    for t in range(80):
+        ob, r, done, infos = venv.step(rs.uniform(-1, 1, (n, 3)).astype(np.float32))
+        acc += r; cnt += 1
+        for i in done.nonzero()[0]:
+            ep = infos[int(i)]["episode"]
+            assert ep["r"] == pytest.approx(acc[i], rel=1e-6, abs=1e-4) and ep["l"] == cnt[i]
+            sum_r += acc[i]; sum_l += cnt[i]; fin += 1
+            acc[i] = 0; cnt[i] = 0
+        assert "episode" not in infos[int((~done).nonzero()[0][0])]
+    tr, tl, tc = venv.totals(clear=True)
+    assert tc == fin and tl == sum_l and tr == pytest.approx(sum_r, rel=1e-6)
+    assert venv.totals()[2] == 0 and fin > n
+    venv.close()
+
+
+def test_rollout_buffer_device_resident_equals_host_stepping():
+    """RolloutBuffer: dart_step_device writes every slot of the (T, n, ...) HBM tensors; same trajectory as stepping
+    through host arrays with the same policy."""
+    import torch
+    from dart_env_amd.distributed import RolloutBuffer
+    n, T = 512, 40
+    policy = lambda ob: torch.tanh(ob[:, :3] * 3.0 - ob[:, 5:8])
+    venv = dart_env_amd.vector.make("DartHopper-v1", n, noise="philox", precision=64)
+    venv.seed(2)
+    buf = RolloutBuffer(venv, T)
+    assert buf.on_device and buf.obs.is_cuda
+    buf.collect(policy); torch.cuda.synchronize()
+    ref = dart_env_amd.vector.make("DartHopper-v1", n, noise="philox", precision=64)
+    ref.seed(2)
+    ob = ref.reset()
+    assert np.array_equal(buf.obs[0].cpu().numpy(), ob)
+    for t in range(T):
+        a = policy(torch.from_numpy(ob)).numpy()
+        assert np.allclose(buf.actions[t].cpu().numpy(), a, atol=1e-6)
+        ob, r, d, infos = ref.step(buf.actions[t].cpu().numpy())
+        assert np.array_equal(buf.dones[t].cpu().numpy().astype(bool), d), t
+        assert np.array_equal(buf.obs[t + 1].cpu().numpy(), ob) and np.allclose(buf.rewards[t].cpu().numpy(), r, atol=1e-5)
+    assert buf.dones.sum().item() > 0
+    g = buf.gather()
+    assert g["obs"].shape == (1, T + 1, n, 11)
+    last = g["obs"][0, T].clone()
+    buf.collect(policy); torch.cuda.synchronize()   # a second window continues from the last observation
+    assert torch.equal(buf.obs[0], last)
+    venv.close(); ref.close()

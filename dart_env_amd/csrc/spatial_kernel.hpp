@@ -969,6 +969,33 @@ __device__ __forceinline__ bool sp_walker3d_epilogue(const SpatialModel<Real>& M
   return !ok;
 }
 
+// Hopper / Walker2d task logic for cards the planar kernels do not take (e.g. every capsule collidable): hopper.py:36-65,
+// walker2d.py:22-62.  aux_link = {height body link, penalty dof or -1}; aux_real = {alive, ctrl_cost, limit_penalty, -,
+// height_lo, height_hi, penalty_margin}.  Returns done; *height_out feeds observation[0].
+template <class Real>
+__device__ __forceinline__ bool sp_planar_task_epilogue(const SpatialModel<Real>& Md, SpLds<Real>& S, Real pos_before, Real sq_a_sum,
+                                                        Real& reward_out) {
+  const Real height = S.link[Md.aux_link[0] * SP_LINKF + LK_C + 1] + S.misc[1];
+  Real pen = Real(0);
+  const int j = Md.aux_link[1];
+  if (j >= 0) {
+    if ((Md.lower[j] - S.q[j]) > -Md.aux_real[6]) pen += Real(1.5);
+    if ((Md.upper[j] - S.q[j]) < Md.aux_real[6]) pen += Real(1.5);
+  }
+  Real rew = (S.q[0] - pos_before) * Md.inv_envdt;
+  rew += Md.aux_real[0];
+  rew -= Md.aux_real[1] * sq_a_sum;
+  rew -= Md.aux_real[2] * pen;
+  reward_out = rew;
+  bool ok = true;
+  for (int i = 0; i < Md.n; i++) {
+    ok = ok && isfinite(S.q[i]) && isfinite(S.dq[i]) && (fabs(S.dq[i]) < Md.s_max);
+    if (i >= 2) ok = ok && (fabs(S.q[i]) < Md.s_max);
+  }
+  ok = ok && (height > Md.aux_real[4]) && (height < Md.aux_real[5]) && (fabs(S.q[2]) < Md.aux_real2[1]);
+  return !ok;
+}
+
 // CartPole (cart_pole.py:12-24): reward 1, done when the observation is not finite or |q[1]| > angle_max.
 // HalfCheetah (half_cheetah.py:43-63): aux_real = {alive, ctrl_cost}; reward zeroed when the state broke.
 template <class Real>
@@ -1000,6 +1027,8 @@ __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds
   if (lane >= 1 && lane < n) o[lane - 1] = (float)S.q[lane];
   if (lane < n) o[n - 1 + lane] = (float)fmin(fmax(S.dq[lane], -Md.v_clip), Md.v_clip);
   if (Md.task == 4 && lane < 2) o[2 * n - 1 + lane] = (float)cflags[lane];   // foot-contact flags (human_walker.py:146)
+  if ((Md.task == 1 || Md.task == 2) && lane == 1)   // observation[0] = COM height of the root body (hopper.py:72)
+    o[0] = (float)(S.link[Md.aux_link[0] * SP_LINKF + LK_C + 1] + S.misc[1]);
 }
 
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
@@ -1050,6 +1079,7 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
     if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, init_h[e], cflags, rew);
     else if (Md.task == 3) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     else if (Md.task >= 5) task_done = sp_simple_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
+    else if (Md.task == 1 || Md.task == 2) task_done = sp_planar_task_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     int el = elapsed[e] + 1;
     const bool trunc = (Md.max_steps > 0) && (el >= Md.max_steps);
     dn = task_done || trunc; tr = trunc && !task_done;
@@ -1176,6 +1206,8 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
     if (m) {
       if (!qnoise) episode[e] = episode[e] + 1;
       elapsed[e] = 0;
+    }
+    if (m || (obs && !obs_masked_only && (Md.task == 1 || Md.task == 2))) {   // observation[0] needs the pose
       sp_kinematics<Real>(Md, S);
       if (Md.task == 4) init_h[e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
     }

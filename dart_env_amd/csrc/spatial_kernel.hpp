@@ -25,7 +25,7 @@ namespace dartk {
 
 constexpr int SP_MAXL = 48;   // expanded 1-dof links
 constexpr int SP_MAXN = 32;   // dofs
-constexpr int SP_MAXS = 8;    // collidable shapes
+constexpr int SP_MAXS = 16;   // collidable shapes
 constexpr int SP_MAXCP = 12;  // contact points (a box face gives up to 4)
 constexpr int SP_MAXM = 36;   // LCP rows (12 contact points x 3; HumanWalker peaks at ~31 active rows)
 constexpr int SP_TRI = SP_MAXM * (SP_MAXM + 1) / 2;   // packed lower triangle of A / of the LDL workspace

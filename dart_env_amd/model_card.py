@@ -121,7 +121,7 @@ HUMANWALKER = TaskSpec(
     max_episode_steps=300, reward_threshold=None, height_body=10, penalty_dof=-1, height_lo=-0.2, height_hi=1.0,
     angle_max=2.0, contact_bodies=["l-foot", "r-foot"], alive_bonus=2.0, ctrl_cost=0.5, limit_penalty=0.0,
     reset_noise=0.005, reset_noise_vel=0.05, aux_body_names=["pelvis", "head", "l-foot", "r-foot"],
-    aux_real=[1.0, 2.0, 0.5, 3.0, -0.2, 1.0, 1.3, 0.4], aux_real2=[0.9], contact_cfm=1e-4)
+    aux_real=[1.0, 2.0, 0.5, 3.0, -0.2, 1.0, 1.3, 0.4], aux_real2=[0.9], contact_cfm=1e-4, all_bodies_collide=True)
 
 # DartWalker3d-v1 -- reference gym/envs/dart/walker3d.py:10-15 (15 actions, scale 100 / 150 for the waist / 20 for the
 # ankles, obs 41, frame_skip 4), :45-92 (reward, done; quantities of bodynodes[0] = the translational carrier body),
@@ -131,7 +131,7 @@ WALKER3D = TaskSpec(
     act_scale=[150.0] * 3 + [100.0] * 4 + [20.0] * 2 + [100.0] * 4 + [20.0] * 2,
     max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1, height_lo=1.05, height_hi=2.0,
     angle_max=0.84, contact_bodies=["h_foot", "h_foot_left"], alive_bonus=1.0, ctrl_cost=1e-3, limit_penalty=0.2,
-    aux_body_names=["h_torso_aux"], aux_ints=[18, 12], aux_real=[1e-3], contact_cfm=1e-4)
+    aux_body_names=["h_torso_aux"], aux_ints=[18, 12], aux_real=[1e-3], contact_cfm=1e-4, all_bodies_collide=True)
 
 # DartCartPole-v1 -- reference gym/envs/dart/cart_pole.py:6-39 (dt 0.02, frame_skip 2, obs [q, dq], scale 100, no clamp,
 # reward 1, done |q[1]| > 0.2 or non-finite obs, reset noise +-0.01), gym/envs/__init__.py:220-225

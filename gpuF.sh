@@ -1,17 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import torch; torch.cuda.init()
-import numpy as np, time, dart_env_amd
-for env_id, kw in [("DartWalker2d-v1", True), ("DartHalfCheetah-v1", False), ("DartHopper-v1", True)]:
-    v = dart_env_amd.vector.make(env_id, 65536, noise="philox", all_bodies_collide=kw)
-    v.reset(); a = np.random.RandomState(0).uniform(-1,1,(8, 65536, v.env.act_dim)).astype(np.float32)
-    s = v.env._stepper
-    d_a = torch.from_numpy(a).cuda()
-    for w in (0, 1):
-        for i in range(100): s.step_device(d_a[i % 8].data_ptr())
-        s.sync(); t0=time.perf_counter()
-        for i in range(50): s.step_device(d_a[i % 8].data_ptr())
-        s.sync(); dt=(time.perf_counter()-t0)/50
-        print(env_id, "spatial kernel: %.3f ms/step, %.3e env-steps/s" % (dt*1e3, 65536/dt))
-    v.close()
-PY
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+python bench.py --env-id DartWalker3d-v1 --envs 16384 --steps 100 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+python bench.py --env-id DartHumanWalker-v1 --steps 100 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"

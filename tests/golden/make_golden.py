@@ -167,7 +167,7 @@ class StubWorld:
     def __init__(self, dt, skel_path=None):
         name = os.path.basename(skel_path)
         contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"],
-                   "kima_human_edited.skel": ["l-foot", "r-foot"], "walker3d_waist.skel": ["h_foot", "h_foot_left"],
+                   "kima_human_edited.skel": None, "walker3d_waist.skel": None,
                    "cartpole.skel": None, "half_cheetah.skel": None}[name]   # None: every collision shape
         model = parse_skel(skel_path, dt=dt, collidable_bodies=contact)
         self.model = model

@@ -74,9 +74,11 @@ def test_spatial_physics_only_fp64_matches_oracle(force_spatial, name, bodies):
     gpu.close()
 
 
-def test_humanwalker_env_fp64_matches_oracle():
+@pytest.mark.parametrize("all_collide", [False, True])
+def test_humanwalker_env_fp64_matches_oracle(all_collide):
+    """all_collide=True: all ten link boxes are tested against the floor ("full LCP contact"), not only the feet."""
     from dart_env_amd.stepper import HipStepper
-    card = card_for("DartHumanWalker-v1")
+    card = card_for("DartHumanWalker-v1", all_bodies_collide=all_collide)
     n, nd, na = 64, card.ndofs, card.act_dim
     rng = np.random.RandomState(1)
     gpu = HipStepper(card, n, precision=64)

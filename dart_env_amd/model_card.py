@@ -56,7 +56,7 @@ class DartModelCard(C.Structure):
         ("angle_max", C.c_double), ("state_abs_max", C.c_double), ("obs_vel_clip", C.c_double),
         ("reset_noise", C.c_double), ("reset_noise_vel", C.c_double),
         ("aux_body", C.c_int32 * 4), ("aux_real", C.c_double * 8), ("aux_real2", C.c_double * 4),
-        ("contact_cfm", C.c_double),
+        ("contact_cfm", C.c_double), ("self_collision", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -97,6 +97,7 @@ class TaskSpec:
     clamp_actions: bool = True            # False: the env passes a[k] * scale on unclamped (cart_pole.py:16)
     all_bodies_collide: bool = False      # every collision shape of the robot vs. the ground (half_cheetah)
     physics_dt: float = 0.002             # DartEnv.__init__'s dt argument (dart_env.py:29)
+    self_collision: bool = False          # robot_skeleton.set_self_collision_check(True) (walker3d.py:26)
 
 
 HOPPER = TaskSpec(
@@ -131,7 +132,8 @@ WALKER3D = TaskSpec(
     act_scale=[150.0] * 3 + [100.0] * 4 + [20.0] * 2 + [100.0] * 4 + [20.0] * 2,
     max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1, height_lo=1.05, height_hi=2.0,
     angle_max=0.84, contact_bodies=["h_foot", "h_foot_left"], alive_bonus=1.0, ctrl_cost=1e-3, limit_penalty=0.2,
-    aux_body_names=["h_torso_aux"], aux_ints=[18, 12], aux_real=[1e-3], contact_cfm=1e-4, all_bodies_collide=True)
+    aux_body_names=["h_torso_aux"], aux_ints=[18, 12], aux_real=[1e-3], contact_cfm=1e-4, all_bodies_collide=True,
+    self_collision=True)
 
 # DartCartPole-v1 -- reference gym/envs/dart/cart_pole.py:6-39 (dt 0.02, frame_skip 2, obs [q, dq], scale 100, no clamp,
 # reward 1, done |q[1]| > 0.2 or non-finite obs, reset noise +-0.01), gym/envs/__init__.py:220-225
@@ -225,6 +227,7 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         c.reset_noise_vel = task.reset_noise_vel
         if task.contact_cfm is not None:
             c.contact_cfm = task.contact_cfm
+        c.self_collision = int(task.self_collision)
         names = [b.name for b in model.bodies]
         for k, nm in enumerate(task.aux_body_names):
             c.aux_body[k] = names.index(nm)

@@ -135,6 +135,11 @@ typedef struct DartModelCard {
    * Delassus matrix singular up to that 1e-9 -- the split of the normal impulse (and with it the friction bounds) is
    * then decided by rounding / pivoting order, in DART as much as here.  A larger value makes the LCP well posed. */
   double contact_cfm;
+  /* 1: link-link contacts between the robot's own collision shapes (boxes) are generated for every pair of bodies
+   * that are not parent and child -- `robot_skeleton.set_self_collision_check(True)` (walker3d.py:26) with DART's
+   * default of skipping adjacent bodies. */
+  int32_t self_collision;
+  int32_t reserved0;
 } DartModelCard;
 
 #ifdef __cplusplus

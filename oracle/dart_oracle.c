@@ -441,6 +441,158 @@ static void point_jacobian(OracleWorld* w, int li, const double* P, const double
   }
 }
 
+
+/* ------------------------------------------------------------------ box-box contacts (link-link self-collision)
+ * Restatement of ODE's dBoxBox (ode/src/box.cpp, the routine DART's ODE detector calls for two boxes; third-party,
+ * unpinned): 15-axis separating-axis test with the 1.05 fudge factor that prefers face axes, then either the single
+ * edge-edge point (closest points of the two edges, midpoint) or the face case -- the incident face of the other box
+ * is clipped against the reference face's rectangle (intersectRectQuad) and the clipped points that lie below the
+ * reference face are the contacts.  R1, R2: row-major 3x3 whose COLUMNS are the box axes in world coordinates;
+ * h1, h2: HALF extents.  Output normal points from box 1 towards box 2.  Returns the number of points (<= 8). */
+typedef struct { double pos[3], depth; } BoxContact;
+
+static int rect_quad(const double h[2], const double p[8], double ret[16]) {
+  int nq = 4, nr = 0;
+  double buffer[16];
+  const double* q = p;
+  double* r = ret;
+  for (int dir = 0; dir <= 1; dir++) {
+    for (int sign = -1; sign <= 1; sign += 2) {
+      const double* pq = q;
+      double* pr = r;
+      nr = 0;
+      for (int i = nq; i > 0; i--) {
+        if (sign * pq[dir] < h[dir]) {
+          pr[0] = pq[0]; pr[1] = pq[1]; pr += 2; nr++;
+          if (nr & 8) { q = r; goto done; }
+        }
+        const double* nextq = (i > 1) ? pq + 2 : q;
+        if ((sign * pq[dir] < h[dir]) ^ (sign * nextq[dir] < h[dir])) {
+          pr[1 - dir] = pq[1 - dir] + (nextq[1 - dir] - pq[1 - dir]) / (nextq[dir] - pq[dir]) * (sign * h[dir] - pq[dir]);
+          pr[dir] = sign * h[dir];
+          pr += 2; nr++;
+          if (nr & 8) { q = r; goto done; }
+        }
+        pq += 2;
+      }
+      q = r;
+      r = (q == ret) ? buffer : ret;
+      nq = nr;
+    }
+  }
+done:
+  if (q != ret) memcpy(ret, q, nr * 2 * sizeof(double));
+  return nr;
+}
+
+static void col3(const double* R, int j, double* out) { out[0] = R[j]; out[1] = R[3 + j]; out[2] = R[6 + j]; }
+
+static int box_box(const double* p1, const double* R1, const double* A, const double* p2, const double* R2, const double* B,
+                   double* normal, BoxContact* out) {
+  const double fudge_factor = 1.05, fudge2 = 1.0e-5, eps = 2.220446049250313e-16;
+  double p[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, pp[3], R[3][3], Q[3][3];
+  double u[3][3], v[3][3];
+  for (int j = 0; j < 3; j++) { col3(R1, j, u[j]); col3(R2, j, v[j]); }
+  for (int i = 0; i < 3; i++) { pp[i] = dot3(u[i], p); for (int j = 0; j < 3; j++) { R[i][j] = dot3(u[i], v[j]); Q[i][j] = fabs(R[i][j]); } }
+  double s = -INFINITY, normalC[3] = {0, 0, 0};
+  const double* normalR = NULL;
+  int invert_normal = 0, code = 0;
+#define TST1(expr1, expr2, nrm, cc)                                                              \
+  { double e1 = (expr1), s2 = fabs(e1) - (expr2); if (s2 > 0) return 0;                          \
+    if (s2 > s) { s = s2; normalR = (nrm); invert_normal = (e1 < 0); code = (cc); } }
+  TST1(pp[0], A[0] + B[0] * Q[0][0] + B[1] * Q[0][1] + B[2] * Q[0][2], u[0], 1);
+  TST1(pp[1], A[1] + B[0] * Q[1][0] + B[1] * Q[1][1] + B[2] * Q[1][2], u[1], 2);
+  TST1(pp[2], A[2] + B[0] * Q[2][0] + B[1] * Q[2][1] + B[2] * Q[2][2], u[2], 3);
+  TST1(dot3(v[0], p), A[0] * Q[0][0] + A[1] * Q[1][0] + A[2] * Q[2][0] + B[0], v[0], 4);
+  TST1(dot3(v[1], p), A[0] * Q[0][1] + A[1] * Q[1][1] + A[2] * Q[2][1] + B[1], v[1], 5);
+  TST1(dot3(v[2], p), A[0] * Q[0][2] + A[1] * Q[1][2] + A[2] * Q[2][2] + B[2], v[2], 6);
+#undef TST1
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Q[i][j] += fudge2;
+#define TST2(expr1, expr2, n1, n2, n3, cc)                                                       \
+  { double e1 = (expr1), s2 = fabs(e1) - (expr2); if (s2 > eps) return 0;                        \
+    double l = sqrt((n1) * (n1) + (n2) * (n2) + (n3) * (n3));                                    \
+    if (l > eps) { s2 /= l; if (s2 * fudge_factor > s) { s = s2; normalR = NULL;                 \
+      normalC[0] = (n1) / l; normalC[1] = (n2) / l; normalC[2] = (n3) / l; invert_normal = (e1 < 0); code = (cc); } } }
+  TST2(pp[2] * R[1][0] - pp[1] * R[2][0], A[1] * Q[2][0] + A[2] * Q[1][0] + B[1] * Q[0][2] + B[2] * Q[0][1], 0, -R[2][0], R[1][0], 7);
+  TST2(pp[2] * R[1][1] - pp[1] * R[2][1], A[1] * Q[2][1] + A[2] * Q[1][1] + B[0] * Q[0][2] + B[2] * Q[0][0], 0, -R[2][1], R[1][1], 8);
+  TST2(pp[2] * R[1][2] - pp[1] * R[2][2], A[1] * Q[2][2] + A[2] * Q[1][2] + B[0] * Q[0][1] + B[1] * Q[0][0], 0, -R[2][2], R[1][2], 9);
+  TST2(pp[0] * R[2][0] - pp[2] * R[0][0], A[0] * Q[2][0] + A[2] * Q[0][0] + B[1] * Q[1][2] + B[2] * Q[1][1], R[2][0], 0, -R[0][0], 10);
+  TST2(pp[0] * R[2][1] - pp[2] * R[0][1], A[0] * Q[2][1] + A[2] * Q[0][1] + B[0] * Q[1][2] + B[2] * Q[1][0], R[2][1], 0, -R[0][1], 11);
+  TST2(pp[0] * R[2][2] - pp[2] * R[0][2], A[0] * Q[2][2] + A[2] * Q[0][2] + B[0] * Q[1][1] + B[1] * Q[1][0], R[2][2], 0, -R[0][2], 12);
+  TST2(pp[1] * R[0][0] - pp[0] * R[1][0], A[0] * Q[1][0] + A[1] * Q[0][0] + B[1] * Q[2][2] + B[2] * Q[2][1], -R[1][0], R[0][0], 0, 13);
+  TST2(pp[1] * R[0][1] - pp[0] * R[1][1], A[0] * Q[1][1] + A[1] * Q[0][1] + B[0] * Q[2][2] + B[2] * Q[2][0], -R[1][1], R[0][1], 0, 14);
+  TST2(pp[1] * R[0][2] - pp[0] * R[1][2], A[0] * Q[1][2] + A[1] * Q[0][2] + B[0] * Q[2][1] + B[1] * Q[2][0], -R[1][2], R[0][2], 0, 15);
+#undef TST2
+  if (!code) return 0;
+  if (normalR) { normal[0] = normalR[0]; normal[1] = normalR[1]; normal[2] = normalR[2]; }
+  else for (int a = 0; a < 3; a++) normal[a] = u[0][a] * normalC[0] + u[1][a] * normalC[1] + u[2][a] * normalC[2];
+  if (invert_normal) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+  const double depth = -s;
+  if (code > 6) { /* edge-edge: the closest points of the two edges */
+    double pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+    for (int j = 0; j < 3; j++) {
+      double sg = dot3(normal, u[j]) > 0 ? 1.0 : -1.0;
+      for (int a = 0; a < 3; a++) pa[a] += sg * A[j] * u[j][a];
+      sg = dot3(normal, v[j]) > 0 ? -1.0 : 1.0;
+      for (int a = 0; a < 3; a++) pb[a] += sg * B[j] * v[j][a];
+    }
+    const double* ua = u[(code - 7) / 3];
+    const double* ub = v[(code - 7) % 3];
+    double d3[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    double uaub = dot3(ua, ub), q1 = dot3(ua, d3), q2 = -dot3(ub, d3), d = 1 - uaub * uaub, alpha = 0, beta = 0;
+    if (d > 1e-4) { d = 1 / d; alpha = (q1 + uaub * q2) * d; beta = (uaub * q1 + q2) * d; }
+    for (int a = 0; a < 3; a++) out[0].pos[a] = 0.5 * ((pa[a] + ua[a] * alpha) + (pb[a] + ub[a] * beta));
+    out[0].depth = depth;
+    return 1;
+  }
+  /* face case: reference face on box a, incident face on box b */
+  const double (*Ra)[3] = code <= 3 ? u : v;
+  const double (*Rb)[3] = code <= 3 ? v : u;
+  const double *pa = code <= 3 ? p1 : p2, *pb = code <= 3 ? p2 : p1, *Sa = code <= 3 ? A : B, *Sb = code <= 3 ? B : A;
+  double normal2[3], nr[3], anr[3];
+  for (int a = 0; a < 3; a++) normal2[a] = code <= 3 ? normal[a] : -normal[a];
+  for (int j = 0; j < 3; j++) { nr[j] = dot3(Rb[j], normal2); anr[j] = fabs(nr[j]); }
+  int lanr, a1, a2;
+  if (anr[1] > anr[0]) { if (anr[1] > anr[2]) { a1 = 0; lanr = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; } }
+  else { if (anr[0] > anr[2]) { lanr = 0; a1 = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; } }
+  double center[3];
+  for (int a = 0; a < 3; a++) center[a] = pb[a] - pa[a] + (nr[lanr] < 0 ? 1.0 : -1.0) * Sb[lanr] * Rb[lanr][a];
+  int codeN = code <= 3 ? code - 1 : code - 4, code1, code2;
+  if (codeN == 0) { code1 = 1; code2 = 2; } else if (codeN == 1) { code1 = 0; code2 = 2; } else { code1 = 0; code2 = 1; }
+  double quad[8], c1 = dot3(center, Ra[code1]), c2 = dot3(center, Ra[code2]);
+  double m11 = dot3(Ra[code1], Rb[a1]), m12 = dot3(Ra[code1], Rb[a2]), m21 = dot3(Ra[code2], Rb[a1]), m22 = dot3(Ra[code2], Rb[a2]);
+  {
+    double k1 = m11 * Sb[a1], k2 = m21 * Sb[a1], k3 = m12 * Sb[a2], k4 = m22 * Sb[a2];
+    quad[0] = c1 - k1 - k3; quad[1] = c2 - k2 - k4; quad[2] = c1 - k1 + k3; quad[3] = c2 - k2 + k4;
+    quad[4] = c1 + k1 + k3; quad[5] = c2 + k2 + k4; quad[6] = c1 + k1 - k3; quad[7] = c2 + k2 - k4;
+  }
+  double rect[2] = {Sa[code1], Sa[code2]}, ret[16];
+  int nq = rect_quad(rect, quad, ret);
+  if (nq < 1) return 0;
+  double det1 = 1.0 / (m11 * m22 - m12 * m21);
+  m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;
+  int cnum = 0;
+  for (int j = 0; j < nq; j++) {
+    double k1 = m22 * (ret[j * 2] - c1) - m12 * (ret[j * 2 + 1] - c2), k2 = -m21 * (ret[j * 2] - c1) + m11 * (ret[j * 2 + 1] - c2);
+    double pt[3];
+    for (int a = 0; a < 3; a++) pt[a] = center[a] + k1 * Rb[a1][a] + k2 * Rb[a2][a];
+    double dep = Sa[codeN] - dot3(normal2, pt);
+    if (dep >= 0) {
+      for (int a = 0; a < 3; a++) out[cnum].pos[a] = pt[a] + pa[a] - (code < 4 ? 0.0 : normal[a] * dep);
+      out[cnum].depth = dep;
+      cnum++;
+    }
+  }
+  return cnum;
+}
+int oracle_box_box(const double* p1, const double* R1, const double* h1, const double* p2, const double* R2, const double* h2,
+                   double* normal, double* pos_depth /* [8][4] */) {
+  BoxContact c[8];
+  int k = box_box(p1, R1, h1, p2, R2, h2, normal, c);
+  for (int i = 0; i < k; i++) { pos_depth[4 * i] = c[i].pos[0]; pos_depth[4 * i + 1] = c[i].pos[1]; pos_depth[4 * i + 2] = c[i].pos[2]; pos_depth[4 * i + 3] = c[i].depth; }
+  return k;
+}
+
 /* ------------------------------------------------------------------ dense SPD solve */
 static int cholesky(double* A, int n) { /* in place lower, row-major */
   for (int j = 0; j < n; j++) {
@@ -570,8 +722,8 @@ int oracle_step(OracleWorld* w) {
   w->ncontacts_last = 0;
   /* ---- contact points against the ground plane y = ground_y (normal +y) ---- */
   int ncp = 0;
-  int cp_shape[MAXC];
-  double cp_P[MAXC][3], cp_depth[MAXC];
+  int cp_shape[MAXC], cp_shape_b[MAXC];   /* cp_shape_b: -1 = the ground, else the second shape of a link-link contact */
+  double cp_P[MAXC][3], cp_depth[MAXC], cp_n[MAXC][3];
   for (int s = 0; s < c->nshapes && ncp < MAXC - 4; s++) {
     if (!c->shape_collidable[s] || !isfinite(c->ground_y)) continue;
     int li = w->body_link[c->shape_body[s]];
@@ -586,7 +738,7 @@ int oracle_step(OracleWorld* w) {
       if (d > r) continue;
       /* ODE dCollideSpheres(pl, r, pb, 0): pos = pl - n (r + d)/2 */
       cp_P[ncp][0] = pe[0]; cp_P[ncp][1] = pe[1] - 0.5 * (r + d); cp_P[ncp][2] = pe[2];
-      cp_depth[ncp] = r - d; cp_shape[ncp] = s; ncp++;
+      cp_depth[ncp] = r - d; cp_shape[ncp] = s; cp_shape_b[ncp] = -1; cp_n[ncp][0] = 0; cp_n[ncp][1] = 1; cp_n[ncp][2] = 0; ncp++;
     } else if (c->shape_type[s] == DART_SH_BOX) {
       /* box vs. the (huge) ground box, ODE/DART dBoxBox face case with the ground's +y face as reference: the
        * incident face is the box face most anti-parallel to the normal; its vertices that lie below the ground
@@ -605,33 +757,70 @@ int oracle_step(OracleWorld* w) {
         double depth = c->ground_y - P[1];
         if (depth < 0) continue;
         memcpy(cp_P[ncp], P, sizeof P);
-        cp_depth[ncp] = depth; cp_shape[ncp] = s; ncp++;
+        cp_depth[ncp] = depth; cp_shape[ncp] = s; cp_shape_b[ncp] = -1; cp_n[ncp][0] = 0; cp_n[ncp][1] = 1; cp_n[ncp][2] = 0; ncp++;
       }
     }
+  }
+  /* ---- link-link contacts (set_self_collision_check(True), walker3d.py:26): every pair of box shapes whose bodies are
+   * not parent and child (DART skips adjacent bodies by default).  The lower-indexed shape is ODE's o1; the contact
+   * normal handed to the constraint points into o1 (dCollideBoxBox negates dBoxBox's). */
+  if (c->self_collision) {
+    for (int sa = 0; sa < c->nshapes; sa++)
+      for (int sb = sa + 1; sb < c->nshapes; sb++) {
+        int ba = c->shape_body[sa], bb = c->shape_body[sb];
+        if (c->shape_type[sa] != DART_SH_BOX || c->shape_type[sb] != DART_SH_BOX) continue;
+        if (!c->shape_collidable[sa] || !c->shape_collidable[sb]) continue;
+        if (ba == bb || c->parent[ba] == bb || c->parent[bb] == ba) continue;
+        double Ta[16], Tb[16], Ra[9], Rb[9], pa[3], pb[3], ha[3], hb[3], nrm[3];
+        mat4_mul(w->W[w->body_link[ba]], c->shape_pose[sa], Ta);
+        mat4_mul(w->W[w->body_link[bb]], c->shape_pose[sb], Tb);
+        for (int i = 0; i < 3; i++) {
+          pa[i] = Ta[4 * i + 3]; pb[i] = Tb[4 * i + 3]; ha[i] = 0.5 * c->shape_size[sa][i]; hb[i] = 0.5 * c->shape_size[sb][i];
+          for (int j = 0; j < 3; j++) { Ra[3 * i + j] = Ta[4 * i + j]; Rb[3 * i + j] = Tb[4 * i + j]; }
+        }
+        BoxContact bc[8];
+        int k = box_box(pa, Ra, ha, pb, Rb, hb, nrm, bc);
+        for (int i = 0; i < k && ncp < MAXC; i++) {
+          memcpy(cp_P[ncp], bc[i].pos, sizeof bc[i].pos);
+          cp_depth[ncp] = bc[i].depth; cp_shape[ncp] = sa; cp_shape_b[ncp] = sb;
+          cp_n[ncp][0] = -nrm[0]; cp_n[ncp][1] = -nrm[1]; cp_n[ncp][2] = -nrm[2];
+          ncp++;
+        }
+      }
   }
   for (int ci = 0; ci < ncp; ci++) {
     int s = cp_shape[ci];
     int li = w->body_link[c->shape_body[s]];
+    int lb = cp_shape_b[ci] >= 0 ? w->body_link[c->shape_body[cp_shape_b[ci]]] : -1;
     const double* P = cp_P[ci];
     double depth = cp_depth[ci];
-    double nrm[3] = {0, 1, 0}, t1[3] = {-1, 0, 0}, t2[3] = {0, 0, 1}; /* t1 = normalize(z x n), t2 = n x t1 */
+    /* DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1 */
+    const double* nrm = cp_n[ci];
+    static const double ez[3] = {0, 0, 1}, ex[3] = {1, 0, 0};
+    double t1[3], t2[3];
+    cross3(ez, nrm, t1);
+    if (dot3(t1, t1) < 1e-12) cross3(ex, nrm, t1);
+    { double l = sqrt(dot3(t1, t1)); t1[0] /= l; t1[1] /= l; t1[2] /= l; }
+    cross3(nrm, t1, t2);
+    const double* dirs[3] = {nrm, t1, t2};
     int base = m;
-    point_jacobian(w, li, P, nrm, J[m]); lo[m] = 0; hi[m] = INFINITY; findex[m] = -1;
-    {
-      double bounce = depth * c->erp / dt;
-      if (bounce > c->max_erv) bounce = c->max_erv;
-      double rel = 0;
-      for (int k = 0; k < n; k++) rel += J[m][k] * vs[k];
-      b[m] = -rel + bounce;
-    }
-    m++;
-    const double* tt[2] = {t1, t2};
-    for (int k2 = 0; k2 < 2; k2++) {
-      point_jacobian(w, li, P, tt[k2], J[m]);
+    for (int k2 = 0; k2 < 3; k2++) {
+      point_jacobian(w, li, P, dirs[k2], J[m]);
+      if (lb >= 0) {   /* relative motion of the two links: J = J_a - J_b */
+        double Jb[MAXN];
+        point_jacobian(w, lb, P, dirs[k2], Jb);
+        for (int k = 0; k < n; k++) J[m][k] -= Jb[k];
+      }
       double rel = 0, nn = 0;
       for (int k = 0; k < n; k++) { rel += J[m][k] * vs[k]; nn += J[m][k] * J[m][k]; }
-      if (w->planar_drop_z && nn == 0.0) continue; /* out-of-plane direction of a planar model */
-      b[m] = -rel; lo[m] = -c->friction; hi[m] = c->friction; findex[m] = base;
+      if (k2 == 0) {
+        double bounce = depth * c->erp / dt;
+        if (bounce > c->max_erv) bounce = c->max_erv;
+        b[m] = -rel + bounce; lo[m] = 0; hi[m] = INFINITY; findex[m] = -1;
+      } else {
+        if (w->planar_drop_z && nn == 0.0) continue; /* out-of-plane direction of a planar model */
+        b[m] = -rel; lo[m] = -c->friction; hi[m] = c->friction; findex[m] = base;
+      }
       m++;
     }
     double* cl = w->contact_last[w->ncontacts_last++];

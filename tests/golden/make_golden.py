@@ -146,7 +146,7 @@ class StubSkeleton:
         return np.zeros(3)
 
     def set_self_collision_check(self, flag):
-        pass
+        assert bool(flag) == bool(self.world.oracle.card.self_collision)   # the card was built for this env's choice
 
 
 class StubContact:
@@ -179,6 +179,7 @@ class StubWorld:
                 "cartpole.skel": "DartCartPole-v1", "half_cheetah.skel": "DartHalfCheetah-v1"}[name]
         if TASKS[spec].contact_cfm is not None:   # same contact regularisation as the shipped task card
             card.contact_cfm = TASKS[spec].contact_cfm
+        card.self_collision = int(TASKS[spec].self_collision)   # what the env's set_self_collision_check() call will ask for
         self.oracle = OracleWorld(card)
         self.skeletons = [Anything(), StubSkeleton(self, model)]
         self.collision_result = StubCollisionResult()

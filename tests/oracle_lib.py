@@ -56,6 +56,8 @@ def lib():
         L.oracle_env_after_reset.argtypes = [C.c_void_p]
         L.oracle_last_Ab.argtypes = [C.c_void_p, dp, dp]
         L.oracle_last_Ab.restype = C.c_int
+        L.oracle_box_box.argtypes = [dp, dp, dp, dp, dp, dp, dp, dp]
+        L.oracle_box_box.restype = C.c_int
         L.oracle_rollout.restype = C.c_int64
         L.oracle_rollout.argtypes = [C.POINTER(DartModelCard), C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float),
                                      C.c_uint64, C.c_uint64, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), dp]
@@ -201,3 +203,11 @@ def philox_noise(seed, gid, ep, r, rv, n):
     q = np.zeros(n); dq = np.zeros(n)
     lib().oracle_philox_noise(seed, gid, ep, r, rv, n, _p(q), _p(dq))
     return q, dq
+
+
+def box_box(p1, R1, h1, p2, R2, h2):
+    """ODE dBoxBox restatement: -> (normal from box 1 to box 2, contacts (k, 4) = position, depth)."""
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (p1, R1, h1, p2, R2, h2)]
+    nrm = np.zeros(3); out = np.zeros((8, 4))
+    k = lib().oracle_box_box(*[_p(x) for x in a], _p(nrm), _p(out))
+    return nrm, out[:k]

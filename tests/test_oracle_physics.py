@@ -211,3 +211,64 @@ def test_foot_only_contacts_equal_all_capsules_until_done():
             if da:
                 break
             assert np.array_equal(oa, of) and ra == rf
+
+
+# ------------------------------------------------------------------ link-link box contacts (Walker3d self-collision)
+def _rot(axis, ang):
+    a = np.asarray(axis, dtype=float); a /= np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def test_box_box_known_answers():
+    from tests.oracle_lib import box_box
+    I = np.eye(3)
+    h = np.array([0.5, 0.5, 0.5])
+    # separated -> nothing
+    assert len(box_box([0, 0, 0], I, h, [1.2, 0, 0], I, h)[1]) == 0
+    # face-face along x, overlap 0.1: normal +x (from 1 to 2), four points, depth 0.1, on the touching faces' overlap
+    n, c = box_box([0, 0, 0], I, h, [0.9, 0.2, 0], I, h)
+    assert np.allclose(n, [1, 0, 0]) and len(c) == 4 and np.allclose(c[:, 3], 0.1)
+    assert np.allclose(sorted(c[:, 1]), [-0.3, -0.3, 0.5, 0.5]) and np.allclose(sorted(c[:, 2]), [-0.5, -0.5, 0.5, 0.5])
+    # vertex of a tilted box 2 pushed 0.05 into the top face of box 1: one point, normal +y, depth 0.05
+    R2 = _rot([1, 0, 1], np.arccos(1 / np.sqrt(3)))         # body diagonal along y: a vertex points down
+    low = (R2 @ (np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) * 0.5).T).T[:, 1].min()
+    n, c = box_box([0, 0, 0], I, h, [0.1, 0.5 - low - 0.05, -0.1], R2, h)
+    assert np.allclose(n, [0, 1, 0]) and len(c) == 1 and c[0, 3] == pytest.approx(0.05) and np.allclose(c[0, :3], [0.1, 0.45, -0.1], atol=1e-9)
+    # crossed edges: box 2 rotated 45 deg about z and 45 deg about x sits edge-on above an edge of box 1 -> edge-edge, 1 point
+    Ra = _rot([0, 0, 1], np.pi / 4); Rb = _rot([1, 0, 0], np.pi / 4)
+    d = 0.5 * np.sqrt(2)
+    n, c = box_box([0, 0, 0], Ra, h, [0, 2 * d - 0.02, 0], Rb, h)
+    assert len(c) == 1 and np.allclose(n, [0, 1, 0], atol=1e-9) and c[0, 3] == pytest.approx(0.02, abs=5e-5) and np.allclose(c[0, :3], [0, d - 0.01, 0], atol=1e-9)   # ODE's fudge2 = 1e-5 on the edge axes
+    # swapping the boxes flips the normal and keeps the depths
+    n2, c2 = box_box([0.9, 0.2, 0], I, h, [0, 0, 0], I, h)
+    assert np.allclose(n2, [-1, 0, 0]) and len(c2) == 4 and np.allclose(c2[:, 3], 0.1)
+
+
+def test_walker3d_self_collision_keeps_the_legs_apart():
+    """With card.self_collision the oracle generates link-link contacts: pressing the thighs together with constant hip
+    torques stops at a few mm of overlap; without them the boxes pass through each other."""
+    from tests.oracle_lib import box_box
+
+    shp = [(3, [0, -0.225, 0], [0.05, 0.225, 0.05]), (4, [0, -0.25, 0], [0.04, 0.25, 0.04]), (5, [0.065, 0, 0], [0.1, 0.06, 0.06])]
+    left = {3: 6, 4: 7, 5: 8}                              # thigh / shin / foot and their left twins (same boxes)
+
+    def overlap_after(self_collision):
+        card = card_for("DartWalker3d-v1")
+        card.self_collision = int(self_collision)
+        w = OracleWorld(card)
+        w.reset()
+        worst = 0.0
+        for t in range(300):
+            tau = np.zeros(21); tau[1] = 41.512 * 9.81          # hold the root up
+            tau[11] = 15.0; tau[17] = -15.0                     # hip rotation about x (limits +-0.25 rad): squeeze the legs
+            w.set_forces(tau); w.step()
+            for b, off, h in shp:
+                Ta, Tb = w.body_pose(b), w.body_pose(left[b])
+                n, c = box_box(Ta[:3, 3] + Ta[:3, :3] @ off, Ta[:3, :3], h, Tb[:3, 3] + Tb[:3, :3] @ off, Tb[:3, :3], h)
+                if len(c):
+                    worst = max(worst, c[:, 3].max())
+        return worst
+    on, off = overlap_after(True), overlap_after(False)
+    print("max leg-leg penetration with / without self-collision:", on, off)
+    assert off > 0.03 and 0 < on < 0.01

@@ -319,6 +319,25 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     ns++;
   }
   M.nshapes = ns;
+  // link-link contact candidates (card.self_collision): box pairs whose bodies are not parent and child, in the
+  // oracle's order (first shape ascending, then the second)
+  M.npairs = 0;
+  M.maxm = 36; M.maxcp = 12;
+  if (c.self_collision) {
+    int slot_of[DART_MAX_SHAPES];
+    { int k = 0; for (int s2 = 0; s2 < c.nshapes; s2++) slot_of[s2] = c.shape_collidable[s2] ? k++ : -1; }
+    for (int sa = 0; sa < c.nshapes; sa++)
+      for (int sb = sa + 1; sb < c.nshapes; sb++) {
+        const int ba = c.shape_body[sa], bb = c.shape_body[sb];
+        if (c.shape_type[sa] != DART_SH_BOX || c.shape_type[sb] != DART_SH_BOX) continue;
+        if (!c.shape_collidable[sa] || !c.shape_collidable[sb]) continue;
+        if (ba == bb || c.parent[ba] == bb || c.parent[bb] == ba) continue;
+        if (M.npairs >= SP_MAXPAIRS) return "too many self-collision pairs";
+        M.pair_a[M.npairs] = slot_of[sa]; M.pair_b[M.npairs] = slot_of[sb]; M.npairs++;
+      }
+    if (M.npairs > 0) { M.maxm = 64; M.maxcp = 20; }
+    if (M.npairs * 40 > 2 * sp_tri(M.maxm)) return "self-collision clipping workspace";
+  }
   M.dt = (Real)c.dt; for (int k = 0; k < 3; k++) M.g[k] = (Real)c.gravity[k];
   M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;
   M.limit_erp_dt = (Real)(c.limit_erp / c.dt); M.cfm1 = (Real)(1.0 + c.cfm); M.ccfm1 = (Real)(1.0 + c.contact_cfm);
@@ -366,7 +385,7 @@ struct SpatialImplT : Impl {
     if ((e = hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&init_h, sizeof(Real) * (size_t)n)) != hipSuccess) return e;
     if ((e = hipMemset(init_h, 0, sizeof(Real) * (size_t)n)) != hipSuccess) return e;
-    lds = sp_lds_bytes(M.nl, M.n, sizeof(Real));
+    lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp);
     if ((e = hipFuncSetAttribute((const void*)sp_step_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     return hipSuccess;
@@ -402,7 +421,7 @@ struct SpatialImplT : Impl {
     upload();
   }
   hipError_t debug_dump(double* out) override { return dbg ? hipMemcpy(out, dbg, sizeof(double) * 160 * (size_t)nenv, hipMemcpyDeviceToHost) : hipErrorInvalidValue; }
-  int slots() const override { return SP_MAXM; }
+  int slots() const override { return M.maxm; }
 };
 
 // generic (runtime-parameter) kernel, or the compile-time specialisation when the card is bit-identical to a baked one
@@ -495,7 +514,7 @@ static int dynamics_impl(DartStepper* h, double* mass, double* bias) {
     if (!w.empty()) { h->err = "dynamics getters: " + w; return DART_E_UNSUPPORTED; }
     CHK(h, hipMalloc(&h->dyn_model, sizeof(SpatialModel<Real>)));
     CHK(h, hipMemcpy(h->dyn_model, M.get(), sizeof(SpatialModel<Real>), hipMemcpyHostToDevice));
-    h->dyn_lds = sp_lds_bytes(M->nl, M->n, sizeof(Real));
+    h->dyn_lds = sp_lds_bytes(M->nl, M->n, sizeof(Real), M->maxm, M->maxcp);
     CHK(h, hipFuncSetAttribute((const void*)sp_dynamics_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds));
     CHK(h, hipMalloc((void**)&h->d_dynM, sizeof(double) * N * nd * nd));
     CHK(h, hipMalloc((void**)&h->d_dync, sizeof(double) * N * nd));

@@ -26,9 +26,10 @@ namespace dartk {
 constexpr int SP_MAXL = 48;   // expanded 1-dof links
 constexpr int SP_MAXN = 32;   // dofs
 constexpr int SP_MAXS = 16;   // collidable shapes
-constexpr int SP_MAXCP = 12;  // contact points (a box face gives up to 4)
-constexpr int SP_MAXM = 36;   // LCP rows (12 contact points x 3; HumanWalker peaks at ~31 active rows)
-constexpr int SP_TRI = SP_MAXM * (SP_MAXM + 1) / 2;   // packed lower triangle of A / of the LDL workspace
+// LCP capacity is a property of the model (SpatialModel::maxm / maxcp): 36 rows / 12 contact points by default
+// (HumanWalker peaks at ~31 active rows), 64 rows / 20 points for models with link-link contacts (rows = lanes <= 64)
+constexpr int SP_MAXPAIRS = 40;   // non-adjacent shape pairs tested for link-link contacts
+__device__ __host__ constexpr int sp_tri(int m) { return m * (m + 1) / 2; }   // packed lower triangle of A / LDL workspace
 __device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 __device__ __host__ constexpr int sp_npad(int n) { return (n + 7) & ~7; }   // H is stored padded with identity rows to a multiple of 8
 __device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
@@ -60,6 +61,8 @@ struct SpatialModel {
   Real mass[SP_MAXL], com[SP_MAXL][3], inertia[SP_MAXL][9];
   int dof_link[SP_MAXN], limited[SP_MAXN];
   Real lower[SP_MAXN], upper[SP_MAXN], damp[SP_MAXN], stiff[SP_MAXN], rest[SP_MAXN], q0[SP_MAXN], dq0[SP_MAXN];
+  int maxm, maxcp;                   // LCP rows / contact points this model's LDS block is carved for
+  int npairs, pair_a[SP_MAXPAIRS], pair_b[SP_MAXPAIRS];   // link-link contact candidates: shape slots, a < b
   int sh_link[SP_MAXS], sh_type[SP_MAXS];
   Real sh_R[SP_MAXS][9], sh_p[SP_MAXS][3], sh_size[SP_MAXS][3];
   Real dt, g[3], ground_y, mu, erp_dt, max_erv, limit_erp_dt, cfm1, ccfm1;   // ccfm1 = 1 + contact_cfm
@@ -103,14 +106,16 @@ struct SpLds {
   Real* link;    // [nl][SP_LINKF]
   Real* q; Real* dq; Real* tau; Real* rhs; Real* vs;   // [n]
   Real* H;       // [n(n+1)/2] packed lower triangle -> Cholesky factor
-  Real* W;       // [SP_MAXM+1][n]: constraint Jacobian rows, then W = L^-1 J^T
-  Real* A;       // [SP_TRI] packed symmetric
-  Real* Lw;      // [SP_TRI] packed lower
-  Real* b; Real* lo; Real* hi; Real* x; Real* r; Real* x0;   // [SP_MAXM]
-  int* rdof;     // [SP_MAXM] limit rows: dof index, contact rows: -1
-  int* rfidx;    // [SP_MAXM] friction rows: index of their normal row, else -1
-  Real* cpP;     // [SP_MAXCP][4]: contact point (relative coords) + depth
-  int* cplink;   // [SP_MAXCP]
+  Real* W;       // [maxm+1][n]: constraint Jacobian rows, then W = L^-1 J^T
+  Real* A;       // [tri(maxm)] packed symmetric
+  Real* Lw;      // [tri(maxm)] packed lower
+  Real* b; Real* lo; Real* hi; Real* x; Real* r; Real* x0;   // [maxm]
+  int* rdof;     // [maxm] limit rows: dof index, contact rows: -1
+  int* rfidx;    // [maxm] friction rows: index of their normal row, else -1
+  Real* cpP;     // [maxcp][4]: contact point (relative coords) + depth
+  Real* cpN;     // [maxcp][3]: contact normal, pointing into the first link (ground: +y)
+  int* cplink;   // [maxcp] first link
+  int* cplinkB;  // [maxcp] second link of a link-link contact, -1 for the ground
   Real* sinv;    // [n]: 1 / L_jj of the mass-matrix Cholesky factor
   Real* misc;    // [16]: roff(3), scalars
   int* imisc;    // [8]: ncp, m, contact flags
@@ -122,36 +127,33 @@ __device__ __forceinline__ int topo_dof(int w) { return ((w >> 8) & 0xff) - 1; }
 __device__ __forceinline__ int topo_jtype(int w) { return (w >> 16) & 0xff; }
 
 template <class Real>
-__device__ __forceinline__ size_t sp_lds_reals(int nl, int n) {
-  return (size_t)nl * SP_LINKF + 6 * n + sp_npad(n) * (sp_npad(n) + 1) / 2 + (SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM + SP_MAXCP * 4 + 16;
-}
-
-template <class Real>
-__device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n) {
+__device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int maxm, int maxcp) {
   SpLds<Real> S;
   Real* p = base;
   S.link = p; p += nl * SP_LINKF;
   S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n; S.vs = p; p += n;
   S.H = p; p += sp_npad(n) * (sp_npad(n) + 1) / 2;
-  S.W = p; p += (SP_MAXM + 1) * n;
-  S.A = p; p += SP_TRI;
-  S.Lw = p; p += SP_TRI;
-  S.b = p; p += SP_MAXM; S.lo = p; p += SP_MAXM; S.hi = p; p += SP_MAXM; S.x = p; p += SP_MAXM; S.r = p; p += SP_MAXM; S.x0 = p; p += SP_MAXM;
-  S.cpP = p; p += SP_MAXCP * 4;
+  S.W = p; p += (maxm + 1) * n;
+  S.A = p; p += sp_tri(maxm);
+  S.Lw = p; p += sp_tri(maxm);
+  S.b = p; p += maxm; S.lo = p; p += maxm; S.hi = p; p += maxm; S.x = p; p += maxm; S.r = p; p += maxm; S.x0 = p; p += maxm;
+  S.cpP = p; p += maxcp * 4;
+  S.cpN = p; p += maxcp * 3;
   S.misc = p; p += 16;
   S.sinv = p; p += n;
-  S.rdof = (int*)p; p += SP_MAXM * sizeof(int) / sizeof(Real) + 1;
-  S.rfidx = (int*)p; p += SP_MAXM * sizeof(int) / sizeof(Real) + 1;
-  S.cplink = (int*)p; p += SP_MAXCP * sizeof(int) / sizeof(Real) + 1;
+  S.rdof = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
+  S.rfidx = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
+  S.cplink = (int*)p; p += maxcp * sizeof(int) / sizeof(Real) + 1;
+  S.cplinkB = (int*)p; p += maxcp * sizeof(int) / sizeof(Real) + 1;
   S.imisc = (int*)p;
   S.topo = S.imisc + 8;
   S.ticks = (unsigned long long*)(((size_t)(S.topo + nl) + 7) & ~(size_t)7);
   return S;
 }
-__host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes) {
-  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(SP_MAXM + 1) * n + 2 * SP_TRI + 6 * SP_MAXM +
-                 SP_MAXCP * 4 + 16;
-  return reals * real_bytes + (2 * SP_MAXM + SP_MAXCP + 8 + nl) * sizeof(int) + 3 * real_bytes + 64 + 10 * sizeof(unsigned long long);
+__host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp) {
+  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(maxm + 1) * n + 2 * sp_tri(maxm) + 6 * maxm +
+                 maxcp * 7 + 16;
+  return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 64 + 10 * sizeof(unsigned long long);
 }
 
 // ------------------------------------------------------------------ lane-0 recursions
@@ -644,6 +646,184 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
   __syncthreads();
 }
 
+// ------------------------------------------------------------------ box-box contacts between two links
+// ODE's dBoxBox (the routine behind DART's ODE detector for two boxes): separating-axis test over the 15 axes with the
+// 1.05 preference for face axes; edge-edge -> one point midway between the closest points of the two edges; face case
+// -> the incident face of the other box is clipped against the reference face's rectangle and the clipped vertices
+// below the reference face are the contacts.  Returns the number of points (<= 8) written as (x, y, z, depth) to `out`
+// (40 Reals of LDS workspace); `normal` points from the first box to the second.
+template <class Real>
+__device__ __forceinline__ int sp_clip_rect_quad(const Real* h, Real* p, Real* ret, Real* buffer) {
+  int nq = 4, nr = 0;
+  Real* q = p;
+  Real* r = ret;
+  for (int dir = 0; dir <= 1; dir++) {
+    for (int sign = -1; sign <= 1; sign += 2) {
+      Real* pq = q;
+      Real* pr = r;
+      nr = 0;
+      bool full = false;
+      for (int i = nq; i > 0 && !full; i--) {
+        const bool in0 = Real(sign) * pq[dir] < h[dir];
+        if (in0) {
+          pr[0] = pq[0]; pr[1] = pq[1]; pr += 2; nr++;
+          if (nr & 8) { full = true; break; }
+        }
+        Real* nextq = (i > 1) ? pq + 2 : q;
+        const bool in1 = Real(sign) * nextq[dir] < h[dir];
+        if (in0 != in1) {
+          pr[1 - dir] = pq[1 - dir] + (nextq[1 - dir] - pq[1 - dir]) / (nextq[dir] - pq[dir]) * (Real(sign) * h[dir] - pq[dir]);
+          pr[dir] = Real(sign) * h[dir];
+          pr += 2; nr++;
+          if (nr & 8) { full = true; break; }
+        }
+        pq += 2;
+      }
+      q = r;
+      if (full) { dir = 2; break; }
+      r = (q == ret) ? buffer : ret;
+      nq = nr;
+    }
+  }
+  if (q != ret) for (int i = 0; i < 2 * nr; i++) ret[i] = q[i];
+  return nr;
+}
+
+template <class Real>
+__device__ __forceinline__ int sp_box_box(const SpatialModel<Real>& Md, SpLds<Real>& S, int sa, int sb, Real* out, V3<Real>& normal,
+                                          int& la, int& lb) {
+  const Real eps = sizeof(Real) == 4 ? Real(1.1920929e-7) : Real(2.220446049250313e-16);
+  la = Md.sh_link[sa]; lb = Md.sh_link[sb];
+  V3<Real> u[3], v[3], p1, p2, A, B;
+  {
+    const Real* La = S.link + la * SP_LINKF;
+    const Real* Lb = S.link + lb * SP_LINKF;
+    Real Ta[9], Tb[9], ra[9], rb[9];
+    for (int k = 0; k < 9; k++) { ra[k] = Md.sh_R[sa][k]; rb[k] = Md.sh_R[sb][k]; }
+    mulRR(La + LK_R, ra, Ta);
+    mulRR(Lb + LK_R, rb, Tb);
+    p1 = ld3(La + LK_P) + mulR(La + LK_R, ld3(Md.sh_p[sa]));
+    p2 = ld3(Lb + LK_P) + mulR(Lb + LK_R, ld3(Md.sh_p[sb]));
+    for (int j = 0; j < 3; j++) { u[j] = v3<Real>(Ta[j], Ta[3 + j], Ta[6 + j]); v[j] = v3<Real>(Tb[j], Tb[3 + j], Tb[6 + j]); }
+    A = ld3(Md.sh_size[sa]) * Real(0.5); B = ld3(Md.sh_size[sb]) * Real(0.5);
+  }
+  const V3<Real> p = p2 - p1;
+  const Real pp[3] = {dot(u[0], p), dot(u[1], p), dot(u[2], p)};
+  const Real Av[3] = {A.x, A.y, A.z}, Bv[3] = {B.x, B.y, B.z};
+  Real R[3][3], Q[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = dot(u[i], v[j]); Q[i][j] = fabs(R[i][j]); }
+  Real s = -inf_<Real>();
+  V3<Real> nC = v3<Real>(0, 0, 0);
+  int code = 0;
+  bool invert = false, sep = false;
+  // face axes of box 1, then of box 2
+  for (int i = 0; i < 3; i++) {
+    const Real e1 = pp[i], s2 = fabs(e1) - (Av[i] + Bv[0] * Q[i][0] + Bv[1] * Q[i][1] + Bv[2] * Q[i][2]);
+    sep = sep || (s2 > Real(0));
+    if (s2 > s) { s = s2; invert = e1 < Real(0); code = i + 1; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const Real e1 = dot(v[j], p), s2 = fabs(e1) - (Av[0] * Q[0][j] + Av[1] * Q[1][j] + Av[2] * Q[2][j] + Bv[j]);
+    sep = sep || (s2 > Real(0));
+    if (s2 > s) { s = s2; invert = e1 < Real(0); code = j + 4; }
+  }
+  if (sep) return 0;
+  // edge axes u_i x v_j (i = 0: (0,-R2j,R1j), i = 1: (R2j,0,-R0j), i = 2: (-R1j,R0j,0)), Q padded by 1e-5 like ODE
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Q[i][j] += Real(1.0e-5);
+  for (int i = 0; i < 3; i++) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    for (int j = 0; j < 3; j++) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const Real e1 = pp[i2] * R[i1][j] - pp[i1] * R[i2][j];
+      Real s2 = fabs(e1) - (Av[i1] * Q[i2][j] + Av[i2] * Q[i1][j] + Bv[j1] * Q[i][j2] + Bv[j2] * Q[i][j1]);
+      sep = sep || (s2 > eps);
+      Real nv[3] = {0, 0, 0};
+      nv[i1] = -R[i2][j]; nv[i2] = R[i1][j];
+      const Real l = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+      if (!sep && l > eps) {
+        s2 /= l;
+        if (s2 * Real(1.05) > s) { s = s2; nC = v3<Real>(nv[0] / l, nv[1] / l, nv[2] / l); invert = e1 < Real(0); code = 7 + 3 * i + j; }
+      }
+    }
+  }
+  if (sep || code == 0) return 0;
+  if (code <= 3) normal = u[code - 1];
+  else if (code <= 6) normal = v[code - 4];
+  else normal = u[0] * nC.x + u[1] * nC.y + u[2] * nC.z;
+  if (invert) normal = normal * Real(-1);
+  const Real depth = -s;
+  if (code > 6) {   // edge-edge
+    V3<Real> pa = p1, pb = p2;
+    for (int j = 0; j < 3; j++) {
+      pa = pa + u[j] * ((dot(normal, u[j]) > Real(0) ? Real(1) : Real(-1)) * Av[j]);
+      pb = pb + v[j] * ((dot(normal, v[j]) > Real(0) ? Real(-1) : Real(1)) * Bv[j]);
+    }
+    const int ia = (code - 7) / 3, ib = (code - 7) % 3;
+    const V3<Real> ua = ia == 0 ? u[0] : (ia == 1 ? u[1] : u[2]), ub = ib == 0 ? v[0] : (ib == 1 ? v[1] : v[2]);
+    const V3<Real> d3 = pb - pa;
+    const Real uaub = dot(ua, ub), q1 = dot(ua, d3), q2 = -dot(ub, d3);
+    Real d = Real(1) - uaub * uaub, alpha = Real(0), beta = Real(0);
+    if (d > Real(1e-4)) { d = Real(1) / d; alpha = (q1 + uaub * q2) * d; beta = (uaub * q1 + q2) * d; }
+    const V3<Real> mid = ((pa + ua * alpha) + (pb + ub * beta)) * Real(0.5);
+    out[0] = mid.x; out[1] = mid.y; out[2] = mid.z; out[3] = depth;
+    return 1;
+  }
+  // face case: the reference face belongs to box a (box 1 for codes 1..3, box 2 otherwise)
+  const bool first = code <= 3;
+  V3<Real> Ra[3], Rb[3];
+  for (int j = 0; j < 3; j++) { Ra[j] = first ? u[j] : v[j]; Rb[j] = first ? v[j] : u[j]; }
+  const V3<Real> pa = first ? p1 : p2, pb = first ? p2 : p1;
+  const Real* Sa = first ? Av : Bv;
+  const Real* Sb = first ? Bv : Av;
+  const V3<Real> normal2 = first ? normal : normal * Real(-1);
+  const Real nr[3] = {dot(Rb[0], normal2), dot(Rb[1], normal2), dot(Rb[2], normal2)};
+  const Real anr[3] = {fabs(nr[0]), fabs(nr[1]), fabs(nr[2])};
+  int lanr, a1, a2;
+  if (anr[1] > anr[0]) { if (anr[1] > anr[2]) { a1 = 0; lanr = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; } }
+  else { if (anr[0] > anr[2]) { lanr = 0; a1 = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; } }
+  auto pick = [](const V3<Real>* M3, int k) -> V3<Real> { return k == 0 ? M3[0] : (k == 1 ? M3[1] : M3[2]); };
+  auto pickr = [](const Real* a3, int k) -> Real { return k == 0 ? a3[0] : (k == 1 ? a3[1] : a3[2]); };
+  const V3<Real> Rbl = pick(Rb, lanr), Rb1 = pick(Rb, a1), Rb2 = pick(Rb, a2);
+  const V3<Real> center = pb - pa + Rbl * ((pickr(nr, lanr) < Real(0) ? Real(1) : Real(-1)) * pickr(Sb, lanr));
+  const int codeN = first ? code - 1 : code - 4;
+  const int code1 = codeN == 0 ? 1 : 0, code2 = codeN == 2 ? 1 : 2;
+  const V3<Real> Ra1 = pick(Ra, code1), Ra2 = pick(Ra, code2);
+  const Real c1 = dot(center, Ra1), c2 = dot(center, Ra2);
+  Real m11 = dot(Ra1, Rb1), m12 = dot(Ra1, Rb2), m21 = dot(Ra2, Rb1), m22 = dot(Ra2, Rb2);
+  Real* quad = out + 32;
+  Real* ret = out;
+  Real* buffer = out + 16;
+  {
+    const Real k1 = m11 * pickr(Sb, a1), k2 = m21 * pickr(Sb, a1), k3 = m12 * pickr(Sb, a2), k4 = m22 * pickr(Sb, a2);
+    quad[0] = c1 - k1 - k3; quad[1] = c2 - k2 - k4; quad[2] = c1 - k1 + k3; quad[3] = c2 - k2 + k4;
+    quad[4] = c1 + k1 + k3; quad[5] = c2 + k2 + k4; quad[6] = c1 + k1 - k3; quad[7] = c2 + k2 - k4;
+  }
+  const Real rect[2] = {pickr(Sa, code1), pickr(Sa, code2)};
+  const int nq = sp_clip_rect_quad<Real>(rect, quad, ret, buffer);
+  if (nq < 1) return 0;
+  Real rx[8], ry[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { rx[j] = j < nq ? ret[2 * j] : Real(0); ry[j] = j < nq ? ret[2 * j + 1] : Real(0); }
+  const Real det1 = Real(1) / (m11 * m22 - m12 * m21);
+  m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;
+  const Real SaN = pickr(Sa, codeN);
+  int cnum = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (j < nq) {
+      const Real k1 = m22 * (rx[j] - c1) - m12 * (ry[j] - c2), k2 = -m21 * (rx[j] - c1) + m11 * (ry[j] - c2);
+      const V3<Real> pt = center + Rb1 * k1 + Rb2 * k2;
+      const Real dep = SaN - dot(normal2, pt);
+      if (dep >= Real(0)) {
+        const V3<Real> pos = first ? pt + pa : pt + pa - normal * dep;
+        out[4 * cnum + 0] = pos.x; out[4 * cnum + 1] = pos.y; out[4 * cnum + 2] = pos.z; out[4 * cnum + 3] = dep;
+        cnum++;
+      }
+    }
+  }
+  return cnum;
+}
+
 // ------------------------------------------------------------------ one world step for the env owned by this wavefront
 #define SP_TICK(ph)                                                                              \
   do {                                                                                            \
@@ -729,15 +909,38 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     int idx = before;
     for (int v = 0; v < 4; v++) {
       if (hit[v]) {
-        if (idx < SP_MAXCP) { S.cpP[4 * idx + 0] = P[v].x; S.cpP[4 * idx + 1] = P[v].y; S.cpP[4 * idx + 2] = P[v].z; S.cpP[4 * idx + 3] = dep[v]; S.cplink[idx] = slink; }
+        if (idx < Md.maxcp) {
+          S.cpP[4 * idx + 0] = P[v].x; S.cpP[4 * idx + 1] = P[v].y; S.cpP[4 * idx + 2] = P[v].z; S.cpP[4 * idx + 3] = dep[v];
+          S.cpN[3 * idx + 0] = Real(0); S.cpN[3 * idx + 1] = Real(1); S.cpN[3 * idx + 2] = Real(0);
+          S.cplink[idx] = slink; S.cplinkB[idx] = -1;
+        }
         idx++;
       }
     }
-    ncp = total < SP_MAXCP ? total : SP_MAXCP;
+    ncp = total < Md.maxcp ? total : Md.maxcp;
     // foot-contact flags of the observation (human_walker.py:97-106): any contact on aux_link[2], aux_link[3]
     const bool anyhit = hit[0] || hit[1] || hit[2] || hit[3];
     const uint64_t f0 = __ballot(anyhit && slink == Md.aux_link[2]), f1 = __ballot(anyhit && slink == Md.aux_link[3]);
     if (lane == 0) { contact_flags[0] = f0 != 0ull; contact_flags[1] = f1 != 0ull; }
+    // link-link contacts (walker3d.py:26): lane p tests shape pair p; the points follow the ground contacts, pair by pair
+    if (Md.npairs > 0) {
+      const bool has_pair = lane < Md.npairs;
+      Real* scratch = S.A + lane * 40;          // A / Lw are idle in this phase: 40 Reals of clipping workspace per lane
+      int k = 0, la = 0, lb = 0;
+      V3<Real> nrm = v3<Real>(0, 1, 0);
+      if (has_pair) k = sp_box_box<Real>(Md, S, Md.pair_a[lane], Md.pair_b[lane], scratch, nrm, la, lb);
+      int before = 0, total = 0;
+      for (int v = 0; v < 8; v++) { const uint64_t hm8 = __ballot(v < k); before += __popcll(hm8 & lt); total += __popcll(hm8); }
+      for (int v = 0; v < k; v++) {
+        const int id2 = ncp + before + v;
+        if (id2 < Md.maxcp) {
+          for (int t = 0; t < 4; t++) S.cpP[4 * id2 + t] = scratch[4 * v + t];
+          S.cpN[3 * id2 + 0] = -nrm.x; S.cpN[3 * id2 + 1] = -nrm.y; S.cpN[3 * id2 + 2] = -nrm.z;   // into the first link
+          S.cplink[id2] = la; S.cplinkB[id2] = lb;
+        }
+      }
+      ncp = (ncp + total) < Md.maxcp ? (ncp + total) : Md.maxcp;
+    }
     // contact rows: normal, two tangents
     if (lane < 3 * ncp) { S.rdof[lane] = -1; S.rfidx[lane] = (lane % 3 == 0) ? -1 : (lane - lane % 3); }
     // joint-limit rows
@@ -746,7 +949,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     const bool up = lane < n && lc.d_limited && !low && qd >= lc.d_upper;
     const uint64_t lm = __ballot(low || up);
     const int row = 3 * ncp + __popcll(lm & lt);
-    if ((low || up) && row < SP_MAXM) {
+    if ((low || up) && row < Md.maxm) {
       const Real viol = low ? qd - lc.d_lower : qd - lc.d_upper;
       const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
       S.rdof[row] = lane; S.rfidx[row] = -1;
@@ -755,7 +958,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       S.hi[row] = low ? inf_<Real>() : Real(0);
     }
     m = 3 * ncp + __popcll(lm);
-    m = m < SP_MAXM ? m : SP_MAXM;
+    m = m < Md.maxm ? m : Md.maxm;
   }
   __syncthreads();
   SP_TICK(3);
@@ -770,19 +973,27 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         Jr[d] = Real(1);
       } else {
         const int cidx = lane / 3, kind = lane % 3;
-        const V3<Real> dir = kind == 0 ? v3<Real>(0, 1, 0) : (kind == 1 ? v3<Real>(-1, 0, 0) : v3<Real>(0, 0, 1));
+        // DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1
+        const V3<Real> nn = ld3(S.cpN + 3 * cidx);
+        V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
+        if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
+        t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
+        const V3<Real> dir = kind == 0 ? nn : (kind == 1 ? t1 : cross(nn, t1));
         const V3<Real> P = ld3(S.cpP + 4 * cidx);
         Real rel = Real(0);
-        for (int j = S.cplink[cidx]; j >= 0;) {
-          const int w = S.topo[j];
-          const int dj = topo_dof(w), jcur = j;
-          j = topo_parent(w);
-          if (dj < 0) continue;
-          const Real* Lj = S.link + jcur * SP_LINKF;
-          const V3<Real> aj = ld3(Lj + LK_A);
-          const Real v = (topo_jtype(w) == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj);
-          Jr[dj] = v;
-          rel += v * S.dq[dj];
+        for (int side = 0; side < 2; side++) {   // J = J_a - J_b for a link-link contact
+          const Real sg = side == 0 ? Real(1) : Real(-1);
+          for (int j = side == 0 ? S.cplink[cidx] : S.cplinkB[cidx]; j >= 0;) {
+            const int w = S.topo[j];
+            const int dj = topo_dof(w), jcur = j;
+            j = topo_parent(w);
+            if (dj < 0) continue;
+            const Real* Lj = S.link + jcur * SP_LINKF;
+            const V3<Real> aj = ld3(Lj + LK_A);
+            const Real v = sg * ((topo_jtype(w) == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj));
+            Jr[dj] += v;
+            rel += v * S.dq[dj];
+          }
         }
         const Real depth = S.cpP[4 * cidx + 3];
         S.b[lane] = (kind == 0 ? fmin(depth * Md.erp_dt, Md.max_erv) : Real(0)) - rel;
@@ -1046,7 +1257,7 @@ __global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>
   const int64_t e = blockIdx.x;
   if (e >= n_envs) return;
   const int n = Md.n;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp);
   int* cflags = S.imisc + 2;
   Real* sh_scal = S.misc + 8;
   if (lane < n) { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; S.tau[lane] = Real(0); }
@@ -1130,7 +1341,7 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
   const int64_t e = blockIdx.x;
   if (e >= n_envs) return;
   const int n = Md.n, nl = Md.nl;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl, n);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl, n, Md.maxm, Md.maxcp);
   if (lane < n) {
     const int64_t at = soa ? (int64_t)lane * n_envs + e : e * n + lane;
     S.q[lane] = qs[at]; S.dq[lane] = dqs[at]; S.tau[lane] = Real(0);
@@ -1181,7 +1392,7 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
   const int64_t e = blockIdx.x;
   if (e >= n_envs) return;
   const int n = Md.n;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp);
   int* cflags = S.imisc + 2;
   const bool m = (mask == nullptr) || mask[e];
   if (lane < n) {

@@ -3,8 +3,8 @@
 reward dx/dt + 1 - 1e-3 sum a^2 - 0.2 knee-limit penalty - 1e-3 |z|, zero when done (:75-92), done on height in
 (1.05, 2.0) and up/forward angles of bodynodes[0] < 0.84 (:87-89).  Runs on the generic spatial kernel.
 
-Deviation: the reference switches the skeleton's self-collision check on (:26); link-link
-box contacts are not generated here, only link-ground contacts."""
+The reference switches the skeleton's self-collision check on (:26): the card carries self_collision = 1 and the kernel
+generates link-link box contacts (ODE dBoxBox restated) next to the link-ground ones."""
 from .hopper import _SingleEnv
 
 

@@ -221,6 +221,14 @@ def main():
                               "envs_same_episode_history": int(same.sum()), "envs": ne, "env_steps": ns},
         }
         small.close()
+        if args.env_id in ("DartHopper-v1", "DartWalker2d-v1"):
+            # The default cards of these two envs test only the feet against the floor (BASELINE config[1]); rerun the
+            # CPU sample with EVERY capsule collidable, as DART has it: identical final states = the deviation is
+            # never exercised by this workload (a second ~7 s of host time, same sample).
+            ref_all = ol.rollout(card_for(args.env_id, all_bodies_collide=True), acts, seed=0, env_offset=0, solver=0)
+            result["cpu_baseline"]["all_capsule_contacts_identical"] = bool(
+                np.array_equal(ref_all["q"], ref["q"]) and np.array_equal(ref_all["dq"], ref["dq"])
+                and np.array_equal(ref_all["episode"], ref["episode"]))
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()

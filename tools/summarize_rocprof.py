@@ -15,8 +15,10 @@ def short(name):
 def main():
     prof, out = sys.argv[1], sys.argv[2]
     lines = []
-    for db in sorted(glob.glob(os.path.join(prof, "*", "*_results.db"))):
-        tag = os.path.basename(os.path.dirname(db))
+    dbs = sorted(glob.glob(os.path.join(prof, "*", "*_results.db")) + glob.glob(os.path.join(prof, "*", "*", "*_results.db")))
+    for db in dbs:
+        rel = os.path.relpath(db, prof).split(os.sep)
+        tag = rel[0] if len(rel) > 2 else os.path.basename(os.path.dirname(db))   # <run>/<host>/<pid>_results.db -> <run>
         con = sqlite3.connect(db)
         cur = con.cursor()
         lines.append("## %s" % tag)

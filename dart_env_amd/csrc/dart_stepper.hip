@@ -336,7 +336,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
         M.pair_a[M.npairs] = slot_of[sa]; M.pair_b[M.npairs] = slot_of[sb]; M.npairs++;
       }
     if (M.npairs > 0) { M.maxm = 64; M.maxcp = 20; }
-    if (M.npairs * 40 > 2 * sp_tri(M.maxm)) return "self-collision clipping workspace";
+    if (M.npairs * 40 > sp_tri(M.maxm)) return "self-collision clipping workspace";
   }
   M.dt = (Real)c.dt; for (int k = 0; k < 3; k++) M.g[k] = (Real)c.gravity[k];
   M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;

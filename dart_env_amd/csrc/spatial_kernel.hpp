@@ -30,6 +30,10 @@ constexpr int SP_MAXS = 16;   // collidable shapes
 // (HumanWalker peaks at ~31 active rows), 64 rows / 20 points for models with link-link contacts (rows = lanes <= 64)
 constexpr int SP_MAXPAIRS = 40;   // non-adjacent shape pairs tested for link-link contacts
 __device__ __host__ constexpr int sp_tri(int m) { return m * (m + 1) / 2; }   // packed lower triangle of A / LDL workspace
+// The pivoting solver's LDL^T workspace (and its PGS start vector) are live only after the Jacobian rows have been
+// built, the per-link records only before: when the link block is big enough the two share LDS (HumanWalker: 2.8 KB
+// less per workgroup = 10 instead of 8 workgroups per CU).
+__device__ __host__ constexpr bool sp_lw_aliases_links(int nl, int maxm) { return nl * 37 >= sp_tri(maxm) + maxm; }
 __device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 __device__ __host__ constexpr int sp_npad(int n) { return (n + 7) & ~7; }   // H is stored padded with identity rows to a multiple of 8
 __device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
@@ -104,7 +108,7 @@ enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_C = 18, LK_F = 21, LK_N = 2
 template <class Real>
 struct SpLds {
   Real* link;    // [nl][SP_LINKF]
-  Real* q; Real* dq; Real* tau; Real* rhs; Real* vs;   // [n]
+  Real* q; Real* dq; Real* tau; Real* rhs;   // [n]
   Real* H;       // [n(n+1)/2] packed lower triangle -> Cholesky factor
   Real* W;       // [maxm+1][n]: constraint Jacobian rows, then W = L^-1 J^T
   Real* A;       // [tri(maxm)] packed symmetric
@@ -131,12 +135,13 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   SpLds<Real> S;
   Real* p = base;
   S.link = p; p += nl * SP_LINKF;
-  S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n; S.vs = p; p += n;
+  S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n;
   S.H = p; p += sp_npad(n) * (sp_npad(n) + 1) / 2;
   S.W = p; p += (maxm + 1) * n;
   S.A = p; p += sp_tri(maxm);
-  S.Lw = p; p += sp_tri(maxm);
-  S.b = p; p += maxm; S.lo = p; p += maxm; S.hi = p; p += maxm; S.x = p; p += maxm; S.r = p; p += maxm; S.x0 = p; p += maxm;
+  if (sp_lw_aliases_links(nl, maxm)) { S.Lw = S.link; S.x0 = S.link + sp_tri(maxm); }
+  else { S.Lw = p; p += sp_tri(maxm); S.x0 = p; p += maxm; }
+  S.b = p; p += maxm; S.lo = p; p += maxm; S.hi = p; p += maxm; S.x = p; p += maxm; S.r = p; p += maxm;
   S.cpP = p; p += maxcp * 4;
   S.cpN = p; p += maxcp * 3;
   S.misc = p; p += 16;
@@ -151,9 +156,10 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   return S;
 }
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp) {
-  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(maxm + 1) * n + 2 * sp_tri(maxm) + 6 * maxm +
+  const size_t lw = sp_lw_aliases_links(nl, maxm) ? 0 : (size_t)sp_tri(maxm) + maxm;
+  size_t reals = (size_t)nl * SP_LINKF + 5 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(maxm + 1) * n + sp_tri(maxm) + lw + 5 * maxm +
                  maxcp * 7 + 16;
-  return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 64 + 10 * sizeof(unsigned long long);
+  return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }
 
 // ------------------------------------------------------------------ lane-0 recursions
@@ -1106,10 +1112,8 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   }
   __syncthreads();
   sp_chol_backsolve<Real>(S.H, S.sinv, n, S.rhs, lane);
-  if (lane < n) S.vs[lane] = S.dq[lane] + S.rhs[lane];
   SP_TICK(9);
-  __syncthreads();
-  if (lane < n) { S.dq[lane] = S.vs[lane]; S.q[lane] += Md.dt * S.vs[lane]; }
+  if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
   __syncthreads();
   (void)nl;
 }
@@ -1244,7 +1248,7 @@ __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds
 
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
 template <class Real>
-__global__ void __launch_bounds__(64, 2) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
+__global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ init_h,
                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
                                                       const float* __restrict__ actions, float* __restrict__ obs,

@@ -411,7 +411,12 @@ struct SpatialImplT : Impl {
     return hipGetLastError();
   }
   void set_solver(int solver, int it1, int it2) override {   // one wavefront per env: a high cap only costs the hard envs
-    (void)solver; (void)it2; M.solver_iters = it1 > 0 ? it1 : 200; upload();
+    // solver 1 = projected Gauss-Seidel only: no pivoting iterations, `it1` wave-level sweeps per stage (row dot products
+    // reduced across the wavefront with __shfl_xor); solver 0 = pivoting with the PGS safety net
+    (void)it2;
+    if (solver == 1) { M.solver_iters = 0; M.pgs_fallback_sweeps = it1 > 0 ? it1 : 30; }
+    else { M.solver_iters = it1 > 0 ? it1 : 200; M.pgs_fallback_sweeps = 600; }
+    upload();
   }
   double* dbg = nullptr; int64_t nenv = 0;
   void set_stats(unsigned long long* p) override {

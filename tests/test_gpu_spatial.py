@@ -390,3 +390,25 @@ def test_walker3d_link_link_contacts_match_oracle():
     print("link-link contact points seen (8 envs):", self_rows, "worst |dq|", worst_q, worst_dq, "fallback env-steps", bad_env_steps)
     assert self_rows > 100 and bad_env_steps <= 0.02 * n * 200
     gpu.close()
+
+
+def test_spatial_pgs_solver_converges_to_pivoting_solver(force_spatial):
+    """DART_CFG_SOLVER = PGS on the wave-per-env kernel: sweeps with wavefront reductions approach the exact solve."""
+    from dart_env_amd import stepper as st
+    card = card_for("DartHopper-v1")
+    n = 256
+    acts = np.random.RandomState(3).uniform(-1, 1, (20, n, 3)).astype(np.float32)
+    out = {}
+    for tag, sweeps in (("exact", 0), ("pgs30", 30), ("pgs400", 400)):
+        s = st.HipStepper(card, n, precision=64)
+        if sweeps:
+            s.configure(st.CFG_SOLVER, st.SOLVER_PGS); s.configure(st.CFG_ITERS_STAGE1, sweeps)
+        s.configure(st.CFG_SEED, 11)
+        s.reset(None, None, None, want_obs=False)
+        for t in range(20):
+            s.step(acts[t])
+        out[tag] = s.get_state()[0]
+        s.close()
+    e30 = np.abs(out["pgs30"] - out["exact"]).max(axis=1); e400 = np.abs(out["pgs400"] - out["exact"]).max(axis=1)
+    print("median |dq| vs exact: 30 sweeps", np.median(e30), " 400 sweeps", np.median(e400))
+    assert np.median(e400) < 1e-6 and np.median(e400) < 0.1 * np.median(e30) + 1e-12

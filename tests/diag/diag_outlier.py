@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): find the first step where an fp32 env departs from the oracle by > thr and dump context."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from dart_env_amd.model_card import card_for
 from dart_env_amd.stepper import HipStepper

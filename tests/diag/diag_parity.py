@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): per-step fp32-vs-oracle error breakdown."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from dart_env_amd.model_card import card_for
 from dart_env_amd.stepper import HipStepper

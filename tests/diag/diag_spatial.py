@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): spatial kernel vs oracle, step by step."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from dart_env_amd.model_card import build_card, load_model
 from dart_env_amd.stepper import HipStepper

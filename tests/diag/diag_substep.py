@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): replay one env-step as 4 single substeps, fp32 vs fp64 kernel vs oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from dart_env_amd.model_card import card_for
 from dart_env_amd.stepper import HipStepper

@@ -3,8 +3,8 @@
 Rolls the CPU oracle (ground contacts only) with random actions and tests every NON-adjacent pair of link boxes for
 overlap (separating-axis test) after every env step.  Diagnostic for DESIGN.md's deviation table."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from dart_env_amd.model_card import card_for
 import oracle_lib as ol

@@ -7,7 +7,7 @@ Tolerances (stated here, as the task requires):
     error over those envs x dofs is < 1e-4 (BASELINE.json target); an env that took a contact event one substep
     early/late stays decorrelated until its episode ends and is counted, not averaged.
     Velocities are compared with robust statistics: a contact that switches on one 2 ms substep earlier or later in
-    fp32 than in fp64 changes dq by O(1) for that substep and then collapses again (tools/diag_substep.py shows the
+    fp32 than in fp64 changes dq by O(1) for that substep and then collapses again (tests/diag/diag_substep.py shows the
     per-substep fp32 error is ~1e-6), so the 99th percentile of |d dq| must be < 5e-3 while isolated spikes are
     tolerated; obs / reward are held to 5e-3 on the 99th percentile; done flags agree on >= 99 % of env-steps.
 """

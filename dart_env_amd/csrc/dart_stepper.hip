@@ -342,7 +342,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;
   M.limit_erp_dt = (Real)(c.limit_erp / c.dt); M.cfm1 = (Real)(1.0 + c.cfm); M.ccfm1 = (Real)(1.0 + c.contact_cfm);
   if (physics_only) { M.task = 0; return ""; }   // dynamics getters: geometry, inertia and topology only
-  if (c.task < DART_TASK_NONE || c.task > DART_TASK_HALFCHEETAH) return "task not served by the spatial kernel";
+  if (c.task < DART_TASK_NONE || c.task > DART_TASK_DOUBLE_PENDULUM) return "task not served by the spatial kernel";
   M.task = c.task; M.frame_skip = c.frame_skip; M.act_dim = c.act_dim; M.obs_dim = c.obs_dim; M.act_dof0 = c.act_dof0;
   M.max_steps = c.max_episode_steps;
   if (c.act_dim > 32 || c.act_dof0 + c.act_dim > c.ndofs) return "action layout";
@@ -357,6 +357,11 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     const double ar[7] = {c.alive_bonus, c.ctrl_cost, c.limit_penalty, 0.0, c.height_lo, c.height_hi, c.penalty_margin};
     for (int k = 0; k < 7; k++) M.aux_real[k] = (Real)ar[k];
   }
+  if (c.task == DART_TASK_DOUBLE_PENDULUM) {
+    if (c.ndofs != 3 || c.aux_body[0] < 0 || c.aux_body[0] >= c.nbodies || c.aux_body[1] < 0 || c.aux_body[1] >= c.nbodies) return "double pendulum card";
+    M.aux_link[0] = body_link[c.aux_body[0]]; M.aux_link[1] = body_link[c.aux_body[1]];
+  }
+  if (c.task == DART_TASK_CARTPOLE_SWINGUP && c.ndofs != 2) return "swing-up card";
   if (c.task == DART_TASK_CARTPOLE || c.task == DART_TASK_HALFCHEETAH) { M.aux_real[0] = (Real)c.alive_bonus; M.aux_real[1] = (Real)c.ctrl_cost; }
   if (c.task == DART_TASK_WALKER3D) {
     M.aux_link[0] = body_link[c.aux_body[0]]; M.aux_link[1] = c.aux_body[1]; M.aux_link[2] = c.aux_body[2];

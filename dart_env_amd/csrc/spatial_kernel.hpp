@@ -1225,6 +1225,18 @@ __device__ __forceinline__ bool sp_simple_epilogue(const SpatialModel<Real>& Md,
     reward_out = Md.aux_real[0];
     return !(fin && fabs(S.q[1]) <= Md.aux_real2[1]);
   }
+  if (Md.task == 7) {   // cart-pole swing-up (cartpole_swingup.py:22-31); sq_a_sum = a^2 of the single action
+    reward_out = Md.aux_real[0] - fabs(S.q[1]) - Md.aux_real[1] * sq_a_sum - Md.aux_real[2] * fabs(S.q[0]);
+    return (fabs(S.q[1]) > Md.aux_real[3]) || (fabs(S.dq[1]) > Md.aux_real[4]) || (fabs(S.q[0]) > Md.aux_real[5]);
+  }
+  if (Md.task == 8) {   // double inverted pendulum (inverted_double_pendulum.py:27-42): tip height above the cart
+    const Real base = S.link[Md.aux_link[0] * SP_LINKF + LK_P + 1], raw = S.link[Md.aux_link[1] * SP_LINKF + LK_P + 1];
+    const Real height = Real(2) * (raw - base - Md.aux_real[4]) / Md.aux_real[5];
+    const Real dist_pen = Md.aux_real[1] * (S.q[0] * S.q[0]) + (height - Real(2)) * (height - Real(2));
+    const Real vel_pen = Md.aux_real[2] * (S.dq[1] * S.dq[1]) + Md.aux_real[3] * (S.dq[2] * S.dq[2]);
+    reward_out = Md.aux_real[0] - dist_pen - vel_pen;
+    return height <= Real(1);
+  }
   const bool ok = fin && bounded;
   Real rew = (S.q[0] - pos_before) * Md.inv_envdt + Md.aux_real[0];
   rew -= Md.aux_real[1] * sq_a_sum;
@@ -1235,7 +1247,13 @@ __device__ __forceinline__ bool sp_simple_epilogue(const SpatialModel<Real>& Md,
 template <class Real>
 __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds<Real>& S, const int* cflags, float* __restrict__ o, int lane) {
   const int n = Md.n;
-  if (Md.task == 0 || Md.task == 5) {   // physics only, CartPole: [q, dq]
+  if (Md.task == 8) {   // double pendulum: [q0, sin q1, sin q2, cos q1, cos q2, dq] (inverted_double_pendulum.py:45-51)
+    if (lane == 0) o[0] = (float)S.q[0];
+    if (lane == 1 || lane == 2) { Real sn, cs; sincos_<Real>(S.q[lane], sn, cs); o[lane] = (float)sn; o[lane + 2] = (float)cs; }
+    if (lane < 3) o[5 + lane] = (float)S.dq[lane];
+    return;
+  }
+  if (Md.task == 0 || Md.task == 5 || Md.task == 7) {   // physics only, CartPole, swing-up: [q, dq]
     if (lane < n) { o[lane] = (float)S.q[lane]; o[n + lane] = (float)S.dq[lane]; }
     return;
   }

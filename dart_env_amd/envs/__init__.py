@@ -5,3 +5,4 @@ from .human_walker import DartHumanWalkerEnv  # noqa: F401
 from .walker3d import DartWalker3dEnv  # noqa: F401
 from .cart_pole import DartCartPoleEnv  # noqa: F401
 from .half_cheetah import DartHalfCheetahEnv  # noqa: F401
+from .cartpole_swingup import DartCartPoleSwingUpEnv, DartDoubleInvertedPendulumEnv  # noqa: F401

@@ -20,7 +20,8 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from .. import seeding, spaces
-from ..model_card import DartModelCard, TASKS, card_for
+from ..model_card import (DartModelCard, HOST_RESET_TASKS, TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASKS,
+                          card_for)
 from .. import stepper as _st
 
 
@@ -86,6 +87,10 @@ class BatchedDartEnv:
         self._stepper = factory(self.card, self.num_envs, device, precision)
         if noise == "mt19937" and not hasattr(self._stepper, "seed_mt19937"):
             noise = self.noise = "mt19937-host"     # injected test stepper without a device bank
+        if self.task.task in HOST_RESET_TASKS:      # reset_model draws beyond two uniform vectors: drawn by numpy
+            if noise == "philox":
+                raise ValueError("%s resets with host-drawn noise only (noise='mt19937')" % env_id)
+            noise = self.noise = "mt19937-host"
         self.device_noise = noise in ("mt19937", "philox")
         # spaces exactly as DartEnv.__init__ builds them (dart_env.py:85-86, 97-100)
         # control_bounds of the reference env (the card carries +-inf instead when the env does not clamp)
@@ -143,10 +148,16 @@ class BatchedDartEnv:
         qn = np.zeros((self.num_envs, self.ndofs))
         vn = np.zeros((self.num_envs, self.ndofs))
         idx = range(self.num_envs) if mask is None else np.flatnonzero(mask)
+        kind = self.task.task
         for i in idx:
             rng = self._rng(i)
             qn[i] = rng.uniform(low=-r, high=r, size=self.ndofs)   # qpos first (hopper.py:78)
-            vn[i] = rng.uniform(low=-rv, high=rv, size=self.ndofs) # qvel second (hopper.py:79, human_walker.py:154)
+            if kind == TASK_DOUBLE_PENDULUM:                       # inverted_double_pendulum.py:50-51
+                vn[i] = rng.randn(self.ndofs) * rv
+            else:
+                vn[i] = rng.uniform(low=-rv, high=rv, size=self.ndofs)   # qvel second (hopper.py:79, human_walker.py:154)
+            if kind == TASK_CARTPOLE_SWINGUP:                      # cartpole_swingup.py:41-44: the pole starts hanging
+                qn[i, 1] += np.pi if rng.uniform(low=0, high=1, size=1) > 0.5 else -np.pi
         return qn, vn
 
     def reset(self, mask=None):

@@ -25,6 +25,7 @@ MAX_ACTIONS = 32
 CARD_VERSION = 1
 
 TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER, TASK_CARTPOLE, TASK_HALFCHEETAH = 0, 1, 2, 3, 4, 5, 6
+TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM = 7, 8
 
 
 class DartModelCard(C.Structure):
@@ -152,7 +153,29 @@ HALFCHEETAH = TaskSpec(
     height_body=2, penalty_dof=-1, height_lo=-np.inf, height_hi=np.inf, angle_max=1.3, alive_bonus=1.0, ctrl_cost=0.1,
     limit_penalty=0.0, obs_vel_clip=np.inf, all_bodies_collide=True, physics_dt=0.01)
 
-TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH)}
+# DartCartPoleSwingUp-v1 -- reference gym/envs/dart/cartpole_swingup.py:7-47 (dt 0.01, frame_skip 2, scale 40, no clamp,
+# reward 6 - |ang| - 0.01 sum a^2 - 0.01 |x|, done |ang| > 8 pi or |dang| > 25 or |x| > 5; reset: q + U(+-0.1),
+# dq + U(+-0.01), then the pole hangs down: q[1] +- pi by a third draw), gym/envs/__init__.py:260-264 (500 steps)
+CARTPOLE_SWINGUP = TaskSpec(
+    env_id="DartCartPoleSwingUp-v1", model="cartpole_swingup", task=TASK_CARTPOLE_SWINGUP, frame_skip=2, act_dim=1,
+    obs_dim=4, act_dof0=0, act_scale=[40.0], max_episode_steps=500, reward_threshold=None, height_body=0, penalty_dof=-1,
+    height_lo=-np.inf, height_hi=np.inf, angle_max=np.inf, state_abs_max=np.inf, obs_vel_clip=np.inf, reset_noise=0.1,
+    reset_noise_vel=0.01, clamp_actions=False, physics_dt=0.01,
+    aux_real=[6.0, 0.01, 0.01, 8 * np.pi, 25.0, 5.0])
+
+# DartDoubleInvertedPendulumEnv-v1 -- reference gym/envs/dart/inverted_double_pendulum.py:9-65 (dt 0.01, frame_skip 2,
+# scale 40, no clamp, obs 8; reset: q + U(+-0.1), dq + 0.1 randn), gym/envs/__init__.py:227-231 (1000 steps)
+DOUBLE_PENDULUM = TaskSpec(
+    env_id="DartDoubleInvertedPendulumEnv-v1", model="double_pendulum", task=TASK_DOUBLE_PENDULUM, frame_skip=2, act_dim=1,
+    obs_dim=8, act_dof0=0, act_scale=[40.0], max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1,
+    height_lo=-np.inf, height_hi=np.inf, angle_max=np.inf, state_abs_max=np.inf, obs_vel_clip=np.inf, reset_noise=0.1,
+    reset_noise_vel=0.1, clamp_actions=False, physics_dt=0.01, aux_body_names=["cart", "weight"],
+    aux_real=[10.0, 0.01, 1e-3, 5e-3, 0.02, 0.6])
+
+TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH, CARTPOLE_SWINGUP,
+                               DOUBLE_PENDULUM)}
+# tasks whose reset_model draws more than the two uniform vectors: the host draws them (see envs/dart_env.py)
+HOST_RESET_TASKS = (TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM)
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 

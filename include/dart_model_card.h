@@ -48,8 +48,15 @@ enum {
   DART_TASK_HUMANWALKER = 4, /* reference gym/envs/dart/human_walker.py:60-165 */
   DART_TASK_CARTPOLE = 5,    /* reference gym/envs/dart/cart_pole.py:12-39: obs [q, dq], reward 1, done |q[1]| > angle_max,
                                  action NOT clamped (act_low/high = -/+inf), tau[0] = a[0] * 100 */
-  DART_TASK_HALFCHEETAH = 6  /* reference gym/envs/dart/half_cheetah.py:28-93: reward dx/dt + 1 - 0.1 sum a^2 (0 if the
+  DART_TASK_HALFCHEETAH = 6, /* reference gym/envs/dart/half_cheetah.py:28-93: reward dx/dt + 1 - 0.1 sum a^2 (0 if the
                                  state broke), done adds |q[2]| >= angle_max (1.3), obs q[1:], dq (unclipped) */
+  DART_TASK_CARTPOLE_SWINGUP = 7, /* reference gym/envs/dart/cartpole_swingup.py:14-33: obs [q, dq], no clamp, reward
+                                 aux_real[0] - |q[1]| - aux_real[1] sum a^2 - aux_real[2] |q[0]|, done |q[1]| > aux_real[3]
+                                 or |dq[1]| > aux_real[4] or |q[0]| > aux_real[5] */
+  DART_TASK_DOUBLE_PENDULUM = 8 /* reference gym/envs/dart/inverted_double_pendulum.py:19-53: obs [q0, sin q1..2, cos q1..2,
+                                 dq], height = 2 (y(aux_body[1]) - y(aux_body[0]) - aux_real[4]) / aux_real[5], reward
+                                 aux_real[0] - (aux_real[1] q0^2 + (height - 2)^2) - (aux_real[2] dq1^2 + aux_real[3] dq2^2),
+                                 done height <= 1 */
 };
 
 typedef struct DartModelCard {

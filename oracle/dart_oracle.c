@@ -1126,8 +1126,43 @@ static int halfcheetah_step(OracleWorld* w, const double* a, double* obs, double
   return done;
 }
 
+/* DartCartPoleSwingUpEnv.step (cartpole_swingup.py:14-33) */
+static int swingup_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  double tau[MAXN] = {0};
+  tau[c->act_dof0] = a[0] * c->act_scale[0];
+  for (int f = 0; f < c->frame_skip; f++) { oracle_set_forces(w, tau); oracle_step(w); }
+  qdq_obs(w, 0, obs);
+  double ang = w->q[1];
+  double ang_cost = 1.0 * fabs(ang), quad_ctrl_cost = c->aux_real[1] * (a[0] * a[0]), com_cost = c->aux_real[2] * fabs(w->q[0]);
+  *reward = c->aux_real[0] - ang_cost - quad_ctrl_cost - com_cost;
+  return (fabs(ang) > c->aux_real[3]) || (fabs(w->dq[1]) > c->aux_real[4]) || (fabs(w->q[0]) > c->aux_real[5]);
+}
+/* DartDoubleInvertedPendulumEnv.step / _get_obs (inverted_double_pendulum.py:19-53) */
+static void double_pendulum_obs(OracleWorld* w, double* obs) {
+  obs[0] = w->q[0]; obs[1] = sin(w->q[1]); obs[2] = sin(w->q[2]); obs[3] = cos(w->q[1]); obs[4] = cos(w->q[2]);
+  obs[5] = w->dq[0]; obs[6] = w->dq[1]; obs[7] = w->dq[2];
+}
+static int double_pendulum_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  double tau[MAXN] = {0};
+  tau[c->act_dof0] = a[0] * c->act_scale[0];
+  for (int f = 0; f < c->frame_skip; f++) { oracle_set_forces(w, tau); oracle_step(w); }
+  double_pendulum_obs(w, obs);
+  kinematics(w);
+  double base = w->W[w->body_link[c->aux_body[0]]][4 * 1 + 3], raw = w->W[w->body_link[c->aux_body[1]]][4 * 1 + 3];
+  double height = 2.0 * (raw - base - c->aux_real[4]) / c->aux_real[5];
+  double v1 = w->dq[1], v2 = w->dq[2];
+  double dist_penalty = c->aux_real[1] * (obs[0] * obs[0]) + (height - 2.) * (height - 2.);
+  double vel_penalty = c->aux_real[2] * (v1 * v1) + c->aux_real[3] * (v2 * v2);
+  *reward = c->aux_real[0] - dist_penalty - vel_penalty;
+  return height <= 1;
+}
+
 int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
   const DartModelCard* c = &w->card;
+  if (c->task == DART_TASK_CARTPOLE_SWINGUP) return swingup_step(w, a, obs, reward);
+  if (c->task == DART_TASK_DOUBLE_PENDULUM) return double_pendulum_step(w, a, obs, reward);
   if (c->task == DART_TASK_CARTPOLE) return cartpole_step(w, a, obs, reward);
   if (c->task == DART_TASK_HALFCHEETAH) return halfcheetah_step(w, a, obs, reward);
   if (c->task == DART_TASK_HUMANWALKER) return humanwalker_step(w, a, obs, reward);
@@ -1184,7 +1219,8 @@ void oracle_env_obs(OracleWorld* w, double* obs) {
   const DartModelCard* c = &w->card;
   if (c->task == DART_TASK_HUMANWALKER) { int z[2] = {0, 0}; humanwalker_obs(w, z, obs); return; } /* reset_model zeroes contact_info */
   if (c->task == DART_TASK_WALKER3D) { walker3d_obs(w, obs); return; }
-  if (c->task == DART_TASK_CARTPOLE) { qdq_obs(w, 0, obs); return; }
+  if (c->task == DART_TASK_CARTPOLE || c->task == DART_TASK_CARTPOLE_SWINGUP) { qdq_obs(w, 0, obs); return; }
+  if (c->task == DART_TASK_DOUBLE_PENDULUM) { double_pendulum_obs(w, obs); return; }
   if (c->task == DART_TASK_HALFCHEETAH) { qdq_obs(w, 1, obs); return; }
   int n = w->n;
   double cm[3];

@@ -126,6 +126,7 @@ class StubSkeleton:
         self.joints = [StubJoint([model.limited[b.dof_offset + k] for k in range(b.ndof)]) for b in model.bodies]
         self.bodynodes = [StubBody(world, i) for i in range(model.nbodies)]
         self._by_name = {b.name: self.bodynodes[i] for i, b in enumerate(model.bodies)}
+        self.name_to_body = self._by_name
 
     def bodynode(self, name):
         return self._by_name[name]
@@ -168,7 +169,8 @@ class StubWorld:
         name = os.path.basename(skel_path)
         contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"],
                    "kima_human_edited.skel": None, "walker3d_waist.skel": None,
-                   "cartpole.skel": None, "half_cheetah.skel": None}[name]   # None: every collision shape
+                   "cartpole.skel": None, "half_cheetah.skel": None, "cartpole_swingup.skel": None,
+                   "inverted_double_pendulum.skel": None}[name]   # None: every collision shape
         model = parse_skel(skel_path, dt=dt, collidable_bodies=contact)
         self.model = model
         self.dt = dt
@@ -176,7 +178,9 @@ class StubWorld:
         from dart_env_amd.model_card import TASKS
         spec = {"hopper_capsule.skel": "DartHopper-v1", "walker2d.skel": "DartWalker2d-v1",
                 "kima_human_edited.skel": "DartHumanWalker-v1", "walker3d_waist.skel": "DartWalker3d-v1",
-                "cartpole.skel": "DartCartPole-v1", "half_cheetah.skel": "DartHalfCheetah-v1"}[name]
+                "cartpole.skel": "DartCartPole-v1", "half_cheetah.skel": "DartHalfCheetah-v1",
+                "cartpole_swingup.skel": "DartCartPoleSwingUp-v1",
+                "inverted_double_pendulum.skel": "DartDoubleInvertedPendulumEnv-v1"}[name]
         if TASKS[spec].contact_cfm is not None:   # same contact regularisation as the shipped task card
             card.contact_cfm = TASKS[spec].contact_cfm
         card.self_collision = int(TASKS[spec].self_collision)   # what the env's set_self_collision_check() call will ask for
@@ -318,6 +322,10 @@ def main():
         np.savez_compressed(os.path.join(out, "%s_single_seed1_big.npz" % tag),
                             **rollout_single(gym, env_id, 1, 200, act_scale=1.5))   # beyond +-1: clamp / no clamp
         np.savez_compressed(os.path.join(out, "%s_vector4_seed3.npz" % tag), **rollout_vector(gym, env_id, 4, 3, 120))
+    # (9) cart-pole swing-up (third reset draw: +-pi) and double inverted pendulum (Gaussian velocity noise, sin/cos obs)
+    for env_id, tag in (("DartCartPoleSwingUp-v1", "swingup"), ("DartDoubleInvertedPendulumEnv-v1", "doublependulum")):
+        np.savez_compressed(os.path.join(out, "%s_single_seed0.npz" % tag), **rollout_single(gym, env_id, 0, 300, act_scale=1.5))
+        np.savez_compressed(os.path.join(out, "%s_vector4_seed3.npz" % tag), **rollout_vector(gym, env_id, 4, 3, 150, act_scale=1.5))
     print("world.step() calls issued by the reference code:", StubWorld.n_steps)
 
 

@@ -9,7 +9,7 @@ import pytest
 import dart_env_amd
 from dart_env_amd import seeding, spaces
 from dart_env_amd.model_card import card_for
-from dart_env_amd.envs import (DartCartPoleEnv, DartHalfCheetahEnv, DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv,
+from dart_env_amd.envs import (DartCartPoleEnv, DartCartPoleSwingUpEnv, DartDoubleInvertedPendulumEnv, DartHalfCheetahEnv, DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv,
                                DartWalker3dEnv)
 from dart_env_amd.wrappers import TimeLimit
 from tests.fake_stepper import OracleStepper
@@ -17,9 +17,11 @@ from tests.oracle_lib import OracleWorld
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 IDS = {"hopper": "DartHopper-v1", "walker2d": "DartWalker2d-v1", "humanwalker": "DartHumanWalker-v1",
-       "walker3d": "DartWalker3d-v1", "cartpole": "DartCartPole-v1", "halfcheetah": "DartHalfCheetah-v1"}
+       "walker3d": "DartWalker3d-v1", "cartpole": "DartCartPole-v1", "halfcheetah": "DartHalfCheetah-v1",
+       "swingup": "DartCartPoleSwingUp-v1", "doublependulum": "DartDoubleInvertedPendulumEnv-v1"}
 CLS = {"hopper": DartHopperEnv, "walker2d": DartWalker2dEnv, "humanwalker": DartHumanWalkerEnv,
-       "walker3d": DartWalker3dEnv, "cartpole": DartCartPoleEnv, "halfcheetah": DartHalfCheetahEnv}
+       "walker3d": DartWalker3dEnv, "cartpole": DartCartPoleEnv, "halfcheetah": DartHalfCheetahEnv,
+       "swingup": DartCartPoleSwingUpEnv, "doublependulum": DartDoubleInvertedPendulumEnv}
 
 
 def test_seeding_and_reset_noise_stream():
@@ -79,7 +81,8 @@ def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
             assert np.array_equal(do_reset(), d["reset_obs"][t])
 
 
-@pytest.mark.parametrize("tag", ["hopper", "walker2d", "humanwalker", "walker3d", "cartpole", "halfcheetah"])
+@pytest.mark.parametrize("tag", ["hopper", "walker2d", "humanwalker", "walker3d", "cartpole", "halfcheetah", "swingup",
+                                 "doublependulum"])
 def test_single_env_facade_vs_reference(tag):
     """make(id): seed -> reset -> step loop reproduces the reference's obs/reward/done (obs cross the ABI as float32)."""
     d = np.load(os.path.join(G, "%s_single_seed0.npz" % tag))
@@ -98,7 +101,8 @@ def test_single_env_facade_vs_reference(tag):
         assert np.allclose(env.state_vector(), np.concatenate([d["q"][t], d["dq"][t]]), atol=0)
         if done:
             assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-7)
-    assert env.dt == pytest.approx({"humanwalker": 0.03, "cartpole": 0.04, "halfcheetah": 0.05}.get(tag, 0.008))
+    assert env.dt == pytest.approx({"humanwalker": 0.03, "cartpole": 0.04, "halfcheetah": 0.05, "swingup": 0.02,
+                                    "doublependulum": 0.02}.get(tag, 0.008))
     env.close()
 
 
@@ -117,7 +121,7 @@ def test_time_limit_truncation_vs_reference(tag):
     assert d["truncated"].sum() >= 3
 
 
-@pytest.mark.parametrize("tag", ["hopper", "walker2d", "cartpole", "halfcheetah"])
+@pytest.mark.parametrize("tag", ["hopper", "walker2d", "cartpole", "halfcheetah", "swingup", "doublependulum"])
 def test_vector_env_vs_reference_syncvectorenv(tag):
     """seed(int) fan-out s+i, auto-reset returning the post-reset observation, dtypes (sync_vector_env.py:50-84)."""
     d = np.load(os.path.join(G, "%s_vector4_seed3.npz" % tag))

@@ -227,7 +227,8 @@ def test_walker3d_fp32_and_device_autoreset():
 
 
 # ------------------------------------------------------------------ DartCartPole-v1 / DartHalfCheetah-v1 on the spatial kernel
-@pytest.mark.parametrize("env_id,noise", [("DartCartPole-v1", 0.01), ("DartHalfCheetah-v1", 0.005)])
+@pytest.mark.parametrize("env_id,noise", [("DartCartPole-v1", 0.01), ("DartHalfCheetah-v1", 0.005),
+                                          ("DartCartPoleSwingUp-v1", 0.1), ("DartDoubleInvertedPendulumEnv-v1", 0.1)])
 def test_classic_env_fp64_matches_oracle(env_id, noise):
     from dart_env_amd.stepper import HipStepper
     card = card_for(env_id)
@@ -260,7 +261,9 @@ def test_classic_env_fp64_matches_oracle(env_id, noise):
     gpu.close()
 
 
-@pytest.mark.parametrize("tag,env_id", [("cartpole", "DartCartPole-v1"), ("halfcheetah", "DartHalfCheetah-v1")])
+@pytest.mark.parametrize("tag,env_id", [("cartpole", "DartCartPole-v1"), ("halfcheetah", "DartHalfCheetah-v1"),
+                                        ("swingup", "DartCartPoleSwingUp-v1"),
+                                        ("doublependulum", "DartDoubleInvertedPendulumEnv-v1")])
 def test_classic_env_vector_fixture_and_fp32(tag, env_id):
     """Reference SyncVectorEnv fixture through the default (device MT19937) vector env in fp64; fp32 stays close."""
     import dart_env_amd

@@ -16,6 +16,7 @@
 #include "planar_kernel.hpp"
 #include "static_models.hpp"
 #include "spatial_kernel.hpp"
+#include <vector>
 #include "mt19937_kernels.hpp"
 #include "episode_kernels.hpp"
 
@@ -39,6 +40,7 @@ struct Impl {
   virtual hipError_t prepare(int64_t) { return hipSuccess; }   // per-handle device allocations of the implementation
   virtual void release() {}
   virtual hipError_t debug_dump(double*) { return hipErrorInvalidValue; }
+  virtual int set_ext_force(int /*body*/, const double* /*host_force*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int slots() const = 0;
   bool soa = true;         // state layout: q[n][N] (planar kernels) or q[N][n] (spatial kernel)
   int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
@@ -174,7 +176,7 @@ void inv_Rp(const double* R, const double* p, double* Ri, double* pi) {
 
 // Expand every multi-dof joint of the card into a chain of 1-dof links (massless carriers in between).
 template <class Real>
-std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool physics_only = false) {
+std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool physics_only = false, int* body_link_out = nullptr) {
   memset(&M, 0, sizeof(M));
   if (c.ndofs > SP_MAXN) return "too many dofs";
   int body_link[DART_MAX_BODIES];
@@ -235,6 +237,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     for (int k = 0; k < 9; k++) M.inertia[last][k] = (Real)(c.mass[b] > 0 ? c.inertia[b][k] : 0.0);
   }
   M.nl = nl; M.n = c.ndofs;
+  if (body_link_out) for (int b = 0; b < c.nbodies; b++) body_link_out[b] = body_link[b];
   {  // depth levels, children lists, constant world axes of the root-chain prismatic links
     int depth[SP_MAXL], maxd = 0;
     double Rw[SP_MAXL][9];   // world rotation of each link's JOINT frame at q = 0 (valid for root-chain links)
@@ -395,7 +398,10 @@ struct SpatialImplT : Impl {
     if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     return hipSuccess;
   }
-  void release() override { if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); dM = nullptr; init_h = nullptr; }
+  void release() override {
+    if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); if (d_ext) (void)hipFree(d_ext);
+    dM = nullptr; init_h = nullptr; d_ext = nullptr;
+  }
   void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
                   float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
@@ -424,6 +430,17 @@ struct SpatialImplT : Impl {
     upload();
   }
   double* dbg = nullptr; int64_t nenv = 0;
+  Real* d_ext = nullptr;
+  int body_link_map[DART_MAX_BODIES];
+  int set_ext_force(int body, const double* host_force, int64_t n) override {
+    if (!host_force) { M.ext_force = nullptr; upload(); return DART_OK; }
+    if (!d_ext && hipMalloc((void**)&d_ext, sizeof(Real) * 3 * (size_t)n) != hipSuccess) return DART_E_HIP;
+    std::vector<Real> tmp(3 * (size_t)n);
+    for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (Real)host_force[i];
+    if (hipMemcpy(d_ext, tmp.data(), sizeof(Real) * tmp.size(), hipMemcpyHostToDevice) != hipSuccess) return DART_E_HIP;
+    M.ext_link = body_link_map[body]; M.ext_force = d_ext; upload();
+    return DART_OK;
+  }
   void set_stats(unsigned long long* p) override {
     M.stats = p;
     if (p && !dbg) { (void)hipMalloc((void**)&dbg, sizeof(double) * 160 * (size_t)nenv); (void)hipMemset(dbg, 0, sizeof(double) * 160 * (size_t)nenv); }
@@ -455,7 +472,7 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
 template <class Real>
 std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why, bool allow_static) {
   const char* fs = getenv("DART_FORCE_SPATIAL");   // testing aid: run planar models through the general kernel
-  const bool force_spatial = fs && fs[0] == '1';
+  const bool force_spatial = (fs && fs[0] == '1') || c.generic_kernel != 0;
   why = "hopper-chain: ";
   if (!force_spatial)
   if (auto p = make_for_topology<Real, HopperTopo, HopperStatic<Real>>(c, why, allow_static)) return p;
@@ -465,7 +482,7 @@ std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why, bool a
   why += "; spatial: ";
   {
     auto p = std::make_unique<SpatialImplT<Real>>();
-    std::string w = fill_spatial<Real>(c, p->M);
+    std::string w = fill_spatial<Real>(c, p->M, false, p->body_link_map);
     if (w.empty()) return p;
     why += w;
   }
@@ -892,6 +909,18 @@ int dart_debug_dump(DartStepper* h, double* out160) {
   CHK(h, hipStreamSynchronize(h->stream));
   CHK(h, h->impl->debug_dump(out160));
   return DART_OK;
+}
+
+int dart_set_ext_force(DartStepper* h, int body, const double* force) {
+  if (!h) return DART_E_INVALID;
+  if (force && (body < 0 || body >= h->card.nbodies)) { h->err = "body index"; return DART_E_INVALID; }
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  int rc = h->impl->set_ext_force(body, force, h->n);
+  if (rc == DART_E_UNSUPPORTED) h->err = "external body forces need the generic kernel: set card.generic_kernel = 1 before dart_create";
+  else if (rc != DART_OK) h->err = "dart_set_ext_force: HIP error";
+  return rc;
 }
 
 int dart_get_episode_stats(DartStepper* h, double* last_return, int32_t* last_length, double* totals3, int clear_totals) {

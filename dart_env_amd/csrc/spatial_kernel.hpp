@@ -77,6 +77,8 @@ struct SpatialModel {
   Real aux_real[8], aux_real2[4];
   Real s_max, v_clip, noise, noise_v, inv_envdt;
   int solver_iters, pgs_fallback_sweeps;
+  int ext_link;                // external body force (dart_set_ext_force): link it acts on, at the link frame origin
+  const Real* ext_force;       // [n_envs][3] world-frame force per env, nullptr = none
   double* dbg;                 // optional [n_envs][160] dump of the last LCP (debug builds of the tests only)
   unsigned long long* stats;   // optional [64]: [0..31] pivoting iterations per solve, [32] PGS fallbacks, [33] solves
 };
@@ -257,7 +259,8 @@ template <class Real> __device__ __forceinline__ V3<Real> shfl3(V3<Real> v, int 
 //      (w_i = a_i qd_i;  t_i = om_parent x w_i;  b_i = the centripetal / Coriolis increment): three more prefix sums,
 //   4. the link's wrench and composite-body seeds about its own joint origin go to LDS.
 template <class Real>
-__device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane) {
+__device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane,
+                                           int64_t env = 0) {
   const bool live = lane < Md.nl;
   const bool rev = lc.jtype == 2, slide = lc.jtype == 1 && !lc.root_trans;
   const Real qv = (live && lc.dof >= 0) ? S.q[lc.dof] : Real(0), qd = (live && lc.dof >= 0) ? S.dq[lc.dof] : Real(0);
@@ -363,8 +366,16 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
     f = (ac - ld3(Md.g)) * m;
     nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
   }
+  V3<Real> nj = nrm + cross(dj, f);
+  if (Md.ext_force != nullptr && lane == Md.ext_link) {
+    // bodynode.add_ext_force(F) before every world step (dart_env.py:170-172): a world-frame force at the body frame
+    // origin enters the link's wrench with the opposite sign of its inertial force
+    const V3<Real> fe = ld3(Md.ext_force + env * 3);
+    f = f - fe;
+    nj = nj - cross(p - pj, fe);
+  }
   st3(L + LK_F, f);
-  st3(L + LK_N, nrm + cross(dj, f));
+  st3(L + LK_N, nj);
   L[LK_MC] = m;
   st3(L + LK_H, dj * m);
   const Real d2 = dot(dj, dj);
@@ -847,7 +858,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
   // tree recursions level by level: links of equal depth are independent, one lane each
   if (lane == 0) sp_root_offset<Real>(Md, S);
-  sp_forward<Real>(lc, Md, S, lane);   // lane i owns link i
+  sp_forward<Real>(lc, Md, S, lane, (int64_t)blockIdx.x);   // lane i owns link i
   __syncthreads();
   for (int lv = Md.n_group_levels - 1; lv >= 0; lv--) {
     if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);

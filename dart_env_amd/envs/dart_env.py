@@ -71,12 +71,12 @@ class BatchedDartEnv:
 
     def __init__(self, env_id: str, num_envs: int = 1, device: int = 0, precision: int = 32, noise: str = "mt19937",
                  max_episode_steps: Optional[int] = None, card: Optional[DartModelCard] = None,
-                 stepper_factory: Optional[Callable] = None):
+                 stepper_factory: Optional[Callable] = None, generic_kernel: bool = False):
         if noise not in ("mt19937", "mt19937-host", "philox"):
             raise ValueError("noise must be 'mt19937', 'mt19937-host' or 'philox'")
         self.env_id = env_id
         self.task = TASKS[env_id]
-        self.card = card if card is not None else card_for(env_id)
+        self.card = card if card is not None else card_for(env_id, generic_kernel=generic_kernel)
         if max_episode_steps is not None:
             self.card.max_episode_steps = int(max_episode_steps)
         self.num_envs = int(num_envs)
@@ -177,6 +177,12 @@ class BatchedDartEnv:
 
     def step_wait(self):
         return self._stepper.step_wait()
+
+    def set_ext_force(self, body, forces):
+        """``bodynodes[body].add_ext_force(F_i)`` before every world step of env i from now on -- the perturbation branch
+        of DartEnv.do_simulation (dart_env.py:159-172), with the host choosing the forces.  ``forces``: (num_envs, 3)
+        world-frame vectors or None to stop.  Needs ``generic_kernel=True`` for the planar models."""
+        self._stepper.set_ext_force(body, forces)
 
     def set_state(self, qpos, qvel):
         qpos = np.asarray(qpos, dtype=np.float64).reshape(self.num_envs, self.ndofs)

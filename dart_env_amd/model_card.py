@@ -57,7 +57,7 @@ class DartModelCard(C.Structure):
         ("angle_max", C.c_double), ("state_abs_max", C.c_double), ("obs_vel_clip", C.c_double),
         ("reset_noise", C.c_double), ("reset_noise_vel", C.c_double),
         ("aux_body", C.c_int32 * 4), ("aux_real", C.c_double * 8), ("aux_real2", C.c_double * 4),
-        ("contact_cfm", C.c_double), ("self_collision", C.c_int32), ("reserved0", C.c_int32),
+        ("contact_cfm", C.c_double), ("self_collision", C.c_int32), ("generic_kernel", C.c_int32),
     ]
 
 
@@ -263,10 +263,12 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
     return c
 
 
-def card_for(env_id: str, all_bodies_collide: bool = False) -> DartModelCard:
+def card_for(env_id: str, all_bodies_collide: bool = False, generic_kernel: bool = False) -> DartModelCard:
     """The card the batched env for ``env_id`` runs on."""
     task = TASKS[env_id]
     model = load_model(task.model)
     for s in model.shapes:
         s.collidable = all_bodies_collide or task.all_bodies_collide or model.bodies[s.body].name in task.contact_bodies
-    return build_card(model, task)
+    c = build_card(model, task)
+    c.generic_kernel = int(generic_kernel)
+    return c

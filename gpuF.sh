@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_spatial.py -m gpu -q -x -k classic 2>&1 | tail -12
+python -m pytest tests/test_gpu_spatial.py -m gpu -q -x -k "external" 2>&1 | tail -8

@@ -146,7 +146,9 @@ typedef struct DartModelCard {
    * that are not parent and child -- `robot_skeleton.set_self_collision_check(True)` (walker3d.py:26) with DART's
    * default of skipping adjacent bodies. */
   int32_t self_collision;
-  int32_t reserved0;
+  /* 1: always use the generic tree kernel, even if a faster specialised kernel matches the model (needed for features
+   * only the generic kernel has: external body forces, link-link contacts, contacts on every shape). */
+  int32_t generic_kernel;
 } DartModelCard;
 
 #ifdef __cplusplus

@@ -126,6 +126,12 @@ int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear);
  * of the last LCP solved. */
 int dart_debug_dump(DartStepper* h, double* out160);
 
+/* External body force: `bodynodes[body].add_ext_force(F)` before every world step, the perturbation branch of
+ * DartEnv.do_simulation (reference gym/envs/dart/dart_env.py:159-172).  force = (N, 3) world-frame vectors, applied at the
+ * body frame origin (pydart2's default offset) in every substep until replaced; NULL switches it off.  Only the generic
+ * kernel implements it: set card.generic_kernel = 1 (DART_E_UNSUPPORTED otherwise). */
+int dart_set_ext_force(DartStepper* h, int body, const double* force);
+
 /* Episode statistics kept on the device (DART_CFG_EPISODE_STATS = 1) -- the batched form of the reference's
  * RecordEpisodeStatistics wrapper (gym/wrappers/record_episode_statistics.py:22-34): every step adds the reward to the
  * env's running return and 1 to its length; an env that reports done latches them into last_return[i] /

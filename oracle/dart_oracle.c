@@ -90,6 +90,8 @@ typedef struct OracleWorld {
   double lcp_residual_last;
   double A_last[MAXM * MAXM], b_last[MAXM]; /* debug copies of the last LCP */
   double init_height; /* human_walker.py:163 head COM height right after reset_model's set_state */
+  int ext_body;       /* -1: none.  bodynodes[ext_body].add_ext_force(ext_f) before every world step (dart_env.py:170-172) */
+  double ext_f[3];    /* world-frame force applied at the body frame origin (pydart2's default offset) */
 } OracleWorld;
 
 /* ------------------------------------------------------------------ small linear algebra */
@@ -257,7 +259,7 @@ OracleWorld* oracle_create(const DartModelCard* card) {
   OracleWorld* w = (OracleWorld*)calloc(1, sizeof(OracleWorld));
   w->card = *card;
   w->n = card->ndofs;
-  w->solver = 0; w->pgs_k1 = 30; w->pgs_k2 = 30; w->planar_drop_z = 1;
+  w->solver = 0; w->pgs_k1 = 30; w->pgs_k2 = 30; w->planar_drop_z = 1; w->ext_body = -1;
   static const double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, ez[3] = {0, 0, 1};
   for (int b = 0; b < card->nbodies; b++) {
     int pl = card->parent[b] < 0 ? -1 : w->body_link[card->parent[b]];
@@ -309,6 +311,10 @@ void oracle_get_state(const OracleWorld* w, double* q, double* dq) {
   memcpy(q, w->q, w->n * sizeof(double)); memcpy(dq, w->dq, w->n * sizeof(double));
 }
 void oracle_set_forces(OracleWorld* w, const double* tau) { memcpy(w->tau, tau, w->n * sizeof(double)); }
+void oracle_set_ext_force(OracleWorld* w, int body, const double* f3) {
+  w->ext_body = (f3 && body >= 0 && body < w->card.nbodies) ? body : -1;
+  if (w->ext_body >= 0) memcpy(w->ext_f, f3, sizeof w->ext_f);
+}
 /* pydart2 World.reset: time 0, positions/velocities back to initial, forces cleared (dart_world.py:20-22) */
 void oracle_reset(OracleWorld* w) {
   for (int i = 0; i < w->n; i++) { w->q[i] = w->card.init_pos[i]; w->dq[i] = w->card.init_vel[i]; w->tau[i] = 0; }
@@ -708,6 +714,15 @@ int oracle_step(OracleWorld* w) {
     H[i * n + i] += dt * c->damping[i] + dt * dt * c->stiffness[i];
     rhs[i] = w->tau[i] - w->C[i] - c->damping[i] * w->dq[i] -
              c->stiffness[i] * (w->q[i] + dt * w->dq[i] - c->rest[i]);
+  }
+  if (w->ext_body >= 0) { /* generalized force of the external body force: J(origin)^T f */
+    int li = w->body_link[w->ext_body];
+    double P[3] = {w->W[li][3], w->W[li][7], w->W[li][11]}, Jd[MAXN];
+    static const double E3[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int a = 0; a < 3; a++) {
+      point_jacobian(w, li, P, E3[a], Jd);
+      for (int i = 0; i < n; i++) rhs[i] += Jd[i] * w->ext_f[a];
+    }
   }
   if (cholesky(H, n) != 0) return -1;
   chol_solve(H, n, rhs);

@@ -56,6 +56,7 @@ def lib():
         L.oracle_env_after_reset.argtypes = [C.c_void_p]
         L.oracle_last_Ab.argtypes = [C.c_void_p, dp, dp]
         L.oracle_last_Ab.restype = C.c_int
+        L.oracle_set_ext_force.argtypes = [C.c_void_p, C.c_int, dp]
         L.oracle_box_box.argtypes = [dp, dp, dp, dp, dp, dp, dp, dp]
         L.oracle_box_box.restype = C.c_int
         L.oracle_rollout.restype = C.c_int64
@@ -113,6 +114,13 @@ class OracleWorld:
     def set_forces(self, tau):
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         self.L.oracle_set_forces(self.h, _p(tau))
+
+    def set_ext_force(self, body, f3):
+        """bodynodes[body].add_ext_force(f3) before every following world step; f3 = None switches it off."""
+        if f3 is None:
+            self.L.oracle_set_ext_force(self.h, -1, None)
+        else:
+            self.L.oracle_set_ext_force(self.h, int(body), _p(np.ascontiguousarray(f3, dtype=np.float64)))
 
     def reset(self):
         self.L.oracle_reset(self.h)

@@ -415,3 +415,40 @@ def test_spatial_pgs_solver_converges_to_pivoting_solver(force_spatial):
     e30 = np.abs(out["pgs30"] - out["exact"]).max(axis=1); e400 = np.abs(out["pgs400"] - out["exact"]).max(axis=1)
     print("median |dq| vs exact: 30 sweeps", np.median(e30), " 400 sweeps", np.median(e400))
     assert np.median(e400) < 1e-6 and np.median(e400) < 0.1 * np.median(e30) + 1e-12
+
+
+@pytest.mark.parametrize("env_id,body", [("DartHopper-v1", 3), ("DartHumanWalker-v1", 9)])
+def test_external_body_force_matches_oracle(env_id, body):
+    """dart_set_ext_force = bodynodes[b].add_ext_force(F) before every world step (perturbation branch, dart_env.py:159-172)."""
+    from dart_env_amd.stepper import HipStepper, StepperError
+    card = card_for(env_id, generic_kernel=True)
+    n, nd, na = 32, card.ndofs, card.act_dim
+    rng = np.random.RandomState(9)
+    gpu = HipStepper(card, n, precision=64)
+    ora = OracleBatch(card, n)
+    qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+    gpu.reset(None, qn, vn, want_obs=False); ora.reset(None, qn, vn)
+    F = rng.uniform(-40, 40, (n, 3)); F[: n // 2, 2] = 0 if nd < 10 else F[: n // 2, 2]
+    if nd < 10:
+        F[:, 2] = 0                                    # planar model: no out-of-plane push
+    plain = HipStepper(card, n, precision=64); plain.reset(None, qn, vn, want_obs=False)
+    for t in range(12):
+        if t == 2:
+            gpu.set_ext_force(body, F)
+            for i, w in enumerate(ora.worlds):
+                w.set_ext_force(body, F[i])
+        if t == 9:
+            gpu.set_ext_force(body, None)
+            for w in ora.worlds:
+                w.set_ext_force(body, None)
+        a = rng.uniform(-1, 1, (n, na)).astype(np.float32)
+        gpu.step(a); plain.step(a); ora.step(a)
+        qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+        assert np.abs(qg - qo).max() < 1e-7 and np.abs(dqg - dqo).max() < 1e-5, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+    assert np.abs(plain.get_state()[0] - gpu.get_state()[0]).max() > 1e-3       # the push did something
+    gpu.close(); plain.close()
+    if env_id == "DartHopper-v1":                      # the specialised planar kernel declines, loudly
+        fast = HipStepper(card_for(env_id), n, precision=64)
+        with pytest.raises(StepperError):
+            fast.set_ext_force(body, F)
+        fast.close()

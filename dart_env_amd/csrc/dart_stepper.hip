@@ -232,6 +232,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     }
     if (last < 0) return "too many links";
     body_link[b] = last;
+    M.link_is_body[last] = 1;
     M.mass[last] = (Real)c.mass[b];
     for (int k = 0; k < 3; k++) M.com[last][k] = (Real)c.com[b][k];
     for (int k = 0; k < 9; k++) M.inertia[last][k] = (Real)(c.mass[b] > 0 ? c.inertia[b][k] : 0.0);
@@ -263,7 +264,9 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
       const int p = M.parent[i];
       if (p < 0) continue;
       const bool still = M.jtype[p] == 2 || M.jtype[p] == 0 || (M.jtype[p] == 1 && M.root_trans[p]);
-      if (M.mass[p] == (Real)0 && M.child_start[p + 1] - M.child_start[p] == 1 && M.pre_ident[i] && M.post_ident[p] && still)
+      // (the snake's fluid model pushes massless carrier bodies too: every link keeps its own wrench there)
+      if (c.task != DART_TASK_SNAKE && M.mass[p] == (Real)0 && M.child_start[p + 1] - M.child_start[p] == 1 && M.pre_ident[i] &&
+          M.post_ident[p] && still)
         M.group_leader[p] = M.group_leader[i];
     }
     int gd[SP_MAXL], maxg = 0;
@@ -345,7 +348,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;
   M.limit_erp_dt = (Real)(c.limit_erp / c.dt); M.cfm1 = (Real)(1.0 + c.cfm); M.ccfm1 = (Real)(1.0 + c.contact_cfm);
   if (physics_only) { M.task = 0; return ""; }   // dynamics getters: geometry, inertia and topology only
-  if (c.task < DART_TASK_NONE || c.task > DART_TASK_DOUBLE_PENDULUM) return "task not served by the spatial kernel";
+  if (c.task < DART_TASK_NONE || c.task > DART_TASK_SNAKE) return "task not served by the spatial kernel";
   M.task = c.task; M.frame_skip = c.frame_skip; M.act_dim = c.act_dim; M.obs_dim = c.obs_dim; M.act_dof0 = c.act_dof0;
   M.max_steps = c.max_episode_steps;
   if (c.act_dim > 32 || c.act_dof0 + c.act_dim > c.ndofs) return "action layout";
@@ -438,7 +441,9 @@ struct SpatialImplT : Impl {
     std::vector<Real> tmp(3 * (size_t)n);
     for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (Real)host_force[i];
     if (hipMemcpy(d_ext, tmp.data(), sizeof(Real) * tmp.size(), hipMemcpyHostToDevice) != hipSuccess) return DART_E_HIP;
-    M.ext_link = body_link_map[body]; M.ext_force = d_ext; upload();
+    // a massless carrier body shares its origin with its group's joint origin: the force moves to the group leader
+    const int lk = body_link_map[body];
+    M.ext_link = M.group_leader[lk]; M.ext_at_joint_origin = M.group_leader[lk] != lk; M.ext_force = d_ext; upload();
     return DART_OK;
   }
   void set_stats(unsigned long long* p) override {

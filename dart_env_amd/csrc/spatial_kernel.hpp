@@ -52,6 +52,7 @@ struct SpatialModel {
   int anc[SP_MAXL][SP_ROUNDS];       // anc[i][k] = 2^k-th ancestor of link i, -1 beyond the root
   // backward pass: links of one expanded joint share their joint origin, so their composite bodies are identical;
   // only the group's last link (the leader, the one that carries the mass) gathers, level by level over GROUPS
+  int link_is_body[SP_MAXL];                         // 1: the link that carries a card body (last link of its joint)
   int group_leader[SP_MAXL], group_level[SP_MAXL];   // group_level: depth of the group for leaders, -1 for the others
   int n_group_levels;
   // the forward pass re-reads its link's geometry from here every substep (48 contiguous Reals per link, 12 x 16-byte
@@ -77,6 +78,7 @@ struct SpatialModel {
   Real aux_real[8], aux_real2[4];
   Real s_max, v_clip, noise, noise_v, inv_envdt;
   int solver_iters, pgs_fallback_sweeps;
+  int ext_at_joint_origin;     // 1: the force acts at the link's joint origin (redirected from a massless carrier body)
   int ext_link;                // external body force (dart_set_ext_force): link it acts on, at the link frame origin
   const Real* ext_force;       // [n_envs][3] world-frame force per env, nullptr = none
   double* dbg;                 // optional [n_envs][160] dump of the last LCP (debug builds of the tests only)
@@ -221,7 +223,7 @@ template <class Real>
 struct LinkConst {
   int parent, jtype, dof, root_trans;
   int anc[SP_ROUNDS];
-  int group_leader, group_level;
+  int group_leader, group_level, is_body;
   int nchild; unsigned long long children;   // leaders: the leaders of up to 8 child groups, one byte each
   Real mass;
   Real damp, stiff, rest;                    // of this link's dof
@@ -233,7 +235,7 @@ template <class Real>
 __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md, int i, LinkConst<Real>& c) {
   c.parent = Md.parent[i]; c.jtype = Md.jtype[i]; c.dof = Md.dof[i]; c.root_trans = Md.root_trans[i];
   for (int k = 0; k < SP_ROUNDS; k++) c.anc[k] = Md.anc[i][k];
-  c.group_leader = Md.group_leader[i]; c.group_level = Md.group_level[i];
+  c.group_leader = Md.group_leader[i]; c.group_level = Md.group_level[i]; c.is_body = Md.link_is_body[i];
   c.mass = Md.mass[i];
   c.nchild = Md.child_start[i + 1] - Md.child_start[i];
   c.children = 0ull;
@@ -367,12 +369,31 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
     nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
   }
   V3<Real> nj = nrm + cross(dj, f);
+  if (Md.task == 9) {
+    // Snake fluid model (snake_7link.py:37-47): every body is pushed by -k (v_com . n) n at its frame origin, n = its z axis.
+    // The link-origin velocity is one more path sum of per-link terms.
+    V3<Real> vo = cross(omp, r) + (rev ? cross(om, sv) : cross(omp, sv) + a * qd);
+#pragma unroll
+    for (int k = 0; k < SP_ROUNDS; k++) {
+      if (k < nr) {
+        const int hop = lc.anc[k];
+        const V3<Real> t = shfl3(vo, hop >= 0 ? hop : lane);
+        if (hop >= 0) vo = vo + t;
+      }
+    }
+    if (lc.is_body) {
+      const V3<Real> vc = vo + cross(om, c - p), nd = v3<Real>(R[2], R[5], R[8]);
+      const V3<Real> fe = nd * (-Md.aux_real[3] * dot(vc, nd));
+      f = f - fe;
+      nj = nj - cross(p - pj, fe);
+    }
+  }
   if (Md.ext_force != nullptr && lane == Md.ext_link) {
     // bodynode.add_ext_force(F) before every world step (dart_env.py:170-172): a world-frame force at the body frame
     // origin enters the link's wrench with the opposite sign of its inertial force
     const V3<Real> fe = ld3(Md.ext_force + env * 3);
     f = f - fe;
-    nj = nj - cross(p - pj, fe);
+    if (!Md.ext_at_joint_origin) nj = nj - cross(p - pj, fe);
   }
   st3(L + LK_F, f);
   st3(L + LK_N, nj);
@@ -1235,6 +1256,14 @@ __device__ __forceinline__ bool sp_simple_epilogue(const SpatialModel<Real>& Md,
   if (Md.task == 5) {
     reward_out = Md.aux_real[0];
     return !(fin && fabs(S.q[1]) <= Md.aux_real2[1]);
+  }
+  if (Md.task == 9) {   // snake (snake_7link.py:72-84); aux_real = {alive, ctrl_cost, deviation cost, fluid k}
+    Real rew = (S.q[0] - pos_before) * Md.inv_envdt;
+    rew += Md.aux_real[0];
+    rew -= Md.aux_real[1] * sq_a_sum;
+    rew -= fabs(S.q[2]) * Md.aux_real[2];
+    reward_out = rew;
+    return !(fin && bounded && fabs(S.q[2]) < Md.aux_real2[1]);
   }
   if (Md.task == 7) {   // cart-pole swing-up (cartpole_swingup.py:22-31); sq_a_sum = a^2 of the single action
     reward_out = Md.aux_real[0] - fabs(S.q[1]) - Md.aux_real[1] * sq_a_sum - Md.aux_real[2] * fabs(S.q[0]);

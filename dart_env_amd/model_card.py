@@ -25,7 +25,7 @@ MAX_ACTIONS = 32
 CARD_VERSION = 1
 
 TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER, TASK_CARTPOLE, TASK_HALFCHEETAH = 0, 1, 2, 3, 4, 5, 6
-TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM = 7, 8
+TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_SNAKE = 7, 8, 9
 
 
 class DartModelCard(C.Structure):
@@ -172,8 +172,17 @@ DOUBLE_PENDULUM = TaskSpec(
     reset_noise_vel=0.1, clamp_actions=False, physics_dt=0.01, aux_body_names=["cart", "weight"],
     aux_real=[10.0, 0.01, 1e-3, 5e-3, 0.02, 0.6])
 
+# DartSnake7Link-v1 -- reference gym/envs/dart/snake_7link.py:7-124 (7 capsule links sliding in the x-z plane 1 mm above the
+# floor, frame_skip 4, scale 200, fluid forces on every body before every world step, reward dx/dt + 0.1 - 1e-3 sum a^2
+# - 0.1 |q[2]|, done |q[2]| >= 1.5, obs q[1:], dq), gym/envs/__init__.py:290-294
+SNAKE = TaskSpec(
+    env_id="DartSnake7Link-v1", model="snake7link", task=TASK_SNAKE, frame_skip=4, act_dim=6, obs_dim=17, act_dof0=3,
+    act_scale=[200.0] * 6, max_episode_steps=1000, reward_threshold=None, height_body=2, penalty_dof=-1,
+    height_lo=-np.inf, height_hi=np.inf, angle_max=1.5, obs_vel_clip=np.inf, all_bodies_collide=True,
+    aux_real=[0.1, 1e-3, 0.1, 50.0])
+
 TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH, CARTPOLE_SWINGUP,
-                               DOUBLE_PENDULUM)}
+                               DOUBLE_PENDULUM, SNAKE)}
 # tasks whose reset_model draws more than the two uniform vectors: the host draws them (see envs/dart_env.py)
 HOST_RESET_TASKS = (TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM)
 

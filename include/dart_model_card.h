@@ -53,6 +53,10 @@ enum {
   DART_TASK_CARTPOLE_SWINGUP = 7, /* reference gym/envs/dart/cartpole_swingup.py:14-33: obs [q, dq], no clamp, reward
                                  aux_real[0] - |q[1]| - aux_real[1] sum a^2 - aux_real[2] |q[0]|, done |q[1]| > aux_real[3]
                                  or |dq[1]| > aux_real[4] or |q[0]| > aux_real[5] */
+  DART_TASK_SNAKE = 9,       /* reference gym/envs/dart/snake_7link.py:35-96: before every world step each body gets the fluid
+                                 force -aux_real[3] (v_com . n) n at its frame origin, n = the body's z axis (:37-47); reward
+                                 dx/dt + aux_real[0] - aux_real[1] sum a^2 - aux_real[2] |q[2]|, done |q[2]| >= angle_max or a
+                                 broken state, obs q[1:], dq */
   DART_TASK_DOUBLE_PENDULUM = 8 /* reference gym/envs/dart/inverted_double_pendulum.py:19-53: obs [q0, sin q1..2, cos q1..2,
                                  dq], height = 2 (y(aux_body[1]) - y(aux_body[0]) - aux_real[4]) / aux_real[5], reward
                                  aux_real[0] - (aux_real[1] q0^2 + (height - 2)^2) - (aux_real[2] dq1^2 + aux_real[3] dq2^2),

@@ -90,6 +90,8 @@ typedef struct OracleWorld {
   double lcp_residual_last;
   double A_last[MAXM * MAXM], b_last[MAXM]; /* debug copies of the last LCP */
   double init_height; /* human_walker.py:163 head COM height right after reset_model's set_state */
+  int ext_all;        /* 1: ext_fb holds one world-frame force per body (snake fluid model), applied at the body origins */
+  double ext_fb[DART_MAX_BODIES][3];
   int ext_body;       /* -1: none.  bodynodes[ext_body].add_ext_force(ext_f) before every world step (dart_env.py:170-172) */
   double ext_f[3];    /* world-frame force applied at the body frame origin (pydart2's default offset) */
 } OracleWorld;
@@ -715,6 +717,18 @@ int oracle_step(OracleWorld* w) {
     rhs[i] = w->tau[i] - w->C[i] - c->damping[i] * w->dq[i] -
              c->stiffness[i] * (w->q[i] + dt * w->dq[i] - c->rest[i]);
   }
+  if (w->ext_all) {
+    static const double E3b[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int bdy = 0; bdy < c->nbodies; bdy++) {
+      int li = w->body_link[bdy];
+      double P[3] = {w->W[li][3], w->W[li][7], w->W[li][11]}, Jd[MAXN];
+      for (int a = 0; a < 3; a++) {
+        if (w->ext_fb[bdy][a] == 0.0) continue;
+        point_jacobian(w, li, P, E3b[a], Jd);
+        for (int i = 0; i < n; i++) rhs[i] += Jd[i] * w->ext_fb[bdy][a];
+      }
+    }
+  }
   if (w->ext_body >= 0) { /* generalized force of the external body force: J(origin)^T f */
     int li = w->body_link[w->ext_body];
     double P[3] = {w->W[li][3], w->W[li][7], w->W[li][11]}, Jd[MAXN];
@@ -918,6 +932,7 @@ int oracle_step(OracleWorld* w) {
     }
   }
   for (int i = 0; i < n; i++) { w->dq[i] = vs[i]; w->q[i] += dt * vs[i]; w->tau[i] = 0; }
+  if (w->ext_all) { memset(w->ext_fb, 0, sizeof w->ext_fb); w->ext_all = 0; }   /* like DART: per-step external forces */
   w->time += dt;
   return 0;
 }
@@ -929,6 +944,34 @@ void oracle_inverse_dynamics(OracleWorld* w, const double* dq, const double* ddq
   kinematics(w); rnea(w, dq, ddq, with_gravity, tau);
 }
 void oracle_body_pose(OracleWorld* w, int body, double* T16) { kinematics(w); memcpy(T16, w->W[w->body_link[body]], 16 * sizeof(double)); }
+/* bodynode.add_ext_force(f) for the NEXT world step only (world frame, at the body frame origin) */
+void oracle_add_body_force(OracleWorld* w, int body, const double* f3) {
+  for (int a = 0; a < 3; a++) w->ext_fb[body][a] += f3[a];
+  w->ext_all = 1;
+}
+/* pydart2 bodynode.com_spatial_velocity(): [angular; linear velocity of the COM], world frame */
+void oracle_body_com_spatial_velocity(OracleWorld* w, int body, double* out6) {
+  kinematics(w);
+  int li = w->body_link[body];
+  const double* T = w->W[li];
+  const double* cb = w->card.com[body];
+  double cm[3];
+  for (int a = 0; a < 3; a++) cm[a] = T[4 * a] * cb[0] + T[4 * a + 1] * cb[1] + T[4 * a + 2] * cb[2] + T[4 * a + 3];
+  for (int a = 0; a < 6; a++) out6[a] = 0;
+  for (int j = li; j >= 0; j = w->L[j].parent) {
+    Link* l = &w->L[j];
+    if (l->dof < 0) continue;
+    const double* Wm = w->W[j];
+    double ww[3], vw[3], rel[3], t[3];
+    for (int a = 0; a < 3; a++) {
+      ww[a] = Wm[4 * a] * l->S[0] + Wm[4 * a + 1] * l->S[1] + Wm[4 * a + 2] * l->S[2];
+      vw[a] = Wm[4 * a] * l->S[3] + Wm[4 * a + 1] * l->S[4] + Wm[4 * a + 2] * l->S[5];
+      rel[a] = cm[a] - Wm[4 * a + 3];
+    }
+    cross3(ww, rel, t);
+    for (int a = 0; a < 3; a++) { out6[a] += ww[a] * w->dq[l->dof]; out6[3 + a] += (vw[a] + t[a]) * w->dq[l->dof]; }
+  }
+}
 void oracle_body_com(OracleWorld* w, int body, double* out3) {
   kinematics(w);
   const double* T = w->W[w->body_link[body]];
@@ -1174,8 +1217,55 @@ static int double_pendulum_step(OracleWorld* w, const double* a, double* obs, do
   return height <= 1;
 }
 
+/* DartSnake7LinkEnv (snake_7link.py:35-96).  do_simulation adds, before EVERY world step, a fluid force to EVERY body:
+ * with n = the body's z axis in the world and v = its COM velocity, vel_pos/neg = v +- (w x n) 0.05 have the same
+ * component along n as v itself, so the force is -50 (v . n) n whenever that component is non-zero. */
+static int snake_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double tau[MAXN] = {0}, sq = 0;
+  double posbefore = w->q[0];
+  for (int k = 0; k < c->act_dim; k++) {
+    double cl = a[k];
+    if (cl > c->act_high[k]) cl = c->act_high[k];
+    if (cl < c->act_low[k]) cl = c->act_low[k];
+    tau[c->act_dof0 + k] = cl * c->act_scale[k];
+    sq += a[k] * a[k];
+  }
+  for (int f = 0; f < c->frame_skip; f++) {
+    kinematics(w);
+    for (int bdy = 0; bdy < c->nbodies; bdy++) {
+      int li = w->body_link[bdy];
+      const double* Wm = w->W[li];
+      double nd[3] = {Wm[2], Wm[6], Wm[10]}, cm[3], Jd[MAXN], vn = 0;
+      for (int x = 0; x < 3; x++) cm[x] = Wm[4 * x] * c->com[bdy][0] + Wm[4 * x + 1] * c->com[bdy][1] + Wm[4 * x + 2] * c->com[bdy][2] + Wm[4 * x + 3];
+      point_jacobian(w, li, cm, nd, Jd);
+      for (int i = 0; i < n; i++) vn += Jd[i] * w->dq[i];
+      for (int x = 0; x < 3; x++) w->ext_fb[bdy][x] = (vn != 0.0) ? -c->aux_real[3] * vn * nd[x] : 0.0;
+    }
+    w->ext_all = 1;
+    oracle_set_forces(w, tau);
+    oracle_step(w);
+  }
+  double envdt = c->dt * c->frame_skip;
+  double r = (w->q[0] - posbefore) / envdt;
+  r += c->aux_real[0];
+  r -= c->aux_real[1] * sq;
+  r -= fabs(w->q[2]) * c->aux_real[2];
+  *reward = r;
+  int ok = 1;
+  for (int i = 0; i < n; i++) {
+    if (!isfinite(w->q[i]) || !isfinite(w->dq[i])) ok = 0;
+    if (i >= 2 && !(fabs(w->q[i]) < c->state_abs_max)) ok = 0;
+    if (!(fabs(w->dq[i]) < c->state_abs_max)) ok = 0;
+  }
+  qdq_obs(w, 1, obs);
+  return !(ok && fabs(w->q[2]) < c->angle_max);
+}
+
 int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
   const DartModelCard* c = &w->card;
+  if (c->task == DART_TASK_SNAKE) return snake_step(w, a, obs, reward);
   if (c->task == DART_TASK_CARTPOLE_SWINGUP) return swingup_step(w, a, obs, reward);
   if (c->task == DART_TASK_DOUBLE_PENDULUM) return double_pendulum_step(w, a, obs, reward);
   if (c->task == DART_TASK_CARTPOLE) return cartpole_step(w, a, obs, reward);
@@ -1236,7 +1326,7 @@ void oracle_env_obs(OracleWorld* w, double* obs) {
   if (c->task == DART_TASK_WALKER3D) { walker3d_obs(w, obs); return; }
   if (c->task == DART_TASK_CARTPOLE || c->task == DART_TASK_CARTPOLE_SWINGUP) { qdq_obs(w, 0, obs); return; }
   if (c->task == DART_TASK_DOUBLE_PENDULUM) { double_pendulum_obs(w, obs); return; }
-  if (c->task == DART_TASK_HALFCHEETAH) { qdq_obs(w, 1, obs); return; }
+  if (c->task == DART_TASK_HALFCHEETAH || c->task == DART_TASK_SNAKE) { qdq_obs(w, 1, obs); return; }
   int n = w->n;
   double cm[3];
   oracle_body_com(w, c->height_body, cm);

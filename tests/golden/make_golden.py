@@ -109,6 +109,15 @@ class StubBody:
 
     C = property(lambda self: self.com())
 
+    def com_spatial_velocity(self):
+        return self.world.oracle.body_com_spatial_velocity(self.index)
+
+    def add_ext_force(self, f):
+        self.world.oracle.add_body_force(self.index, np.asarray(f, dtype=np.float64))
+
+    def set_friction_coeff(self, mu):
+        pass   # snake_7link.py:29-31: the snake never touches the floor (no vertical dof, 1 mm clearance)
+
     def local_com(self):
         return np.array(self.world.model.bodies[self.index].com, dtype=np.float64)
 
@@ -170,7 +179,7 @@ class StubWorld:
         contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"],
                    "kima_human_edited.skel": None, "walker3d_waist.skel": None,
                    "cartpole.skel": None, "half_cheetah.skel": None, "cartpole_swingup.skel": None,
-                   "inverted_double_pendulum.skel": None}[name]   # None: every collision shape
+                   "inverted_double_pendulum.skel": None, "snake_7link.skel": None}[name]   # None: every collision shape
         model = parse_skel(skel_path, dt=dt, collidable_bodies=contact)
         self.model = model
         self.dt = dt
@@ -180,7 +189,8 @@ class StubWorld:
                 "kima_human_edited.skel": "DartHumanWalker-v1", "walker3d_waist.skel": "DartWalker3d-v1",
                 "cartpole.skel": "DartCartPole-v1", "half_cheetah.skel": "DartHalfCheetah-v1",
                 "cartpole_swingup.skel": "DartCartPoleSwingUp-v1",
-                "inverted_double_pendulum.skel": "DartDoubleInvertedPendulumEnv-v1"}[name]
+                "inverted_double_pendulum.skel": "DartDoubleInvertedPendulumEnv-v1",
+                "snake_7link.skel": "DartSnake7Link-v1"}[name]
         if TASKS[spec].contact_cfm is not None:   # same contact regularisation as the shipped task card
             card.contact_cfm = TASKS[spec].contact_cfm
         card.self_collision = int(TASKS[spec].self_collision)   # what the env's set_self_collision_check() call will ask for
@@ -326,6 +336,9 @@ def main():
     for env_id, tag in (("DartCartPoleSwingUp-v1", "swingup"), ("DartDoubleInvertedPendulumEnv-v1", "doublependulum")):
         np.savez_compressed(os.path.join(out, "%s_single_seed0.npz" % tag), **rollout_single(gym, env_id, 0, 300, act_scale=1.5))
         np.savez_compressed(os.path.join(out, "%s_vector4_seed3.npz" % tag), **rollout_vector(gym, env_id, 4, 3, 150, act_scale=1.5))
+    # (10) DartSnake7Link-v1: the reference's own fluid-force loop (com_spatial_velocity / add_ext_force per body and substep)
+    np.savez_compressed(os.path.join(out, "snake_single_seed0.npz"), **rollout_single(gym, "DartSnake7Link-v1", 0, 300))
+    np.savez_compressed(os.path.join(out, "snake_vector4_seed3.npz"), **rollout_vector(gym, "DartSnake7Link-v1", 4, 3, 120))
     print("world.step() calls issued by the reference code:", StubWorld.n_steps)
 
 

@@ -57,6 +57,8 @@ def lib():
         L.oracle_last_Ab.argtypes = [C.c_void_p, dp, dp]
         L.oracle_last_Ab.restype = C.c_int
         L.oracle_set_ext_force.argtypes = [C.c_void_p, C.c_int, dp]
+        L.oracle_add_body_force.argtypes = [C.c_void_p, C.c_int, dp]
+        L.oracle_body_com_spatial_velocity.argtypes = [C.c_void_p, C.c_int, dp]
         L.oracle_box_box.argtypes = [dp, dp, dp, dp, dp, dp, dp, dp]
         L.oracle_box_box.restype = C.c_int
         L.oracle_rollout.restype = C.c_int64
@@ -114,6 +116,15 @@ class OracleWorld:
     def set_forces(self, tau):
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         self.L.oracle_set_forces(self.h, _p(tau))
+
+    def add_body_force(self, body, f3):
+        """bodynode.add_ext_force(f3): world-frame force at the body origin for the next world step only."""
+        self.L.oracle_add_body_force(self.h, int(body), _p(np.ascontiguousarray(f3, dtype=np.float64)))
+
+    def body_com_spatial_velocity(self, body):
+        out = np.zeros(6)
+        self.L.oracle_body_com_spatial_velocity(self.h, int(body), _p(out))
+        return out
 
     def set_ext_force(self, body, f3):
         """bodynodes[body].add_ext_force(f3) before every following world step; f3 = None switches it off."""

@@ -9,7 +9,8 @@ import pytest
 import dart_env_amd
 from dart_env_amd import seeding, spaces
 from dart_env_amd.model_card import card_for
-from dart_env_amd.envs import (DartCartPoleEnv, DartCartPoleSwingUpEnv, DartDoubleInvertedPendulumEnv, DartHalfCheetahEnv, DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv,
+from dart_env_amd.envs import (DartCartPoleEnv, DartCartPoleSwingUpEnv, DartDoubleInvertedPendulumEnv, DartHalfCheetahEnv,
+                               DartSnake7LinkEnv, DartHopperEnv, DartHumanWalkerEnv, DartWalker2dEnv,
                                DartWalker3dEnv)
 from dart_env_amd.wrappers import TimeLimit
 from tests.fake_stepper import OracleStepper
@@ -18,10 +19,11 @@ from tests.oracle_lib import OracleWorld
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 IDS = {"hopper": "DartHopper-v1", "walker2d": "DartWalker2d-v1", "humanwalker": "DartHumanWalker-v1",
        "walker3d": "DartWalker3d-v1", "cartpole": "DartCartPole-v1", "halfcheetah": "DartHalfCheetah-v1",
-       "swingup": "DartCartPoleSwingUp-v1", "doublependulum": "DartDoubleInvertedPendulumEnv-v1"}
+       "swingup": "DartCartPoleSwingUp-v1", "doublependulum": "DartDoubleInvertedPendulumEnv-v1",
+       "snake": "DartSnake7Link-v1"}
 CLS = {"hopper": DartHopperEnv, "walker2d": DartWalker2dEnv, "humanwalker": DartHumanWalkerEnv,
        "walker3d": DartWalker3dEnv, "cartpole": DartCartPoleEnv, "halfcheetah": DartHalfCheetahEnv,
-       "swingup": DartCartPoleSwingUpEnv, "doublependulum": DartDoubleInvertedPendulumEnv}
+       "swingup": DartCartPoleSwingUpEnv, "doublependulum": DartDoubleInvertedPendulumEnv, "snake": DartSnake7LinkEnv}
 
 
 def test_seeding_and_reset_noise_stream():
@@ -119,6 +121,25 @@ def test_time_limit_truncation_vs_reference(tag):
         if done:
             env.reset()
     assert d["truncated"].sum() >= 3
+
+
+def test_snake_vs_reference_fluid_force_loop():
+    """The reference computes the snake's fluid forces in Python (com_spatial_velocity, add_ext_force per body and
+    substep, snake_7link.py:37-47); the oracle's C restatement and the env facade follow the same trajectory.  Not
+    bitwise: the Python expression carries a (w x n) . n term that is zero only up to rounding."""
+    d = np.load(os.path.join(G, "snake_single_seed0.npz"))
+    env = TimeLimit(DartSnake7LinkEnv(stepper_factory=OracleStepper), max_episode_steps=1000)
+    env.seed(0)
+    assert np.allclose(env.reset(), d["obs0"], atol=1e-7)
+    for t in range(len(d["done"])):
+        ob, r, done, info = env.step(d["actions"][t])
+        assert done == bool(d["done"][t]), t
+        assert np.allclose(ob, d["obs"][t], rtol=0, atol=2e-6) and abs(r - d["reward"][t]) < 1e-9, t
+        assert np.allclose(env.state_vector(), np.concatenate([d["q"][t], d["dq"][t]]), rtol=0, atol=1e-10)
+        if done:
+            assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-7)
+    assert np.abs(d["q"][:, 0]).max() > 0.5 and d["done"].sum() >= 1    # it swims, and an episode ends
+    env.close()
 
 
 @pytest.mark.parametrize("tag", ["hopper", "walker2d", "cartpole", "halfcheetah", "swingup", "doublependulum"])

@@ -228,7 +228,8 @@ def test_walker3d_fp32_and_device_autoreset():
 
 # ------------------------------------------------------------------ DartCartPole-v1 / DartHalfCheetah-v1 on the spatial kernel
 @pytest.mark.parametrize("env_id,noise", [("DartCartPole-v1", 0.01), ("DartHalfCheetah-v1", 0.005),
-                                          ("DartCartPoleSwingUp-v1", 0.1), ("DartDoubleInvertedPendulumEnv-v1", 0.1)])
+                                          ("DartCartPoleSwingUp-v1", 0.1), ("DartDoubleInvertedPendulumEnv-v1", 0.1),
+                                          ("DartSnake7Link-v1", 0.005)])
 def test_classic_env_fp64_matches_oracle(env_id, noise):
     from dart_env_amd.stepper import HipStepper
     card = card_for(env_id)
@@ -242,6 +243,11 @@ def test_classic_env_fp64_matches_oracle(env_id, noise):
     n_done = 0
     for t in range(100):
         a = rng.uniform(-1.5, 1.5, (n, na)).astype(np.float32)     # beyond +-1: the cheetah clamps, the cart-pole does not
+        if env_id == "DartSnake7Link-v1" and t == 40:               # turn a few snakes past |q[2]| >= 1.5
+            q, dq = gpu.get_state(); q[:8, 2] = 1.6
+            gpu.set_state(q, dq)
+            for i in range(8):
+                ora.worlds[i].set_state(q[i], dq[i])
         if env_id == "DartHalfCheetah-v1" and t == 40:              # flip a few cheetahs to exercise |q[2]| >= 1.3
             q, dq = gpu.get_state(); q[:8, 2] = 1.4; q[:8, 1] += 0.5
             gpu.set_state(q, dq)
@@ -263,7 +269,8 @@ def test_classic_env_fp64_matches_oracle(env_id, noise):
 
 @pytest.mark.parametrize("tag,env_id", [("cartpole", "DartCartPole-v1"), ("halfcheetah", "DartHalfCheetah-v1"),
                                         ("swingup", "DartCartPoleSwingUp-v1"),
-                                        ("doublependulum", "DartDoubleInvertedPendulumEnv-v1")])
+                                        ("doublependulum", "DartDoubleInvertedPendulumEnv-v1"),
+                                        ("snake", "DartSnake7Link-v1")])
 def test_classic_env_vector_fixture_and_fp32(tag, env_id):
     """Reference SyncVectorEnv fixture through the default (device MT19937) vector env in fp64; fp32 stays close."""
     import dart_env_amd
@@ -417,7 +424,7 @@ def test_spatial_pgs_solver_converges_to_pivoting_solver(force_spatial):
     assert np.median(e400) < 1e-6 and np.median(e400) < 0.1 * np.median(e30) + 1e-12
 
 
-@pytest.mark.parametrize("env_id,body", [("DartHopper-v1", 3), ("DartHumanWalker-v1", 9)])
+@pytest.mark.parametrize("env_id,body", [("DartHopper-v1", 3), ("DartHumanWalker-v1", 9), ("DartWalker3d-v1", 0)])  # 0: massless carrier
 def test_external_body_force_matches_oracle(env_id, body):
     """dart_set_ext_force = bodynodes[b].add_ext_force(F) before every world step (perturbation branch, dart_env.py:159-172)."""
     from dart_env_amd.stepper import HipStepper, StepperError

@@ -21,6 +21,7 @@ ASSETS = {
     "halfcheetah": "half_cheetah.skel",     # half_cheetah.py:18 (dt 0.01)
     "cartpole_swingup": "cartpole_swingup.skel",        # cartpole_swingup.py:11 (dt 0.01)
     "double_pendulum": "inverted_double_pendulum.skel",  # inverted_double_pendulum.py:14 (dt 0.01)
+    "snake7link": "snake_7link.skel",                    # snake_7link.py:18
 }
 DT = {"cartpole": 0.02, "halfcheetah": 0.01, "cartpole_swingup": 0.01, "double_pendulum": 0.01}
 

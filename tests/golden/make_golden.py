@@ -318,11 +318,11 @@ def main():
         # (5) SyncVectorEnv semantics: seed fan-out s+i, auto-reset with post-reset obs, dtypes
         np.savez_compressed(os.path.join(out, "%s_vector4_seed3.npz" % tag), **rollout_vector(gym, env_id, 4, 3, 120))
     # (6) DartHumanWalker-v1 (29 dof, box feet, springs, contact flags in the observation), 300-step TimeLimit
-    np.savez_compressed(os.path.join(out, "humanwalker_single_seed0.npz"), **rollout_single(gym, "DartHumanWalker-v1", 0, 120))
+    np.savez_compressed(os.path.join(out, "humanwalker_single_seed0.npz"), **rollout_single(gym, "DartHumanWalker-v1", 0, 1000))
     np.savez_compressed(os.path.join(out, "humanwalker_single_seed4_small.npz"),
                         **rollout_single(gym, "DartHumanWalker-v1", 4, 150, act_scale=0.05))
     # (7) DartWalker3d-v1 (21 dof, box links; the stub world ignores set_self_collision_check, like the HIP kernel)
-    np.savez_compressed(os.path.join(out, "walker3d_single_seed0.npz"), **rollout_single(gym, "DartWalker3d-v1", 0, 300))
+    np.savez_compressed(os.path.join(out, "walker3d_single_seed0.npz"), **rollout_single(gym, "DartWalker3d-v1", 0, 1000))
     np.savez_compressed(os.path.join(out, "walker3d_single_seed6_small.npz"),
                         **rollout_single(gym, "DartWalker3d-v1", 6, 400, act_scale=0.05))
     np.savez_compressed(os.path.join(out, "walker3d_vector4_seed3.npz"), **rollout_vector(gym, "DartWalker3d-v1", 4, 3, 120))

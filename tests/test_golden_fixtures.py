@@ -73,7 +73,7 @@ def test_oracle_task_epilogue_bitwise_vs_reference_python(tag, fix):
         w.env_after_reset()
         return w.env_obs()
     assert np.array_equal(do_reset(), d["obs0"])
-    steps = min(len(d["done"]), 400)
+    steps = min(len(d["done"]), 1100)
     for t in range(steps):
         ob, r, done = w.env_step(d["actions"][t].astype(np.float64))
         assert np.array_equal(ob, d["obs"][t]), t

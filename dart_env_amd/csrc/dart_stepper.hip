@@ -41,6 +41,7 @@ struct Impl {
   virtual void release() {}
   virtual hipError_t debug_dump(double*) { return hipErrorInvalidValue; }
   virtual int set_ext_force(int /*body*/, const double* /*host_force*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
+  virtual int set_task_state(hipStream_t, const uint8_t* /*d_mask*/, const double* /*d_values*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int slots() const = 0;
   bool soa = true;         // state layout: q[n][N] (planar kernels) or q[N][n] (spatial kernel)
   int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
@@ -90,6 +91,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   if (c.nbodies != NL + 2 || c.ndofs != T::NDOF) return "body/dof count";
   if (c.act_dim != T::NA || c.act_dof0 != T::NDOF - T::NA) return "action layout";
   if (c.obs_dim != 2 * T::NDOF - 1 && c.task != DART_TASK_NONE) return "obs_dim";
+  for (int d = 0; d < c.ndofs; d++) if (c.joint_friction[d] != 0.0) return "joint Coulomb friction";
   if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
   if (c.contact_cfm != c.cfm) return "contact_cfm differs from cfm";
   // floating base: prismatic x, prismatic y, revolute +-z
@@ -238,6 +240,12 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     for (int k = 0; k < 9; k++) M.inertia[last][k] = (Real)(c.mass[b] > 0 ? c.inertia[b][k] : 0.0);
   }
   M.nl = nl; M.n = c.ndofs;
+  M.has_joint_friction = 0;
+  for (int d = 0; d < c.ndofs; d++) {
+    if (c.joint_friction[d] < 0) return "negative joint friction";
+    M.jfric_dt[d] = (Real)(c.joint_friction[d] * c.dt);
+    if (c.joint_friction[d] != 0.0) M.has_joint_friction = 1;
+  }
   if (body_link_out) for (int b = 0; b < c.nbodies; b++) body_link_out[b] = body_link[b];
   {  // depth levels, children lists, constant world axes of the root-chain prismatic links
     int depth[SP_MAXL], maxd = 0;
@@ -348,7 +356,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;
   M.limit_erp_dt = (Real)(c.limit_erp / c.dt); M.cfm1 = (Real)(1.0 + c.cfm); M.ccfm1 = (Real)(1.0 + c.contact_cfm);
   if (physics_only) { M.task = 0; return ""; }   // dynamics getters: geometry, inertia and topology only
-  if (c.task < DART_TASK_NONE || c.task > DART_TASK_SNAKE) return "task not served by the spatial kernel";
+  if (c.task < DART_TASK_NONE || c.task > DART_TASK_REACHER3D) return "task not served by the spatial kernel";
   M.task = c.task; M.frame_skip = c.frame_skip; M.act_dim = c.act_dim; M.obs_dim = c.obs_dim; M.act_dof0 = c.act_dof0;
   M.max_steps = c.max_episode_steps;
   if (c.act_dim > 32 || c.act_dof0 + c.act_dim > c.ndofs) return "action layout";
@@ -362,6 +370,10 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     M.aux_link[0] = body_link[c.height_body]; M.aux_link[1] = c.penalty_dof;
     const double ar[7] = {c.alive_bonus, c.ctrl_cost, c.limit_penalty, 0.0, c.height_lo, c.height_hi, c.penalty_margin};
     for (int k = 0; k < 7; k++) M.aux_real[k] = (Real)ar[k];
+  }
+  if (c.task == DART_TASK_REACHER2D || c.task == DART_TASK_REACHER3D) {
+    if (c.aux_body[0] < 0 || c.aux_body[0] >= c.nbodies || c.obs_dim != 3 * c.ndofs + (c.task == DART_TASK_REACHER2D ? 5 : 6)) return "reacher card";
+    M.aux_link[0] = body_link[c.aux_body[0]];
   }
   if (c.task == DART_TASK_DOUBLE_PENDULUM) {
     if (c.ndofs != 3 || c.aux_body[0] < 0 || c.aux_body[0] >= c.nbodies || c.aux_body[1] < 0 || c.aux_body[1] >= c.nbodies) return "double pendulum card";
@@ -394,8 +406,8 @@ struct SpatialImplT : Impl {
     nenv = n;
     if ((e = hipMalloc((void**)&dM, sizeof(M))) != hipSuccess) return e;
     if ((e = hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&init_h, sizeof(Real) * (size_t)n)) != hipSuccess) return e;
-    if ((e = hipMemset(init_h, 0, sizeof(Real) * (size_t)n)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&init_h, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
+    if ((e = hipMemset(init_h, 0, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
     lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp);
     if ((e = hipFuncSetAttribute((const void*)sp_step_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
@@ -435,6 +447,10 @@ struct SpatialImplT : Impl {
   double* dbg = nullptr; int64_t nenv = 0;
   Real* d_ext = nullptr;
   int body_link_map[DART_MAX_BODIES];
+  int set_task_state(hipStream_t s, const uint8_t* d_mask, const double* d_values, int64_t n) override {
+    hipLaunchKernelGGL((sp_task_state_kernel<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_mask, d_values, init_h);
+    return hipGetLastError() == hipSuccess ? DART_OK : DART_E_HIP;
+  }
   int set_ext_force(int body, const double* host_force, int64_t n) override {
     if (!host_force) { M.ext_force = nullptr; upload(); return DART_OK; }
     if (!d_ext && hipMalloc((void**)&d_ext, sizeof(Real) * 3 * (size_t)n) != hipSuccess) return DART_E_HIP;
@@ -913,6 +929,25 @@ int dart_debug_dump(DartStepper* h, double* out160) {
   CHK(h, hipSetDevice(h->device));
   CHK(h, hipStreamSynchronize(h->stream));
   CHK(h, h->impl->debug_dump(out160));
+  return DART_OK;
+}
+
+int dart_set_task_state(DartStepper* h, const uint8_t* mask, const double* values) {
+  if (!h || !values) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  const size_t N = (size_t)h->n;
+  double* dv = nullptr;
+  CHK(h, hipMalloc((void**)&dv, 8 * 4 * N));
+  CHK(h, hipMemcpy(dv, values, 8 * 4 * N, hipMemcpyHostToDevice));
+  const uint8_t* dmask = nullptr;
+  if (mask) { memcpy(h->h_mask, mask, N); CHK(h, hipMemcpy(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice)); dmask = h->d_mask; }
+  int rc = h->impl->set_task_state(h->stream, dmask, dv, h->n);
+  hipError_t e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dv);
+  if (rc == DART_E_UNSUPPORTED) h->err = "this model's kernel keeps no per-env task state";
+  if (rc != DART_OK) return rc;
+  CHK(h, e);
   return DART_OK;
 }
 

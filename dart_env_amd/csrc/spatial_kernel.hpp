@@ -66,6 +66,8 @@ struct SpatialModel {
   Real mass[SP_MAXL], com[SP_MAXL][3], inertia[SP_MAXL][9];
   int dof_link[SP_MAXN], limited[SP_MAXN];
   Real lower[SP_MAXN], upper[SP_MAXN], damp[SP_MAXN], stiff[SP_MAXN], rest[SP_MAXN], q0[SP_MAXN], dq0[SP_MAXN];
+  Real jfric_dt[SP_MAXN];            // Coulomb joint friction * dt: impulse bound of the dof's friction row (0 = none)
+  int has_joint_friction;
   int maxm, maxcp;                   // LCP rows / contact points this model's LDS block is carved for
   int npairs, pair_a[SP_MAXPAIRS], pair_b[SP_MAXPAIRS];   // link-link contact candidates: shape slots, a < b
   int sh_link[SP_MAXS], sh_type[SP_MAXS];
@@ -229,7 +231,7 @@ struct LinkConst {
   Real damp, stiff, rest;                    // of this link's dof
   // the same lane also owns dof `lane` (mass-matrix row, limits)
   int d_link; Real d_diag;                   // link of dof `lane`; dt*damping + dt^2*stiffness
-  int d_limited; Real d_lower, d_upper;
+  int d_limited; Real d_lower, d_upper, d_fric;
 };
 template <class Real>
 __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md, int i, LinkConst<Real>& c) {
@@ -247,6 +249,7 @@ __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md,
   c.d_link = Md.dof_link[dl];
   c.d_diag = Md.dt * Md.damp[dl] + Md.dt * Md.dt * Md.stiff[dl];
   c.d_limited = (i < Md.n) ? Md.limited[dl] : 0; c.d_lower = Md.lower[dl]; c.d_upper = Md.upper[dl];
+  c.d_fric = (i < Md.n) ? Md.jfric_dt[dl] : Real(0);
 }
 
 template <class Real> __device__ __forceinline__ V3<Real> shfl3(V3<Real> v, int src) {
@@ -996,6 +999,17 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       S.hi[row] = low ? inf_<Real>() : Real(0);
     }
     m = 3 * ncp + __popcll(lm);
+    if (Md.has_joint_friction) {   // DART JointCoulombFrictionConstraint rows: joint velocity -> 0, impulse within +-mu dt
+      const bool fr = lane < n && lc.d_fric > Real(0);
+      const uint64_t fm = __ballot(fr);
+      const int frow = m + __popcll(fm & lt);
+      if (fr && frow < Md.maxm) {
+        S.rdof[frow] = lane; S.rfidx[frow] = -1;
+        S.b[frow] = -S.dq[lane];
+        S.lo[frow] = -lc.d_fric; S.hi[frow] = lc.d_fric;
+      }
+      m += __popcll(fm);
+    }
     m = m < Md.maxm ? m : Md.maxm;
   }
   __syncthreads();
@@ -1127,7 +1141,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         F = (F & ~fr) | (fr & ~pf);
         U &= ~fr;
       }
-      sp_blcp<Real>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0);
+      sp_blcp<Real>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !Md.has_joint_friction);
     }
     SP_TICK(8);
     if (Md.dbg) {
@@ -1243,6 +1257,13 @@ __device__ __forceinline__ bool sp_planar_task_epilogue(const SpatialModel<Real>
   return !ok;
 }
 
+// Reacher tip: to_world(aux body, aux_real[0..2]) in absolute coordinates (no floating base in these models)
+template <class Real>
+__device__ __forceinline__ V3<Real> sp_reacher_tip(const SpatialModel<Real>& Md, SpLds<Real>& S) {
+  const Real* L = S.link + Md.aux_link[0] * SP_LINKF;
+  return ld3(L + LK_P) + mulR(L + LK_R, v3<Real>(Md.aux_real[0], Md.aux_real[1], Md.aux_real[2])) + ld3(S.misc);
+}
+
 // CartPole (cart_pole.py:12-24): reward 1, done when the observation is not finite or |q[1]| > angle_max.
 // HalfCheetah (half_cheetah.py:43-63): aux_real = {alive, ctrl_cost}; reward zeroed when the state broke.
 template <class Real>
@@ -1287,6 +1308,22 @@ __device__ __forceinline__ bool sp_simple_epilogue(const SpatialModel<Real>& Md,
 template <class Real>
 __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds<Real>& S, const int* cflags, float* __restrict__ o, int lane) {
   const int n = Md.n;
+  if (Md.task == 10 || Md.task == 11) {   // reachers: cos q, sin q, target (2-D: x, z), dq, tip - target (reacher.py:38-42)
+    const V3<Real> tgt = ld3(S.misc + 4);       // staged by the caller from the per-env task state
+    int o0 = 2 * n;
+    if (lane < n) { Real sn, cs; sincos_<Real>(S.q[lane], sn, cs); o[lane] = (float)cs; o[n + lane] = (float)sn; }
+    if (lane == 0) {
+      if (Md.task == 10) { o[o0] = (float)tgt.x; o[o0 + 1] = (float)tgt.z; }
+      else { o[o0] = (float)tgt.x; o[o0 + 1] = (float)tgt.y; o[o0 + 2] = (float)tgt.z; }
+    }
+    o0 += (Md.task == 10) ? 2 : 3;
+    if (lane < n) o[o0 + lane] = (float)S.dq[lane];
+    if (lane == 0) {
+      const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - tgt;
+      o[o0 + n] = (float)vec.x; o[o0 + n + 1] = (float)vec.y; o[o0 + n + 2] = (float)vec.z;
+    }
+    return;
+  }
   if (Md.task == 8) {   // double pendulum: [q0, sin q1, sin q2, cos q1, cos q2, dq] (inverted_double_pendulum.py:45-51)
     if (lane == 0) o[0] = (float)S.q[0];
     if (lane == 1 || lane == 2) { Real sn, cs; sincos_<Real>(S.q[lane], sn, cs); o[lane] = (float)sn; o[lane + 2] = (float)cs; }
@@ -1307,7 +1344,7 @@ __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
 template <class Real>
 __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
-                                                      Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ init_h,
+                                                      Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ tstate,
                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
                                                       const float* __restrict__ actions, float* __restrict__ obs,
                                                       float* __restrict__ reward, uint8_t* __restrict__ done,
@@ -1337,6 +1374,13 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
     }
     sp_kinematics<Real>(Md, S);
     sh_scal[0] = (Md.task == 3 || Md.task == 4) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
+    if (Md.task == 11) {   // DartReacher3d: distance to the target BEFORE the step, and sum tau^2 (reacher.py:23-27)
+      const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - ld3(tstate + 4 * e);
+      sh_scal[0] = sqrt(dot(vec, vec));
+      Real st2 = Real(0);
+      for (int k = 0; k < Md.act_dim; k++) st2 += S.tau[Md.act_dof0 + k] * S.tau[Md.act_dof0 + k];
+      sh_scal[2] = st2;
+    }
     cflags[0] = 0; cflags[1] = 0;
   }
   __syncthreads();
@@ -1349,10 +1393,24 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
     sp_kinematics<Real>(Md, S);
     Real rew = Real(0);
     bool task_done = false;
-    if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, init_h[e], cflags, rew);
+    if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, tstate[4 * e], cflags, rew);
     else if (Md.task == 3) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     else if (Md.task >= 5) task_done = sp_simple_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     else if (Md.task == 1 || Md.task == 2) task_done = sp_planar_task_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
+    if (Md.task == 10 || Md.task == 11) {   // reachers: reward from the tip-target distance (2-D: after, 3-D: before the step)
+      const V3<Real> tgt = ld3(tstate + 4 * e);
+      bool fin = true;
+      for (int i = 0; i < Md.n; i++) fin = fin && isfinite(S.q[i]) && isfinite(S.dq[i]);
+      if (Md.task == 11) {
+        const Real dist0 = sh_scal[0];
+        rew = -dist0 + -(sh_scal[2] * Md.aux_real[3]);
+        task_done = !(fin && (dist0 > Md.aux_real[4]));
+      } else {
+        const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - tgt;
+        rew = -sqrt(dot(vec, vec)) + -sq_sum;
+        task_done = false;
+      }
+    }
     int el = elapsed[e] + 1;
     const bool trunc = (Md.max_steps > 0) && (el >= Md.max_steps);
     dn = task_done || trunc; tr = trunc && !task_done;
@@ -1381,12 +1439,14 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
     if (lane == 0) {
       episode[e] = ep;
       sp_kinematics<Real>(Md, S);
-      if (Md.task == 4) init_h[e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
+      if (Md.task == 4) tstate[4 * e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
       cflags[0] = 0; cflags[1] = 0;
     }
     __syncthreads();
   }
   if (lane < n) { qs[e * n + lane] = S.q[lane]; dqs[e * n + lane] = S.dq[lane]; }
+  if ((Md.task == 10 || Md.task == 11) && lane < 3) S.misc[4 + lane] = tstate[4 * e + lane];
+  __syncthreads();
   sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
 }
 
@@ -1440,10 +1500,18 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
   }
 }
 
+// per-env task state (reach targets): masked copy of (N, 4) doubles
+template <class Real>
+__global__ void sp_task_state_kernel(int64_t n_envs, const uint8_t* __restrict__ mask, const double* __restrict__ values, Real* __restrict__ tstate) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_envs || (mask && !mask[e])) return;
+  for (int k = 0; k < 4; k++) tstate[4 * e + k] = (Real)values[4 * e + k];
+}
+
 // masked reset: q = init + noise (host rows or Philox), elapsed = 0, init height, obs
 template <class Real>
 __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
-                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ init_h,
+                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ tstate,
                                                        int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
                                                        const uint8_t* __restrict__ mask, const double* __restrict__ qnoise,
                                                        const double* __restrict__ vnoise, float* __restrict__ obs,
@@ -1480,13 +1548,15 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
       if (!qnoise) episode[e] = episode[e] + 1;
       elapsed[e] = 0;
     }
-    if (m || (obs && !obs_masked_only && (Md.task == 1 || Md.task == 2))) {   // observation[0] needs the pose
+    if (m || (obs && !obs_masked_only && (Md.task == 1 || Md.task == 2 || Md.task == 10 || Md.task == 11))) {   // these observations need the pose
       sp_kinematics<Real>(Md, S);
-      if (Md.task == 4) init_h[e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
+      if (Md.task == 4) tstate[4 * e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
     }
   }
   __syncthreads();
   if (m && lane < n) { qs[e * n + lane] = S.q[lane]; dqs[e * n + lane] = S.dq[lane]; }
+  if ((Md.task == 10 || Md.task == 11) && lane < 3) S.misc[4 + lane] = tstate[4 * e + lane];
+  __syncthreads();
   if (obs && (m || !obs_masked_only)) sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
 }
 

@@ -7,3 +7,4 @@ from .cart_pole import DartCartPoleEnv  # noqa: F401
 from .half_cheetah import DartHalfCheetahEnv  # noqa: F401
 from .cartpole_swingup import DartCartPoleSwingUpEnv, DartDoubleInvertedPendulumEnv  # noqa: F401
 from .snake_7link import DartSnake7LinkEnv  # noqa: F401
+from .reacher import DartReacher2dEnv, DartReacherEnv  # noqa: F401

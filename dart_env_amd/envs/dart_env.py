@@ -20,8 +20,8 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from .. import seeding, spaces
-from ..model_card import (DartModelCard, HOST_RESET_TASKS, TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASKS,
-                          card_for)
+from ..model_card import (DartModelCard, HOST_RESET_TASKS, TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D,
+                          TASK_REACHER3D, TASK_STATE_TASKS, TASKS, card_for)
 from .. import stepper as _st
 
 
@@ -102,6 +102,7 @@ class BatchedDartEnv:
         self.robot_skeleton = SkeletonView(self)
         self._rngs = [None] * self.num_envs
         self._seeds = [None] * self.num_envs
+        self._task_state = np.zeros((self.num_envs, 4))   # per-env state reset_model draws besides (q, dq): reach targets
         self.seed(None)
 
     # ---- reference API -------------------------------------------------------------------------------------
@@ -158,6 +159,20 @@ class BatchedDartEnv:
                 vn[i] = rng.uniform(low=-rv, high=rv, size=self.ndofs)   # qvel second (hopper.py:79, human_walker.py:154)
             if kind == TASK_CARTPOLE_SWINGUP:                      # cartpole_swingup.py:41-44: the pole starts hanging
                 qn[i, 1] += np.pi if rng.uniform(low=0, high=1, size=1) > 0.5 else -np.pi
+            if kind == TASK_REACHER2D:                             # reacher2d.py:53-57: target in the disc of radius 0.2
+                while True:
+                    tgt = rng.uniform(low=-.2, high=.2, size=3)
+                    tgt[1] = 0.0
+                    if np.linalg.norm(tgt) < .2:
+                        break
+                tgt[1] = 0.01
+                self._task_state[i, :3] = tgt
+            if kind == TASK_REACHER3D:                             # reacher.py:50-52: target in the ball of radius 1.5
+                while True:
+                    tgt = rng.uniform(low=-1, high=1, size=3)
+                    if np.linalg.norm(tgt) < 1.5:
+                        break
+                self._task_state[i, :3] = tgt
         return qn, vn
 
     def reset(self, mask=None):
@@ -166,6 +181,8 @@ class BatchedDartEnv:
         if self.device_noise:
             return self._stepper.reset(m, None, None)
         qn, vn = self._draw_noise(m)
+        if self.task.task in TASK_STATE_TASKS:      # the new targets must be on the device before the reset observation
+            self._stepper.set_task_state(m, self._task_state)
         return self._stepper.reset(m, qn, vn)
 
     def step(self, actions):

@@ -25,7 +25,7 @@ MAX_ACTIONS = 32
 CARD_VERSION = 1
 
 TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER, TASK_CARTPOLE, TASK_HALFCHEETAH = 0, 1, 2, 3, 4, 5, 6
-TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_SNAKE = 7, 8, 9
+TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_SNAKE, TASK_REACHER2D, TASK_REACHER3D = 7, 8, 9, 10, 11
 
 
 class DartModelCard(C.Structure):
@@ -58,6 +58,7 @@ class DartModelCard(C.Structure):
         ("reset_noise", C.c_double), ("reset_noise_vel", C.c_double),
         ("aux_body", C.c_int32 * 4), ("aux_real", C.c_double * 8), ("aux_real2", C.c_double * 4),
         ("contact_cfm", C.c_double), ("self_collision", C.c_int32), ("generic_kernel", C.c_int32),
+        ("joint_friction", C.c_double * MAX_DOFS),
     ]
 
 
@@ -181,10 +182,28 @@ SNAKE = TaskSpec(
     height_lo=-np.inf, height_hi=np.inf, angle_max=1.5, obs_vel_clip=np.inf, all_bodies_collide=True,
     aux_real=[0.1, 1e-3, 0.1, 50.0])
 
+# DartReacher-v1 -- reference gym/envs/dart/reacher2d.py:5-66 (2-dof arm about y, dt 0.01 x frame_skip 2, scale 200,
+# nothing collides (:11-14), target resampled in reset_model by rejection (:53-57)), gym/envs/__init__.py:233-238 (50 steps)
+REACHER2D = TaskSpec(
+    env_id="DartReacher-v1", model="reacher2d", task=TASK_REACHER2D, frame_skip=2, act_dim=2, obs_dim=11, act_dof0=0,
+    act_scale=[200.0, 200.0], max_episode_steps=50, reward_threshold=-3.75, height_body=0, penalty_dof=-1,
+    height_lo=-np.inf, height_hi=np.inf, angle_max=np.inf, state_abs_max=np.inf, obs_vel_clip=np.inf, reset_noise=0.01,
+    reset_noise_vel=0.005, physics_dt=0.01, contact_bodies=[], aux_body_names=["link2"], aux_real=[0.0, 0.0, 0.0, 1.0, 0.0])
+
+# DartReacher3d-v1 -- reference gym/envs/dart/reacher.py:5-61 (5-dof arm, dt 0.002 x 4, scale 10, fingertip (0,-0.25,0) on
+# bodynodes[2], reward and done use the distance BEFORE the step (:23-35)), gym/envs/__init__.py:240-245 (500 steps)
+REACHER3D = TaskSpec(
+    env_id="DartReacher3d-v1", model="reacher3d", task=TASK_REACHER3D, frame_skip=4, act_dim=5, obs_dim=21, act_dof0=0,
+    act_scale=[10.0] * 5, max_episode_steps=500, reward_threshold=-200.0, height_body=0, penalty_dof=-1,
+    height_lo=-np.inf, height_hi=np.inf, angle_max=np.inf, state_abs_max=np.inf, obs_vel_clip=np.inf, reset_noise=0.01,
+    reset_noise_vel=0.01, contact_bodies=[], aux_body_names=["link 3"], aux_real=[0.0, -0.25, 0.0, 0.001, 0.1])
+
 TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH, CARTPOLE_SWINGUP,
-                               DOUBLE_PENDULUM, SNAKE)}
+                               DOUBLE_PENDULUM, SNAKE, REACHER2D, REACHER3D)}
 # tasks whose reset_model draws more than the two uniform vectors: the host draws them (see envs/dart_env.py)
-HOST_RESET_TASKS = (TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM)
+HOST_RESET_TASKS = (TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D, TASK_REACHER3D)
+# tasks with per-env state beyond (q, dq) that reset_model draws (the reach target): dart_set_task_state
+TASK_STATE_TASKS = (TASK_REACHER2D, TASK_REACHER3D)
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 
@@ -226,6 +245,7 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         c.limited[i] = int(model.limited[i])
         c.damping[i], c.stiffness[i], c.rest[i] = model.damping[i], model.stiffness[i], model.rest[i]
         c.init_pos[i], c.init_vel[i] = model.init_pos[i], model.init_vel[i]
+        c.joint_friction[i] = 0.0 if model.joint_friction is None else float(model.joint_friction[i])
     c.contact_cfm = model.cfm
     c.nshapes = len(model.shapes)
     for i, s in enumerate(model.shapes):

@@ -159,6 +159,7 @@ class ModelCard:
     cfm: float = 1e-9
     limit_erp: float = 0.0      # DART 6 joint-limit rows carry no position correction (allowance 0)
     dof_names: List[str] = field(default_factory=list)
+    joint_friction: Optional[np.ndarray] = None   # Coulomb friction per dof (<dynamics><friction>); None = all zero
 
     @property
     def ndofs(self) -> int:
@@ -185,6 +186,7 @@ class ModelCard:
             limited=[bool(x) for x in self.limited], damping=arr(self.damping),
             stiffness=arr(self.stiffness), rest=arr(self.rest), init_pos=arr(self.init_pos),
             init_vel=arr(self.init_vel),
+            joint_friction=arr(self.joint_friction if self.joint_friction is not None else np.zeros(self.ndofs)),
             bodies=[dict(name=b.name, parent=b.parent, jname=b.jname, jtype=b.jtype,
                          dof_offset=b.dof_offset, ndof=b.ndof, mass=b.mass, com=arr(b.com),
                          inertia=arr(b.inertia), T_pj=arr(b.T_pj), T_cj=arr(b.T_cj), axes=arr(b.axes))
@@ -211,7 +213,8 @@ class ModelCard:
             limited=np.asarray(d["limited"], dtype=bool), damping=f(d["damping"]),
             stiffness=f(d["stiffness"]), rest=f(d["rest"]), init_pos=f(d["init_pos"]),
             init_vel=f(d["init_vel"]), ground_y=d["ground_y"], friction=d["friction"], erp=d["erp"],
-            max_erv=d["max_erv"], cfm=d["cfm"], limit_erp=d["limit_erp"], dof_names=d["dof_names"])
+            max_erv=d["max_erv"], cfm=d["cfm"], limit_erp=d["limit_erp"], dof_names=d["dof_names"],
+            joint_friction=f(d["joint_friction"]) if "joint_friction" in d else None)
 
 
 # ----------------------------------------------------------------------------
@@ -370,6 +373,7 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
     bodies: List[Body] = []
     shapes: List[Shape] = []
     lower, upper, limited, damping, stiff, rest, ipos, ivel, dof_names = [], [], [], [], [], [], [], [], []
+    jfric = []
     dof_off = 0
     for i, j in enumerate(order):
         cname = j.find("child").text.strip()
@@ -397,6 +401,7 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
         jd = [0.0] * ndof
         jk = [0.0] * ndof
         jr = [0.0] * ndof
+        jf = [0.0] * ndof
         for k in range(min(ndof, 3)):
             a = j.find(ax_tags[k])
             if a is None:
@@ -418,6 +423,8 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
                     jk[k] = float(dyn.find("spring_stiffness").text)
                 if dyn.find("spring_rest_position") is not None:
                     jr[k] = float(dyn.find("spring_rest_position").text)
+                if dyn.find("friction") is not None:
+                    jf[k] = float(dyn.find("friction").text)
         if jtype in (JT_EULER_XYZ, JT_EULER_ZYX, JT_TRANSLATIONAL):
             axes = np.eye(3)
         ip = _floats(j.find("init_pos").text) if j.find("init_pos") is not None and j.find("init_pos").text else []
@@ -461,7 +468,7 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
         for k in range(ndof):
             lower.append(jl[k]); upper.append(ju[k])
             limited.append(bool(np.isfinite(jl[k]) or np.isfinite(ju[k])))
-            damping.append(jd[k]); stiff.append(jk[k]); rest.append(jr[k])
+            damping.append(jd[k]); stiff.append(jk[k]); rest.append(jr[k]); jfric.append(jf[k])
             ipos.append(ip[k]); ivel.append(iv[k])
             dof_names.append(j.get("name") if ndof == 1 else "%s_%d" % (j.get("name"), k))
         dof_off += ndof
@@ -473,4 +480,4 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
                      bodies=bodies, shapes=shapes, lower=f(lower), upper=f(upper),
                      limited=np.asarray(limited, dtype=bool), damping=f(damping), stiffness=f(stiff),
                      rest=f(rest), init_pos=f(ipos), init_vel=f(ivel), ground_y=float(ground_y),
-                     dof_names=dof_names)
+                     dof_names=dof_names, joint_friction=f(jfric))

@@ -28,7 +28,7 @@ SOLVER_BPP, SOLVER_PGS = 0, 1
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state",
 ]
 
 
@@ -78,6 +78,7 @@ def load_library(path: Optional[str] = None):
     L.dart_seed_mt19937.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     L.dart_get_dynamics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dart_set_ext_force.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.dart_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
     L.dart_get_episode_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]
     L.dart_debug_dump.argtypes = [vp, dp]
     L.dart_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
@@ -146,6 +147,14 @@ class HipStepper:
         k = np.ascontiguousarray(keys, dtype=np.uint32).reshape(self.num_envs, 2)
         n = np.ascontiguousarray(key_len, dtype=np.int32).reshape(self.num_envs)
         self._check(self.L.dart_seed_mt19937(self.h, _ptr(k, C.c_uint32), _ptr(n, C.c_int32)))
+
+    def set_task_state(self, mask, values):
+        """(N, <=4) per-env task state (reach target) for the masked envs; call before reset()."""
+        v = np.zeros((self.num_envs, 4), dtype=np.float64)
+        vv = np.asarray(values, dtype=np.float64).reshape(self.num_envs, -1)
+        v[:, :vv.shape[1]] = vv
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self.L.dart_set_task_state(self.h, _ptr(m, C.c_uint8) if m is not None else None, _ptr(v, C.c_double)))
 
     def set_ext_force(self, body, force):
         """(N, 3) world-frame forces on body `body` in every substep from now on (None = off); generic kernel only."""

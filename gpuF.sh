@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_spatial.py -m gpu -q -x -k "classic or external" 2>&1 | tail -5
-python bench.py --env-id DartSnake7Link-v1 --steps 60 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+python -m pytest tests/test_gpu_spatial.py -m gpu -q -x -k "reacher" 2>&1 | tail -8

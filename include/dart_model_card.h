@@ -57,6 +57,12 @@ enum {
                                  force -aux_real[3] (v_com . n) n at its frame origin, n = the body's z axis (:37-47); reward
                                  dx/dt + aux_real[0] - aux_real[1] sum a^2 - aux_real[2] |q[2]|, done |q[2]| >= angle_max or a
                                  broken state, obs q[1:], dq */
+  DART_TASK_REACHER2D = 10,  /* reference gym/envs/dart/reacher2d.py:18-45 (DartReacher-v1): per-env target (task state
+                                 [0..2]); tip = to_world(aux_body[0], aux_real[0..2]); reward -|tip - target| - sum a^2 after
+                                 the step, never done; obs cos q, sin q, target x z, dq, tip - target */
+  DART_TASK_REACHER3D = 11,  /* reference gym/envs/dart/reacher.py:13-45 (DartReacher3d-v1): reward -|tip - target| -
+                                 aux_real[3] sum tau^2 with the tip BEFORE the step, done when that distance <= aux_real[4]
+                                 or the state is not finite; obs cos q, sin q, target, dq, tip - target (after) */
   DART_TASK_DOUBLE_PENDULUM = 8 /* reference gym/envs/dart/inverted_double_pendulum.py:19-53: obs [q0, sin q1..2, cos q1..2,
                                  dq], height = 2 (y(aux_body[1]) - y(aux_body[0]) - aux_real[4]) / aux_real[5], reward
                                  aux_real[0] - (aux_real[1] q0^2 + (height - 2)^2) - (aux_real[2] dq1^2 + aux_real[3] dq2^2),
@@ -153,6 +159,10 @@ typedef struct DartModelCard {
   /* 1: always use the generic tree kernel, even if a faster specialised kernel matches the model (needed for features
    * only the generic kernel has: external body forces, link-link contacts, contacts on every shape). */
   int32_t generic_kernel;
+  /* Coulomb friction of each dof (<dynamics><friction> in the .skel; only reacher2d.skel has non-zero values): DART's
+   * JointCoulombFrictionConstraint -- an LCP row that drives the joint velocity to zero with an impulse bounded by
+   * +-joint_friction * dt. */
+  double joint_friction[DART_MAX_DOFS];
 } DartModelCard;
 
 #ifdef __cplusplus

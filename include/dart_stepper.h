@@ -126,6 +126,11 @@ int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear);
  * of the last LCP solved. */
 int dart_debug_dump(DartStepper* h, double* out160);
 
+/* Per-env task state that reset_model draws besides (q, dq): the reach target of DartReacher-v1 / DartReacher3d-v1
+ * (reference gym/envs/dart/reacher2d.py:53-59, reacher.py:50-55).  values = (N, 4) doubles, slots 0..2 = target x, y, z;
+ * mask as in dart_reset.  Call it before dart_reset so that the reset observation sees the new target. */
+int dart_set_task_state(DartStepper* h, const uint8_t* mask, const double* values);
+
 /* External body force: `bodynodes[body].add_ext_force(F)` before every world step, the perturbation branch of
  * DartEnv.do_simulation (reference gym/envs/dart/dart_env.py:159-172).  force = (N, 3) world-frame vectors, applied at the
  * body frame origin (pydart2's default offset) in every substep until replaced; NULL switches it off.  Only the generic

@@ -90,6 +90,7 @@ typedef struct OracleWorld {
   double lcp_residual_last;
   double A_last[MAXM * MAXM], b_last[MAXM]; /* debug copies of the last LCP */
   double init_height; /* human_walker.py:163 head COM height right after reset_model's set_state */
+  double task_state[4]; /* per-env task state beyond (q, dq): the reach target of the reacher envs */
   int ext_all;        /* 1: ext_fb holds one world-frame force per body (snake fluid model), applied at the body origins */
   double ext_fb[DART_MAX_BODIES][3];
   int ext_body;       /* -1: none.  bodynodes[ext_body].add_ext_force(ext_f) before every world step (dart_env.py:170-172) */
@@ -313,6 +314,8 @@ void oracle_get_state(const OracleWorld* w, double* q, double* dq) {
   memcpy(q, w->q, w->n * sizeof(double)); memcpy(dq, w->dq, w->n * sizeof(double));
 }
 void oracle_set_forces(OracleWorld* w, const double* tau) { memcpy(w->tau, tau, w->n * sizeof(double)); }
+void oracle_set_task_state(OracleWorld* w, const double* v4) { memcpy(w->task_state, v4, sizeof w->task_state); }
+void oracle_get_task_state(const OracleWorld* w, double* v4) { memcpy(v4, w->task_state, sizeof w->task_state); }
 void oracle_set_ext_force(OracleWorld* w, int body, const double* f3) {
   w->ext_body = (f3 && body >= 0 && body < w->card.nbodies) ? body : -1;
   if (w->ext_body >= 0) memcpy(w->ext_f, f3, sizeof w->ext_f);
@@ -873,6 +876,16 @@ int oracle_step(OracleWorld* w) {
     findex[m] = -1;
     m++;
   }
+  /* DART JointCoulombFrictionConstraint: drive the joint velocity to zero with an impulse within +-friction * dt */
+  for (int i = 0; i < n; i++) {
+    if (!(c->joint_friction[i] != 0.0)) continue;
+    memset(J[m], 0, sizeof J[m]);
+    J[m][i] = 1.0;
+    b[m] = -vs[i];
+    lo[m] = -c->joint_friction[i] * dt; hi[m] = c->joint_friction[i] * dt;
+    findex[m] = -1;
+    m++;
+  }
   w->m_last = m;
   w->lcp_residual_last = 0;
   if (m > 0) {
@@ -1263,8 +1276,58 @@ static int snake_step(OracleWorld* w, const double* a, double* obs, double* rewa
   return !(ok && fabs(w->q[2]) < c->angle_max);
 }
 
+/* DartReacherEnv (reacher.py:13-45, DartReacher3d-v1) and DartReacher2dEnv (reacher2d.py:18-45, DartReacher-v1).
+ * tip = to_world(aux_body[0], aux_real[0..2]); target = task_state[0..2]. */
+static void reacher_tip(OracleWorld* w, double* tip) {
+  const DartModelCard* c = &w->card;
+  kinematics(w);
+  const double* T = w->W[w->body_link[c->aux_body[0]]];
+  for (int a = 0; a < 3; a++) tip[a] = T[4 * a] * c->aux_real[0] + T[4 * a + 1] * c->aux_real[1] + T[4 * a + 2] * c->aux_real[2] + T[4 * a + 3];
+}
+static void reacher_obs(OracleWorld* w, double* obs) {
+  const DartModelCard* c = &w->card;
+  int n = w->n, o = 0;
+  double tip[3];
+  reacher_tip(w, tip);
+  for (int i = 0; i < n; i++) obs[o++] = cos(w->q[i]);
+  for (int i = 0; i < n; i++) obs[o++] = sin(w->q[i]);
+  if (c->task == DART_TASK_REACHER2D) { obs[o++] = w->task_state[0]; obs[o++] = w->task_state[2]; }
+  else for (int a = 0; a < 3; a++) obs[o++] = w->task_state[a];
+  for (int i = 0; i < n; i++) obs[o++] = w->dq[i];
+  for (int a = 0; a < 3; a++) obs[o++] = tip[a] - w->task_state[a];
+}
+static int reacher_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double tau[MAXN] = {0}, sq_a = 0, sq_tau = 0, tip[3], vec[3];
+  for (int k = 0; k < c->act_dim; k++) {
+    double cl = a[k];
+    if (cl > c->act_high[k]) cl = c->act_high[k];
+    if (cl < c->act_low[k]) cl = c->act_low[k];
+    tau[c->act_dof0 + k] = cl * c->act_scale[k];
+    sq_a += a[k] * a[k]; sq_tau += tau[c->act_dof0 + k] * tau[c->act_dof0 + k];
+  }
+  reacher_tip(w, tip);
+  for (int x = 0; x < 3; x++) vec[x] = tip[x] - w->task_state[x];
+  double dist_before = sqrt(dot3(vec, vec));
+  for (int f = 0; f < c->frame_skip; f++) { oracle_set_forces(w, tau); oracle_step(w); }
+  reacher_obs(w, obs);
+  if (c->task == DART_TASK_REACHER3D) {
+    double reward_dist = -dist_before, reward_ctrl = -sq_tau * c->aux_real[3];
+    *reward = reward_dist + reward_ctrl + 0;
+    int fin = 1;
+    for (int i = 0; i < n; i++) if (!isfinite(w->q[i]) || !isfinite(w->dq[i])) fin = 0;
+    return !(fin && (-reward_dist > c->aux_real[4]));
+  }
+  reacher_tip(w, tip);
+  for (int x = 0; x < 3; x++) vec[x] = tip[x] - w->task_state[x];
+  *reward = -sqrt(dot3(vec, vec)) + -sq_a;
+  return 0;
+}
+
 int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
   const DartModelCard* c = &w->card;
+  if (c->task == DART_TASK_REACHER2D || c->task == DART_TASK_REACHER3D) return reacher_step(w, a, obs, reward);
   if (c->task == DART_TASK_SNAKE) return snake_step(w, a, obs, reward);
   if (c->task == DART_TASK_CARTPOLE_SWINGUP) return swingup_step(w, a, obs, reward);
   if (c->task == DART_TASK_DOUBLE_PENDULUM) return double_pendulum_step(w, a, obs, reward);
@@ -1326,6 +1389,7 @@ void oracle_env_obs(OracleWorld* w, double* obs) {
   if (c->task == DART_TASK_WALKER3D) { walker3d_obs(w, obs); return; }
   if (c->task == DART_TASK_CARTPOLE || c->task == DART_TASK_CARTPOLE_SWINGUP) { qdq_obs(w, 0, obs); return; }
   if (c->task == DART_TASK_DOUBLE_PENDULUM) { double_pendulum_obs(w, obs); return; }
+  if (c->task == DART_TASK_REACHER2D || c->task == DART_TASK_REACHER3D) { reacher_obs(w, obs); return; }
   if (c->task == DART_TASK_HALFCHEETAH || c->task == DART_TASK_SNAKE) { qdq_obs(w, 1, obs); return; }
   int n = w->n;
   double cm[3];

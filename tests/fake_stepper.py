@@ -42,6 +42,11 @@ class OracleStepper:
         self.batch.reset(m, qn, vn)
         return self.batch.obs().astype(np.float32) if want_obs else None
 
+    def set_task_state(self, mask, values):
+        m = np.ones(self.num_envs, dtype=bool) if mask is None else np.asarray(mask).astype(bool)
+        for i in np.flatnonzero(m):
+            self.batch.worlds[i].set_task_state(np.asarray(values)[i])
+
     def set_state(self, q, dq):
         for i, w in enumerate(self.batch.worlds):
             w.set_state(q[i], dq[i])

@@ -115,6 +115,9 @@ class StubBody:
     def add_ext_force(self, f):
         self.world.oracle.add_body_force(self.index, np.asarray(f, dtype=np.float64))
 
+    def set_collidable(self, flag):
+        pass   # reacher2d.py:13-14: the card for that env marks no shape collidable
+
     def set_friction_coeff(self, mu):
         pass   # snake_7link.py:29-31: the snake never touches the floor (no vertical dof, 1 mm clearance)
 
@@ -179,7 +182,8 @@ class StubWorld:
         contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"],
                    "kima_human_edited.skel": None, "walker3d_waist.skel": None,
                    "cartpole.skel": None, "half_cheetah.skel": None, "cartpole_swingup.skel": None,
-                   "inverted_double_pendulum.skel": None, "snake_7link.skel": None}[name]   # None: every collision shape
+                   "inverted_double_pendulum.skel": None, "snake_7link.skel": None, "reacher2d.skel": [],
+                   "reacher.skel": []}[name]   # None: every collision shape
         model = parse_skel(skel_path, dt=dt, collidable_bodies=contact)
         self.model = model
         self.dt = dt
@@ -190,19 +194,22 @@ class StubWorld:
                 "cartpole.skel": "DartCartPole-v1", "half_cheetah.skel": "DartHalfCheetah-v1",
                 "cartpole_swingup.skel": "DartCartPoleSwingUp-v1",
                 "inverted_double_pendulum.skel": "DartDoubleInvertedPendulumEnv-v1",
-                "snake_7link.skel": "DartSnake7Link-v1"}[name]
+                "snake_7link.skel": "DartSnake7Link-v1", "reacher2d.skel": "DartReacher-v1",
+                "reacher.skel": "DartReacher3d-v1"}[name]
         if TASKS[spec].contact_cfm is not None:   # same contact regularisation as the shipped task card
             card.contact_cfm = TASKS[spec].contact_cfm
         card.self_collision = int(TASKS[spec].self_collision)   # what the env's set_self_collision_check() call will ask for
         self.oracle = OracleWorld(card)
-        self.skeletons = [Anything(), StubSkeleton(self, model)]
+        # ground (and target) skeletons are permissive dummies; the robot is the last one (dart_env.py:62)
+        n_other = {"reacher2d.skel": 2}.get(name, 1)
+        self.skeletons = [Anything() for _ in range(n_other)] + [StubSkeleton(self, model)]
         self.collision_result = StubCollisionResult()
 
     def step(self):
         StubWorld.n_steps += 1
         self.oracle.step()
         # pydart2 refreshes collision_result after every world step
-        robot = self.skeletons[1]
+        robot = self.skeletons[-1]
         self.collision_result.contacts = [
             StubContact(self.skeletons[0], robot.bodynodes[int(c[0])], np.array([c[6], c[5], c[7]]) / self.dt)
             for c in self.oracle.last_contacts()]
@@ -339,6 +346,12 @@ def main():
     # (10) DartSnake7Link-v1: the reference's own fluid-force loop (com_spatial_velocity / add_ext_force per body and substep)
     np.savez_compressed(os.path.join(out, "snake_single_seed0.npz"), **rollout_single(gym, "DartSnake7Link-v1", 0, 300))
     np.savez_compressed(os.path.join(out, "snake_vector4_seed3.npz"), **rollout_vector(gym, "DartSnake7Link-v1", 4, 3, 120))
+    # (12) DartReacher-v1 (2-D): Coulomb joint friction rows, target in the x-z disc, never done (TimeLimit 50)
+    np.savez_compressed(os.path.join(out, "reacher2d_single_seed0.npz"), **rollout_single(gym, "DartReacher-v1", 0, 260))
+    np.savez_compressed(os.path.join(out, "reacher2d_vector4_seed3.npz"), **rollout_vector(gym, "DartReacher-v1", 4, 3, 120))
+    # (11) DartReacher3d-v1 (target resampled by rejection, reward / done from the pre-step fingertip distance)
+    np.savez_compressed(os.path.join(out, "reacher3d_single_seed0.npz"), **rollout_single(gym, "DartReacher3d-v1", 0, 700))
+    np.savez_compressed(os.path.join(out, "reacher3d_vector4_seed3.npz"), **rollout_vector(gym, "DartReacher3d-v1", 4, 3, 120))
     print("world.step() calls issued by the reference code:", StubWorld.n_steps)
 
 

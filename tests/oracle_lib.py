@@ -57,6 +57,7 @@ def lib():
         L.oracle_last_Ab.argtypes = [C.c_void_p, dp, dp]
         L.oracle_last_Ab.restype = C.c_int
         L.oracle_set_ext_force.argtypes = [C.c_void_p, C.c_int, dp]
+        L.oracle_set_task_state.argtypes = [C.c_void_p, dp]
         L.oracle_add_body_force.argtypes = [C.c_void_p, C.c_int, dp]
         L.oracle_body_com_spatial_velocity.argtypes = [C.c_void_p, C.c_int, dp]
         L.oracle_box_box.argtypes = [dp, dp, dp, dp, dp, dp, dp, dp]
@@ -116,6 +117,10 @@ class OracleWorld:
     def set_forces(self, tau):
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         self.L.oracle_set_forces(self.h, _p(tau))
+
+    def set_task_state(self, v4):
+        v = np.zeros(4); v[:len(v4)] = v4
+        self.L.oracle_set_task_state(self.h, _p(v))
 
     def add_body_force(self, body, f3):
         """bodynode.add_ext_force(f3): world-frame force at the body origin for the next world step only."""

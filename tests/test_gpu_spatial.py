@@ -270,7 +270,8 @@ def test_classic_env_fp64_matches_oracle(env_id, noise):
 @pytest.mark.parametrize("tag,env_id", [("cartpole", "DartCartPole-v1"), ("halfcheetah", "DartHalfCheetah-v1"),
                                         ("swingup", "DartCartPoleSwingUp-v1"),
                                         ("doublependulum", "DartDoubleInvertedPendulumEnv-v1"),
-                                        ("snake", "DartSnake7Link-v1")])
+                                        ("snake", "DartSnake7Link-v1"), ("reacher3d", "DartReacher3d-v1"),
+                                        ("reacher2d", "DartReacher-v1")])
 def test_classic_env_vector_fixture_and_fp32(tag, env_id):
     """Reference SyncVectorEnv fixture through the default (device MT19937) vector env in fp64; fp32 stays close."""
     import dart_env_amd
@@ -459,3 +460,70 @@ def test_external_body_force_matches_oracle(env_id, body):
         with pytest.raises(StepperError):
             fast.set_ext_force(body, F)
         fast.close()
+
+
+def test_reacher3d_env_fp64_matches_oracle_with_targets():
+    """Per-env reach targets (dart_set_task_state) enter reward, done and observation on the device exactly as in the
+    oracle; masked updates leave the other envs' targets alone."""
+    from dart_env_amd.stepper import HipStepper
+    card = card_for("DartReacher3d-v1")
+    n, nd, na = 64, card.ndofs, card.act_dim
+    rng = np.random.RandomState(12)
+    gpu = HipStepper(card, n, precision=64)
+    ora = OracleBatch(card, n)
+    tg = rng.uniform(-1, 1, (n, 3))
+    qn = rng.uniform(-.01, .01, (n, nd)); vn = rng.uniform(-.01, .01, (n, nd))
+    ora.reset(None, qn, vn)
+    tip = ora.obs()[:, -3:]                     # targets are still zero: the last three entries are the fingertip itself
+    tg[:8] = tip[:8] + [0.03, 0.0, 0.04]        # within 0.1 of the fingertip: those envs finish on the first step
+    gpu.set_task_state(None, tg)
+    for i, w in enumerate(ora.worlds):
+        w.set_task_state(tg[i])
+    og = gpu.reset(None, qn, vn); ora.reset(None, qn, vn)
+    assert og.shape == (n, 21) and np.allclose(og, ora.obs(), atol=1e-6)
+    n_done = 0
+    for t in range(60):
+        a = rng.uniform(-1.3, 1.3, (n, na)).astype(np.float32)
+        og, rg, dg, tgl = gpu.step(a)
+        oo, ro, do, to = ora.step(a)
+        assert np.array_equal(dg, do), t
+        assert np.allclose(og, oo, atol=2e-5) and np.allclose(rg, ro, atol=1e-4)
+        n_done += int(do.sum())
+        if do.any():                           # new targets for the finished envs only
+            tg2 = rng.uniform(-1, 1, (n, 3))
+            gpu.set_task_state(do.astype(np.uint8), tg2)
+            for i in np.flatnonzero(do):
+                ora.worlds[i].set_task_state(tg2[i])
+            qn = rng.uniform(-.01, .01, (n, nd)); vn = rng.uniform(-.01, .01, (n, nd))
+            gpu.reset(do.astype(np.uint8), qn, vn, want_obs=False); ora.reset(do, qn, vn)
+    assert n_done >= 8
+    gpu.close()
+
+
+def test_reacher2d_joint_coulomb_friction_matches_oracle():
+    """reacher2d.skel is the one asset with <friction> on its joints: DART's JointCoulombFrictionConstraint rows (impulse
+    within +-0.05 dt) in the device LCP = oracle, and a small torque below the friction level does not move the arm."""
+    from dart_env_amd.stepper import HipStepper
+    card = card_for("DartReacher-v1")
+    n, nd = 64, card.ndofs
+    rng = np.random.RandomState(4)
+    gpu = HipStepper(card, n, precision=64)
+    ora = OracleBatch(card, n)
+    tg = np.zeros((n, 3)); tg[:, 0] = 0.1; tg[:, 1] = 0.01
+    gpu.set_task_state(None, tg)
+    for i, w in enumerate(ora.worlds):
+        w.set_task_state(tg[i])
+    qn = rng.uniform(-.01, .01, (n, nd)); vn = np.zeros((n, nd)); vn[n // 2:] = rng.uniform(-.005, .005, (n // 2, nd))
+    gpu.reset(None, qn, vn, want_obs=False); ora.reset(None, qn, vn)
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        a[: n // 2] = 0.0002 * np.sign(a[: n // 2])          # 0.04 Nm < 0.05 Nm of Coulomb friction: the arm stays put
+        og, rg, dg, _ = gpu.step(a)
+        oo, ro, do, _ = ora.step(a)
+        qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+        assert np.abs(qg - qo).max() < 1e-8 and np.abs(dqg - dqo).max() < 1e-6, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        assert np.allclose(og, oo, atol=2e-5) and np.allclose(rg, ro, atol=1e-5) and not dg.any()
+    q, dq = gpu.get_state()
+    assert np.abs(dq[: n // 2]).max() < 1e-9 and np.abs(q[: n // 2] - qn[: n // 2]).max() < 1e-9   # stuck by friction
+    assert np.abs(dq[n // 2:]).max() > 0.1
+    gpu.close()

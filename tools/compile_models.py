@@ -22,8 +22,10 @@ ASSETS = {
     "cartpole_swingup": "cartpole_swingup.skel",        # cartpole_swingup.py:11 (dt 0.01)
     "double_pendulum": "inverted_double_pendulum.skel",  # inverted_double_pendulum.py:14 (dt 0.01)
     "snake7link": "snake_7link.skel",                    # snake_7link.py:18
+    "reacher2d": "reacher2d.skel",                       # reacher2d.py:10 (dt 0.01)
+    "reacher3d": "reacher.skel",                         # reacher.py:10
 }
-DT = {"cartpole": 0.02, "halfcheetah": 0.01, "cartpole_swingup": 0.01, "double_pendulum": 0.01}
+DT = {"reacher2d": 0.01, "cartpole": 0.02, "halfcheetah": 0.01, "cartpole_swingup": 0.01, "double_pendulum": 0.01}
 
 
 def main():

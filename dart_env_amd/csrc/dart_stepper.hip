@@ -409,7 +409,12 @@ struct SpatialImplT : Impl {
     if ((e = hipMalloc((void**)&init_h, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
     if ((e = hipMemset(init_h, 0, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
     lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp);
-    if ((e = hipFuncSetAttribute((const void*)sp_step_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    // lean / pairs / extras instantiations of the step kernel (see sp_world_step)
+    pairs = M.npairs > 0;
+    const void* fns[4] = {(const void*)sp_step_kernel<Real, false, false>, (const void*)sp_step_kernel<Real, true, false>,
+                          (const void*)sp_step_kernel<Real, false, true>, (const void*)sp_step_kernel<Real, true, true>};
+    for (const void* fn : fns)
+      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     return hipSuccess;
   }
@@ -420,8 +425,12 @@ struct SpatialImplT : Impl {
   void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
                   float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
-    hipLaunchKernelGGL((sp_step_kernel<Real>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep,
-                       act, obs, rew, done, trunc, autoreset, seed, off);
+#define SP_LAUNCH(P, X)                                                                                                 \
+  hipLaunchKernelGGL((sp_step_kernel<Real, P, X>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep, \
+                     act, obs, rew, done, trunc, autoreset, seed, off)
+    if (pairs) { if (extras) SP_LAUNCH(true, true); else SP_LAUNCH(true, false); }
+    else { if (extras) SP_LAUNCH(false, true); else SP_LAUNCH(false, false); }
+#undef SP_LAUNCH
     return hipGetLastError();
   }
   hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
@@ -446,12 +455,14 @@ struct SpatialImplT : Impl {
   }
   double* dbg = nullptr; int64_t nenv = 0;
   Real* d_ext = nullptr;
+  bool pairs = false, extras = false;   // which instantiation of the step kernel this model runs
   int body_link_map[DART_MAX_BODIES];
   int set_task_state(hipStream_t s, const uint8_t* d_mask, const double* d_values, int64_t n) override {
     hipLaunchKernelGGL((sp_task_state_kernel<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_mask, d_values, init_h);
     return hipGetLastError() == hipSuccess ? DART_OK : DART_E_HIP;
   }
   int set_ext_force(int body, const double* host_force, int64_t n) override {
+    if (!extras) return DART_E_UNSUPPORTED;   // the lean kernel has no external-force code: card.generic_kernel = 1
     if (!host_force) { M.ext_force = nullptr; upload(); return DART_OK; }
     if (!d_ext && hipMalloc((void**)&d_ext, sizeof(Real) * 3 * (size_t)n) != hipSuccess) return DART_E_HIP;
     std::vector<Real> tmp(3 * (size_t)n);
@@ -504,6 +515,7 @@ std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why, bool a
   {
     auto p = std::make_unique<SpatialImplT<Real>>();
     std::string w = fill_spatial<Real>(c, p->M, false, p->body_link_map);
+    p->extras = c.generic_kernel != 0 || c.task == DART_TASK_SNAKE || p->M.has_joint_friction != 0;
     if (w.empty()) return p;
     why += w;
   }

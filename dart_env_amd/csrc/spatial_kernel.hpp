@@ -263,7 +263,7 @@ template <class Real> __device__ __forceinline__ V3<Real> shfl3(V3<Real> v, int 
 //   3. angular velocity, velocity-product angular and linear accelerations are path sums of per-link terms
 //      (w_i = a_i qd_i;  t_i = om_parent x w_i;  b_i = the centripetal / Coriolis increment): three more prefix sums,
 //   4. the link's wrench and composite-body seeds about its own joint origin go to LDS.
-template <class Real>
+template <class Real, bool EXTRAS = false>
 __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane,
                                            int64_t env = 0) {
   const bool live = lane < Md.nl;
@@ -372,7 +372,7 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
     nrm = mulR(Iw, al) + cross(om, mulR(Iw, om));
   }
   V3<Real> nj = nrm + cross(dj, f);
-  if (Md.task == 9) {
+  if (EXTRAS && Md.task == 9) {
     // Snake fluid model (snake_7link.py:37-47): every body is pushed by -k (v_com . n) n at its frame origin, n = its z axis.
     // The link-origin velocity is one more path sum of per-link terms.
     V3<Real> vo = cross(omp, r) + (rev ? cross(om, sv) : cross(omp, sv) + a * qd);
@@ -391,7 +391,7 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
       nj = nj - cross(p - pj, fe);
     }
   }
-  if (Md.ext_force != nullptr && lane == Md.ext_link) {
+  if (EXTRAS && Md.ext_force != nullptr && lane == Md.ext_link) {
     // bodynode.add_ext_force(F) before every world step (dart_env.py:170-172): a world-frame force at the body frame
     // origin enters the link's wrench with the opposite sign of its inertial force
     const V3<Real> fe = ld3(Md.ext_force + env * 3);
@@ -875,14 +875,16 @@ __device__ __forceinline__ int sp_box_box(const SpatialModel<Real>& Md, SpLds<Re
     }                                                                                             \
   } while (0)
 
-template <class Real>
+// PAIRS: link-link contacts (box pairs, general contact normals); EXTRAS: snake fluid forces, external body force, Coulomb
+// joint friction rows.  Models that need neither run the lean instantiation (HumanWalker: 8 % faster than the full one).
+template <class Real, bool PAIRS, bool EXTRAS>
 __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, const LinkConst<Real>& lc, SpLds<Real>& S, int lane,
                                               int* contact_flags) {
   const int n = Md.n, nl = Md.nl;
   unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
   // tree recursions level by level: links of equal depth are independent, one lane each
   if (lane == 0) sp_root_offset<Real>(Md, S);
-  sp_forward<Real>(lc, Md, S, lane, (int64_t)blockIdx.x);   // lane i owns link i
+  sp_forward<Real, EXTRAS>(lc, Md, S, lane, (int64_t)blockIdx.x);   // lane i owns link i
   __syncthreads();
   for (int lv = Md.n_group_levels - 1; lv >= 0; lv--) {
     if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);
@@ -964,7 +966,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     const uint64_t f0 = __ballot(anyhit && slink == Md.aux_link[2]), f1 = __ballot(anyhit && slink == Md.aux_link[3]);
     if (lane == 0) { contact_flags[0] = f0 != 0ull; contact_flags[1] = f1 != 0ull; }
     // link-link contacts (walker3d.py:26): lane p tests shape pair p; the points follow the ground contacts, pair by pair
-    if (Md.npairs > 0) {
+    if (PAIRS && Md.npairs > 0) {
       const bool has_pair = lane < Md.npairs;
       Real* scratch = S.A + lane * 40;          // A / Lw are idle in this phase: 40 Reals of clipping workspace per lane
       int k = 0, la = 0, lb = 0;
@@ -999,7 +1001,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       S.hi[row] = low ? inf_<Real>() : Real(0);
     }
     m = 3 * ncp + __popcll(lm);
-    if (Md.has_joint_friction) {   // DART JointCoulombFrictionConstraint rows: joint velocity -> 0, impulse within +-mu dt
+    if (EXTRAS && Md.has_joint_friction) {   // DART JointCoulombFrictionConstraint rows: joint velocity -> 0, impulse within +-mu dt
       const bool fr = lane < n && lc.d_fric > Real(0);
       const uint64_t fm = __ballot(fr);
       const int frow = m + __popcll(fm & lt);
@@ -1026,14 +1028,19 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       } else {
         const int cidx = lane / 3, kind = lane % 3;
         // DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1
-        const V3<Real> nn = ld3(S.cpN + 3 * cidx);
-        V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
-        if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
-        t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
-        const V3<Real> dir = kind == 0 ? nn : (kind == 1 ? t1 : cross(nn, t1));
+        V3<Real> dir;
+        if (PAIRS) {
+          const V3<Real> nn = ld3(S.cpN + 3 * cidx);
+          V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
+          if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
+          t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
+          dir = kind == 0 ? nn : (kind == 1 ? t1 : cross(nn, t1));
+        } else {   // ground contacts only: n = +y, t1 = z x n = -x, t2 = n x t1 = +z
+          dir = kind == 0 ? v3<Real>(0, 1, 0) : (kind == 1 ? v3<Real>(-1, 0, 0) : v3<Real>(0, 0, 1));
+        }
         const V3<Real> P = ld3(S.cpP + 4 * cidx);
         Real rel = Real(0);
-        for (int side = 0; side < 2; side++) {   // J = J_a - J_b for a link-link contact
+        for (int side = 0; side < (PAIRS ? 2 : 1); side++) {   // J = J_a - J_b for a link-link contact
           const Real sg = side == 0 ? Real(1) : Real(-1);
           for (int j = side == 0 ? S.cplink[cidx] : S.cplinkB[cidx]; j >= 0;) {
             const int w = S.topo[j];
@@ -1141,7 +1148,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         F = (F & ~fr) | (fr & ~pf);
         U &= ~fr;
       }
-      sp_blcp<Real>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !Md.has_joint_friction);
+      sp_blcp<Real>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction));
     }
     SP_TICK(8);
     if (Md.dbg) {
@@ -1342,7 +1349,7 @@ __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds
 }
 
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
-template <class Real>
+template <class Real, bool PAIRS, bool EXTRAS>
 __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ tstate,
                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
@@ -1372,7 +1379,9 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
       cl = (cl < Md.act_lo[k]) ? Md.act_lo[k] : cl;
       S.tau[Md.act_dof0 + k] = cl * Md.act_scale[k];
     }
-    sp_kinematics<Real>(Md, S);
+    // link poses are needed before the step only by the tasks that measure progress on a body (3, 4) or a tip (11), after
+    // it only by the tasks whose reward / done / observation read a body pose
+    if (Md.task == 3 || Md.task == 4 || Md.task == 11) sp_kinematics<Real>(Md, S);
     sh_scal[0] = (Md.task == 3 || Md.task == 4) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
     if (Md.task == 11) {   // DartReacher3d: distance to the target BEFORE the step, and sum tau^2 (reacher.py:23-27)
       const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - ld3(tstate + 4 * e);
@@ -1386,11 +1395,12 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
   __syncthreads();
   LinkConst<Real> lc;
   sp_load_link_const<Real>(Md, lane < Md.nl ? lane : 0, lc);
-  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real>(Md, lc, S, lane, cflags);
+  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS>(Md, lc, S, lane, cflags);
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
+  const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task == 10 || Md.task == 11;
   if (lane == 0) {
-    sp_kinematics<Real>(Md, S);
+    if (pose_last) sp_kinematics<Real>(Md, S);
     Real rew = Real(0);
     bool task_done = false;
     if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, tstate[4 * e], cflags, rew);
@@ -1438,7 +1448,7 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
     __syncthreads();
     if (lane == 0) {
       episode[e] = ep;
-      sp_kinematics<Real>(Md, S);
+      if (pose_last) sp_kinematics<Real>(Md, S);
       if (Md.task == 4) tstate[4 * e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
       cflags[0] = 0; cflags[1] = 0;
     }

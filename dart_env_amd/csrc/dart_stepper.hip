@@ -356,7 +356,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;
   M.limit_erp_dt = (Real)(c.limit_erp / c.dt); M.cfm1 = (Real)(1.0 + c.cfm); M.ccfm1 = (Real)(1.0 + c.contact_cfm);
   if (physics_only) { M.task = 0; return ""; }   // dynamics getters: geometry, inertia and topology only
-  if (c.task < DART_TASK_NONE || c.task > DART_TASK_REACHER3D) return "task not served by the spatial kernel";
+  if (c.task < DART_TASK_NONE || c.task > DART_TASK_WALKER3D_SPD) return "task not served by the spatial kernel";
   M.task = c.task; M.frame_skip = c.frame_skip; M.act_dim = c.act_dim; M.obs_dim = c.obs_dim; M.act_dof0 = c.act_dof0;
   M.max_steps = c.max_episode_steps;
   if (c.act_dim > 32 || c.act_dof0 + c.act_dim > c.ndofs) return "action layout";
@@ -381,7 +381,16 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   }
   if (c.task == DART_TASK_CARTPOLE_SWINGUP && c.ndofs != 2) return "swing-up card";
   if (c.task == DART_TASK_CARTPOLE || c.task == DART_TASK_HALFCHEETAH) { M.aux_real[0] = (Real)c.alive_bonus; M.aux_real[1] = (Real)c.ctrl_cost; }
+  M.envdt = (Real)(c.dt * c.frame_skip);
+  for (int d = 0; d < c.ndofs; d++) { M.spd_kp[d] = (Real)c.spd_kp[d]; M.spd_kd[d] = (Real)c.spd_kd[d]; }
+  if (c.task == DART_TASK_WALKER3D_SPD) {   // same epilogue as Walker3d: reward = aux_real2[2] dx/dt + alive - ctrl sum a^2 - dev |z|
+    M.aux_link[0] = body_link[c.aux_body[0]]; M.aux_link[1] = -1; M.aux_link[2] = -1;
+    const double ar[7] = {c.alive_bonus, c.ctrl_cost, 0.0, c.aux_real[0], c.height_lo, c.height_hi, c.penalty_margin};
+    for (int k = 0; k < 7; k++) M.aux_real[k] = (Real)ar[k];
+    M.aux_real2[2] = (Real)c.aux_real[1];   // velocity-reward weight 0.45
+  }
   if (c.task == DART_TASK_WALKER3D) {
+    M.aux_real2[2] = (Real)1;
     M.aux_link[0] = body_link[c.aux_body[0]]; M.aux_link[1] = c.aux_body[1]; M.aux_link[2] = c.aux_body[2];
     if (c.aux_body[1] < 0 || c.aux_body[1] >= c.ndofs || c.aux_body[2] < 0 || c.aux_body[2] >= c.ndofs) return "penalty dof index";
     const double ar[7] = {c.alive_bonus, c.ctrl_cost, c.limit_penalty, c.aux_real[0], c.height_lo, c.height_hi, c.penalty_margin};
@@ -408,6 +417,12 @@ struct SpatialImplT : Impl {
     if ((e = hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&init_h, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
     if ((e = hipMemset(init_h, 0, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
+    if (M.task == DART_TASK_WALKER3D_SPD) {   // per-env constraint forces of the last world step, read by the SPD law
+      if ((e = hipMalloc((void**)&d_cf, sizeof(Real) * (size_t)n * M.n)) != hipSuccess) return e;
+      if ((e = hipMemset(d_cf, 0, sizeof(Real) * (size_t)n * M.n)) != hipSuccess) return e;
+      M.cf_store = d_cf;
+      if ((e = hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    }
     lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp);
     // lean / pairs / extras instantiations of the step kernel (see sp_world_step)
     pairs = M.npairs > 0;
@@ -419,8 +434,8 @@ struct SpatialImplT : Impl {
     return hipSuccess;
   }
   void release() override {
-    if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); if (d_ext) (void)hipFree(d_ext);
-    dM = nullptr; init_h = nullptr; d_ext = nullptr;
+    if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); if (d_ext) (void)hipFree(d_ext); if (d_cf) (void)hipFree(d_cf);
+    dM = nullptr; init_h = nullptr; d_ext = nullptr; d_cf = nullptr;
   }
   void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
@@ -455,6 +470,7 @@ struct SpatialImplT : Impl {
   }
   double* dbg = nullptr; int64_t nenv = 0;
   Real* d_ext = nullptr;
+  Real* d_cf = nullptr;
   bool pairs = false, extras = false;   // which instantiation of the step kernel this model runs
   int body_link_map[DART_MAX_BODIES];
   int set_task_state(hipStream_t s, const uint8_t* d_mask, const double* d_values, int64_t n) override {
@@ -515,7 +531,7 @@ std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why, bool a
   {
     auto p = std::make_unique<SpatialImplT<Real>>();
     std::string w = fill_spatial<Real>(c, p->M, false, p->body_link_map);
-    p->extras = c.generic_kernel != 0 || c.task == DART_TASK_SNAKE || p->M.has_joint_friction != 0;
+    p->extras = c.generic_kernel != 0 || c.task == DART_TASK_SNAKE || c.task == DART_TASK_WALKER3D_SPD || p->M.has_joint_friction != 0;
     if (w.empty()) return p;
     why += w;
   }

@@ -66,6 +66,9 @@ struct SpatialModel {
   Real mass[SP_MAXL], com[SP_MAXL][3], inertia[SP_MAXL][9];
   int dof_link[SP_MAXN], limited[SP_MAXN];
   Real lower[SP_MAXN], upper[SP_MAXN], damp[SP_MAXN], stiff[SP_MAXN], rest[SP_MAXN], q0[SP_MAXN], dq0[SP_MAXN];
+  Real spd_kp[SP_MAXN], spd_kd[SP_MAXN];   // DartWalker3dSPD-v1 stable-PD gains (task 12); act_scale = torque limits
+  Real envdt;                        // dt * frame_skip (the SPD law uses the env step, walker3d_spd.py:41-46)
+  Real* cf_store;                    // [n_envs][n] generalized constraint forces of each env's last world step (task 12)
   Real jfric_dt[SP_MAXN];            // Coulomb joint friction * dt: impulse bound of the dof's friction row (0 = none)
   int has_joint_friction;
   int maxm, maxcp;                   // LCP rows / contact points this model's LDS block is carved for
@@ -127,6 +130,7 @@ struct SpLds {
   int* cplink;   // [maxcp] first link
   int* cplinkB;  // [maxcp] second link of a link-link contact, -1 for the ground
   Real* sinv;    // [n]: 1 / L_jj of the mass-matrix Cholesky factor
+  Real* cf;      // [n]: J^T lambda / dt of the previous world step (pydart2 constraint_forces(), SPD task only)
   Real* misc;    // [16]: roff(3), scalars
   int* imisc;    // [8]: ncp, m, contact flags
   unsigned long long* ticks;   // [10] phase cycle counters of this env-step (diagnostics, only touched when stats are on)
@@ -152,6 +156,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   S.cpN = p; p += maxcp * 3;
   S.misc = p; p += 16;
   S.sinv = p; p += n;
+  S.cf = p; p += n;
   S.rdof = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
   S.rfidx = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
   S.cplink = (int*)p; p += maxcp * sizeof(int) / sizeof(Real) + 1;
@@ -163,7 +168,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
 }
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp) {
   const size_t lw = sp_lw_aliases_links(nl, maxm) ? 0 : (size_t)sp_tri(maxm) + maxm;
-  size_t reals = (size_t)nl * SP_LINKF + 5 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(maxm + 1) * n + sp_tri(maxm) + lw + 5 * maxm +
+  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(maxm + 1) * n + sp_tri(maxm) + lw + 5 * maxm +
                  maxcp * 7 + 16;
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }
@@ -454,7 +459,7 @@ __device__ __forceinline__ void sp_gather_children(const LinkConst<Real>& lc, co
   Lp[LK_IC + 0] = I0; Lp[LK_IC + 1] = I1; Lp[LK_IC + 2] = I2; Lp[LK_IC + 3] = I3; Lp[LK_IC + 4] = I4; Lp[LK_IC + 5] = I5;
 }
 // every link of a group takes the leader's composite (same joint origin, massless carriers), then emits its rhs entry
-template <class Real>
+template <class Real, bool EXTRAS = false>
 __device__ __forceinline__ void sp_link_rhs(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
   Real* L = S.link + i * SP_LINKF;
   if (lc.group_leader != i) {
@@ -465,7 +470,12 @@ __device__ __forceinline__ void sp_link_rhs(const LinkConst<Real>& lc, const Spa
   if (d >= 0) {
     const V3<Real> a = ld3(L + LK_A);
     const Real Cb = (lc.jtype == 2) ? dot(a, ld3(L + LK_N)) : dot(a, ld3(L + LK_F));
-    S.rhs[d] = S.tau[d] - Cb - lc.damp * S.dq[d] - lc.stiff * (S.q[d] + Md.dt * S.dq[d] - lc.rest);
+    if (EXTRAS && Md.task == 12) {   // SPD: S.tau holds the target pose; the torque is added once M and c are known
+      S.b[d] = Cb;
+      S.rhs[d] = -Cb - lc.damp * S.dq[d] - lc.stiff * (S.q[d] + Md.dt * S.dq[d] - lc.rest);
+    } else {
+      S.rhs[d] = S.tau[d] - Cb - lc.damp * S.dq[d] - lc.stiff * (S.q[d] + Md.dt * S.dq[d] - lc.rest);
+    }
   }
 }
 
@@ -557,6 +567,52 @@ __device__ __forceinline__ void sp_chol_backsolve(const Real* Lf, const Real* si
     const Real xj = x[j] * sinv[j];
     if (lane == j) x[j] = xj;
     if (lane < j) x[lane] -= Lf[TL(j, lane)] * xj;
+  }
+  __syncthreads();
+}
+
+// x <- L^-1 x (forward), column-oriented like the back-substitution
+template <class Real>
+__device__ __forceinline__ void sp_chol_fwdsolve(const Real* Lf, const Real* sinv, int n, Real* x, int lane) {
+  for (int j = 0; j < n; j++) {
+    __syncthreads();
+    const Real xj = x[j] * sinv[j];
+    if (lane == j) x[j] = xj;
+    if (lane > j && lane < n) x[lane] -= Lf[TL(lane, j)] * xj;
+  }
+  __syncthreads();
+}
+
+// Stable-PD torque of DartWalker3dSPD-v1 (walker3d_spd.py:40-55), evaluated before every world step once M (in S.H with
+// the integrator's diagonal terms), the bias forces c (S.b) and the previous step's constraint forces (S.cf) are known:
+//   qdd = (M + Kd dt_env)^-1 (-c + p + d + cf),  tau = p + d - Kd qdd dt_env,  root dofs zeroed, |tau| <= limit.
+// S.tau holds the target pose; the torque goes straight into the right-hand side.  Workspace: S.A (factor), S.r (1/L_jj),
+// S.lo (the solve) -- all idle until the constraint phase.
+template <class Real>
+__device__ __forceinline__ void sp_spd_torque(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane) {
+  const int n = Md.n, np = sp_npad(n);
+  Real pd = Real(0), kd = Real(0);
+  if (lane < np) {
+    for (int k = 0; k <= lane; k++) S.A[TL(lane, k)] = S.H[TL(lane, k)];
+    if (lane < n) {
+      kd = Md.spd_kd[lane];
+      S.A[TL(lane, lane)] += kd * Md.envdt - lc.d_diag;
+      const Real p = -Md.spd_kp[lane] * (S.q[lane] + S.dq[lane] * Md.envdt - S.tau[lane]);
+      const Real d = -kd * S.dq[lane];
+      pd = p + d;
+      S.lo[lane] = -S.b[lane] + p + d + S.cf[lane];
+    }
+  }
+  __syncthreads();
+  sp_cholesky<Real>(S.A, S.r, n, lane);
+  sp_chol_fwdsolve<Real>(S.A, S.r, n, S.lo, lane);
+  sp_chol_backsolve<Real>(S.A, S.r, n, S.lo, lane);
+  if (lane < n) {
+    Real tq = pd - kd * S.lo[lane] * Md.envdt;
+    const int k = lane - Md.act_dof0;
+    if (k < 0 || k >= Md.act_dim) tq = Real(0);
+    else if (fabs(tq) > Md.act_scale[k]) tq = (tq > Real(0) ? Real(1) : Real(-1)) * Md.act_scale[k];
+    S.rhs[lane] += tq;
   }
   __syncthreads();
 }
@@ -890,12 +946,13 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);
     __syncthreads();
   }
-  if (lane < nl) sp_link_rhs<Real>(lc, Md, S, lane);
+  if (lane < nl) sp_link_rhs<Real, EXTRAS>(lc, Md, S, lane);
   __syncthreads();
   SP_TICK(0);
   if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
   else if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[TL(lane, k)] = Real(0); S.H[TL(lane, lane)] = Real(1); }
   __syncthreads();
+  if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
   SP_TICK(1);
   sp_cholesky<Real>(S.H, S.sinv, n, lane);
   SP_TICK(2);
@@ -1159,11 +1216,20 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   }
   // ---- new velocity: vs = dq + L^-T (dt y + W^T lambda)
   if (lane < n) {
-    Real u = Md.dt * S.W[m * n + lane];
-    for (int i = 0; i < m; i++) u += S.W[i * n + lane] * S.x[i];
+    Real u = Md.dt * S.W[m * n + lane], ul = Real(0);
+    for (int i = 0; i < m; i++) { const Real t = S.W[i * n + lane] * S.x[i]; u += t; ul += t; }
+    if (EXTRAS && Md.task == 12) S.lo[lane] = ul;   // W^T lambda = L^-1 J^T lambda
     S.rhs[lane] = u;
   }
   __syncthreads();
+  if (EXTRAS && Md.task == 12) {   // constraint_forces() of this step: J^T lambda / dt = L (W^T lambda) / dt
+    if (lane < n) {
+      Real t = Real(0);
+      for (int k = 0; k <= lane; k++) t += S.H[TL(lane, k)] * S.lo[k];
+      S.cf[lane] = t / Md.dt;
+    }
+    __syncthreads();
+  }
   sp_chol_backsolve<Real>(S.H, S.sinv, n, S.rhs, lane);
   SP_TICK(9);
   if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
@@ -1219,10 +1285,11 @@ __device__ __forceinline__ bool sp_walker3d_epilogue(const SpatialModel<Real>& M
   Real pen = Real(0);
   for (int k = 1; k <= 2; k++) {
     const int j = Md.aux_link[k];
+    if (j < 0) continue;
     if ((Md.lower[j] - S.q[j]) > -Md.aux_real[6]) pen += Real(1.5);
     if ((Md.upper[j] - S.q[j]) < Md.aux_real[6]) pen += Real(1.5);
   }
-  Real rew = (pos_after - pos_before) * Md.inv_envdt + Md.aux_real[0];
+  Real rew = Md.aux_real2[2] * ((pos_after - pos_before) * Md.inv_envdt) + Md.aux_real[0];   // weight 1 (Walker3d) / 0.45 (SPD)
   rew -= Md.aux_real[1] * sq_a_sum;
   rew -= Md.aux_real[2] * pen;
   rew -= Md.aux_real[3] * fabs(side);
@@ -1232,7 +1299,7 @@ __device__ __forceinline__ bool sp_walker3d_epilogue(const SpatialModel<Real>& M
     if (i >= 2) ok = ok && (fabs(S.q[i]) < Md.s_max);
   }
   ok = ok && (height > Md.aux_real[4]) && (height < Md.aux_real[5]) && (fabs(ang_u) < Md.aux_real2[1]) && (fabs(ang_f) < Md.aux_real2[1]);
-  if (!ok) rew = Real(0);
+  if (!ok && Md.task == 3) rew = Real(0);   // the SPD variant (task 12) keeps the reward of the terminal step
   reward_out = rew;
   return !ok;
 }
@@ -1369,6 +1436,7 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
   if (lane < n) { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; S.tau[lane] = Real(0); }
   if (lane < Md.nl) S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16);
   if (Md.stats && lane < 10) S.ticks[lane] = 0ull;
+  if (EXTRAS && Md.task == 12 && lane < n) S.cf[lane] = Md.cf_store[e * n + lane];
   __syncthreads();
   Real abs_sum = Real(0), sq_sum = Real(0);
   if (lane == 0) {
@@ -1377,12 +1445,16 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
       abs_sum += fabs(a); sq_sum += a * a;
       Real cl = (a > Md.act_hi[k]) ? Md.act_hi[k] : a;
       cl = (cl < Md.act_lo[k]) ? Md.act_lo[k] : cl;
-      S.tau[Md.act_dof0 + k] = cl * Md.act_scale[k];
+      const int dd = Md.act_dof0 + k;
+      if (EXTRAS && Md.task == 12)   // SPD: the action is a target pose inside the joint's limits (walker3d_spd.py:68-70)
+        S.tau[dd] = (cl + Real(1)) / Real(2) * (Md.upper[dd] - Md.lower[dd]) + Md.lower[dd];
+      else
+        S.tau[dd] = cl * Md.act_scale[k];
     }
     // link poses are needed before the step only by the tasks that measure progress on a body (3, 4) or a tip (11), after
     // it only by the tasks whose reward / done / observation read a body pose
-    if (Md.task == 3 || Md.task == 4 || Md.task == 11) sp_kinematics<Real>(Md, S);
-    sh_scal[0] = (Md.task == 3 || Md.task == 4) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
+    if (Md.task == 3 || Md.task == 4 || Md.task == 11 || Md.task == 12) sp_kinematics<Real>(Md, S);
+    sh_scal[0] = (Md.task == 3 || Md.task == 4 || Md.task == 12) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
     if (Md.task == 11) {   // DartReacher3d: distance to the target BEFORE the step, and sum tau^2 (reacher.py:23-27)
       const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - ld3(tstate + 4 * e);
       sh_scal[0] = sqrt(dot(vec, vec));
@@ -1398,13 +1470,13 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
   for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS>(Md, lc, S, lane, cflags);
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
-  const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task == 10 || Md.task == 11;
+  const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task >= 10;
   if (lane == 0) {
     if (pose_last) sp_kinematics<Real>(Md, S);
     Real rew = Real(0);
     bool task_done = false;
     if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, tstate[4 * e], cflags, rew);
-    else if (Md.task == 3) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
+    else if (Md.task == 3 || Md.task == 12) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     else if (Md.task >= 5) task_done = sp_simple_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     else if (Md.task == 1 || Md.task == 2) task_done = sp_planar_task_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     if (Md.task == 10 || Md.task == 11) {   // reachers: reward from the tip-target distance (2-D: after, 3-D: before the step)
@@ -1455,6 +1527,7 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
     __syncthreads();
   }
   if (lane < n) { qs[e * n + lane] = S.q[lane]; dqs[e * n + lane] = S.dq[lane]; }
+  if (EXTRAS && Md.task == 12 && lane < n) Md.cf_store[e * n + lane] = (autoreset && dn) ? Real(0) : S.cf[lane];
   if ((Md.task == 10 || Md.task == 11) && lane < 3) S.misc[4 + lane] = tstate[4 * e + lane];
   __syncthreads();
   sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
@@ -1565,6 +1638,7 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
   }
   __syncthreads();
   if (m && lane < n) { qs[e * n + lane] = S.q[lane]; dqs[e * n + lane] = S.dq[lane]; }
+  if (m && Md.task == 12 && Md.cf_store && lane < n) Md.cf_store[e * n + lane] = Real(0);   // world.reset() clears them
   if ((Md.task == 10 || Md.task == 11) && lane < 3) S.misc[4 + lane] = tstate[4 * e + lane];
   __syncthreads();
   if (obs && (m || !obs_masked_only)) sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);

@@ -8,3 +8,4 @@ from .half_cheetah import DartHalfCheetahEnv  # noqa: F401
 from .cartpole_swingup import DartCartPoleSwingUpEnv, DartDoubleInvertedPendulumEnv  # noqa: F401
 from .snake_7link import DartSnake7LinkEnv  # noqa: F401
 from .reacher import DartReacher2dEnv, DartReacherEnv  # noqa: F401
+from .walker3d_spd import DartWalker3dSPDEnv  # noqa: F401

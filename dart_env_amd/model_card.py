@@ -26,6 +26,7 @@ CARD_VERSION = 1
 
 TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER, TASK_CARTPOLE, TASK_HALFCHEETAH = 0, 1, 2, 3, 4, 5, 6
 TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_SNAKE, TASK_REACHER2D, TASK_REACHER3D = 7, 8, 9, 10, 11
+TASK_WALKER3D_SPD = 12
 
 
 class DartModelCard(C.Structure):
@@ -58,7 +59,7 @@ class DartModelCard(C.Structure):
         ("reset_noise", C.c_double), ("reset_noise_vel", C.c_double),
         ("aux_body", C.c_int32 * 4), ("aux_real", C.c_double * 8), ("aux_real2", C.c_double * 4),
         ("contact_cfm", C.c_double), ("self_collision", C.c_int32), ("generic_kernel", C.c_int32),
-        ("joint_friction", C.c_double * MAX_DOFS),
+        ("joint_friction", C.c_double * MAX_DOFS), ("spd_kp", C.c_double * MAX_DOFS), ("spd_kd", C.c_double * MAX_DOFS),
     ]
 
 
@@ -100,6 +101,7 @@ class TaskSpec:
     all_bodies_collide: bool = False      # every collision shape of the robot vs. the ground (half_cheetah)
     physics_dt: float = 0.002             # DartEnv.__init__'s dt argument (dart_env.py:29)
     self_collision: bool = False          # robot_skeleton.set_self_collision_check(True) (walker3d.py:26)
+    spd_kp: List[float] = field(default_factory=list)   # stable-PD gains per dof (walker3d_spd.py:13-18); kd = kp / 10
 
 
 HOPPER = TaskSpec(
@@ -198,8 +200,20 @@ REACHER3D = TaskSpec(
     height_lo=-np.inf, height_hi=np.inf, angle_max=np.inf, state_abs_max=np.inf, obs_vel_clip=np.inf, reset_noise=0.01,
     reset_noise_vel=0.01, contact_bodies=[], aux_body_names=["link 3"], aux_real=[0.0, -0.25, 0.0, 0.001, 0.1])
 
+# DartWalker3dSPD-v1 -- reference gym/envs/dart/walker3d_spd.py:9-138: the Walker3d model driven by a stable-PD controller
+# that runs before every world step; kp per dof as the reference indexes it (300 on the root translation, 30 on dofs 7-8 and 13-14, else 100), kd = kp / 10, torque limits
+# 200 / 100 / 20 (:20-22, stored in act_scale), reward 0.45 dx/dt + 1 - 1e-2 sum a^2 - 0.1 |z| (:96-102), angles < 0.54
+# kp_diag = [0]*6 + [100]*15; kp_diag[0:3] = 300; kp_diag[7:9] = 30; kp_diag[13:15] = 30  -- indices of the 21-vector (:13-16)
+_SPD_KP = [300.0] * 3 + [0.0] * 3 + [100.0] + [30.0] * 2 + [100.0] * 4 + [30.0] * 2 + [100.0] * 6
+WALKER3D_SPD = TaskSpec(
+    env_id="DartWalker3dSPD-v1", model="walker3d", task=TASK_WALKER3D_SPD, frame_skip=4, act_dim=15, obs_dim=41, act_dof0=6,
+    act_scale=[100.0] * 3 + [200.0] * 4 + [20.0] * 2 + [200.0] * 4 + [20.0] * 2,
+    max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1, height_lo=1.05, height_hi=2.0,
+    angle_max=0.54, alive_bonus=1.0, ctrl_cost=1e-2, limit_penalty=0.0, aux_body_names=["h_torso_aux"], aux_ints=[18, 12],
+    aux_real=[0.1, 0.45], contact_cfm=1e-4, all_bodies_collide=True, self_collision=True, spd_kp=_SPD_KP)
+
 TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH, CARTPOLE_SWINGUP,
-                               DOUBLE_PENDULUM, SNAKE, REACHER2D, REACHER3D)}
+                               DOUBLE_PENDULUM, SNAKE, REACHER2D, REACHER3D, WALKER3D_SPD)}
 # tasks whose reset_model draws more than the two uniform vectors: the host draws them (see envs/dart_env.py)
 HOST_RESET_TASKS = (TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D, TASK_REACHER3D)
 # tasks with per-env state beyond (q, dq) that reset_model draws (the reach target): dart_set_task_state
@@ -280,6 +294,8 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         if task.contact_cfm is not None:
             c.contact_cfm = task.contact_cfm
         c.self_collision = int(task.self_collision)
+        for k, v in enumerate(task.spd_kp):
+            c.spd_kp[k], c.spd_kd[k] = v, v / 10.0
         names = [b.name for b in model.bodies]
         for k, nm in enumerate(task.aux_body_names):
             c.aux_body[k] = names.index(nm)

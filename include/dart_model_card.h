@@ -63,6 +63,11 @@ enum {
   DART_TASK_REACHER3D = 11,  /* reference gym/envs/dart/reacher.py:13-45 (DartReacher3d-v1): reward -|tip - target| -
                                  aux_real[3] sum tau^2 with the tip BEFORE the step, done when that distance <= aux_real[4]
                                  or the state is not finite; obs cos q, sin q, target, dq, tip - target (after) */
+  DART_TASK_WALKER3D_SPD = 12, /* reference gym/envs/dart/walker3d_spd.py:40-113 (DartWalker3dSPD-v1): the action is a target pose
+                                 (a + 1) / 2 mapped onto each joint's limits; before EVERY world step the torque comes from the
+                                 stable-PD law with M, c and the previous step's constraint forces (:40-55, env dt in the law),
+                                 clipped to act_scale; reward aux_real[1] dx/dt + 1 - aux_real[2] sum a^2 - aux_real[3] |z|;
+                                 done as Walker3d with angle_max 0.54; obs q[1:], clip(dq) */
   DART_TASK_DOUBLE_PENDULUM = 8 /* reference gym/envs/dart/inverted_double_pendulum.py:19-53: obs [q0, sin q1..2, cos q1..2,
                                  dq], height = 2 (y(aux_body[1]) - y(aux_body[0]) - aux_real[4]) / aux_real[5], reward
                                  aux_real[0] - (aux_real[1] q0^2 + (height - 2)^2) - (aux_real[2] dq1^2 + aux_real[3] dq2^2),
@@ -163,6 +168,10 @@ typedef struct DartModelCard {
    * JointCoulombFrictionConstraint -- an LCP row that drives the joint velocity to zero with an impulse bounded by
    * +-joint_friction * dt. */
   double joint_friction[DART_MAX_DOFS];
+  /* DART_TASK_WALKER3D_SPD: stable-PD gains per dof (walker3d_spd.py:13-18); act_scale[k] holds the torque limit of
+   * actuated dof k (:20-22) for that task. */
+  double spd_kp[DART_MAX_DOFS];
+  double spd_kd[DART_MAX_DOFS];
 } DartModelCard;
 
 #ifdef __cplusplus

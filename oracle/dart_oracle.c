@@ -90,6 +90,7 @@ typedef struct OracleWorld {
   double lcp_residual_last;
   double A_last[MAXM * MAXM], b_last[MAXM]; /* debug copies of the last LCP */
   double init_height; /* human_walker.py:163 head COM height right after reset_model's set_state */
+  double cf_last[MAXN]; /* generalized constraint forces of the last world step: J^T lambda / dt (pydart2 constraint_forces()) */
   double task_state[4]; /* per-env task state beyond (q, dq): the reach target of the reacher envs */
   int ext_all;        /* 1: ext_fb holds one world-frame force per body (snake fluid model), applied at the body origins */
   double ext_fb[DART_MAX_BODIES][3];
@@ -321,7 +322,9 @@ void oracle_set_ext_force(OracleWorld* w, int body, const double* f3) {
   if (w->ext_body >= 0) memcpy(w->ext_f, f3, sizeof w->ext_f);
 }
 /* pydart2 World.reset: time 0, positions/velocities back to initial, forces cleared (dart_world.py:20-22) */
+void oracle_constraint_forces(const OracleWorld* w, double* out) { memcpy(out, w->cf_last, w->n * sizeof(double)); }
 void oracle_reset(OracleWorld* w) {
+  memset(w->cf_last, 0, sizeof w->cf_last);
   for (int i = 0; i < w->n; i++) { w->q[i] = w->card.init_pos[i]; w->dq[i] = w->card.init_vel[i]; w->tau[i] = 0; }
   w->time = 0;
 }
@@ -888,6 +891,7 @@ int oracle_step(OracleWorld* w) {
   }
   w->m_last = m;
   w->lcp_residual_last = 0;
+  for (int k = 0; k < n; k++) w->cf_last[k] = 0;
   if (m > 0) {
     for (int i = 0; i < m; i++) {
       memcpy(Y[i], J[i], n * sizeof(double));
@@ -921,7 +925,7 @@ int oracle_step(OracleWorld* w) {
       }
     }
     for (int i = 0; i < m; i++) {
-      for (int k = 0; k < n; k++) vs[k] += Y[i][k] * x[i];
+      for (int k = 0; k < n; k++) { vs[k] += Y[i][k] * x[i]; w->cf_last[k] += J[i][k] * x[i] / dt; }
     }
     /* diagnostics: complementarity residual */
     double res = 0;
@@ -1325,8 +1329,71 @@ static int reacher_step(OracleWorld* w, const double* a, double* obs, double* re
   return 0;
 }
 
+/* DartWalker3dSPDEnv.step (walker3d_spd.py:40-113).  _spd runs before EVERY world step with the env dt (0.008) in the law. */
+static void spd_torque(OracleWorld* w, const double* target, double* tau) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double envdt = c->dt * c->frame_skip;
+  static double A2[MAXN * MAXN];
+  double rhs2[MAXN], p[MAXN], d[MAXN], cb[MAXN];
+  kinematics(w);
+  crba(w, w->M);
+  rnea(w, w->dq, NULL, 1, cb);
+  memcpy(A2, w->M, n * n * sizeof(double));
+  for (int i = 0; i < n; i++) {
+    A2[i * n + i] += c->spd_kd[i] * envdt;
+    p[i] = -c->spd_kp[i] * (w->q[i] + w->dq[i] * envdt - target[i]);
+    d[i] = -c->spd_kd[i] * w->dq[i];
+    rhs2[i] = -cb[i] + p[i] + d[i] + w->cf_last[i];
+  }
+  cholesky(A2, n);
+  chol_solve(A2, n, rhs2);   /* qddot */
+  for (int i = 0; i < n; i++) tau[i] = p[i] + d[i] - c->spd_kd[i] * rhs2[i] * envdt;
+  for (int i = 0; i < c->act_dof0; i++) tau[i] = 0;
+  for (int k = 0; k < c->act_dim; k++) {
+    double lim = c->act_scale[k];
+    if (fabs(tau[c->act_dof0 + k]) > lim) tau[c->act_dof0 + k] = (tau[c->act_dof0 + k] > 0 ? 1.0 : -1.0) * lim;
+  }
+}
+static int walker3d_spd_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double target[MAXN] = {0}, tau[MAXN], sq = 0;
+  for (int k = 0; k < c->act_dim; k++) {
+    double cl = a[k];
+    if (cl > c->act_high[k]) cl = c->act_high[k];
+    if (cl < c->act_low[k]) cl = c->act_low[k];
+    int dd = c->act_dof0 + k;
+    target[dd] = (cl + 1.0) / 2.0 * (c->upper[dd] - c->lower[dd]) + c->lower[dd];
+    sq += a[k] * a[k];
+  }
+  double cm[3];
+  oracle_body_com(w, c->aux_body[0], cm);
+  double posbefore = cm[0];
+  for (int f = 0; f < c->frame_skip; f++) { spd_torque(w, target, tau); oracle_set_forces(w, tau); oracle_step(w); }
+  oracle_body_com(w, c->aux_body[0], cm);
+  double posafter = cm[0], height = cm[1], side = cm[2];
+  const double* Tb = w->W[w->body_link[c->aux_body[0]]];
+  double up[3] = {Tb[1], Tb[5], Tb[9]}, fw[3] = {Tb[0], Tb[4], Tb[8]};
+  double ang_uwd = acos(up[1] / sqrt(dot3(up, up))), ang_fwd = acos(fw[0] / sqrt(dot3(fw, fw)));
+  double envdt = c->dt * c->frame_skip;
+  double vel_rew = c->aux_real[1] * (posafter - posbefore) / envdt;
+  double action_pen = c->ctrl_cost * sq, deviation_pen = c->aux_real[0] * fabs(side);
+  *reward = vel_rew + c->alive_bonus - action_pen - deviation_pen;
+  int ok = 1;
+  for (int i = 0; i < n; i++) {
+    if (!isfinite(w->q[i]) || !isfinite(w->dq[i])) ok = 0;
+    if (i >= 2 && !(fabs(w->q[i]) < c->state_abs_max)) ok = 0;
+    if (!(fabs(w->dq[i]) < c->state_abs_max)) ok = 0;
+  }
+  if (!(height > c->height_lo && height < c->height_hi && fabs(ang_uwd) < c->angle_max && fabs(ang_fwd) < c->angle_max)) ok = 0;
+  walker3d_obs(w, obs);
+  return !ok;
+}
+
 int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
   const DartModelCard* c = &w->card;
+  if (c->task == DART_TASK_WALKER3D_SPD) return walker3d_spd_step(w, a, obs, reward);
   if (c->task == DART_TASK_REACHER2D || c->task == DART_TASK_REACHER3D) return reacher_step(w, a, obs, reward);
   if (c->task == DART_TASK_SNAKE) return snake_step(w, a, obs, reward);
   if (c->task == DART_TASK_CARTPOLE_SWINGUP) return swingup_step(w, a, obs, reward);
@@ -1386,7 +1453,7 @@ int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward
 void oracle_env_obs(OracleWorld* w, double* obs) {
   const DartModelCard* c = &w->card;
   if (c->task == DART_TASK_HUMANWALKER) { int z[2] = {0, 0}; humanwalker_obs(w, z, obs); return; } /* reset_model zeroes contact_info */
-  if (c->task == DART_TASK_WALKER3D) { walker3d_obs(w, obs); return; }
+  if (c->task == DART_TASK_WALKER3D || c->task == DART_TASK_WALKER3D_SPD) { walker3d_obs(w, obs); return; }
   if (c->task == DART_TASK_CARTPOLE || c->task == DART_TASK_CARTPOLE_SWINGUP) { qdq_obs(w, 0, obs); return; }
   if (c->task == DART_TASK_DOUBLE_PENDULUM) { double_pendulum_obs(w, obs); return; }
   if (c->task == DART_TASK_REACHER2D || c->task == DART_TASK_REACHER3D) { reacher_obs(w, obs); return; }

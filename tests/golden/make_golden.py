@@ -146,6 +146,12 @@ class StubSkeleton:
     q = property(lambda self: SkelVector(self.world.oracle.get_state()[0]))
     dq = property(lambda self: SkelVector(self.world.oracle.get_state()[1]))
 
+    M = property(lambda self: self.world.oracle.mass_matrix())
+    c = property(lambda self: self.world.oracle.bias())
+
+    def constraint_forces(self):
+        return self.world.oracle.constraint_forces()
+
     def set_positions(self, q):
         self.world.oracle.set_state(np.asarray(q, dtype=np.float64), self.world.oracle.get_state()[1])
 
@@ -177,6 +183,8 @@ class StubCollisionResult:
 class StubWorld:
     n_steps = 0
 
+    spd = False   # walker3d_waist.skel serves two env ids; the generator flips this before making the SPD one
+
     def __init__(self, dt, skel_path=None):
         name = os.path.basename(skel_path)
         contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"],
@@ -196,6 +204,8 @@ class StubWorld:
                 "inverted_double_pendulum.skel": "DartDoubleInvertedPendulumEnv-v1",
                 "snake_7link.skel": "DartSnake7Link-v1", "reacher2d.skel": "DartReacher-v1",
                 "reacher.skel": "DartReacher3d-v1"}[name]
+        if StubWorld.spd and name == "walker3d_waist.skel":
+            spec = "DartWalker3dSPD-v1"
         if TASKS[spec].contact_cfm is not None:   # same contact regularisation as the shipped task card
             card.contact_cfm = TASKS[spec].contact_cfm
         card.self_collision = int(TASKS[spec].self_collision)   # what the env's set_self_collision_check() call will ask for
@@ -352,6 +362,10 @@ def main():
     # (11) DartReacher3d-v1 (target resampled by rejection, reward / done from the pre-step fingertip distance)
     np.savez_compressed(os.path.join(out, "reacher3d_single_seed0.npz"), **rollout_single(gym, "DartReacher3d-v1", 0, 700))
     np.savez_compressed(os.path.join(out, "reacher3d_vector4_seed3.npz"), **rollout_vector(gym, "DartReacher3d-v1", 4, 3, 120))
+    # (13) DartWalker3dSPD-v1: the reference's _spd (numpy inverse of M + Kd dt, skel.c, constraint_forces()) per substep
+    StubWorld.spd = True
+    np.savez_compressed(os.path.join(out, "walker3dspd_single_seed0.npz"), **rollout_single(gym, "DartWalker3dSPD-v1", 0, 400))
+    StubWorld.spd = False
     print("world.step() calls issued by the reference code:", StubWorld.n_steps)
 
 

@@ -58,6 +58,7 @@ def lib():
         L.oracle_last_Ab.restype = C.c_int
         L.oracle_set_ext_force.argtypes = [C.c_void_p, C.c_int, dp]
         L.oracle_set_task_state.argtypes = [C.c_void_p, dp]
+        L.oracle_constraint_forces.argtypes = [C.c_void_p, dp]
         L.oracle_add_body_force.argtypes = [C.c_void_p, C.c_int, dp]
         L.oracle_body_com_spatial_velocity.argtypes = [C.c_void_p, C.c_int, dp]
         L.oracle_box_box.argtypes = [dp, dp, dp, dp, dp, dp, dp, dp]
@@ -117,6 +118,11 @@ class OracleWorld:
     def set_forces(self, tau):
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         self.L.oracle_set_forces(self.h, _p(tau))
+
+    def constraint_forces(self):
+        out = np.zeros(self.n)
+        self.L.oracle_constraint_forces(self.h, _p(out))
+        return out
 
     def set_task_state(self, v4):
         v = np.zeros(4); v[:len(v4)] = v4

@@ -143,6 +143,26 @@ def test_snake_vs_reference_fluid_force_loop():
     env.close()
 
 
+def test_walker3d_spd_vs_reference_controller_loop():
+    """The reference evaluates the stable-PD law in Python every substep (np.linalg.inv(M + Kd dt), skel.c,
+    constraint_forces(), walker3d_spd.py:40-55); the oracle's C restatement (Cholesky solve) and the env facade follow the
+    same trajectory to solver precision."""
+    from dart_env_amd.envs import DartWalker3dSPDEnv
+    d = np.load(os.path.join(G, "walker3dspd_single_seed0.npz"))
+    env = TimeLimit(DartWalker3dSPDEnv(stepper_factory=OracleStepper), max_episode_steps=1000)
+    env.seed(0)
+    assert np.allclose(env.reset(), d["obs0"], atol=1e-7)
+    for t in range(len(d["done"])):
+        ob, r, done, info = env.step(d["actions"][t])
+        assert done == bool(d["done"][t]) and info["done_return"] == done, t
+        assert np.allclose(ob, d["obs"][t], rtol=2e-7, atol=2e-6) and abs(r - d["reward"][t]) < 1e-7, t
+        assert np.allclose(env.state_vector(), np.concatenate([d["q"][t], d["dq"][t]]), rtol=0, atol=1e-8), t
+        if done:
+            assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-7)
+    assert d["done"].sum() >= 2
+    env.close()
+
+
 @pytest.mark.parametrize("tag", ["hopper", "walker2d", "cartpole", "halfcheetah", "swingup", "doublependulum", "reacher3d", "reacher2d"])
 def test_vector_env_vs_reference_syncvectorenv(tag):
     """seed(int) fan-out s+i, auto-reset returning the post-reset observation, dtypes (sync_vector_env.py:50-84)."""

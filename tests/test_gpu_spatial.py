@@ -527,3 +527,44 @@ def test_reacher2d_joint_coulomb_friction_matches_oracle():
     assert np.abs(dq[: n // 2]).max() < 1e-9 and np.abs(q[: n // 2] - qn[: n // 2]).max() < 1e-9   # stuck by friction
     assert np.abs(dq[n // 2:]).max() > 0.1
     gpu.close()
+
+
+def test_walker3d_spd_env_matches_oracle_and_fixture():
+    """DartWalker3dSPD-v1: the stable-PD controller (second Cholesky per substep, constraint forces carried from the
+    previous world step, also across env-steps) inside the kernel = oracle; single-env facade = reference fixture."""
+    from dart_env_amd.stepper import HipStepper
+    from dart_env_amd.envs import DartWalker3dSPDEnv
+    card = card_for("DartWalker3dSPD-v1")
+    n, nd, na = 48, card.ndofs, card.act_dim
+    rng = np.random.RandomState(21)
+    gpu = HipStepper(card, n, precision=64)
+    ora = OracleBatch(card, n)
+    qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+    og = gpu.reset(None, qn, vn); ora.reset(None, qn, vn)
+    assert np.allclose(og, ora.obs(), atol=1e-6)
+    n_done = 0
+    for t in range(60):
+        a = rng.uniform(-1.2, 1.2, (n, na)).astype(np.float32)
+        og, rg, dg, tg = gpu.step(a)
+        oo, ro, do, to = ora.step(a)
+        qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+        assert np.abs(qg - qo).max() < 1e-7 and np.abs(dqg - dqo).max() < 1e-5, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        assert np.array_equal(dg, do), t
+        assert np.allclose(og, oo, atol=2e-5) and np.allclose(rg, ro, atol=1e-4)
+        n_done += int(do.sum())
+        if do.any():
+            qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+            gpu.reset(do.astype(np.uint8), qn, vn, want_obs=False); ora.reset(do, qn, vn)
+    assert n_done > 3
+    gpu.close()
+    d = np.load(os.path.join(G, "walker3dspd_single_seed0.npz"))
+    env = DartWalker3dSPDEnv(precision=64)
+    env.seed(0)
+    assert np.allclose(env.reset(), d["obs0"], atol=1e-6)
+    for t in range(200):
+        ob, r, done, info = env.step(d["actions"][t])
+        assert done == bool(d["done"][t]), t
+        assert np.allclose(ob, d["obs"][t], rtol=1e-6, atol=2e-5) and abs(r - d["reward"][t]) < 1e-4
+        if done:
+            assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-6)
+    env.close()

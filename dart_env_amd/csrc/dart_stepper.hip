@@ -568,7 +568,7 @@ struct DartStepper {
   bool ep_stats = false;
   void* dyn_model = nullptr;     // device SpatialModel<float|double> used by dart_get_dynamics (built on first use)
   size_t dyn_lds = 0;
-  double *d_dynM = nullptr, *d_dync = nullptr;
+  double *d_dynM = nullptr, *d_dync = nullptr, *d_tstage = nullptr;
   std::string err;
 };
 
@@ -677,7 +677,7 @@ int dart_destroy(DartStepper* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->impl) h->impl->release();
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync, h->d_tstage, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -965,14 +965,13 @@ int dart_set_task_state(DartStepper* h, const uint8_t* mask, const double* value
   if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
   CHK(h, hipSetDevice(h->device));
   const size_t N = (size_t)h->n;
-  double* dv = nullptr;
-  CHK(h, hipMalloc((void**)&dv, 8 * 4 * N));
+  if (!h->d_tstage) CHK(h, hipMalloc((void**)&h->d_tstage, 8 * 4 * N));   // staging buffer, kept for the handle's lifetime
+  double* dv = h->d_tstage;
   CHK(h, hipMemcpy(dv, values, 8 * 4 * N, hipMemcpyHostToDevice));
   const uint8_t* dmask = nullptr;
   if (mask) { memcpy(h->h_mask, mask, N); CHK(h, hipMemcpy(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice)); dmask = h->d_mask; }
   int rc = h->impl->set_task_state(h->stream, dmask, dv, h->n);
   hipError_t e = hipStreamSynchronize(h->stream);
-  (void)hipFree(dv);
   if (rc == DART_E_UNSUPPORTED) h->err = "this model's kernel keeps no per-env task state";
   if (rc != DART_OK) return rc;
   CHK(h, e);

@@ -124,6 +124,10 @@ class DartVectorEnv:
         return "DartVectorEnv(%s, %d)" % (self.spec_id, self.num_envs)
 
 
-def make(env_id, num_envs=1, **kwargs):
-    """gym.vector.make counterpart (reference gym/vector/__init__.py:12-61) for the Dart ids."""
+def make(env_id, num_envs=1, asynchronous=True, wrappers=None, **kwargs):
+    """gym.vector.make counterpart (reference gym/vector/__init__.py:12-61) for the Dart ids.  `asynchronous` only chose
+    between worker processes and a serial loop in the reference; here every env of the batch advances in one kernel launch
+    either way.  `wrappers` (callables applied to each single env in the reference) have no per-env object to wrap."""
+    if wrappers:
+        raise NotImplementedError("per-env wrappers do not apply to a batched device env; wrap the DartVectorEnv instead")
     return DartVectorEnv(env_id, num_envs, **kwargs)

@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (0: 65536, or 16384 for DartHumanWalker-v1 = BASELINE config 4)")
+    ap.add_argument("--all-bodies-collide", action="store_true",
+                    help="every collision shape vs the floor (DART's behaviour) instead of the feet-only default cards of Hopper / Walker2d")
     ap.add_argument("--env-id", default="DartHopper-v1")
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--solver", default="bpp", choices=["bpp", "pgs"])
@@ -75,7 +77,7 @@ def main():
     from dart_env_amd.model_card import card_for
     from dart_env_amd import stepper as st
 
-    card = card_for(args.env_id)
+    card = card_for(args.env_id, all_bodies_collide=args.all_bodies_collide)
     n = args.envs or (16384 if args.env_id == "DartHumanWalker-v1" else 65536)
     env = st.HipStepper(card, n, device=local_rank, precision=args.precision)
     env.configure(st.CFG_AUTORESET, 1)
@@ -165,7 +167,8 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
-        "config": {"workload": "%s batch %d per GPU, random actions U[-1,1), on-device auto-reset" % (args.env_id, n),
+        "config": {"workload": "%s batch %d per GPU, random actions U[-1,1), on-device auto-reset%s"
+                               % (args.env_id, n, ", every capsule collides" if args.all_bodies_collide else ""),
                    "envs_per_gpu": n, "frame_skip": int(card.frame_skip), "physics_dt": card.dt,
                    "lcp_solver": "two-stage boxed LCP, %s" % ("block principal pivoting (exact)" if args.solver == "bpp"
                                                                else "PGS x%d" % args.pgs_iters),
@@ -182,7 +185,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        key = "%s/%d/f%d" % (args.env_id, n, args.precision)
+        key = "%s/%d/f%d%s" % (args.env_id, n, args.precision, "/allcaps" if args.all_bodies_collide else "")
         if key in pmc:
             result["roofline"]["traffic"] = pmc[key]["bytes_per_launch"]
             result["roofline"]["traffic_source"] = pmc[key]["source"]

@@ -16,6 +16,7 @@
 #include "planar_kernel.hpp"
 #include "static_models.hpp"
 #include "spatial_kernel.hpp"
+#include <type_traits>
 #include <vector>
 #include "mt19937_kernels.hpp"
 #include "episode_kernels.hpp"
@@ -505,12 +506,14 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
   Params<Real, T> R;
   std::string w = fill_params<Real, T>(c, R);
   if (!w.empty()) { why += w; return nullptr; }
-  if (allow_static && Static::matches(R)) {
-    auto p = std::make_unique<ImplT<Real, T, Static>>();
-    p->P.max_steps = R.max_steps; p->P.solver = R.solver; p->P.iters1 = R.iters1; p->P.iters2 = R.iters2;
-    p->P.stats = nullptr;
-    p->is_static = true;
-    return p;
+  if constexpr (!std::is_void<Static>::value) {
+    if (allow_static && Static::matches(R)) {
+      auto p = std::make_unique<ImplT<Real, T, Static>>();
+      p->P.max_steps = R.max_steps; p->P.solver = R.solver; p->P.iters1 = R.iters1; p->P.iters2 = R.iters2;
+      p->P.stats = nullptr;
+      p->is_static = true;
+      return p;
+    }
   }
   auto p = std::make_unique<ImplT<Real, T>>();
   p->P = R;
@@ -524,6 +527,9 @@ std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why, bool a
   why = "hopper-chain: ";
   if (!force_spatial)
   if (auto p = make_for_topology<Real, HopperTopo, HopperStatic<Real>>(c, why, allow_static)) return p;
+  why += "; hopper-chain, all capsules: ";
+  if (!force_spatial)
+  if (auto p = make_for_topology<Real, HopperAllTopo, void>(c, why, allow_static)) return p;
   why += "; walker2d-tree: ";
   if (!force_spatial)
   if (auto p = make_for_topology<Real, Walker2dTopo, Walker2dStatic<Real>>(c, why, allow_static)) return p;

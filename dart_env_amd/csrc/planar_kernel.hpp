@@ -58,6 +58,13 @@ struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - s
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
+struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour; 11 LCP rows instead of 5)
+  static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3;
+  static constexpr bool WARM = false;
+  __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
+  __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3}; return L[c]; }
+  __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
+};
 struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin foot) x 2
   static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6;
   static constexpr bool WARM = true;   // measured +26 % (persistent double-support contacts)

@@ -913,6 +913,15 @@ int dart_step_wait(DartStepper* h, float* obs_out, double* reward_out, uint8_t* 
   return DART_OK;
 }
 
+int dart_host_views(DartStepper* h, const float** obs, const float** reward_f32, const uint8_t** done, const uint8_t** truncated) {
+  if (!h) return DART_E_INVALID;
+  if (obs) *obs = h->h_obs;
+  if (reward_f32) *reward_f32 = h->h_rew;
+  if (done) *done = h->h_done;
+  if (truncated) *truncated = h->h_trunc;
+  return DART_OK;
+}
+
 int dart_step(DartStepper* h, const float* actions, float* obs_out, double* reward_out, uint8_t* done_out,
               uint8_t* truncated_out) {
   int rc = dart_step_async(h, actions);

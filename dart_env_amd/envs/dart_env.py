@@ -192,8 +192,8 @@ class BatchedDartEnv:
     def step_async(self, actions):
         self._stepper.step_async(actions)
 
-    def step_wait(self):
-        return self._stepper.step_wait()
+    def step_wait(self, copy=True):
+        return self._stepper.step_wait() if copy else self._stepper.step_wait(copy=False)
 
     def set_ext_force(self, body, forces):
         """``bodynodes[body].add_ext_force(F_i)`` before every world step of env i from now on -- the perturbation branch

@@ -28,7 +28,7 @@ SOLVER_BPP, SOLVER_PGS = 0, 1
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views",
 ]
 
 
@@ -79,6 +79,8 @@ def load_library(path: Optional[str] = None):
     L.dart_get_dynamics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dart_set_ext_force.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.dart_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
+    L.dart_host_views.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
+                                  C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint8))]
     L.dart_get_episode_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]
     L.dart_debug_dump.argtypes = [vp, dp]
     L.dart_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
@@ -220,7 +222,22 @@ class HipStepper:
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim)
         self._check(self.L.dart_step_async(self.h, _ptr(a, C.c_float)))
 
-    def step_wait(self):
+    def _views(self):
+        if getattr(self, "_host_views", None) is None:
+            po, pr = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+            pd, pt = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint8)()
+            self._check(self.L.dart_host_views(self.h, C.byref(po), C.byref(pr), C.byref(pd), C.byref(pt)))
+            n = self.num_envs
+            self._host_views = (np.ctypeslib.as_array(po, shape=(n, self.obs_dim)), np.ctypeslib.as_array(pr, shape=(n,)),
+                                np.ctypeslib.as_array(pd, shape=(n,)), np.ctypeslib.as_array(pt, shape=(n,)))
+        return self._host_views
+
+    def step_wait(self, copy=True):
+        """copy=False: the observation is a view of the library's pinned staging buffer (valid until the next call)."""
+        if not copy:
+            self._check(self.L.dart_step_wait(self.h, None, None, None, None))
+            o, r, d, t = self._views()
+            return o, r.astype(np.float64), d.astype(np.bool_), t.astype(np.bool_)
         obs, rew, done, trunc = self._outs()
         self._check(self.L.dart_step_wait(self.h, _ptr(obs, C.c_float), _ptr(rew, C.c_double),
                                           _ptr(done, C.c_uint8), _ptr(trunc, C.c_uint8)))

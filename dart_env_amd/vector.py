@@ -99,7 +99,8 @@ class DartVectorEnv:
         if not self._pending:
             raise NoAsyncCallError(_st.E_NOT_PENDING, "Calling `step_wait` without any prior call to `step_async`.")
         self._pending = False
-        obs, rew, done, trunc = self.env.step_wait()
+        zero_copy = not self.copy and self.env.device_noise and hasattr(self.env._stepper, "_views")
+        obs, rew, done, trunc = self.env.step_wait(copy=not zero_copy)
         if not self.env.device_noise and done.any():
             obs = self.env.reset(done)      # post-reset observation for done envs (sync_vector_env.py:77-78)
         return obs, rew, done, InfoList(trunc)

@@ -126,6 +126,12 @@ int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear);
  * of the last LCP solved. */
 int dart_debug_dump(DartStepper* h, double* out160);
 
+/* Zero-copy read access to the pinned host staging buffers that dart_step_wait / dart_step fill: (N, obs_dim) float32
+ * observations, (N,) float32 rewards, (N,) done and truncated flags.  Valid until the next step / reset on this handle;
+ * call dart_step_wait with NULL outputs and read these instead to skip the copy into caller memory (VectorEnv(copy=False),
+ * reference gym/vector/sync_vector_env.py:83). */
+int dart_host_views(DartStepper* h, const float** obs, const float** reward_f32, const uint8_t** done, const uint8_t** truncated);
+
 /* Per-env task state that reset_model draws besides (q, dq): the reach target of DartReacher-v1 / DartReacher3d-v1
  * (reference gym/envs/dart/reacher2d.py:53-59, reacher.py:50-55).  values = (N, 4) doubles, slots 0..2 = target x, y, z;
  * mask as in dart_reset.  Call it before dart_reset so that the reset observation sees the new target. */

@@ -389,3 +389,20 @@ def test_rollout_buffer_device_resident_equals_host_stepping():
     buf.collect(policy); torch.cuda.synchronize()   # a second window continues from the last observation
     assert torch.equal(buf.obs[0], last)
     venv.close(); ref.close()
+
+
+def test_vector_env_copy_false_returns_views_with_the_same_values():
+    """copy=False (sync_vector_env.py:83 semantics): observations are views of the pinned staging buffer."""
+    a = np.random.RandomState(1).uniform(-1, 1, (20, 256, 3)).astype(np.float32)
+    va = dart_env_amd.vector.make("DartHopper-v1", 256, noise="philox"); vb = dart_env_amd.vector.make("DartHopper-v1", 256, noise="philox", copy=False)
+    va.seed(5); vb.seed(5)
+    assert np.array_equal(va.reset(), vb.reset())
+    prev = None
+    for t in range(20):
+        oa, ra, da, ia = va.step(a[t]); ob, rb, db, ib = vb.step(a[t])
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
+        assert not ob.flags.owndata and oa.flags.owndata
+        if prev is not None:
+            assert prev is ob or np.shares_memory(prev, ob)        # the same pinned buffer every step
+        prev = ob
+    va.close(); vb.close()

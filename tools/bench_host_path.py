@@ -31,6 +31,15 @@ for _ in range(K):
     venv.step(a)
 dt = time.perf_counter() - t0
 print("DartVectorEnv.step (python surface, philox): %.1f us/step, %.3e env-steps/s" % (dt / K * 1e6, n * K / dt))
+venvz = dart_env_amd.vector.make("DartHopper-v1", n, noise="philox", copy=False)   # observations = views of the pinned buffer
+venvz.reset()
+for _ in range(5):
+    venvz.step(a)
+t0 = time.perf_counter(); K = 100
+for _ in range(K):
+    venvz.step(a)
+dt = time.perf_counter() - t0
+print("DartVectorEnv.step (python surface, philox, copy=False): %.1f us/step, %.3e env-steps/s" % (dt / K * 1e6, n * K / dt))
 t0 = time.perf_counter()
 venv2 = dart_env_amd.vector.make("DartHopper-v1", n)   # default: reference-exact MT19937 reset noise, bank in HBM
 venv2.seed(0); venv2.reset()

@@ -124,17 +124,12 @@ class BatchedDartEnv:
             self._stepper.configure(_st.CFG_SEED, float(s0 % (1 << 53)))
         elif self.noise == "mt19937":
             # the words numpy's RandomState.seed(list) receives in seeding.np_random (gym/utils/seeding.py:17-18)
-            keys = np.zeros((self.num_envs, 2), dtype=np.uint32)
-            klen = np.zeros(self.num_envs, dtype=np.int32)
             used = []
-            for i, sd in enumerate(seeds):
+            for sd in seeds:
                 if sd is not None and not (isinstance(sd, (int, np.integer)) and 0 <= sd):
                     raise seeding.SeedError("Seed must be a non-negative integer or omitted, not %r" % (sd,))
-                sd = seeding.create_seed(sd)
-                words = seeding.int_list_from_bigint(seeding.hash_seed(sd))
-                klen[i] = len(words)
-                keys[i, :len(words)] = words
-                used.append(sd)
+                used.append(seeding.create_seed(sd))
+            keys, klen = seeding.mt_keys(used)
             self._stepper.seed_mt19937(keys, klen)
             self._seeds = used
         return list(seeds)

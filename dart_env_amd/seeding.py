@@ -59,3 +59,17 @@ def np_random(seed=None):
     rng = np.random.RandomState()
     rng.seed(int_list_from_bigint(hash_seed(seed)))
     return rng, seed
+
+
+def mt_keys(seeds):
+    """The init_by_array keys ``np_random(seed_i)`` would feed MT19937, for many non-negative int seeds at once:
+    -> (keys (n, 2) uint32, key_len (n,) int32).  Same words as ``int_list_from_bigint(hash_seed(create_seed(s)))``
+    (the 8 digest bytes are two little-endian words; a zero high word is dropped, an all-zero value gives [0])."""
+    n = len(seeds)
+    raw = bytearray(8 * n)
+    sha = hashlib.sha512
+    for i, sd in enumerate(seeds):
+        raw[8 * i:8 * i + 8] = sha(str(int(sd) % 2 ** 64).encode("utf8")).digest()[:8]
+    keys = np.frombuffer(bytes(raw), dtype="<u4").reshape(n, 2).astype(np.uint32)
+    key_len = np.where(keys[:, 1] != 0, 2, 1).astype(np.int32)
+    return keys, key_len

@@ -58,6 +58,14 @@ def load_library(path: Optional[str] = None):
     if not os.path.exists(p):
         raise OSError("%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    # PyTorch-ROCm wheels bundle their own HIP / HSA runtime under torch/lib.  Whichever runtime opens the GPU first owns it
+    # for the process, and a second HSA runtime then reports "No HIP GPUs are available": if torch is installed, let it
+    # load its runtime first (this library then shares the one HSA instance, and torch tensors' device pointers can be
+    # handed to dart_step_device).  No torch -> nothing to coordinate with.
+    try:
+        import torch  # noqa: F401
+    except Exception:   # pragma: no cover
+        pass
     L = C.CDLL(p)
     vp, i64, dp, fp, u8 = C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
     L.dart_last_error.restype = C.c_char_p

@@ -171,3 +171,12 @@ def test_record_episode_statistics_wrappers():
                 assert "episode" not in infos[i]
     assert fin >= 6 and len(venv.return_queue) == min(fin, 100)
     venv.close()
+
+
+def test_batched_mt_keys_equal_the_per_seed_path():
+    from dart_env_amd import seeding
+    seeds = list(range(0, 3000, 7)) + [2 ** 63 + 5, 0, 12345678901234567890 % 2 ** 64]
+    keys, klen = seeding.mt_keys(seeds)
+    for i, s in enumerate(seeds):
+        w = seeding.int_list_from_bigint(seeding.hash_seed(seeding.create_seed(s)))
+        assert klen[i] == len(w) and list(keys[i, :len(w)]) == w

@@ -323,6 +323,7 @@ def test_device_resident_step_with_mt19937_resets_equals_host_buffer_step():
         act = rs.uniform(-1, 1, (n, card.act_dim)).astype(np.float32)
         oa, ra, da, ta = a_host.step(act)
         d_act = torch.from_numpy(act).cuda()
+        torch.cuda.current_stream().synchronize()       # the upload ran on torch's stream, the step runs on `stream`
         b_dev.step_device(d_act.data_ptr(), d_obs.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), d_tr.data_ptr(),
                           stream.cuda_stream)
         stream.synchronize()

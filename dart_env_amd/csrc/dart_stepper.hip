@@ -231,6 +231,14 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
         int a = add(pl, 2, d0, ax, Rpj, ppj, I3, Z3);
         last = add(a, 2, d0 + 1, ax + 3, I3, Z3, Rpo, ppo);
       } break;
+      case DART_JT_FREE: {   // translation x y z (dofs d0+3..5), then rotations x y z (dofs d0..d0+2) re-centred on the pose: see spatial_kernel.hpp
+        if (b != 0 || c.parent[b] >= 0 || d0 != 0) return "only the root body may hang on a free joint";
+        int t1 = add(pl, 1, d0 + 3, EX, Rpj, ppj, I3, Z3); int t2 = add(t1, 1, d0 + 4, EY, I3, Z3, I3, Z3);
+        int t3 = add(t2, 1, d0 + 5, EZ, I3, Z3, I3, Z3);
+        int r1 = add(t3, 2, d0, EX, I3, Z3, I3, Z3); int r2 = add(r1, 2, d0 + 1, EY, I3, Z3, I3, Z3);
+        last = add(r2, 2, d0 + 2, EZ, I3, Z3, Rpo, ppo);
+        M.free_root = 1; M.free_link = last;
+      } break;
       default: return "unsupported joint type";
     }
     if (last < 0) return "too many links";
@@ -357,7 +365,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   M.ground_y = (Real)c.ground_y; M.mu = (Real)c.friction; M.erp_dt = (Real)(c.erp / c.dt); M.max_erv = (Real)c.max_erv;
   M.limit_erp_dt = (Real)(c.limit_erp / c.dt); M.cfm1 = (Real)(1.0 + c.cfm); M.ccfm1 = (Real)(1.0 + c.contact_cfm);
   if (physics_only) { M.task = 0; return ""; }   // dynamics getters: geometry, inertia and topology only
-  if (c.task < DART_TASK_NONE || c.task > DART_TASK_WALKER3D_SPD) return "task not served by the spatial kernel";
+  if (c.task < DART_TASK_NONE || c.task > DART_TASK_DOG) return "task not served by the spatial kernel";
   M.task = c.task; M.frame_skip = c.frame_skip; M.act_dim = c.act_dim; M.obs_dim = c.obs_dim; M.act_dof0 = c.act_dof0;
   M.max_steps = c.max_episode_steps;
   if (c.act_dim > 32 || c.act_dof0 + c.act_dim > c.ndofs) return "action layout";
@@ -384,6 +392,11 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   if (c.task == DART_TASK_CARTPOLE || c.task == DART_TASK_HALFCHEETAH) { M.aux_real[0] = (Real)c.alive_bonus; M.aux_real[1] = (Real)c.ctrl_cost; }
   M.envdt = (Real)(c.dt * c.frame_skip);
   for (int d = 0; d < c.ndofs; d++) { M.spd_kp[d] = (Real)c.spd_kp[d]; M.spd_kd[d] = (Real)c.spd_kd[d]; }
+  if (c.task == DART_TASK_DOG) {   // aux_real = {alive, velocity weight, ctrl cost, max side deviation, height lo, height hi}
+    M.aux_link[0] = body_link[c.aux_body[0]];
+    const double ar[6] = {c.alive_bonus, c.aux_real[0], c.ctrl_cost, c.aux_real[1], c.height_lo, c.height_hi};
+    for (int k = 0; k < 6; k++) M.aux_real[k] = (Real)ar[k];
+  }
   if (c.task == DART_TASK_WALKER3D_SPD) {   // same epilogue as Walker3d: reward = aux_real2[2] dx/dt + alive - ctrl sum a^2 - dev |z|
     M.aux_link[0] = body_link[c.aux_body[0]]; M.aux_link[1] = -1; M.aux_link[2] = -1;
     const double ar[7] = {c.alive_bonus, c.ctrl_cost, 0.0, c.aux_real[0], c.height_lo, c.height_hi, c.penalty_margin};
@@ -537,7 +550,8 @@ std::unique_ptr<Impl> make_impl(const DartModelCard& c, std::string& why, bool a
   {
     auto p = std::make_unique<SpatialImplT<Real>>();
     std::string w = fill_spatial<Real>(c, p->M, false, p->body_link_map);
-    p->extras = c.generic_kernel != 0 || c.task == DART_TASK_SNAKE || c.task == DART_TASK_WALKER3D_SPD || p->M.has_joint_friction != 0;
+    p->extras = c.generic_kernel != 0 || c.task == DART_TASK_SNAKE || c.task == DART_TASK_WALKER3D_SPD || p->M.has_joint_friction != 0 ||
+                p->M.free_root != 0;
     if (w.empty()) return p;
     why += w;
   }
@@ -594,6 +608,7 @@ static int dynamics_impl(DartStepper* h, double* mass, double* bias) {
     auto M = std::make_unique<SpatialModel<Real>>();
     std::string w = fill_spatial<Real>(h->card, *M, true);
     if (!w.empty()) { h->err = "dynamics getters: " + w; return DART_E_UNSUPPORTED; }
+    if (M->free_root) { h->err = "dynamics getters: free root joint (the kernel's internal coordinates differ from DART's)"; return DART_E_UNSUPPORTED; }
     CHK(h, hipMalloc(&h->dyn_model, sizeof(SpatialModel<Real>)));
     CHK(h, hipMemcpy(h->dyn_model, M.get(), sizeof(SpatialModel<Real>), hipMemcpyHostToDevice));
     h->dyn_lds = sp_lds_bytes(M->nl, M->n, sizeof(Real), M->maxm, M->maxcp);

@@ -71,6 +71,8 @@ struct SpatialModel {
   Real* cf_store;                    // [n_envs][n] generalized constraint forces of each env's last world step (task 12)
   Real jfric_dt[SP_MAXN];            // Coulomb joint friction * dt: impulse bound of the dof's friction row (0 = none)
   int has_joint_friction;
+  int free_root;                     // 1: body 0 hangs on a DART FreeJoint (public q[0:3] rotation vector, dq[0:6] body twist)
+  int free_link;                     // the last of the six root links (carries the body); its joint rotation is Rz(c) R0
   int maxm, maxcp;                   // LCP rows / contact points this model's LDS block is carved for
   int npairs, pair_a[SP_MAXPAIRS], pair_b[SP_MAXPAIRS];   // link-link contact candidates: shape slots, a < b
   int sh_link[SP_MAXS], sh_type[SP_MAXS];
@@ -130,6 +132,7 @@ struct SpLds {
   int* cplink;   // [maxcp] first link
   int* cplinkB;  // [maxcp] second link of a link-link contact, -1 for the ground
   Real* sinv;    // [n]: 1 / L_jj of the mass-matrix Cholesky factor
+  Real* root;    // [24] free root joint: R (9), p (3), body twist w v (6), Euler X-Y-Z of R (3)
   Real* cf;      // [n]: J^T lambda / dt of the previous world step (pydart2 constraint_forces(), SPD task only)
   Real* misc;    // [16]: roff(3), scalars
   int* imisc;    // [8]: ncp, m, contact flags
@@ -157,6 +160,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   S.misc = p; p += 16;
   S.sinv = p; p += n;
   S.cf = p; p += n;
+  S.root = p; p += 24;
   S.rdof = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
   S.rfidx = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
   S.cplink = (int*)p; p += maxcp * sizeof(int) / sizeof(Real) + 1;
@@ -169,7 +173,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp) {
   const size_t lw = sp_lw_aliases_links(nl, maxm) ? 0 : (size_t)sp_tri(maxm) + maxm;
   size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(maxm + 1) * n + sp_tri(maxm) + lw + 5 * maxm +
-                 maxcp * 7 + 16;
+                 maxcp * 7 + 16 + 24;
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }
 
@@ -214,7 +218,11 @@ __device__ __forceinline__ void sp_kinematics(const SpatialModel<Real>& Md, SpLd
     }
     Real Ri[9];
     V3<Real> pi = pm;
-    if (Md.post_ident[i]) { for (int k = 0; k < 9; k++) Ri[k] = Rm[k]; }
+    if (Md.free_root && i == Md.free_link) {   // joint rotation Rz(c) R0 (see sp_free_root_to_internal)
+      Real T[9];
+      mulRR(Rm, S.root, T);
+      mulRR(T, Md.Rpost[i], Ri); pi = pm + mulR(T, ld3(Md.ppost[i]));
+    } else if (Md.post_ident[i]) { for (int k = 0; k < 9; k++) Ri[k] = Rm[k]; }
     else { mulRR(Rm, Md.Rpost[i], Ri); pi = pm + mulR(Rm, ld3(Md.ppost[i])); }
     for (int k = 0; k < 9; k++) L[LK_R + k] = Ri[k];
     st3(L + LK_P, pi);
@@ -281,6 +289,14 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
     for (int k = 0; k < SP_LCONST; k++) G[k] = g[k];
   }
   const V3<Real> ax = ld3(G + LC_AXIS);
+  if (EXTRAS && Md.free_root && lane == Md.free_link) {   // joint rotation Rz(c) R0: fold R0 into the joint-to-child transform
+    Real T[9];
+    mulRR(S.root, G + LC_RPOST, T);
+    const V3<Real> t = mulR(S.root, ld3(G + LC_PPOST));
+    for (int k = 0; k < 9; k++) G[LC_RPOST + k] = T[k];
+    st3(G + LC_PPOST, t);
+    st3(G + LC_AXR, v3<Real>(T[0] * ax.x + T[3] * ax.y + T[6] * ax.z, T[1] * ax.x + T[4] * ax.y + T[7] * ax.z, T[2] * ax.x + T[5] * ax.y + T[8] * ax.z));
+  }
   Real R[9];
   V3<Real> p;
   {
@@ -743,6 +759,103 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
   __syncthreads();
 }
 
+// ------------------------------------------------------------------ DART FreeJoint root (dog.skel)
+// Public coordinates: q[0:3] rotation vector, q[3:6] translation, dq[0:6] = twist of the child joint frame in that frame;
+// DART integrates the pose as Q <- Q * [exp(w dt), v dt].  The dynamics run on the internal chain (translation x y z,
+// rotations about x y z in a chart centred on the current orientation); S.root keeps R, p and the twist, the internal
+// coordinates are re-derived from them before every world
+// step and the new velocities are mapped back with the exact instantaneous Jacobian -- only the parametrisation
+// differs from DART, not the integrator.
+template <class Real>
+__device__ __forceinline__ void sp_so3_exp(V3<Real> r, Real* R) {
+  const Real th2 = dot(r, r), th = sqrt(th2);
+  Real a, b;
+  if (th < Real(1e-4)) { a = Real(1) - th2 / Real(6); b = Real(0.5) - th2 / Real(24); }
+  else { Real sn, cs; sincos_<Real>(th, sn, cs); a = sn / th; b = (Real(1) - cs) / th2; }
+  const Real K[9] = {0, -r.z, r.y, r.z, 0, -r.x, -r.y, r.x, 0};
+  Real K2[9];
+  mulRR(K, K, K2);
+  for (int k = 0; k < 9; k++) R[k] = ((k % 4 == 0) ? Real(1) : Real(0)) + a * K[k] + b * K2[k];
+}
+// log map through the unit quaternion (largest-pivot extraction, then 2 atan2(|v|, w)): well conditioned at every angle,
+// including rotations by pi where acos(trace) and R - R^T lose half of the digits -- the pose makes this round trip once per
+// env step because the public state is DART's rotation vector.
+template <class Real>
+__device__ __forceinline__ V3<Real> sp_so3_log(const Real* R) {
+  const Real tr = R[0] + R[4] + R[8];
+  Real w, x, y, z;
+  if (tr > Real(0)) {
+    const Real s = sqrt(tr + Real(1)) * Real(2);
+    w = s * Real(0.25); x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s;
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    const Real s = sqrt(Real(1) + R[0] - R[4] - R[8]) * Real(2);
+    w = (R[7] - R[5]) / s; x = s * Real(0.25); y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s;
+  } else if (R[4] > R[8]) {
+    const Real s = sqrt(Real(1) + R[4] - R[0] - R[8]) * Real(2);
+    w = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; y = s * Real(0.25); z = (R[5] + R[7]) / s;
+  } else {
+    const Real s = sqrt(Real(1) + R[8] - R[0] - R[4]) * Real(2);
+    w = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; z = s * Real(0.25);
+  }
+  if (w < Real(0)) { w = -w; x = -x; y = -y; z = -z; }   // angle in [0, pi]
+  const Real nv = sqrt(x * x + y * y + z * z);
+  const Real k = nv < Real(1e-6) ? Real(2) / w : Real(2) * atan2(nv, w) / nv;
+  return v3<Real>(x * k, y * k, z * k);
+}
+// S.root -> internal coordinates of the six root links (lane 0).  The rotation chart is centred on the current orientation:
+// joint rotation = Rx(a) Ry(b) Rz(c) R0 with R0 = S.root[0:9] and a = b = c = 0, so the rates are the angular velocity in
+// the joint's parent frame (E = I) and the chart has no singularity however far the body turns; R0 enters the forward pass
+// as part of the last root link's joint-to-child transform (sp_forward / sp_kinematics).
+template <class Real>
+__device__ __forceinline__ void sp_free_root_to_internal(SpLds<Real>& S) {
+  const Real* R = S.root;
+  const V3<Real> ww = mulR(R, ld3(S.root + 12)), pd = mulR(R, ld3(S.root + 15));
+  S.q[0] = Real(0); S.q[1] = Real(0); S.q[2] = Real(0);
+  S.q[3] = S.root[9]; S.q[4] = S.root[10]; S.q[5] = S.root[11];
+  S.dq[0] = ww.x; S.dq[1] = ww.y; S.dq[2] = ww.z;
+  S.dq[3] = pd.x; S.dq[4] = pd.y; S.dq[5] = pd.z;
+}
+// after the velocity update: new internal rates (at the old pose) -> new body twist; DART's pose update
+template <class Real>
+__device__ __forceinline__ void sp_free_root_advance(SpLds<Real>& S, Real dt) {
+  Real* R = S.root;
+  const V3<Real> ww = v3<Real>(S.dq[0], S.dq[1], S.dq[2]);
+  const V3<Real> pd = v3<Real>(S.dq[3], S.dq[4], S.dq[5]);
+  const V3<Real> wb = v3<Real>(R[0] * ww.x + R[3] * ww.y + R[6] * ww.z, R[1] * ww.x + R[4] * ww.y + R[7] * ww.z, R[2] * ww.x + R[5] * ww.y + R[8] * ww.z);
+  const V3<Real> vb = v3<Real>(R[0] * pd.x + R[3] * pd.y + R[6] * pd.z, R[1] * pd.x + R[4] * pd.y + R[7] * pd.z, R[2] * pd.x + R[5] * pd.y + R[8] * pd.z);
+  st3(S.root + 12, wb); st3(S.root + 15, vb);
+  S.root[9] += dt * pd.x; S.root[10] += dt * pd.y; S.root[11] += dt * pd.z;   // p += R v_b dt = pdot dt
+  Real dR[9], Rn[9];
+  sp_so3_exp<Real>(wb * dt, dR);
+  mulRR(R, dR, Rn);
+  for (int k = 0; k < 9; k++) R[k] = Rn[k];
+}
+// DART integrates the BODY-FRAME twist: twist' = twist + dt twist_acc.  With dq_int = T(q) twist the accelerations map as
+// qdd_int = T twist_acc + Tdot twist, so the internal velocity that corresponds to DART's unconstrained one is
+// dq_int + dt qdd_int - dt Tdot twist:  rotation (E rates = R w_b): -Tdot twist = E^-1 Edot rates = (rb rc, -ra rc, ra rb) at
+// the chart centre;  translation (pdot = R v_b): -Tdot twist = -(w x pdot).  Applied to S.dq[0:6] after the bias forces have
+// been computed from the true velocities; every later use of S.dq in the world step is at velocity level.
+template <class Real>
+__device__ __forceinline__ void sp_free_root_velocity_correction(SpLds<Real>& S, Real dt) {
+  const Real ra = S.dq[0], rb = S.dq[1], rc = S.dq[2];
+  const V3<Real> wxp = cross(v3<Real>(ra, rb, rc), v3<Real>(S.dq[3], S.dq[4], S.dq[5]));
+  S.dq[0] += dt * (rb * rc); S.dq[1] -= dt * (ra * rc); S.dq[2] += dt * (ra * rb);
+  S.dq[3] -= dt * wxp.x; S.dq[4] -= dt * wxp.y; S.dq[5] -= dt * wxp.z;
+}
+// public root coordinates (already in S.q / S.dq[0:6]) -> S.root
+template <class Real>
+__device__ __forceinline__ void sp_free_root_load(SpLds<Real>& S) {
+  sp_so3_exp<Real>(v3<Real>(S.q[0], S.q[1], S.q[2]), S.root);
+  for (int k = 0; k < 3; k++) { S.root[9 + k] = S.q[3 + k]; S.root[12 + k] = S.dq[k]; S.root[15 + k] = S.dq[3 + k]; }
+}
+// S.root -> public coordinates in S.q / S.dq[0:6]
+template <class Real>
+__device__ __forceinline__ void sp_free_root_store(SpLds<Real>& S) {
+  const V3<Real> r = sp_so3_log<Real>(S.root);
+  S.q[0] = r.x; S.q[1] = r.y; S.q[2] = r.z;
+  for (int k = 0; k < 3; k++) { S.q[3 + k] = S.root[9 + k]; S.dq[k] = S.root[12 + k]; S.dq[3 + k] = S.root[15 + k]; }
+}
+
 // ------------------------------------------------------------------ box-box contacts between two links
 // ODE's dBoxBox (the routine behind DART's ODE detector for two boxes): separating-axis test over the 15 axes with the
 // 1.05 preference for face axes; edge-edge -> one point midway between the closest points of the two edges; face case
@@ -938,6 +1051,10 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
                                               int* contact_flags) {
   const int n = Md.n, nl = Md.nl;
   unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
+  if (EXTRAS && Md.free_root) {
+    if (lane == 0) sp_free_root_to_internal<Real>(S);
+    __syncthreads();
+  }
   // tree recursions level by level: links of equal depth are independent, one lane each
   if (lane == 0) sp_root_offset<Real>(Md, S);
   sp_forward<Real, EXTRAS>(lc, Md, S, lane, (int64_t)blockIdx.x);   // lane i owns link i
@@ -948,6 +1065,10 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   }
   if (lane < nl) sp_link_rhs<Real, EXTRAS>(lc, Md, S, lane);
   __syncthreads();
+  if (EXTRAS && Md.free_root) {
+    if (lane == 0) sp_free_root_velocity_correction<Real>(S, Md.dt);
+    __syncthreads();
+  }
   SP_TICK(0);
   if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
   else if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[TL(lane, k)] = Real(0); S.H[TL(lane, lane)] = Real(1); }
@@ -1234,6 +1355,10 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   SP_TICK(9);
   if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
   __syncthreads();
+  if (EXTRAS && Md.free_root) {   // the six root entries just advanced are placeholders: the pose lives in S.root
+    if (lane == 0) sp_free_root_advance<Real>(S, Md.dt);
+    __syncthreads();
+  }
   (void)nl;
 }
 
@@ -1451,10 +1576,11 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
       else
         S.tau[dd] = cl * Md.act_scale[k];
     }
+    if (EXTRAS && Md.free_root) { sp_free_root_load<Real>(S); sp_free_root_to_internal<Real>(S); }   // S.q / S.dq: internal from here
     // link poses are needed before the step only by the tasks that measure progress on a body (3, 4) or a tip (11), after
     // it only by the tasks whose reward / done / observation read a body pose
-    if (Md.task == 3 || Md.task == 4 || Md.task == 11 || Md.task == 12) sp_kinematics<Real>(Md, S);
-    sh_scal[0] = (Md.task == 3 || Md.task == 4 || Md.task == 12) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
+    if (Md.task == 3 || Md.task == 4 || Md.task == 11 || Md.task == 12 || Md.task == 13) sp_kinematics<Real>(Md, S);
+    sh_scal[0] = (Md.task == 3 || Md.task == 4 || Md.task == 12 || Md.task == 13) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
     if (Md.task == 11) {   // DartReacher3d: distance to the target BEFORE the step, and sum tau^2 (reacher.py:23-27)
       const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - ld3(tstate + 4 * e);
       sh_scal[0] = sqrt(dot(vec, vec));
@@ -1471,13 +1597,32 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
   const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task >= 10;
+  const bool pose_reset = pose_last && Md.task != 13;   // the dog's observation holds no body pose
   if (lane == 0) {
+    if (EXTRAS && Md.free_root) sp_free_root_to_internal<Real>(S);   // internal coordinates of the final pose
     if (pose_last) sp_kinematics<Real>(Md, S);
     Real rew = Real(0);
     bool task_done = false;
+    Real dog_x = Real(0), dog_h = Real(0), dog_side = Real(0);
+    if (Md.task == 13) {
+      const Real* Lb = S.link + Md.aux_link[0] * SP_LINKF;
+      dog_x = Lb[LK_C] + S.misc[0]; dog_h = Lb[LK_C + 1] + S.misc[1]; dog_side = fabs(Lb[LK_C + 2] + S.misc[2]);
+    }
+    if (EXTRAS && Md.free_root) sp_free_root_store<Real>(S);          // S.q / S.dq: public coordinates again
+    if (Md.task == 13) {   // DartDogEnv.step (dog.py:28-46)
+      rew = Md.aux_real[1] * (dog_x - sh_scal[0]) * Md.inv_envdt;
+      rew += Md.aux_real[0];
+      rew -= Md.aux_real[2] * sq_sum;
+      bool ok = true;
+      for (int i = 0; i < Md.n; i++) {
+        ok = ok && isfinite(S.q[i]) && isfinite(S.dq[i]) && (fabs(S.dq[i]) < Md.s_max);
+        if (i >= 2) ok = ok && (fabs(S.q[i]) < Md.s_max);
+      }
+      task_done = !(ok && dog_h > Md.aux_real[4] && dog_h < Md.aux_real[5] && dog_side < Md.aux_real[3]);
+    }
     if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, tstate[4 * e], cflags, rew);
     else if (Md.task == 3 || Md.task == 12) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
-    else if (Md.task >= 5) task_done = sp_simple_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
+    else if (Md.task >= 5 && Md.task != 13) task_done = sp_simple_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     else if (Md.task == 1 || Md.task == 2) task_done = sp_planar_task_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
     if (Md.task == 10 || Md.task == 11) {   // reachers: reward from the tip-target distance (2-D: after, 3-D: before the step)
       const V3<Real> tgt = ld3(tstate + 4 * e);
@@ -1520,7 +1665,7 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
     __syncthreads();
     if (lane == 0) {
       episode[e] = ep;
-      if (pose_last) sp_kinematics<Real>(Md, S);
+      if (pose_reset) sp_kinematics<Real>(Md, S);
       if (Md.task == 4) tstate[4 * e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
       cflags[0] = 0; cflags[1] = 0;
     }

@@ -9,3 +9,4 @@ from .cartpole_swingup import DartCartPoleSwingUpEnv, DartDoubleInvertedPendulum
 from .snake_7link import DartSnake7LinkEnv  # noqa: F401
 from .reacher import DartReacher2dEnv, DartReacherEnv  # noqa: F401
 from .walker3d_spd import DartWalker3dSPDEnv  # noqa: F401
+from .dog import DartDogEnv  # noqa: F401

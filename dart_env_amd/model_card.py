@@ -26,7 +26,7 @@ CARD_VERSION = 1
 
 TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER, TASK_CARTPOLE, TASK_HALFCHEETAH = 0, 1, 2, 3, 4, 5, 6
 TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_SNAKE, TASK_REACHER2D, TASK_REACHER3D = 7, 8, 9, 10, 11
-TASK_WALKER3D_SPD = 12
+TASK_WALKER3D_SPD, TASK_DOG = 12, 13
 
 
 class DartModelCard(C.Structure):
@@ -212,8 +212,17 @@ WALKER3D_SPD = TaskSpec(
     angle_max=0.54, alive_bonus=1.0, ctrl_cost=1e-2, limit_penalty=0.0, aux_body_names=["h_torso_aux"], aux_ints=[18, 12],
     aux_real=[0.1, 0.45], contact_cfm=1e-4, all_bodies_collide=True, self_collision=True, spd_kp=_SPD_KP)
 
+# DartDog-v1 -- reference gym/envs/dart/dog.py:9-65: quadruped on a FREE root joint (22 dofs), 16 actions x 200 on dofs 6..,
+# reward 0.6 dx/dt + 1 - 1e-3 sum a^2 (:35-37), done on height outside (0.7, 1.8) or |z| >= 0.4 (:40-41), obs q[1:], clip(dq)
+# in DART's FreeJoint coordinates (rotation vector first); gym/envs/__init__.py:247-251
+DOG = TaskSpec(
+    env_id="DartDog-v1", model="dog", task=TASK_DOG, frame_skip=4, act_dim=16, obs_dim=43, act_dof0=6, act_scale=[200.0] * 16,
+    max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1, height_lo=0.7, height_hi=1.8,
+    angle_max=np.inf, alive_bonus=1.0, ctrl_cost=1e-3, limit_penalty=0.0, aux_body_names=["main_body"], aux_real=[0.6, 0.4],
+    contact_cfm=1e-4, all_bodies_collide=True)
+
 TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH, CARTPOLE_SWINGUP,
-                               DOUBLE_PENDULUM, SNAKE, REACHER2D, REACHER3D, WALKER3D_SPD)}
+                               DOUBLE_PENDULUM, SNAKE, REACHER2D, REACHER3D, WALKER3D_SPD, DOG)}
 # tasks whose reset_model draws more than the two uniform vectors: the host draws them (see envs/dart_env.py)
 HOST_RESET_TASKS = (TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D, TASK_REACHER3D)
 # tasks with per-env state beyond (q, dq) that reset_model draws (the reach target): dart_set_task_state

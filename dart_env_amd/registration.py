@@ -18,14 +18,14 @@ def spec(env_id):
 
 
 def make(env_id, **kwargs):
-    from .envs import (DartCartPoleEnv, DartCartPoleSwingUpEnv, DartDoubleInvertedPendulumEnv, DartHalfCheetahEnv, DartHopperEnv, DartHumanWalkerEnv, DartReacher2dEnv, DartReacherEnv, DartSnake7LinkEnv, DartWalker2dEnv,
+    from .envs import (DartCartPoleEnv, DartCartPoleSwingUpEnv, DartDogEnv, DartDoubleInvertedPendulumEnv, DartHalfCheetahEnv, DartHopperEnv, DartHumanWalkerEnv, DartReacher2dEnv, DartReacherEnv, DartSnake7LinkEnv, DartWalker2dEnv,
                        DartWalker3dEnv, DartWalker3dSPDEnv)
     cls = {"DartHopper-v1": DartHopperEnv, "DartWalker2d-v1": DartWalker2dEnv,
            "DartWalker3d-v1": DartWalker3dEnv, "DartHumanWalker-v1": DartHumanWalkerEnv,
            "DartCartPole-v1": DartCartPoleEnv, "DartHalfCheetah-v1": DartHalfCheetahEnv,
            "DartCartPoleSwingUp-v1": DartCartPoleSwingUpEnv, "DartDoubleInvertedPendulumEnv-v1": DartDoubleInvertedPendulumEnv,
            "DartSnake7Link-v1": DartSnake7LinkEnv, "DartReacher-v1": DartReacher2dEnv, "DartReacher3d-v1": DartReacherEnv,
-           "DartWalker3dSPD-v1": DartWalker3dSPDEnv}
+           "DartWalker3dSPD-v1": DartWalker3dSPDEnv, "DartDog-v1": DartDogEnv}
     s = spec(env_id)
     env = cls[env_id](**kwargs)
     env.spec = s

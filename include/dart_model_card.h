@@ -68,6 +68,9 @@ enum {
                                  stable-PD law with M, c and the previous step's constraint forces (:40-55, env dt in the law),
                                  clipped to act_scale; reward aux_real[1] dx/dt + 1 - aux_real[2] sum a^2 - aux_real[3] |z|;
                                  done as Walker3d with angle_max 0.54; obs q[1:], clip(dq) */
+  DART_TASK_DOG = 13,        /* reference gym/envs/dart/dog.py:28-46 (DartDog-v1): free root joint; reward aux_real[0] dx/dt + 1 -
+                                 ctrl_cost sum a^2 on bodynodes[0]'s COM, done on height outside (height_lo, height_hi), side
+                                 deviation >= aux_real[1] or a broken state; obs q[1:], clip(dq) in DART's FreeJoint coordinates */
   DART_TASK_DOUBLE_PENDULUM = 8 /* reference gym/envs/dart/inverted_double_pendulum.py:19-53: obs [q0, sin q1..2, cos q1..2,
                                  dq], height = 2 (y(aux_body[1]) - y(aux_body[0]) - aux_real[4]) / aux_real[5], reward
                                  aux_real[0] - (aux_real[1] q0^2 + (height - 2)^2) - (aux_real[2] dq1^2 + aux_real[3] dq2^2),

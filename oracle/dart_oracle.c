@@ -72,8 +72,14 @@ typedef struct OracleWorld {
   int nl, n;
   Link L[MAXL];
   int body_link[DART_MAX_BODIES];
-  /* state */
+  /* state (public coordinates: what pydart2's skel.q / skel.dq hold) */
   double q[MAXN], dq[MAXN], tau[MAXN];
+  /* DART FreeJoint root (dog.skel): q[0:3] = rotation vector, q[3:6] = translation, dq[0:6] = twist of the child joint frame
+   * expressed in that frame [w; v]; positions integrate as Q <- Q * [exp(w dt), v dt].  The dynamics run on an internal chain
+   * of 1-dof links (translation x y z, then rotations about x y z in a chart re-centred on the current orientation) whose coordinates
+   * qi / dqi are re-derived from (q, dq) before every use; velocities are mapped back with the exact instantaneous Jacobian, so only the parametrisation differs from DART. */
+  int free_root, free_rot_link;
+  double qi[MAXN], dqi[MAXN], R0[9], free_Tpost[16];
   double time;
   /* solver options */
   int solver;       /* 0 = exact (block principal pivoting), 1 = PGS fixed count */
@@ -295,6 +301,16 @@ OracleWorld* oracle_create(const DartModelCard* card) {
         int a = add_link(w, pl, DART_JT_REVOLUTE, d0, ax, Tpj, NULL);
         last = add_link(w, a, DART_JT_REVOLUTE, d0 + 1, ax + 3, NULL, Tcj);
       } break;
+      case DART_JT_FREE: { /* translation x y z (dofs d0+3..5), then rotations x y z (dofs d0..d0+2); see OracleWorld.free_root */
+        if (b != 0 || card->parent[b] >= 0 || d0 != 0) { free(w); return NULL; }
+        int a = add_link(w, pl, DART_JT_PRISMATIC, d0 + 3, ex, Tpj, NULL);
+        int c2 = add_link(w, a, DART_JT_PRISMATIC, d0 + 4, ey, NULL, NULL);
+        int c3 = add_link(w, c2, DART_JT_PRISMATIC, d0 + 5, ez, NULL, NULL);
+        int r1 = add_link(w, c3, DART_JT_REVOLUTE, d0, ex, NULL, NULL);
+        int r2 = add_link(w, r1, DART_JT_REVOLUTE, d0 + 1, ey, NULL, NULL);
+        last = add_link(w, r2, DART_JT_REVOLUTE, d0 + 2, ez, NULL, Tcj);
+        w->free_root = 1; w->free_rot_link = last; memcpy(w->free_Tpost, w->L[last].Tpost, sizeof w->free_Tpost);
+      } break;
       default: free(w); return NULL;
     }
     w->body_link[b] = last;
@@ -330,18 +346,90 @@ void oracle_reset(OracleWorld* w) {
 }
 
 /* ------------------------------------------------------------------ kinematics */
+
+/* ------------------------------------------------------------------ free-joint coordinate maps */
+static void so3_exp(const double* r, double* R) {
+  double th = sqrt(dot3(r, r));
+  double a = th < 1e-8 ? 1.0 - th * th / 6.0 : sin(th) / th, b = th < 1e-8 ? 0.5 - th * th / 24.0 : (1.0 - cos(th)) / (th * th);
+  double K[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double k2 = 0;
+      for (int k = 0; k < 3; k++) k2 += K[3 * i + k] * K[3 * k + j];
+      R[3 * i + j] = (i == j ? 1.0 : 0.0) + a * K[3 * i + j] + b * k2;
+    }
+}
+/* log map through the unit quaternion (Shepperd's largest-pivot extraction), angle = 2 atan2(|v|, w) in [0, pi] */
+static void so3_log(const double* R, double* r) {
+  double tr = R[0] + R[4] + R[8], q[4]; /* w x y z */
+  if (tr > 0) {
+    double s = 2.0 * sqrt(tr + 1.0);
+    q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s;
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    double s = 2.0 * sqrt(1.0 + R[0] - R[4] - R[8]);
+    q[0] = (R[7] - R[5]) / s; q[1] = 0.25 * s; q[2] = (R[1] + R[3]) / s; q[3] = (R[2] + R[6]) / s;
+  } else if (R[4] > R[8]) {
+    double s = 2.0 * sqrt(1.0 + R[4] - R[0] - R[8]);
+    q[0] = (R[2] - R[6]) / s; q[1] = (R[1] + R[3]) / s; q[2] = 0.25 * s; q[3] = (R[5] + R[7]) / s;
+  } else {
+    double s = 2.0 * sqrt(1.0 + R[8] - R[0] - R[4]);
+    q[0] = (R[3] - R[1]) / s; q[1] = (R[2] + R[6]) / s; q[2] = (R[5] + R[7]) / s; q[3] = 0.25 * s;
+  }
+  if (q[0] < 0) for (int a = 0; a < 4; a++) q[a] = -q[a];
+  double nv = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  double k = nv < 1e-12 ? 2.0 / q[0] : 2.0 * atan2(nv, q[0]) / nv;
+  for (int a = 0; a < 3; a++) r[a] = k * q[1 + a];
+}
+/* public (q, dq) -> internal (qi, dqi); identity unless the root is a FreeJoint.  The rotation chart is re-centred on the
+ * current orientation R0 = exp(q[0:3]): joint rotation = Rx(a) Ry(b) Rz(c) R0 with a = b = c = 0, so the rate matrix E is the
+ * identity (rates = angular velocity in the joint's parent frame) and there is no chart singularity however far the body turns. */
+static void sync_internal(OracleWorld* w) {
+  memcpy(w->qi, w->q, sizeof w->qi); memcpy(w->dqi, w->dq, sizeof w->dqi);
+  if (!w->free_root) return;
+  double* R = w->R0;
+  so3_exp(w->q, R);
+  for (int a = 0; a < 3; a++) {                                /* w_parent = R w_body, pdot = R v_body */
+    w->qi[a] = 0.0;                                            /* qi[3:6] = translation (same slots) */
+    w->dqi[a] = R[3 * a] * w->dq[0] + R[3 * a + 1] * w->dq[1] + R[3 * a + 2] * w->dq[2];
+    w->dqi[3 + a] = R[3 * a] * w->dq[3] + R[3 * a + 1] * w->dq[4] + R[3 * a + 2] * w->dq[5];
+  }
+  /* joint transform Rz(c) R0: R0 is folded into the last root link's joint-to-child transform, Tpost_eff = Tpost R0^T */
+  Link* l = &w->L[w->free_rot_link];
+  double Rt[16];
+  mat4_identity(Rt);
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rt[4 * a + b] = R[3 * b + a];
+  mat4_mul(w->free_Tpost, Rt, l->Tpost);
+  link_set_S(l);
+}
+/* after a world step: new internal velocities vs (at the old pose) -> new public twist, DART's position update */
+static void free_root_advance(OracleWorld* w, const double* vs, double dt) {
+  double wb[3], vb[3], dR[9], Rn[9], step[3];
+  const double* R = w->R0;
+  for (int a = 0; a < 3; a++) {
+    wb[a] = R[a] * vs[0] + R[3 + a] * vs[1] + R[6 + a] * vs[2];          /* R^T w */
+    vb[a] = R[a] * vs[3] + R[3 + a] * vs[4] + R[6 + a] * vs[5];          /* R^T pdot */
+  }
+  for (int a = 0; a < 3; a++) step[a] = wb[a] * dt;
+  so3_exp(step, dR);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rn[3 * i + j] = 0; for (int k = 0; k < 3; k++) Rn[3 * i + j] += R[3 * i + k] * dR[3 * k + j]; }
+  for (int a = 0; a < 3; a++) w->q[3 + a] += dt * vs[3 + a];             /* p += R v_b dt = pdot dt */
+  so3_log(Rn, w->q);
+  for (int a = 0; a < 3; a++) { w->dq[a] = wb[a]; w->dq[3 + a] = vb[a]; }
+}
+
 static void kinematics(OracleWorld* w) {
+  sync_internal(w);
   for (int i = 0; i < w->nl; i++) {
     Link* l = &w->L[i];
     double TJ[16];
     mat4_identity(TJ);
     if (l->jtype == DART_JT_REVOLUTE) {
       double R[9];
-      rot_axis(l->axis, w->q[l->dof], R);
+      rot_axis(l->axis, w->qi[l->dof], R);
       for (int a = 0; a < 3; a++)
         for (int b = 0; b < 3; b++) TJ[4 * a + b] = R[3 * a + b];
     } else if (l->jtype == DART_JT_PRISMATIC) {
-      for (int a = 0; a < 3; a++) TJ[4 * a + 3] = l->axis[a] * w->q[l->dof];
+      for (int a = 0; a < 3; a++) TJ[4 * a + 3] = l->axis[a] * w->qi[l->dof];
     }
     double Tinv[16], T[16];
     mat4_inv_rigid(l->Tpost, Tinv);
@@ -713,15 +801,15 @@ int oracle_step(OracleWorld* w) {
   double dt = c->dt;
   kinematics(w);
   crba(w, w->M);
-  rnea(w, w->dq, NULL, 1, w->C);
+  rnea(w, w->dqi, NULL, 1, w->C);
   /* H = M + dt D + dt^2 K ; rhs = tau - C - D dq - K (q + dt dq - rest) */
   static double H[MAXN * MAXN];
   double rhs[MAXN];
   memcpy(H, w->M, n * n * sizeof(double));
   for (int i = 0; i < n; i++) {
     H[i * n + i] += dt * c->damping[i] + dt * dt * c->stiffness[i];
-    rhs[i] = w->tau[i] - w->C[i] - c->damping[i] * w->dq[i] -
-             c->stiffness[i] * (w->q[i] + dt * w->dq[i] - c->rest[i]);
+    rhs[i] = w->tau[i] - w->C[i] - c->damping[i] * w->dqi[i] -
+             c->stiffness[i] * (w->qi[i] + dt * w->dqi[i] - c->rest[i]);
   }
   if (w->ext_all) {
     static const double E3b[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
@@ -747,7 +835,19 @@ int oracle_step(OracleWorld* w) {
   if (cholesky(H, n) != 0) return -1;
   chol_solve(H, n, rhs);
   double vs[MAXN];
-  for (int i = 0; i < n; i++) vs[i] = w->dq[i] + dt * rhs[i];
+  for (int i = 0; i < n; i++) vs[i] = w->dqi[i] + dt * rhs[i];
+  if (w->free_root) {
+    /* DART integrates the FreeJoint's BODY-FRAME twist: twist' = twist + dt * twist_acc.  With dq_int = T(q) twist the
+     * acceleration maps as qdd_int = T twist_acc + Tdot twist, so the internal unconstrained velocity that corresponds to
+     * DART's is v* - dt Tdot twist:  rotation  E rates = R w_b  ->  -Tdot twist = E^-1 Edot rates;
+     *                                translation  pdot = R v_b  ->  -Tdot twist = -(w x pdot). */
+    /* at the chart centre E = I and Edot rates = (rb rc, -ra rc, ra rb) */
+    double x[3], wxp[3];
+    double ra = w->dqi[0], rb = w->dqi[1], rc = w->dqi[2];
+    x[0] = rb * rc; x[1] = -ra * rc; x[2] = ra * rb;
+    cross3(w->dqi, w->dqi + 3, wxp);
+    for (int a = 0; a < 3; a++) { vs[a] += dt * x[a]; vs[3 + a] -= dt * wxp[a]; }
+  }
 
   /* ---- constraints at q_t ---- */
   static double J[MAXM][MAXN], Y[MAXM][MAXN], A[MAXM * MAXM];
@@ -866,8 +966,8 @@ int oracle_step(OracleWorld* w) {
     if (!c->limited[i]) continue;
     int side = 0;
     double viol = 0;
-    if (w->q[i] <= c->lower[i]) { side = -1; viol = w->q[i] - c->lower[i]; }
-    else if (w->q[i] >= c->upper[i]) { side = +1; viol = w->q[i] - c->upper[i]; }
+    if (w->qi[i] <= c->lower[i]) { side = -1; viol = w->qi[i] - c->lower[i]; }
+    else if (w->qi[i] >= c->upper[i]) { side = +1; viol = w->qi[i] - c->upper[i]; }
     if (!side) continue;
     memset(J[m], 0, sizeof J[m]);
     J[m][i] = 1.0;
@@ -948,7 +1048,13 @@ int oracle_step(OracleWorld* w) {
       w->contact_last[k][7] = (base + 2 < m && findex[base + 2] == base) ? x[base + 2] : 0.0;
     }
   }
-  for (int i = 0; i < n; i++) { w->dq[i] = vs[i]; w->q[i] += dt * vs[i]; w->tau[i] = 0; }
+  if (w->free_root) {
+    free_root_advance(w, vs, dt);
+    for (int i = 6; i < n; i++) { w->dq[i] = vs[i]; w->q[i] += dt * vs[i]; }
+    for (int i = 0; i < n; i++) w->tau[i] = 0;
+  } else {
+    for (int i = 0; i < n; i++) { w->dq[i] = vs[i]; w->q[i] += dt * vs[i]; w->tau[i] = 0; }
+  }
   if (w->ext_all) { memset(w->ext_fb, 0, sizeof w->ext_fb); w->ext_all = 0; }   /* like DART: per-step external forces */
   w->time += dt;
   return 0;
@@ -956,7 +1062,7 @@ int oracle_step(OracleWorld* w) {
 
 /* ------------------------------------------------------------------ introspection (known-answer tests) */
 void oracle_mass_matrix(OracleWorld* w, double* M) { kinematics(w); crba(w, w->M); memcpy(M, w->M, w->n * w->n * sizeof(double)); }
-void oracle_bias(OracleWorld* w, double* C) { kinematics(w); rnea(w, w->dq, NULL, 1, C); }
+void oracle_bias(OracleWorld* w, double* C) { kinematics(w); rnea(w, w->dqi, NULL, 1, C); }
 void oracle_inverse_dynamics(OracleWorld* w, const double* dq, const double* ddq, int with_gravity, double* tau) {
   kinematics(w); rnea(w, dq, ddq, with_gravity, tau);
 }
@@ -986,7 +1092,7 @@ void oracle_body_com_spatial_velocity(OracleWorld* w, int body, double* out6) {
       rel[a] = cm[a] - Wm[4 * a + 3];
     }
     cross3(ww, rel, t);
-    for (int a = 0; a < 3; a++) { out6[a] += ww[a] * w->dq[l->dof]; out6[3 + a] += (vw[a] + t[a]) * w->dq[l->dof]; }
+    for (int a = 0; a < 3; a++) { out6[a] += ww[a] * w->dqi[l->dof]; out6[3 + a] += (vw[a] + t[a]) * w->dqi[l->dof]; }
   }
 }
 void oracle_body_com(OracleWorld* w, int body, double* out3) {
@@ -1012,7 +1118,7 @@ int oracle_last_contacts(const OracleWorld* w, double* out8) {
 double oracle_energy(OracleWorld* w) {
   kinematics(w); crba(w, w->M);
   double ke = 0, pe = 0;
-  for (int i = 0; i < w->n; i++) for (int j = 0; j < w->n; j++) ke += 0.5 * w->dq[i] * w->M[i * w->n + j] * w->dq[j];
+  for (int i = 0; i < w->n; i++) for (int j = 0; j < w->n; j++) ke += 0.5 * w->dqi[i] * w->M[i * w->n + j] * w->dqi[j];
   for (int b = 0; b < w->card.nbodies; b++) {
     double cm[3];
     const double* T = w->W[w->body_link[b]];
@@ -1391,8 +1497,42 @@ static int walker3d_spd_step(OracleWorld* w, const double* a, double* obs, doubl
   return !ok;
 }
 
+/* DartDogEnv.step (dog.py:18-48).  q / dq are DART's FreeJoint coordinates (see OracleWorld.free_root). */
+static int dog_step(OracleWorld* w, const double* a, double* obs, double* reward) {
+  const DartModelCard* c = &w->card;
+  int n = w->n;
+  double tau[MAXN] = {0}, sq = 0, cm[3];
+  for (int k = 0; k < c->act_dim; k++) {
+    double cl = a[k];
+    if (cl > c->act_high[k]) cl = c->act_high[k];
+    if (cl < c->act_low[k]) cl = c->act_low[k];
+    tau[c->act_dof0 + k] = cl * c->act_scale[k];
+    sq += a[k] * a[k];
+  }
+  oracle_body_com(w, c->aux_body[0], cm);
+  double posbefore = cm[0];
+  for (int f = 0; f < c->frame_skip; f++) { oracle_set_forces(w, tau); oracle_step(w); }
+  oracle_body_com(w, c->aux_body[0], cm);
+  double posafter = cm[0], height = cm[1], side = fabs(cm[2]);
+  double envdt = c->dt * c->frame_skip;
+  double r = c->aux_real[0] * (posafter - posbefore) / envdt;
+  r += c->alive_bonus;
+  r -= c->ctrl_cost * sq;
+  *reward = r;
+  int ok = 1;
+  for (int i = 0; i < n; i++) {
+    if (!isfinite(w->q[i]) || !isfinite(w->dq[i])) ok = 0;
+    if (i >= 2 && !(fabs(w->q[i]) < c->state_abs_max)) ok = 0;
+    if (!(fabs(w->dq[i]) < c->state_abs_max)) ok = 0;
+  }
+  if (!(height > c->height_lo && height < c->height_hi && side < c->aux_real[1])) ok = 0;
+  walker3d_obs(w, obs);   /* q[1:], clip(dq) */
+  return !ok;
+}
+
 int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward) {
   const DartModelCard* c = &w->card;
+  if (c->task == DART_TASK_DOG) return dog_step(w, a, obs, reward);
   if (c->task == DART_TASK_WALKER3D_SPD) return walker3d_spd_step(w, a, obs, reward);
   if (c->task == DART_TASK_REACHER2D || c->task == DART_TASK_REACHER3D) return reacher_step(w, a, obs, reward);
   if (c->task == DART_TASK_SNAKE) return snake_step(w, a, obs, reward);
@@ -1453,7 +1593,7 @@ int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward
 void oracle_env_obs(OracleWorld* w, double* obs) {
   const DartModelCard* c = &w->card;
   if (c->task == DART_TASK_HUMANWALKER) { int z[2] = {0, 0}; humanwalker_obs(w, z, obs); return; } /* reset_model zeroes contact_info */
-  if (c->task == DART_TASK_WALKER3D || c->task == DART_TASK_WALKER3D_SPD) { walker3d_obs(w, obs); return; }
+  if (c->task == DART_TASK_WALKER3D || c->task == DART_TASK_WALKER3D_SPD || c->task == DART_TASK_DOG) { walker3d_obs(w, obs); return; }
   if (c->task == DART_TASK_CARTPOLE || c->task == DART_TASK_CARTPOLE_SWINGUP) { qdq_obs(w, 0, obs); return; }
   if (c->task == DART_TASK_DOUBLE_PENDULUM) { double_pendulum_obs(w, obs); return; }
   if (c->task == DART_TASK_REACHER2D || c->task == DART_TASK_REACHER3D) { reacher_obs(w, obs); return; }

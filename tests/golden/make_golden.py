@@ -191,7 +191,7 @@ class StubWorld:
                    "kima_human_edited.skel": None, "walker3d_waist.skel": None,
                    "cartpole.skel": None, "half_cheetah.skel": None, "cartpole_swingup.skel": None,
                    "inverted_double_pendulum.skel": None, "snake_7link.skel": None, "reacher2d.skel": [],
-                   "reacher.skel": []}[name]   # None: every collision shape
+                   "reacher.skel": [], "dog.skel": None}[name]   # None: every collision shape
         model = parse_skel(skel_path, dt=dt, collidable_bodies=contact)
         self.model = model
         self.dt = dt
@@ -203,7 +203,7 @@ class StubWorld:
                 "cartpole_swingup.skel": "DartCartPoleSwingUp-v1",
                 "inverted_double_pendulum.skel": "DartDoubleInvertedPendulumEnv-v1",
                 "snake_7link.skel": "DartSnake7Link-v1", "reacher2d.skel": "DartReacher-v1",
-                "reacher.skel": "DartReacher3d-v1"}[name]
+                "reacher.skel": "DartReacher3d-v1", "dog.skel": "DartDog-v1"}[name]
         if StubWorld.spd and name == "walker3d_waist.skel":
             spec = "DartWalker3dSPD-v1"
         if TASKS[spec].contact_cfm is not None:   # same contact regularisation as the shipped task card
@@ -366,6 +366,9 @@ def main():
     StubWorld.spd = True
     np.savez_compressed(os.path.join(out, "walker3dspd_single_seed0.npz"), **rollout_single(gym, "DartWalker3dSPD-v1", 0, 400))
     StubWorld.spd = False
+    # (14) DartDog-v1: free root joint; the reference's task code reads q / dq in DART's FreeJoint coordinates
+    np.savez_compressed(os.path.join(out, "dog_single_seed0.npz"), **rollout_single(gym, "DartDog-v1", 0, 300))
+    np.savez_compressed(os.path.join(out, "dog_vector4_seed3.npz"), **rollout_vector(gym, "DartDog-v1", 4, 3, 100))
     print("world.step() calls issued by the reference code:", StubWorld.n_steps)
 
 

@@ -568,3 +568,93 @@ def test_walker3d_spd_env_matches_oracle_and_fixture():
         if done:
             assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-6)
     env.close()
+
+
+def test_dog_free_root_joint_matches_oracle_and_fixture():
+    """DartDog-v1: trunk on a DART FreeJoint (rotation vector / body twist coordinates, pose integrated as Q exp(twist dt)).
+    fp64 kernel = oracle through tumbling, leg contacts and resets; state I/O in DART's coordinates; fixture from the
+    reference's Python."""
+    from dart_env_amd.stepper import HipStepper
+    from dart_env_amd.envs import DartDogEnv
+    card = card_for("DartDog-v1")
+    n, nd, na = 48, card.ndofs, card.act_dim
+    rng = np.random.RandomState(31)
+    gpu = HipStepper(card, n, precision=64)
+    ora = OracleBatch(card, n)
+    qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+    qn[: n // 2, :3] += rng.uniform(-0.5, 0.5, (n // 2, 3))          # start half of the dogs tilted and spinning
+    vn[: n // 2, :6] += rng.uniform(-1.0, 1.0, (n // 2, 6))
+    og = gpu.reset(None, qn, vn); ora.reset(None, qn, vn)
+    assert og.shape == (n, 43) and np.allclose(og, ora.obs(), atol=1e-6)
+    q0, dq0 = gpu.get_state()
+    assert np.allclose(q0, qn, atol=1e-12) and np.allclose(dq0, vn, atol=1e-12)       # init pose is zero: state = noise, DART coordinates
+    n_done = 0
+    for t in range(70):
+        a = rng.uniform(-1.2, 1.2, (n, na)).astype(np.float32)
+        og, rg, dg, tg = gpu.step(a)
+        oo, ro, do, to = ora.step(a)
+        qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+        assert np.abs(qg - qo).max() < 1e-7 and np.abs(dqg - dqo).max() < 1e-5, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        assert np.array_equal(dg, do), t
+        assert np.allclose(og, oo, atol=2e-5) and np.allclose(rg, ro, atol=1e-4)
+        n_done += int(do.sum())
+        if do.any():
+            qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+            gpu.reset(do.astype(np.uint8), qn, vn, want_obs=False); ora.reset(do, qn, vn)
+    assert n_done > 5
+    gpu.close()
+    d = np.load(os.path.join(G, "dog_single_seed0.npz"))
+    env = DartDogEnv(precision=64)
+    env.seed(0)
+    assert np.allclose(env.reset(), d["obs0"], atol=1e-6)
+    for t in range(150):
+        ob, r, done, info = env.step(d["actions"][t])
+        assert done == bool(d["done"][t]), t
+        assert np.allclose(ob, d["obs"][t], rtol=1e-6, atol=2e-5) and abs(r - d["reward"][t]) < 1e-4
+        if done:
+            assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-6)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_free_root_chart_has_no_singular_heading():
+    """Dog physics card without gravity and floor: envs that differ only by a rigid rotation of the initial pose -- including
+    headings of exactly +-90 degrees and upside down, the singular directions of any fixed Euler chart -- must produce the
+    same body twists and joint trajectories, in fp64 to roundoff (= oracle) and in fp32 to rounding noise."""
+    from scipy.spatial.transform import Rotation as Rot
+    from dart_env_amd.stepper import HipStepper
+    m = load_model("dog")
+    m.gravity = np.zeros(3); m.ground_y = -np.inf
+    card = build_card(m, None)
+    rots = [Rot.identity(), Rot.from_euler("y", 90, degrees=True), Rot.from_euler("y", -90, degrees=True),
+            Rot.from_euler("x", 180, degrees=True), Rot.from_euler("z", 90, degrees=True), Rot.from_rotvec([0.7, -2.1, 1.3])]
+    n, nd = len(rots), card.ndofs
+    rng = np.random.RandomState(5)
+    dq0 = rng.uniform(-2, 2, nd); qj = rng.uniform(-.3, .3, 16)
+    q0 = np.zeros((n, nd))
+    for i, Q0 in enumerate(rots):
+        q0[i, :3] = Q0.as_rotvec(); q0[i, 3:6] = Q0.apply([0.3, -0.2, 0.5]); q0[i, 6:] = qj
+    v0 = np.tile(dq0, (n, 1))
+    worlds = [OracleWorld(card) for _ in range(n)]
+    for i, w in enumerate(worlds):
+        w.set_state(q0[i], v0[i])
+    for prec, tol_dq, tol_q in ((64, 1e-9, 1e-10), (32, 2e-3, 2e-4)):
+        gpu = HipStepper(card, n, precision=prec)
+        gpu.set_state(q0, v0)
+        for t in range(150):
+            tau = np.zeros((n, nd), dtype=np.float32); tau[:, 6:] = 30 * np.sin(0.07 * t + np.arange(16))
+            gpu.step(tau)
+            if prec == 64:
+                for i, w in enumerate(worlds):
+                    w.set_forces(tau[i].astype(np.float64)); w.step()
+        qg, dqg = gpu.get_state()
+        assert np.isfinite(qg).all() and np.isfinite(dqg).all()
+        if prec == 64:
+            qo = np.stack([w.q for w in worlds]); dqo = np.stack([w.dq for w in worlds])
+            assert np.abs(dqg - dqo).max() < 1e-8 and np.abs(qg[:, 3:] - qo[:, 3:]).max() < 1e-9
+        Rref = Rot.from_rotvec(qg[0, :3]).as_matrix()
+        for i, Q0 in enumerate(rots):
+            assert np.abs(dqg[i] - dqg[0]).max() < tol_dq and np.abs(qg[i, 6:] - qg[0, 6:]).max() < tol_q, (prec, i)
+            Ri = (Q0.inv() * Rot.from_rotvec(qg[i, :3])).as_matrix()
+            assert np.abs(Ri - Rref).max() < tol_q * 10 and np.abs(Q0.inv().apply(qg[i, 3:6]) - qg[0, 3:6]).max() < tol_q * 10, (prec, i)
+        gpu.close()

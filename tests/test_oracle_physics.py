@@ -272,3 +272,102 @@ def test_walker3d_self_collision_keeps_the_legs_apart():
     on, off = overlap_after(True), overlap_after(False)
     print("max leg-leg penetration with / without self-collision:", on, off)
     assert off > 0.03 and 0 < on < 0.01
+
+
+# ------------------------------------------------------------------ DART FreeJoint root (dog.skel)
+def _dog_card(gravity=True, ground=True):
+    from dart_env_amd.model_card import build_card, load_model
+    m = load_model("dog")
+    if not gravity:
+        m.gravity = np.zeros(3)
+    if not ground:
+        m.ground_y = -np.inf
+    return build_card(m, None), m
+
+
+def test_free_joint_coordinates_are_darts():
+    """q[0:3] rotation vector, q[3:6] translation, dq[0:6] body-frame twist: pose and velocities of the trunk."""
+    from scipy.spatial.transform import Rotation as Rot
+    card, m = _dog_card()
+    w = OracleWorld(card)
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        q = np.zeros(22); dq = np.zeros(22)
+        q[:3] = rng.uniform(-1.2, 1.2, 3); q[3:6] = rng.uniform(-1, 1, 3); q[6:] = rng.uniform(-.2, .2, 16)
+        dq[:] = rng.uniform(-1, 1, 22)
+        w.set_state(q, dq)
+        T = w.body_pose(0)
+        R = Rot.from_rotvec(q[:3]).as_matrix()
+        assert np.allclose(T[:3, :3], R, atol=1e-12) and np.allclose(T[:3, 3], np.array([0, 1.25, 0]) + q[3:6], atol=1e-12)
+        sv = w.body_com_spatial_velocity(0)
+        assert np.allclose(sv[:3], R @ dq[:3], atol=1e-12) and np.allclose(sv[3:], R @ dq[3:6], atol=1e-12)   # trunk COM = frame origin
+        q2, dq2 = w.get_state()
+        assert np.array_equal(q2, q) and np.array_equal(dq2, dq)
+
+
+def test_free_flight_conserves_momentum_to_first_order():
+    """No floor: total linear momentum changes by m g t and the angular momentum about the COM stays put, both up to the
+    O(dt) drift of integrating a BODY-FRAME twist the way DART does (Q <- Q exp(twist dt)) -- the drift halves with dt.
+    Without the Jacobian-derivative terms of the coordinate change (-w x v, Edot rates) the drift would be O(1)."""
+    def run(dt, steps):
+        card, m = _dog_card(ground=False)
+        card.dt = dt
+        w = OracleWorld(card)
+        rng = np.random.RandomState(1)
+        q = np.zeros(22); dq = np.zeros(22)
+        q[:3] = [0.3, -0.4, 0.2]; dq[:3] = [1.5, -0.8, 0.6]; dq[3:6] = [0.4, 1.0, -0.3]; dq[6:] = rng.uniform(-2, 2, 16)
+        w.set_state(q, dq)
+        masses = np.array([b.mass for b in m.bodies])
+        inert = [np.asarray(b.inertia).reshape(3, 3) for b in m.bodies]
+
+        def momenta():
+            P = np.zeros(3); L = np.zeros(3); cs = []; vs = []
+            for b in range(9):
+                sv = w.body_com_spatial_velocity(b); c = w.body_com(b); R = w.body_pose(b)[:3, :3]
+                P += masses[b] * sv[3:]; cs.append(c); vs.append(sv)
+            com = sum(masses[b] * cs[b] for b in range(9)) / masses.sum()
+            for b in range(9):
+                R = w.body_pose(b)[:3, :3]
+                L += R @ inert[b] @ R.T @ vs[b][:3] + masses[b] * np.cross(cs[b] - com, vs[b][3:])
+            return P, L
+        P0, L0 = momenta()
+        for t in range(steps):
+            tau = np.zeros(22); tau[6:] = 20 * np.sin(0.05 * t * dt / 0.002 + np.arange(16))
+            w.set_forces(tau); w.step()
+        P1, L1 = momenta()
+        return P0, P1, L0, L1, masses.sum(), steps * dt
+    P0, P1, L0, L1, M, T = run(0.002, 200)
+    g = np.array([0, -M * 9.81 * T, 0])
+    p1 = np.abs(P1 - P0 - g).max(); d1 = np.abs(L1 - L0).max()
+    P0h, P1h, L0h, L1h, _, _ = run(0.001, 400)
+    p2 = np.abs(P1h - P0h - g).max(); d2 = np.abs(L1h - L0h).max()
+    print("linear momentum drift", p1, p2, "angular momentum drift", d1, d2, "|P0|", np.abs(P0).max(), "|L0|", np.abs(L0).max())
+    assert p1 < 0.02 * np.abs(P0).max() and p2 < 0.65 * p1
+    assert d1 < 0.05 * np.abs(L0).max() and d2 < 0.65 * d1
+
+
+def test_free_root_dynamics_do_not_depend_on_the_orientation_chart():
+    """No gravity, no floor: the body-frame twist and the joint trajectory must not depend on where the trunk points -- also
+    when it points exactly along a singular direction of any fixed Euler chart (heading +-90 degrees, upside down): the
+    chart of the internal root chain is re-centred on the current orientation before every world step."""
+    from scipy.spatial.transform import Rotation as Rot
+    card, m = _dog_card(gravity=False, ground=False)
+    rng = np.random.RandomState(5)
+    dq0 = rng.uniform(-2, 2, 22); qj = rng.uniform(-.3, .3, 16)
+
+    def run(Q0):
+        w = OracleWorld(card)
+        q = np.zeros(22); q[:3] = Q0.as_rotvec(); q[3:6] = Q0.apply([0.3, -0.2, 0.5]); q[6:] = qj
+        w.set_state(q, dq0)
+        for t in range(150):
+            tau = np.zeros(22); tau[6:] = 30 * np.sin(0.07 * t + np.arange(16))
+            w.set_forces(tau); w.step()
+        q1, dq1 = w.get_state()
+        return Rot.from_rotvec(q1[:3]), q1[3:6], q1[6:], dq1
+    R_ref, p_ref, qj_ref, dq_ref = run(Rot.identity())
+    for Q0 in (Rot.from_euler("y", 90, degrees=True), Rot.from_euler("y", -90, degrees=True), Rot.from_euler("x", 180, degrees=True),
+               Rot.from_euler("z", 90, degrees=True), Rot.from_rotvec([0.7, -2.1, 1.3])):
+        R1, p1, qj1, dq1 = run(Q0)
+        assert np.allclose(dq1, dq_ref, atol=1e-9) and np.allclose(qj1, qj_ref, atol=1e-10)
+        assert np.allclose((Q0.inv() * R1).as_matrix(), R_ref.as_matrix(), atol=1e-10)
+        assert np.allclose(Q0.inv().apply(p1), p_ref, atol=1e-10)

@@ -24,6 +24,7 @@ ASSETS = {
     "snake7link": "snake_7link.skel",                    # snake_7link.py:18
     "reacher2d": "reacher2d.skel",                       # reacher2d.py:10 (dt 0.01)
     "reacher3d": "reacher.skel",                         # reacher.py:10
+    "dog": "dog.skel",                                   # dog.py:14 (free root joint)
 }
 DT = {"reacher2d": 0.01, "cartpole": 0.02, "halfcheetah": 0.01, "cartpole_swingup": 0.01, "double_pendulum": 0.01}
 

@@ -44,6 +44,9 @@ struct Impl {
   virtual int set_ext_force(int /*body*/, const double* /*host_force*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int set_task_state(hipStream_t, const uint8_t* /*d_mask*/, const double* /*d_values*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int slots() const = 0;
+  virtual int max_contacts() const { return 0; }
+  virtual int set_contact_report(bool /*on*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
+  virtual int get_contacts(hipStream_t, int64_t /*n*/, int32_t* /*count*/, int32_t* /*bodies*/, double* /*point_force*/, int /*max*/) { return DART_E_UNSUPPORTED; }
   bool soa = true;         // state layout: q[n][N] (planar kernels) or q[N][n] (spatial kernel)
   int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
   bool is_static = false;  // true: model constants are compile-time immediates (static_models.hpp)
@@ -181,6 +184,7 @@ void inv_Rp(const double* R, const double* p, double* Ri, double* pi) {
 template <class Real>
 std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool physics_only = false, int* body_link_out = nullptr) {
   memset(&M, 0, sizeof(M));
+  for (int i = 0; i < SP_MAXL; i++) M.link_body[i] = -1;
   if (c.ndofs > SP_MAXN) return "too many dofs";
   int body_link[DART_MAX_BODIES];
   int nl = 0;
@@ -244,6 +248,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     if (last < 0) return "too many links";
     body_link[b] = last;
     M.link_is_body[last] = 1;
+    M.link_body[last] = b;
     M.mass[last] = (Real)c.mass[b];
     for (int k = 0; k < 3; k++) M.com[last][k] = (Real)c.com[b][k];
     for (int k = 0; k < 9; k++) M.inertia[last][k] = (Real)(c.mass[b] > 0 ? c.inertia[b][k] : 0.0);
@@ -412,7 +417,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   }
   M.s_max = (Real)c.state_abs_max; M.v_clip = (Real)c.obs_vel_clip; M.noise = (Real)c.reset_noise; M.noise_v = (Real)c.reset_noise_vel;
   M.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip));
-  M.solver_iters = 200; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.dbg = nullptr;
+  M.solver_iters = 200; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.dbg = nullptr; M.creport = nullptr; M.creport_count = nullptr;
   if (c.task == DART_TASK_NONE && c.obs_dim != 2 * c.ndofs) return "physics-only obs must be [q, dq]";
   return "";
 }
@@ -449,16 +454,18 @@ struct SpatialImplT : Impl {
   }
   void release() override {
     if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); if (d_ext) (void)hipFree(d_ext); if (d_cf) (void)hipFree(d_cf);
+    if (d_creport) (void)hipFree(d_creport); if (d_ccount) (void)hipFree(d_ccount); d_creport = nullptr; d_ccount = nullptr;
     dM = nullptr; init_h = nullptr; d_ext = nullptr; d_cf = nullptr;
   }
   void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
                   float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
-#define SP_LAUNCH(P, X)                                                                                                 \
-  hipLaunchKernelGGL((sp_step_kernel<Real, P, X>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep, \
+#define SP_LAUNCH(P, X, R)                                                                                              \
+  hipLaunchKernelGGL((sp_step_kernel<Real, P, X, R>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep, \
                      act, obs, rew, done, trunc, autoreset, seed, off)
-    if (pairs) { if (extras) SP_LAUNCH(true, true); else SP_LAUNCH(true, false); }
-    else { if (extras) SP_LAUNCH(false, true); else SP_LAUNCH(false, false); }
+    if (M.creport) SP_LAUNCH(true, true, true);   // contact reporting lives in the most general instantiation only
+    else if (pairs) { if (extras) SP_LAUNCH(true, true, false); else SP_LAUNCH(true, false, false); }
+    else { if (extras) SP_LAUNCH(false, true, false); else SP_LAUNCH(false, false, false); }
 #undef SP_LAUNCH
     return hipGetLastError();
   }
@@ -511,6 +518,37 @@ struct SpatialImplT : Impl {
   }
   hipError_t debug_dump(double* out) override { return dbg ? hipMemcpy(out, dbg, sizeof(double) * 160 * (size_t)nenv, hipMemcpyDeviceToHost) : hipErrorInvalidValue; }
   int slots() const override { return M.maxm; }
+  int max_contacts() const override { return M.maxcp; }
+  Real* d_creport = nullptr; int* d_ccount = nullptr;
+  int set_contact_report(bool on, int64_t n) override {
+    if (on && !d_creport) {
+      if (hipMalloc((void**)&d_creport, sizeof(Real) * 8 * (size_t)M.maxcp * (size_t)n) != hipSuccess) return DART_E_HIP;
+      if (hipMalloc((void**)&d_ccount, sizeof(int) * (size_t)n) != hipSuccess) return DART_E_HIP;
+      (void)hipMemset(d_ccount, 0, sizeof(int) * (size_t)n);
+    }
+    M.creport = on ? d_creport : nullptr; M.creport_count = on ? d_ccount : nullptr;
+    upload();
+    return DART_OK;
+  }
+  int get_contacts(hipStream_t s, int64_t n, int32_t* count, int32_t* bodies, double* point_force, int maxc) override {
+    if (!M.creport) return DART_E_INVALID;
+    if (hipStreamSynchronize(s) != hipSuccess) return DART_E_HIP;
+    std::vector<Real> rec(8 * (size_t)M.maxcp * (size_t)n);
+    std::vector<int> cnt((size_t)n);
+    if (hipMemcpy(rec.data(), d_creport, sizeof(Real) * rec.size(), hipMemcpyDeviceToHost) != hipSuccess) return DART_E_HIP;
+    if (hipMemcpy(cnt.data(), d_ccount, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost) != hipSuccess) return DART_E_HIP;
+    for (int64_t e = 0; e < n; e++) {
+      const int k = cnt[(size_t)e] < maxc ? cnt[(size_t)e] : maxc;
+      count[e] = cnt[(size_t)e];
+      for (int c = 0; c < maxc; c++) {
+        const Real* r = rec.data() + ((size_t)e * M.maxcp + c) * 8;
+        const bool live = c < k;
+        if (bodies) { bodies[((size_t)e * maxc + c) * 2] = live ? (int32_t)r[0] : -1; bodies[((size_t)e * maxc + c) * 2 + 1] = live ? (int32_t)r[1] : -1; }
+        if (point_force) for (int a = 0; a < 6; a++) point_force[((size_t)e * maxc + c) * 6 + a] = live ? (double)r[2 + a] : 0.0;
+      }
+    }
+    return DART_OK;
+  }
 };
 
 // generic (runtime-parameter) kernel, or the compile-time specialisation when the card is bit-identical to a baked one
@@ -719,6 +757,7 @@ int dart_query(const DartStepper* h, int what, int64_t* out) {
     case DART_Q_DEVICE: *out = h->device; break;
     case DART_Q_LCP_SLOTS: *out = h->impl->slots(); break;
     case DART_Q_STATIC_KERNEL: *out = h->impl->is_static ? 1 : 0; break;
+    case DART_Q_MAX_CONTACTS: *out = h->impl->max_contacts(); break;
     default: return DART_E_INVALID;
   }
   return DART_OK;
@@ -740,6 +779,11 @@ int dart_configure(DartStepper* h, int key, double value) {
       }
       h->impl->set_stats(value != 0 ? h->d_stats : nullptr);
       break;
+    case DART_CFG_CONTACT_REPORT: {
+      const int rc = h->impl->set_contact_report(value != 0, h->n);
+      if (rc == DART_E_UNSUPPORTED) h->err = "contact reporting: only the generic kernel implements it (card.generic_kernel = 1)";
+      if (rc != DART_OK) return rc;
+    } break;
     case DART_CFG_EPISODE_STATS:
       if (value != 0 && !h->d_ep_ret) {
         const size_t N = (size_t)h->n;
@@ -1039,6 +1083,15 @@ int dart_get_dynamics(DartStepper* h, double* mass_matrix, double* coriolis_grav
   if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
   CHK(h, hipSetDevice(h->device));
   return h->precision == 32 ? dynamics_impl<float>(h, mass_matrix, coriolis_gravity) : dynamics_impl<double>(h, mass_matrix, coriolis_gravity);
+}
+
+int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* point_force, int32_t max_contacts) {
+  if (!h || !count || max_contacts < 0) return DART_E_INVALID;
+  if (h->pending) { h->err = "dart_get_contacts while a step is pending"; return DART_E_PENDING; }
+  const int rc = h->impl->get_contacts(h->stream, h->n, count, bodies, point_force, max_contacts);
+  if (rc == DART_E_INVALID) h->err = "dart_get_contacts: enable DART_CFG_CONTACT_REPORT before stepping";
+  if (rc == DART_E_UNSUPPORTED) h->err = "contact reporting: only the generic kernel implements it (card.generic_kernel = 1)";
+  return rc;
 }
 
 int dart_sync(DartStepper* h) {

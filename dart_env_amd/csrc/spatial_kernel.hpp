@@ -88,6 +88,9 @@ struct SpatialModel {
   int ext_at_joint_origin;     // 1: the force acts at the link's joint origin (redirected from a massless carrier body)
   int ext_link;                // external body force (dart_set_ext_force): link it acts on, at the link frame origin
   const Real* ext_force;       // [n_envs][3] world-frame force per env, nullptr = none
+  int link_body[SP_MAXL];      // card body carried by a link (-1: carrier link of an expanded joint)
+  Real* creport;               // optional [n_envs][maxcp][8]: contacts of the last world step {body a, body b, point, force on a}
+  int* creport_count;          // [n_envs]
   double* dbg;                 // optional [n_envs][160] dump of the last LCP (debug builds of the tests only)
   unsigned long long* stats;   // optional [64]: [0..31] pivoting iterations per solve, [32] PGS fallbacks, [33] solves
 };
@@ -1046,9 +1049,9 @@ __device__ __forceinline__ int sp_box_box(const SpatialModel<Real>& Md, SpLds<Re
 
 // PAIRS: link-link contacts (box pairs, general contact normals); EXTRAS: snake fluid forces, external body force, Coulomb
 // joint friction rows.  Models that need neither run the lean instantiation (HumanWalker: 8 % faster than the full one).
-template <class Real, bool PAIRS, bool EXTRAS>
+template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false>
 __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, const LinkConst<Real>& lc, SpLds<Real>& S, int lane,
-                                              int* contact_flags) {
+                                              int* contact_flags, bool report = false) {
   const int n = Md.n, nl = Md.nl;
   unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
   if (EXTRAS && Md.free_root) {
@@ -1335,6 +1338,25 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       if (lane < m) { D[2 + lane] = (double)S.x[lane]; D[42 + lane] = (double)S.b[lane]; D[82 + lane] = (double)S.hi[lane]; D[122 + lane] = (double)S.A[TI(lane, lane)]; }
     }
   }
+  if (REPORT && report) {   // world.collision_result.contacts (walker2d.py:38-41, human_walker.py:97-106): point, force on the first body
+    if (lane == 0) Md.creport_count[blockIdx.x] = ncp;
+    if (lane < ncp) {
+      Real* out = Md.creport + ((size_t)blockIdx.x * Md.maxcp + lane) * 8;
+      const V3<Real> nn = ld3(S.cpN + 3 * lane);
+      V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
+      if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
+      t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
+      const V3<Real> t2 = cross(nn, t1);
+      // a tangent the skeleton cannot move along (planar model: z) has A_ii = 0 and stays pinned at a bound: no force
+      const int r1 = 3 * lane + 1, r2 = 3 * lane + 2;
+      const Real l0 = S.x[3 * lane], l1 = S.A[TI(r1, r1)] > Real(1e-12) ? S.x[r1] : Real(0),
+                 l2 = S.A[TI(r2, r2)] > Real(1e-12) ? S.x[r2] : Real(0), idt = Real(1) / Md.dt;
+      const int lb = S.cplinkB[lane];
+      out[0] = (Real)Md.link_body[S.cplink[lane]]; out[1] = lb >= 0 ? (Real)Md.link_body[lb] : Real(-1);
+      st3(out + 2, ld3(S.cpP + 4 * lane) + roff);
+      st3(out + 5, (nn * l0 + t1 * l1 + t2 * l2) * idt);
+    }
+  }
   // ---- new velocity: vs = dq + L^-T (dt y + W^T lambda)
   if (lane < n) {
     Real u = Md.dt * S.W[m * n + lane], ul = Real(0);
@@ -1541,7 +1563,9 @@ __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds
 }
 
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
-template <class Real, bool PAIRS, bool EXTRAS>
+// REPORT: the contact-report variant (dart_get_contacts); only the most general instantiation <true, true, true> is built --
+// the mere presence of the reporting code costs the lean kernels 2.5 % (register allocation), so they do not carry it.
+template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false>
 __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ tstate,
                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
@@ -1593,7 +1617,7 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
   __syncthreads();
   LinkConst<Real> lc;
   sp_load_link_const<Real>(Md, lane < Md.nl ? lane : 0, lc);
-  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS>(Md, lc, S, lane, cflags);
+  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT>(Md, lc, S, lane, cflags, REPORT && Md.creport != nullptr && f == Md.frame_skip - 1);
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
   const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task >= 10;

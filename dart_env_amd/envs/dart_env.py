@@ -196,6 +196,16 @@ class BatchedDartEnv:
         world-frame vectors or None to stop.  Needs ``generic_kernel=True`` for the planar models."""
         self._stepper.set_ext_force(body, forces)
 
+    def enable_contact_report(self, on=True):
+        """Record ``world.collision_result.contacts`` of every env-step's last world step (walker2d.py:38-41,
+        human_walker.py:97-106).  Planar models need ``generic_kernel=True``."""
+        self._stepper.configure(_st.CFG_CONTACT_REPORT, 1 if on else 0)
+
+    def contacts(self):
+        """-> count (N,), bodies (N, K, 2) {bodynode1, bodynode2 as skeleton body indices; -1 = ground}, point (N, K, 3),
+        force (N, K, 3) on the first body -- the fields the reference reads from pydart2 Contact objects."""
+        return self._stepper.contacts()
+
     def set_state(self, qpos, qvel):
         qpos = np.asarray(qpos, dtype=np.float64).reshape(self.num_envs, self.ndofs)
         qvel = np.asarray(qvel, dtype=np.float64).reshape(self.num_envs, self.ndofs)

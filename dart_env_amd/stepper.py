@@ -20,15 +20,15 @@ LIB_PATH = os.environ.get("DART_STEPPER_LIB", os.path.join(_HERE, LIB_NAME))
 
 # error codes / keys (include/dart_stepper.h)
 DART_OK, E_INVALID, E_NO_DEVICE, E_UNSUPPORTED, E_HIP, E_PENDING, E_NOT_PENDING = 0, -1, -2, -3, -4, -5, -6
-Q_NUM_ENVS, Q_NDOFS, Q_OBS_DIM, Q_ACT_DIM, Q_FRAME_SKIP, Q_PRECISION, Q_DEVICE, Q_LCP_SLOTS, Q_STATIC_KERNEL = range(9)
+Q_NUM_ENVS, Q_NDOFS, Q_OBS_DIM, Q_ACT_DIM, Q_FRAME_SKIP, Q_PRECISION, Q_DEVICE, Q_LCP_SLOTS, Q_STATIC_KERNEL, Q_MAX_CONTACTS = range(10)
 (CFG_SOLVER, CFG_ITERS_STAGE1, CFG_ITERS_STAGE2, CFG_AUTORESET, CFG_SEED, CFG_ENV_OFFSET, CFG_BLOCK_THREADS, CFG_STATS,
- CFG_EPISODE_STATS) = range(9)
+ CFG_EPISODE_STATS, CFG_CONTACT_REPORT) = range(10)
 SOLVER_BPP, SOLVER_PGS = 0, 1
 
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library(path: Optional[str] = None):
     L.dart_sync.argtypes = [vp]
     L.dart_seed_mt19937.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     L.dart_get_dynamics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.dart_get_contacts.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int32]
     L.dart_set_ext_force.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.dart_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
     L.dart_host_views.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
@@ -182,6 +183,15 @@ class HipStepper:
         self._check(self.L.dart_get_episode_stats(self.h, _ptr(r, C.c_double) if per_env else None,
                                                   _ptr(l, C.c_int32) if per_env else None, _ptr(tot, C.c_double), int(clear_totals)))
         return r, l, tot
+
+    def contacts(self, max_contacts=None):
+        """Contacts of the last world step of the last env-step (pydart2 world.collision_result.contacts); needs
+        CFG_CONTACT_REPORT.  -> count (N,), bodies (N, K, 2) int32 {a, b; b = -1 ground}, point (N, K, 3), force on a (N, K, 3)."""
+        k = self.query(Q_MAX_CONTACTS) if max_contacts is None else int(max_contacts)
+        n = self.num_envs
+        cnt = np.empty(n, dtype=np.int32); bod = np.empty((n, k, 2), dtype=np.int32); pf = np.empty((n, k, 6), dtype=np.float64)
+        self._check(self.L.dart_get_contacts(self.h, _ptr(cnt, C.c_int32), _ptr(bod, C.c_int32), _ptr(pf, C.c_double), k))
+        return cnt, bod, pf[:, :, :3], pf[:, :, 3:]
 
     def dynamics(self, mass=True, bias=True):
         """-> (M (N, n, n), c (N, n)): pydart2's skel.M and skel.c for every env (None for the one not requested)."""

@@ -42,7 +42,8 @@ enum {
 enum {
   DART_Q_NUM_ENVS = 0, DART_Q_NDOFS = 1, DART_Q_OBS_DIM = 2, DART_Q_ACT_DIM = 3, DART_Q_FRAME_SKIP = 4,
   DART_Q_PRECISION = 5, DART_Q_DEVICE = 6, DART_Q_LCP_SLOTS = 7,
-  DART_Q_STATIC_KERNEL = 8 /* 1: the card matched a model baked in at build time (csrc/static_models.hpp) */
+  DART_Q_STATIC_KERNEL = 8, /* 1: the card matched a model baked in at build time (csrc/static_models.hpp) */
+  DART_Q_MAX_CONTACTS = 9   /* contact points the kernel keeps per env and world step (0: no reporting in this kernel) */
 };
 
 /* dart_configure keys */
@@ -55,7 +56,8 @@ enum {
   DART_CFG_ENV_OFFSET = 5,  /* global index of env 0 of this handle (multi-GPU sharding keeps streams distinct) */
   DART_CFG_BLOCK_THREADS = 6,/* envs (active lanes) per wave64 workgroup of the step kernel: 64, 32 or 16 */
   DART_CFG_STATS = 7,       /* 1: histogram the wave-level pivoting iteration counts (dart_get_stats) */
-  DART_CFG_EPISODE_STATS = 8 /* 1: keep per-env episode return / length accumulators on the device (dart_get_episode_stats) */
+  DART_CFG_EPISODE_STATS = 8,/* 1: keep per-env episode return / length accumulators on the device (dart_get_episode_stats) */
+  DART_CFG_CONTACT_REPORT = 9 /* 1: record the contacts of every env-step's last world step (dart_get_contacts) */
 };
 
 /* Library-level error text for failures that happen before a handle exists (handle == NULL). */
@@ -156,6 +158,18 @@ int dart_get_episode_stats(DartStepper* h, double* last_return, int32_t* last_le
  * WITHOUT the implicit damping / stiffness terms the integrator adds; coriolis_gravity (N, ndofs) = C(q, dq) dq + g(q).
  * Either pointer may be NULL.  Computed by the generic tree kernel for every model (planar ones included). */
 int dart_get_dynamics(DartStepper* h, double* mass_matrix, double* coriolis_gravity);
+
+/* Contacts of the last world step of the last env-step -- pydart2's `world.collision_result.contacts` as the reference
+ * reads it (gym/envs/dart/walker2d.py:38-41: contact.force; human_walker.py:97-106: contact.bodynode1 / bodynode2;
+ * dart_env.py has no getter of its own).  Needs DART_CFG_CONTACT_REPORT = 1 before the step.
+ *   count (N)                      contacts of env i (may exceed max_contacts; only the first max_contacts are returned)
+ *   bodies (N, max_contacts, 2)    card body indices {a, b}; b = -1 for the ground skeleton; unused slots -1
+ *   point_force (N, max_contacts, 6) world contact point, then the world force the contact applies to body a
+ *                                  (= (n l_n + t1 l_1 + t2 l_2) / dt of DART's ContactConstraint; body b receives the opposite)
+ * bodies / point_force may be NULL.  Order: ground contacts in shape order (box vertices in face order), then link-link
+ * pairs.  Implemented by the generic tree kernel: DART_E_UNSUPPORTED on the planar register kernels (card.generic_kernel = 1
+ * routes those models through it). */
+int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* point_force, int32_t max_contacts);
 
 /* Wait for everything enqueued on the handle's stream. */
 int dart_sync(DartStepper* h);

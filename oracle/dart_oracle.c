@@ -93,6 +93,8 @@ typedef struct OracleWorld {
   double lambda_last[MAXM], w_last[MAXM], lo_last[MAXM], hi_last[MAXM];
   int ncontacts_last;
   double contact_last[MAXC][8]; /* body, px,py,pz, depth, fn, ft1, ft2 */
+  double contact_dirs[MAXC][9];  /* normal, t1, t2 of each contact of the last world step */
+  double contact_report[MAXC][8]; /* body a, body b (-1: ground), point, force on body a -- pydart2 Contact.point / .force */
   double lcp_residual_last;
   double A_last[MAXM * MAXM], b_last[MAXM]; /* debug copies of the last LCP */
   double init_height; /* human_walker.py:163 head COM height right after reset_model's set_state */
@@ -960,6 +962,12 @@ int oracle_step(OracleWorld* w) {
     }
     double* cl = w->contact_last[w->ncontacts_last++];
     cl[0] = c->shape_body[s]; cl[1] = P[0]; cl[2] = P[1]; cl[3] = P[2]; cl[4] = depth; cl[5] = base;
+    {
+      double* cd = w->contact_dirs[w->ncontacts_last - 1];
+      double* cr = w->contact_report[w->ncontacts_last - 1];
+      for (int a = 0; a < 3; a++) { cd[a] = nrm[a]; cd[3 + a] = t1[a]; cd[6 + a] = t2[a]; cr[2 + a] = P[a]; cr[5 + a] = 0; }
+      cr[0] = c->shape_body[s]; cr[1] = cp_shape_b[ci] >= 0 ? c->shape_body[cp_shape_b[ci]] : -1;
+    }
   }
   const int contact_rows = m; /* rows [0, contact_rows) belong to contacts, the rest to joint limits */
   for (int i = 0; i < n; i++) {
@@ -1046,6 +1054,9 @@ int oracle_step(OracleWorld* w) {
       w->contact_last[k][5] = x[base];
       w->contact_last[k][6] = (base + 1 < m && findex[base + 1] == base) ? x[base + 1] : 0.0;
       w->contact_last[k][7] = (base + 2 < m && findex[base + 2] == base) ? x[base + 2] : 0.0;
+      for (int a = 0; a < 3; a++)   /* DART ContactConstraint: force on the first body = (n l_n + t1 l_1 + t2 l_2) / dt */
+        w->contact_report[k][5 + a] = (w->contact_dirs[k][a] * w->contact_last[k][5] + w->contact_dirs[k][3 + a] * w->contact_last[k][6] +
+                                       w->contact_dirs[k][6 + a] * w->contact_last[k][7]) / dt;
     }
   }
   if (w->free_root) {
@@ -1112,6 +1123,11 @@ int oracle_last_Ab(const OracleWorld* w, double* A, double* b) {
 }
 int oracle_last_contacts(const OracleWorld* w, double* out8) {
   memcpy(out8, w->contact_last, w->ncontacts_last * 8 * sizeof(double));
+  return w->ncontacts_last;
+}
+/* world.collision_result.contacts of the last world step: per contact {body a, body b (-1 = ground), point[3], force on a[3]} */
+int oracle_contact_report(const OracleWorld* w, double* out8) {
+  memcpy(out8, w->contact_report, w->ncontacts_last * 8 * sizeof(double));
   return w->ncontacts_last;
 }
 /* total mechanical energy (kinetic + gravitational potential) */

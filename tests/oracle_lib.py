@@ -48,6 +48,8 @@ def lib():
         L.oracle_last_lcp.restype = C.c_int
         L.oracle_last_contacts.argtypes = [C.c_void_p, dp]
         L.oracle_last_contacts.restype = C.c_int
+        L.oracle_contact_report.argtypes = [C.c_void_p, dp]
+        L.oracle_contact_report.restype = C.c_int
         L.oracle_energy.argtypes = [C.c_void_p]
         L.oracle_energy.restype = C.c_double
         L.oracle_env_step.argtypes = [C.c_void_p, dp, dp, dp]
@@ -194,6 +196,12 @@ class OracleWorld:
     def last_contacts(self):
         buf = np.zeros((64, 8))
         k = self.L.oracle_last_contacts(self.h, _p(buf))
+        return buf[:k]
+
+    def contact_report(self):
+        """contacts of the last world step: rows {body a, body b (-1 ground), point xyz, force on a xyz}"""
+        buf = np.zeros((64, 8))
+        k = self.L.oracle_contact_report(self.h, _p(buf))
         return buf[:k]
 
     def energy(self):

@@ -658,3 +658,68 @@ def test_free_root_chart_has_no_singular_heading():
             Ri = (Q0.inv() * Rot.from_rotvec(qg[i, :3])).as_matrix()
             assert np.abs(Ri - Rref).max() < tol_q * 10 and np.abs(Q0.inv().apply(qg[i, 3:6]) - qg[0, 3:6]).max() < tol_q * 10, (prec, i)
         gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartHumanWalker-v1", "DartWalker3d-v1"])
+def test_contact_report_matches_oracle(env_id):
+    """dart_get_contacts (pydart2 collision_result.contacts of the last world step): bodies, points and forces equal the
+    oracle's, fp64; fp32 close; the planar register kernels refuse (generic_kernel routes Hopper through the tree kernel)."""
+    from dart_env_amd.stepper import HipStepper, StepperError, CFG_CONTACT_REPORT, Q_MAX_CONTACTS
+    planar = env_id == "DartHopper-v1"
+    if planar:
+        g = HipStepper(card_for(env_id), 4, precision=64)
+        with pytest.raises(StepperError):
+            g.configure(CFG_CONTACT_REPORT, 1)
+        g.close()
+    card = card_for(env_id, generic_kernel=True) if planar else card_for(env_id)
+    n, nd, na = 24, card.ndofs, card.act_dim
+    rng = np.random.RandomState(4)
+    ora = OracleBatch(card, n)
+    gpus = {p: HipStepper(card, n, precision=p) for p in (64, 32)}
+    qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+    ora.reset(None, qn, vn)
+    for g in gpus.values():
+        g.configure(CFG_CONTACT_REPORT, 1)
+        g.reset(None, qn, vn)
+    K = gpus[64].query(Q_MAX_CONTACTS)
+    assert K >= 4
+    with_contacts = pair_contacts = borderline = 0
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, na)).astype(np.float32)
+        oo, ro, do, to = ora.step(a)
+        for p, g in gpus.items():
+            g.step(a)
+            cnt, bod, pt, fc = g.contacts()
+            if p == 32:
+                g.set_state(*ora.state())     # keep the fp32 copy on the oracle's trajectory: compare one step at a time
+            for i, w in enumerate(ora.worlds):
+                rep = w.contact_report()
+                if p == 32 and cnt[i] != len(rep):    # a vertex within rounding of the floor: in or out by precision
+                    borderline += 1
+                    continue
+                assert cnt[i] == len(rep), (t, i, p)
+                k = len(rep)
+                if k == 0:
+                    continue
+                assert np.array_equal(bod[i, :k], rep[:, :2].astype(np.int32)) and np.all(bod[i, k:] == -1)
+                tol_p, tol_f = (1e-9, 1e-5) if p == 64 else (2e-4, 5e-2 * (1 + np.abs(rep[:, 5:8]).max()))
+                assert np.allclose(pt[i, :k], rep[:, 2:5], atol=tol_p), (t, i, p)
+                if p == 64:
+                    assert np.allclose(fc[i, :k], rep[:, 5:8], atol=tol_f, rtol=1e-6), (t, i, p, fc[i, :k], rep[:, 5:8])
+                else:   # coplanar box-face contacts share their load through the cfm regularisation only: in fp32 compare the
+                    for pair in {tuple(r) for r in rep[:, :2].astype(int)}:   # resultant per body pair, not its split
+                        sel = (rep[:, 0] == pair[0]) & (rep[:, 1] == pair[1])
+                        assert np.allclose(fc[i, :k][sel].sum(axis=0), rep[sel, 5:8].sum(axis=0), atol=tol_f, rtol=5e-3), (t, i, pair)
+                if p == 64:
+                    with_contacts += 1
+                    pair_contacts += int((rep[:, 1] >= 0).any())
+        if do.any():
+            qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+            ora.reset(do, qn, vn)
+            for g in gpus.values():
+                g.reset(do.astype(np.uint8), qn, vn, want_obs=False)
+    print(env_id, "env-steps with contacts", with_contacts, "with link-link contacts", pair_contacts)
+    assert with_contacts > 100 and borderline <= 0.02 * with_contacts
+    for g in gpus.values():
+        g.close()

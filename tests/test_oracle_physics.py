@@ -371,3 +371,37 @@ def test_free_root_dynamics_do_not_depend_on_the_orientation_chart():
         assert np.allclose(dq1, dq_ref, atol=1e-9) and np.allclose(qj1, qj_ref, atol=1e-10)
         assert np.allclose((Q0.inv() * R1).as_matrix(), R_ref.as_matrix(), atol=1e-10)
         assert np.allclose(Q0.inv().apply(p1), p_ref, atol=1e-10)
+
+
+# ------------------------------------------------------------------ contact report (pydart2 collision_result.contacts)
+@pytest.mark.parametrize("env_id,trans", [("DartHopper-v1", [0, 1]), ("DartHumanWalker-v1", [0, 1, 2]), ("DartWalker3d-v1", [0, 1, 2])])
+def test_contact_report_forces_sum_to_the_root_constraint_force(env_id, trans):
+    """The reported per-contact forces (n l_n + t1 l_1 + t2 l_2) / dt must add up to the generalized constraint force on the
+    root translation dofs (J^T lambda / dt, assembled independently from the Jacobian rows; joint-limit rows do not touch
+    those dofs, link-link contacts cancel in the sum), points must lie at the floor, bodies must be the colliding ones."""
+    card = card_for(env_id)
+    w = OracleWorld(card)
+    rng = np.random.RandomState(0)
+    w.reset()
+    seen = pairs = 0
+    axes = {3: [0, 1, 2], 2: [0, 1]}[len(trans)]
+    for t in range(600):
+        tau = np.zeros(w.n); tau[6 if w.n > 9 else 3:] = rng.uniform(-1, 1, w.n - (6 if w.n > 9 else 3)) * 30
+        w.set_forces(tau); w.step()
+        rep = w.contact_report()
+        cf = w.constraint_forces()
+        ground = rep[rep[:, 1] < 0]
+        if len(rep) == 0:
+            assert np.abs(cf[trans]).max() < 1e-9
+            continue
+        seen += 1
+        pairs += int((rep[:, 1] >= 0).any())
+        total = ground[:, 5:8].sum(axis=0) if len(ground) else np.zeros(3)
+        assert np.allclose(total[axes], cf[trans], rtol=1e-9, atol=1e-7), (t, total, cf[trans])
+        assert (ground[:, 6] >= -1e-9).all()                                   # the floor pushes up
+        assert np.all(np.abs(ground[:, 3] - card.ground_y) < 0.03)             # contact points at the floor (within the penetration)
+        nb = card.nbodies
+        assert np.all((rep[:, 0] >= 0) & (rep[:, 0] < nb) & (rep[:, 1] < nb))
+    assert seen > 100
+    if env_id == "DartWalker3d-v1":
+        print("world steps with a link-link contact:", pairs)

@@ -37,6 +37,12 @@ def algorithmic_bytes(card) -> int:
     return 16 * card.ndofs + 4 * card.act_dim + 4 * card.obs_dim + 4 + 1
 
 
+# algorithmic flops per env-step (Featherstone operation counts F(n, m, K) x frame_skip); the kernels are
+# bound by the fp32 vector ALU (157.3 TFLOP/s with packed fp32), neither by HBM nor by MFMA -- reported beside the HBM figure
+ALGORITHMIC_FLOPS = {"DartHopper-v1": 2.2e4, "DartWalker2d-v1": 5.3e4, "DartHumanWalker-v1": 3.3e6}
+VALU_PEAK_TFLOPS = 157.3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +184,10 @@ def main():
                      "traffic": None, "algorithmic_bytes_per_env_step": abytes, "kernel_ms": ms_kernel,
                      "note": "kernel is VALU-issue bound (fp32 vector), not HBM or MFMA bound; see DESIGN.md"},
     }
+    if args.env_id in ALGORITHMIC_FLOPS and args.precision == 32:
+        tf = ALGORITHMIC_FLOPS[args.env_id] * n / (ms_kernel * 1e-3) / 1e12
+        result["roofline"]["valu"] = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
+                                      "algorithmic_flops_per_env_step": ALGORITHMIC_FLOPS[args.env_id]}
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
     # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
@@ -189,6 +199,8 @@ def main():
         if key in pmc:
             result["roofline"]["traffic"] = pmc[key]["bytes_per_launch"]
             result["roofline"]["traffic_source"] = pmc[key]["source"]
+            if "valu_issue" in pmc[key] and "valu" in result["roofline"]:
+                result["roofline"]["valu"]["issue"] = pmc[key]["valu_issue"]
     except OSError:
         pass
 

@@ -47,6 +47,7 @@ struct Impl {
   virtual int max_contacts() const { return 0; }
   virtual int set_contact_report(bool /*on*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int get_contacts(hipStream_t, int64_t /*n*/, int32_t* /*count*/, int32_t* /*bodies*/, double* /*point_force*/, int /*max*/) { return DART_E_UNSUPPORTED; }
+  virtual int get_constraint_forces(hipStream_t, int64_t /*n*/, double* /*out*/) { return DART_E_UNSUPPORTED; }
   bool soa = true;         // state layout: q[n][N] (planar kernels) or q[N][n] (spatial kernel)
   int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
   bool is_static = false;  // true: model constants are compile-time immediates (static_models.hpp)
@@ -417,7 +418,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   }
   M.s_max = (Real)c.state_abs_max; M.v_clip = (Real)c.obs_vel_clip; M.noise = (Real)c.reset_noise; M.noise_v = (Real)c.reset_noise_vel;
   M.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip));
-  M.solver_iters = 200; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.dbg = nullptr; M.creport = nullptr; M.creport_count = nullptr;
+  M.solver_iters = 200; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.dbg = nullptr; M.creport = nullptr; M.creport_count = nullptr; M.cf_report = nullptr;
   if (c.task == DART_TASK_NONE && c.obs_dim != 2 * c.ndofs) return "physics-only obs must be [q, dq]";
   return "";
 }
@@ -454,7 +455,7 @@ struct SpatialImplT : Impl {
   }
   void release() override {
     if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); if (d_ext) (void)hipFree(d_ext); if (d_cf) (void)hipFree(d_cf);
-    if (d_creport) (void)hipFree(d_creport); if (d_ccount) (void)hipFree(d_ccount); d_creport = nullptr; d_ccount = nullptr;
+    if (d_creport) (void)hipFree(d_creport); if (d_ccount) (void)hipFree(d_ccount); if (d_cfrep) (void)hipFree(d_cfrep); d_creport = nullptr; d_ccount = nullptr; d_cfrep = nullptr;
     dM = nullptr; init_h = nullptr; d_ext = nullptr; d_cf = nullptr;
   }
   void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
@@ -519,14 +520,16 @@ struct SpatialImplT : Impl {
   hipError_t debug_dump(double* out) override { return dbg ? hipMemcpy(out, dbg, sizeof(double) * 160 * (size_t)nenv, hipMemcpyDeviceToHost) : hipErrorInvalidValue; }
   int slots() const override { return M.maxm; }
   int max_contacts() const override { return M.maxcp; }
-  Real* d_creport = nullptr; int* d_ccount = nullptr;
+  Real* d_creport = nullptr; int* d_ccount = nullptr; Real* d_cfrep = nullptr;
   int set_contact_report(bool on, int64_t n) override {
     if (on && !d_creport) {
       if (hipMalloc((void**)&d_creport, sizeof(Real) * 8 * (size_t)M.maxcp * (size_t)n) != hipSuccess) return DART_E_HIP;
       if (hipMalloc((void**)&d_ccount, sizeof(int) * (size_t)n) != hipSuccess) return DART_E_HIP;
       (void)hipMemset(d_ccount, 0, sizeof(int) * (size_t)n);
+      if (hipMalloc((void**)&d_cfrep, sizeof(Real) * (size_t)M.n * (size_t)n) != hipSuccess) return DART_E_HIP;
+      (void)hipMemset(d_cfrep, 0, sizeof(Real) * (size_t)M.n * (size_t)n);
     }
-    M.creport = on ? d_creport : nullptr; M.creport_count = on ? d_ccount : nullptr;
+    M.creport = on ? d_creport : nullptr; M.creport_count = on ? d_ccount : nullptr; M.cf_report = on ? d_cfrep : nullptr;
     upload();
     return DART_OK;
   }
@@ -547,6 +550,14 @@ struct SpatialImplT : Impl {
         if (point_force) for (int a = 0; a < 6; a++) point_force[((size_t)e * maxc + c) * 6 + a] = live ? (double)r[2 + a] : 0.0;
       }
     }
+    return DART_OK;
+  }
+  int get_constraint_forces(hipStream_t s, int64_t n, double* out) override {
+    if (!M.cf_report) return DART_E_INVALID;
+    if (hipStreamSynchronize(s) != hipSuccess) return DART_E_HIP;
+    std::vector<Real> tmp((size_t)M.n * (size_t)n);
+    if (hipMemcpy(tmp.data(), d_cfrep, sizeof(Real) * tmp.size(), hipMemcpyDeviceToHost) != hipSuccess) return DART_E_HIP;
+    for (size_t i = 0; i < tmp.size(); i++) out[i] = (double)tmp[i];
     return DART_OK;
   }
 };
@@ -1091,6 +1102,15 @@ int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* p
   const int rc = h->impl->get_contacts(h->stream, h->n, count, bodies, point_force, max_contacts);
   if (rc == DART_E_INVALID) h->err = "dart_get_contacts: enable DART_CFG_CONTACT_REPORT before stepping";
   if (rc == DART_E_UNSUPPORTED) h->err = "contact reporting: only the generic kernel implements it (card.generic_kernel = 1)";
+  return rc;
+}
+
+int dart_get_constraint_forces(DartStepper* h, double* constraint_forces) {
+  if (!h || !constraint_forces) return DART_E_INVALID;
+  if (h->pending) { h->err = "dart_get_constraint_forces while a step is pending"; return DART_E_PENDING; }
+  const int rc = h->impl->get_constraint_forces(h->stream, h->n, constraint_forces);
+  if (rc == DART_E_INVALID) h->err = "dart_get_constraint_forces: enable DART_CFG_CONTACT_REPORT before stepping";
+  if (rc == DART_E_UNSUPPORTED) h->err = "constraint forces: only the generic kernel reports them (card.generic_kernel = 1)";
   return rc;
 }
 

@@ -91,6 +91,7 @@ struct SpatialModel {
   int link_body[SP_MAXL];      // card body carried by a link (-1: carrier link of an expanded joint)
   Real* creport;               // optional [n_envs][maxcp][8]: contacts of the last world step {body a, body b, point, force on a}
   int* creport_count;          // [n_envs]
+  Real* cf_report;             // [n_envs][n]: constraint_forces() of the last world step (recorded with the contacts)
   double* dbg;                 // optional [n_envs][160] dump of the last LCP (debug builds of the tests only)
   unsigned long long* stats;   // optional [64]: [0..31] pivoting iterations per solve, [32] PGS fallbacks, [33] solves
 };
@@ -1361,17 +1362,25 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   if (lane < n) {
     Real u = Md.dt * S.W[m * n + lane], ul = Real(0);
     for (int i = 0; i < m; i++) { const Real t = S.W[i * n + lane] * S.x[i]; u += t; ul += t; }
-    if (EXTRAS && Md.task == 12) S.lo[lane] = ul;   // W^T lambda = L^-1 J^T lambda
+    if ((EXTRAS && Md.task == 12) || (REPORT && report)) S.lo[lane] = ul;   // W^T lambda = L^-1 J^T lambda
     S.rhs[lane] = u;
   }
   __syncthreads();
-  if (EXTRAS && Md.task == 12) {   // constraint_forces() of this step: J^T lambda / dt = L (W^T lambda) / dt
+  if ((EXTRAS && Md.task == 12) || (REPORT && report)) {   // constraint_forces() of this step: J^T lambda / dt = L (W^T lambda) / dt
     if (lane < n) {
       Real t = Real(0);
       for (int k = 0; k <= lane; k++) t += S.H[TL(lane, k)] * S.lo[k];
       S.cf[lane] = t / Md.dt;
     }
     __syncthreads();
+    if (REPORT && report && lane < n) {
+      Real v = S.cf[lane];
+      if (EXTRAS && Md.free_root && lane < 6) {   // internal root coordinates are world-frame, DART's body-frame: tau_b = R^T tau_w
+        const int g = lane < 3 ? 0 : 3, a = lane - g;
+        v = S.root[a] * S.cf[g] + S.root[3 + a] * S.cf[g + 1] + S.root[6 + a] * S.cf[g + 2];
+      }
+      Md.cf_report[(size_t)blockIdx.x * n + lane] = v;
+    }
   }
   sp_chol_backsolve<Real>(S.H, S.sinv, n, S.rhs, lane);
   SP_TICK(9);

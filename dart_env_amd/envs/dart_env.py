@@ -53,6 +53,10 @@ class SkeletonView:
         """Coriolis + gravity forces (num_envs, ndofs) -- pydart2 skel.c (reference walker3d_spd.py:49)."""
         return self._env._stepper.dynamics(False, True)[1]
 
+    def constraint_forces(self):
+        """(num_envs, ndofs) -- pydart2 skel.constraint_forces() (reference walker3d_spd.py:51); enable_contact_report() first."""
+        return self._env._stepper.constraint_forces()
+
     @property
     def q_lower(self):
         c = self._env.card

@@ -171,6 +171,11 @@ int dart_get_dynamics(DartStepper* h, double* mass_matrix, double* coriolis_grav
  * routes those models through it). */
 int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* point_force, int32_t max_contacts);
 
+/* pydart2 `skel.constraint_forces()` after the last world step (reference gym/envs/dart/walker3d_spd.py:51 reads it for
+ * its SPD controller): the generalized force J^T lambda / dt of all contact, joint-limit and joint-friction rows,
+ * (N, ndofs).  Recorded together with the contacts: needs DART_CFG_CONTACT_REPORT = 1 before the step. */
+int dart_get_constraint_forces(DartStepper* h, double* constraint_forces);
+
 /* Wait for everything enqueued on the handle's stream. */
 int dart_sync(DartStepper* h);
 

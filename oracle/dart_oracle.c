@@ -1035,6 +1035,12 @@ int oracle_step(OracleWorld* w) {
     for (int i = 0; i < m; i++) {
       for (int k = 0; k < n; k++) { vs[k] += Y[i][k] * x[i]; w->cf_last[k] += J[i][k] * x[i] / dt; }
     }
+    if (w->free_root) {   /* internal root coordinates are world-frame: DART's are body-frame, tau_b = R^T tau_w */
+      double t[6];
+      for (int g = 0; g < 6; g += 3)
+        for (int a = 0; a < 3; a++) t[g + a] = w->R0[a] * w->cf_last[g] + w->R0[3 + a] * w->cf_last[g + 1] + w->R0[6 + a] * w->cf_last[g + 2];
+      memcpy(w->cf_last, t, sizeof t);
+    }
     /* diagnostics: complementarity residual */
     double res = 0;
     for (int i = 0; i < m; i++) {

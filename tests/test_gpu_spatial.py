@@ -661,7 +661,7 @@ def test_free_root_chart_has_no_singular_heading():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartHumanWalker-v1", "DartWalker3d-v1"])
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartHumanWalker-v1", "DartWalker3d-v1", "DartDog-v1"])
 def test_contact_report_matches_oracle(env_id):
     """dart_get_contacts (pydart2 collision_result.contacts of the last world step): bodies, points and forces equal the
     oracle's, fp64; fp32 close; the planar register kernels refuse (generic_kernel routes Hopper through the tree kernel)."""
@@ -691,6 +691,9 @@ def test_contact_report_matches_oracle(env_id):
         for p, g in gpus.items():
             g.step(a)
             cnt, bod, pt, fc = g.contacts()
+            if p == 64:     # skel.constraint_forces() of the same world step (walker3d_spd.py:51); DART coordinates for a free root
+                cfo = np.stack([w.constraint_forces() for w in ora.worlds])
+                assert np.allclose(g.constraint_forces(), cfo, rtol=1e-6, atol=1e-5), t
             if p == 32:
                 g.set_state(*ora.state())     # keep the fp32 copy on the oracle's trajectory: compare one step at a time
             for i, w in enumerate(ora.worlds):

@@ -374,7 +374,8 @@ def test_free_root_dynamics_do_not_depend_on_the_orientation_chart():
 
 
 # ------------------------------------------------------------------ contact report (pydart2 collision_result.contacts)
-@pytest.mark.parametrize("env_id,trans", [("DartHopper-v1", [0, 1]), ("DartHumanWalker-v1", [0, 1, 2]), ("DartWalker3d-v1", [0, 1, 2])])
+@pytest.mark.parametrize("env_id,trans", [("DartHopper-v1", [0, 1]), ("DartHumanWalker-v1", [0, 1, 2]), ("DartWalker3d-v1", [0, 1, 2]),
+                                          ("DartDog-v1", [3, 4, 5])])
 def test_contact_report_forces_sum_to_the_root_constraint_force(env_id, trans):
     """The reported per-contact forces (n l_n + t1 l_1 + t2 l_2) / dt must add up to the generalized constraint force on the
     root translation dofs (J^T lambda / dt, assembled independently from the Jacobian rows; joint-limit rows do not touch
@@ -387,9 +388,13 @@ def test_contact_report_forces_sum_to_the_root_constraint_force(env_id, trans):
     axes = {3: [0, 1, 2], 2: [0, 1]}[len(trans)]
     for t in range(600):
         tau = np.zeros(w.n); tau[6 if w.n > 9 else 3:] = rng.uniform(-1, 1, w.n - (6 if w.n > 9 else 3)) * 30
+        q_prev = w.q.copy()
         w.set_forces(tau); w.step()
         rep = w.contact_report()
         cf = w.constraint_forces()
+        if env_id == "DartDog-v1":   # FreeJoint: generalized forces on the body-frame twist, tau_b = R^T f_world (R of the step's start)
+            from scipy.spatial.transform import Rotation as Rot
+            cf = cf.copy(); cf[3:6] = Rot.from_rotvec(q_prev[:3]).apply(cf[3:6])
         ground = rep[rep[:, 1] < 0]
         if len(rep) == 0:
             assert np.abs(cf[trans]).max() < 1e-9

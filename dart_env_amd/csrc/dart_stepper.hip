@@ -637,7 +637,8 @@ struct DartStepper {
   bool ep_stats = false;
   void* dyn_model = nullptr;     // device SpatialModel<float|double> used by dart_get_dynamics (built on first use)
   size_t dyn_lds = 0;
-  double *d_dynM = nullptr, *d_dync = nullptr, *d_tstage = nullptr;
+  double *d_dynM = nullptr, *d_dync = nullptr, *d_tstage = nullptr, *d_pose = nullptr;
+  bool dyn_free_root = false;
   std::string err;
 };
 
@@ -651,13 +652,14 @@ struct DartStepper {
   } while (0)
 
 template <class Real>
-static int dynamics_impl(DartStepper* h, double* mass, double* bias) {
-  const size_t N = (size_t)h->n, nd = (size_t)h->card.ndofs;
+static int dynamics_impl(DartStepper* h, double* mass, double* bias, double* rot = nullptr, double* pos = nullptr, double* com = nullptr) {
+  const size_t N = (size_t)h->n, nd = (size_t)h->card.ndofs, nb = (size_t)h->card.nbodies;
+  const bool poses = rot || pos || com;
   if (!h->dyn_model) {
     auto M = std::make_unique<SpatialModel<Real>>();
     std::string w = fill_spatial<Real>(h->card, *M, true);
     if (!w.empty()) { h->err = "dynamics getters: " + w; return DART_E_UNSUPPORTED; }
-    if (M->free_root) { h->err = "dynamics getters: free root joint (the kernel's internal coordinates differ from DART's)"; return DART_E_UNSUPPORTED; }
+    h->dyn_free_root = M->free_root != 0;
     CHK(h, hipMalloc(&h->dyn_model, sizeof(SpatialModel<Real>)));
     CHK(h, hipMemcpy(h->dyn_model, M.get(), sizeof(SpatialModel<Real>), hipMemcpyHostToDevice));
     h->dyn_lds = sp_lds_bytes(M->nl, M->n, sizeof(Real), M->maxm, M->maxcp);
@@ -665,13 +667,27 @@ static int dynamics_impl(DartStepper* h, double* mass, double* bias) {
     CHK(h, hipMalloc((void**)&h->d_dynM, sizeof(double) * N * nd * nd));
     CHK(h, hipMalloc((void**)&h->d_dync, sizeof(double) * N * nd));
   }
+  if ((mass || bias) && h->dyn_free_root) {
+    h->err = "dynamics getters: free root joint (the kernel's internal coordinates differ from DART's)"; return DART_E_UNSUPPORTED;
+  }
+  if (poses && !h->d_pose) CHK(h, hipMalloc((void**)&h->d_pose, sizeof(double) * N * nb * 15));
   hipLaunchKernelGGL((sp_dynamics_kernel<Real>), dim3((unsigned)N), dim3(64), h->dyn_lds, h->stream,
                      (const SpatialModel<Real>*)h->dyn_model, h->n, (const Real*)h->q, (const Real*)h->dq, h->impl->soa ? 1 : 0,
-                     mass ? h->d_dynM : nullptr, bias ? h->d_dync : nullptr);
+                     mass ? h->d_dynM : nullptr, bias ? h->d_dync : nullptr, poses ? h->d_pose : nullptr, (int)nb);
   CHK(h, hipGetLastError());
   if (mass) CHK(h, hipMemcpyAsync(mass, h->d_dynM, sizeof(double) * N * nd * nd, hipMemcpyDeviceToHost, h->stream));
   if (bias) CHK(h, hipMemcpyAsync(bias, h->d_dync, sizeof(double) * N * nd, hipMemcpyDeviceToHost, h->stream));
   CHK(h, hipStreamSynchronize(h->stream));
+  if (poses) {
+    std::vector<double> tmp(N * nb * 15);
+    CHK(h, hipMemcpy(tmp.data(), h->d_pose, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N * nb; i++) {
+      const double* t = tmp.data() + i * 15;
+      if (rot) for (int k = 0; k < 9; k++) rot[i * 9 + k] = t[k];
+      if (pos) for (int k = 0; k < 3; k++) pos[i * 3 + k] = t[9 + k];
+      if (com) for (int k = 0; k < 3; k++) com[i * 3 + k] = t[12 + k];
+    }
+  }
   return DART_OK;
 }
 
@@ -747,7 +763,7 @@ int dart_destroy(DartStepper* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->impl) h->impl->release();
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync, h->d_tstage, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -1094,6 +1110,14 @@ int dart_get_dynamics(DartStepper* h, double* mass_matrix, double* coriolis_grav
   if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
   CHK(h, hipSetDevice(h->device));
   return h->precision == 32 ? dynamics_impl<float>(h, mass_matrix, coriolis_gravity) : dynamics_impl<double>(h, mass_matrix, coriolis_gravity);
+}
+
+int dart_get_body_poses(DartStepper* h, double* rotation, double* origin, double* com) {
+  if (!h || (!rotation && !origin && !com)) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  return h->precision == 32 ? dynamics_impl<float>(h, nullptr, nullptr, rotation, origin, com)
+                            : dynamics_impl<double>(h, nullptr, nullptr, rotation, origin, com);
 }
 
 int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* point_force, int32_t max_contacts) {

@@ -1717,7 +1717,8 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
 template <class Real>
 __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
                                                           const Real* __restrict__ qs, const Real* __restrict__ dqs, int soa,
-                                                          double* __restrict__ mass_out, double* __restrict__ bias_out) {
+                                                          double* __restrict__ mass_out, double* __restrict__ bias_out,
+                                                          double* __restrict__ pose_out, int nbodies) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
   const SpatialModel<Real>& Md = *Mp;
   const int lane = threadIdx.x;
@@ -1731,6 +1732,29 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
   }
   if (lane < nl) S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16);
   __syncthreads();
+  if (pose_out) {   // bodynode world transforms / COMs: R (9), origin (3), com (3) per card body; cold path, serial kinematics
+    if (lane == 0) {
+      if (Md.free_root) { sp_free_root_load<Real>(S); sp_free_root_to_internal<Real>(S); }
+      sp_kinematics<Real>(Md, S);
+    }
+    __syncthreads();
+    if (lane < nl && Md.link_body[lane] >= 0) {
+      const Real* L = S.link + lane * SP_LINKF;
+      double* o = pose_out + ((size_t)e * nbodies + Md.link_body[lane]) * 15;
+      // the root translation joints are factored out of the link records (S.misc): a carrier body of that chain has only
+      // the slides up to its own joint behind it, every other body all of them
+      V3<Real> off = v3<Real>(0, 0, 0);
+      for (int j = 0; j < nl; j++)
+        if (Md.root_trans[j] && (j <= lane || !Md.root_trans[lane])) off = off + ld3(S.link + j * SP_LINKF + LK_A) * S.q[Md.dof[j]];
+      const Real offv[3] = {off.x, off.y, off.z};
+      for (int k = 0; k < 9; k++) o[k] = (double)L[LK_R + k];
+      for (int k = 0; k < 3; k++) { o[9 + k] = (double)(L[LK_P + k] + offv[k]); o[12 + k] = (double)(L[LK_C + k] + offv[k]); }
+    }
+    if (!mass_out && !bias_out) return;
+    __syncthreads();
+    if (lane < n) { const int64_t at = soa ? (int64_t)lane * n_envs + e : e * n + lane; S.q[lane] = qs[at]; S.dq[lane] = dqs[at]; }
+    __syncthreads();
+  }
   LinkConst<Real> lc;
   sp_load_link_const<Real>(Md, lane < nl ? lane : 0, lc);
   if (lane == 0) sp_root_offset<Real>(Md, S);

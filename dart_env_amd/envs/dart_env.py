@@ -25,11 +25,49 @@ from ..model_card import (DartModelCard, HOST_RESET_TASKS, TASK_CARTPOLE_SWINGUP
 from .. import stepper as _st
 
 
+class BodyNodeView:
+    """One ``bodynode`` of the robot skeleton for all envs: the pose getters the reference's task code calls
+    (hopper.py:42,72 ``com()``; human_walker.py:81-92 ``com()``, ``to_world()``)."""
+
+    def __init__(self, skel, index, name):
+        self._skel, self.index, self.name = skel, index, name
+
+    def _poses(self):
+        R, p, c = self._skel._env._stepper.body_poses()
+        return self._skel._u(R[:, self.index]), self._skel._u(p[:, self.index]), self._skel._u(c[:, self.index])
+
+    def com(self):
+        """World COM, (num_envs, 3) (pydart2 BodyNode.com() / .C)."""
+        return self._poses()[2]
+
+    C = property(com)
+
+    @property
+    def T(self):
+        """World transform, (num_envs, 4, 4) (pydart2 BodyNode.T / world_transform())."""
+        R, p, _ = self._poses()
+        T = np.zeros(R.shape[:-2] + (4, 4))
+        T[..., :3, :3] = R; T[..., :3, 3] = p; T[..., 3, 3] = 1.0
+        return T
+
+    world_transform = lambda self: self.T
+
+    def to_world(self, x=(0.0, 0.0, 0.0)):
+        """Body-frame point -> world, (num_envs, 3) (pydart2 BodyNode.to_world, human_walker.py:86-92)."""
+        R, p, _ = self._poses()
+        return np.einsum("...ij,j->...i", R, np.asarray(x, dtype=np.float64)) + p
+
+
 class SkeletonView:
-    """The few ``robot_skeleton`` attributes the reference's task code reads (hopper.py:39-49,69-70), batched."""
+    """The ``robot_skeleton`` attributes the reference's task code reads (hopper.py:39-49,69-72; human_walker.py:78-92;
+    walker3d_spd.py:44-51), batched: one row per env (un-batched for the single-env facades)."""
 
     def __init__(self, env):
         self._env = env
+        self._names = None
+
+    def _u(self, a):
+        return a[0] if getattr(self._env, "_unbatched", False) else a
 
     @property
     def ndofs(self):
@@ -37,25 +75,39 @@ class SkeletonView:
 
     @property
     def q(self):
-        return self._env._stepper.get_state()[0]
+        return self._u(self._env._stepper.get_state()[0])
 
     @property
     def dq(self):
-        return self._env._stepper.get_state()[1]
+        return self._u(self._env._stepper.get_state()[1])
 
     @property
     def M(self):
         """Mass matrices (num_envs, ndofs, ndofs) -- pydart2 skel.M (reference walker3d_spd.py:44)."""
-        return self._env._stepper.dynamics(True, False)[0]
+        return self._u(self._env._stepper.dynamics(True, False)[0])
 
     @property
     def c(self):
         """Coriolis + gravity forces (num_envs, ndofs) -- pydart2 skel.c (reference walker3d_spd.py:49)."""
-        return self._env._stepper.dynamics(False, True)[1]
+        return self._u(self._env._stepper.dynamics(False, True)[1])
 
     def constraint_forces(self):
         """(num_envs, ndofs) -- pydart2 skel.constraint_forces() (reference walker3d_spd.py:51); enable_contact_report() first."""
-        return self._env._stepper.constraint_forces()
+        return self._u(self._env._stepper.constraint_forces())
+
+    @property
+    def bodynodes(self):
+        """BodyNodeView per skeleton body, in the .skel file's order (``robot_skeleton.bodynodes[i]``)."""
+        if self._names is None:
+            from ..model_card import load_model
+            self._names = [b.name for b in load_model(self._env.task.model).bodies]
+        return [BodyNodeView(self, i, nm) for i, nm in enumerate(self._names)]
+
+    def bodynode(self, name):
+        for b in self.bodynodes:
+            if b.name == name:
+                return b
+        raise KeyError(name)
 
     @property
     def q_lower(self):

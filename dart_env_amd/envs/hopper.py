@@ -9,6 +9,7 @@ from .dart_env import BatchedDartEnv
 class _SingleEnv(BatchedDartEnv):
     """num_envs == 1 facade: un-batched arguments / return values like a reference env."""
     ENV_ID = None
+    _unbatched = True   # robot_skeleton getters return un-batched arrays, like pydart2's
 
     def __init__(self, device=0, precision=32, stepper_factory=None):
         super().__init__(self.ENV_ID, num_envs=1, device=device, precision=precision, noise="mt19937-host",

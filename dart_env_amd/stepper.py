@@ -28,7 +28,7 @@ SOLVER_BPP, SOLVER_PGS = 0, 1
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses",
 ]
 
 
@@ -87,6 +87,7 @@ def load_library(path: Optional[str] = None):
     L.dart_get_dynamics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dart_get_contacts.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int32]
     L.dart_get_constraint_forces.argtypes = [vp, C.POINTER(C.c_double)]
+    L.dart_get_body_poses.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dart_set_ext_force.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.dart_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
     L.dart_host_views.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
@@ -193,6 +194,13 @@ class HipStepper:
         cnt = np.empty(n, dtype=np.int32); bod = np.empty((n, k, 2), dtype=np.int32); pf = np.empty((n, k, 6), dtype=np.float64)
         self._check(self.L.dart_get_contacts(self.h, _ptr(cnt, C.c_int32), _ptr(bod, C.c_int32), _ptr(pf, C.c_double), k))
         return cnt, bod, pf[:, :, :3], pf[:, :, 3:]
+
+    def body_poses(self):
+        """-> rotation (N, nbodies, 3, 3), origin (N, nbodies, 3), com (N, nbodies, 3): pydart2 bodynode.T / .com() of every body."""
+        n, nb = self.num_envs, self.card.nbodies
+        R = np.empty((n, nb, 3, 3), dtype=np.float64); p = np.empty((n, nb, 3), dtype=np.float64); c = np.empty((n, nb, 3), dtype=np.float64)
+        self._check(self.L.dart_get_body_poses(self.h, _ptr(R, C.c_double), _ptr(p, C.c_double), _ptr(c, C.c_double)))
+        return R, p, c
 
     def constraint_forces(self):
         """pydart2 skel.constraint_forces() of the last world step, (N, ndofs); needs CFG_CONTACT_REPORT."""

@@ -159,6 +159,12 @@ int dart_get_episode_stats(DartStepper* h, double* last_return, int32_t* last_le
  * Either pointer may be NULL.  Computed by the generic tree kernel for every model (planar ones included). */
 int dart_get_dynamics(DartStepper* h, double* mass_matrix, double* coriolis_gravity);
 
+/* World poses of every body of every env in its current state -- pydart2's `bodynode.T` / `.C` / `.com()` as the task code
+ * reads them (reference gym/envs/dart/hopper.py:42,72 `bodynodes[2].com()[1]`; human_walker.py:78-92 `bodynodes[1].com()`,
+ * `bodynode('head').com()`, `.to_world()`): rotation (N, nbodies, 3, 3) row-major body-to-world, origin (N, nbodies, 3) of the
+ * body frame, com (N, nbodies, 3).  Body order = the card's (the .skel file's).  Any pointer may be NULL (not all). */
+int dart_get_body_poses(DartStepper* h, double* rotation, double* origin, double* com);
+
 /* Contacts of the last world step of the last env-step -- pydart2's `world.collision_result.contacts` as the reference
  * reads it (gym/envs/dart/walker2d.py:38-41: contact.force; human_walker.py:97-106: contact.bodynode1 / bodynode2;
  * dart_env.py has no getter of its own).  Needs DART_CFG_CONTACT_REPORT = 1 before the step.

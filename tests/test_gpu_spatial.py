@@ -726,3 +726,37 @@ def test_contact_report_matches_oracle(env_id):
     assert with_contacts > 100 and borderline <= 0.02 * with_contacts
     for g in gpus.values():
         g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartHumanWalker-v1", "DartWalker3d-v1", "DartDog-v1", "DartReacher3d-v1"])
+def test_body_poses_match_oracle(env_id):
+    """dart_get_body_poses (bodynode.T / .com() of every body, hopper.py:42, human_walker.py:78-92) vs the oracle's kinematics,
+    random states, planar-kernel models and a free-root model included; and the robot_skeleton.bodynodes facade."""
+    from dart_env_amd.stepper import HipStepper
+    import dart_env_amd
+    card = card_for(env_id)
+    n, nd, nb = 16, card.ndofs, card.nbodies
+    rng = np.random.RandomState(2)
+    q = rng.uniform(-0.6, 0.6, (n, nd)); dq = rng.uniform(-1, 1, (n, nd))
+    if env_id == "DartDog-v1":
+        q[:, :3] = rng.uniform(-2.5, 2.5, (n, 3))
+    worlds = [OracleWorld(card) for _ in range(n)]
+    for i, w in enumerate(worlds):
+        w.set_state(q[i], dq[i])
+    To = np.stack([[w.body_pose(b) for b in range(nb)] for w in worlds]); co = np.stack([[w.body_com(b) for b in range(nb)] for w in worlds])
+    for prec, tol in ((64, 1e-12), (32, 5e-6)):
+        g = HipStepper(card, n, precision=prec)
+        g.set_state(q, dq)
+        R, p, c = g.body_poses()
+        assert np.abs(R - To[:, :, :3, :3]).max() < tol and np.abs(p - To[:, :, :3, 3]).max() < tol and np.abs(c - co).max() < tol, (prec,)
+        g.close()
+    env = dart_env_amd.make(env_id) if env_id != "DartDog-v1" else dart_env_amd.envs.DartDogEnv()
+    env = getattr(env, "env", env)       # TimeLimit wrapper -> the env itself
+    env.seed(0); env.reset()
+    w = OracleWorld(card); qq = env.robot_skeleton.q; w.set_state(qq, env.robot_skeleton.dq)
+    bn = env.robot_skeleton.bodynodes
+    assert len(bn) == nb and env.robot_skeleton.bodynode(bn[-1].name).index == nb - 1
+    assert qq.shape == (nd,) and np.allclose(bn[-1].com(), w.body_com(nb - 1), atol=5e-6) and np.allclose(bn[-1].T, w.body_pose(nb - 1), atol=5e-6)
+    assert np.allclose(bn[2].to_world([0.1, 0.2, 0.3]), w.body_pose(2)[:3, :3] @ [0.1, 0.2, 0.3] + w.body_pose(2)[:3, 3], atol=5e-6)
+    env.close()

@@ -1,4 +1,4 @@
-from .dart_env import BatchedDartEnv  # noqa: F401
+from .dart_env import BatchedDartEnv, DartEnv  # noqa: F401
 from .hopper import DartHopperEnv  # noqa: F401
 from .walker2d import DartWalker2dEnv  # noqa: F401
 from .human_walker import DartHumanWalkerEnv  # noqa: F401

@@ -99,8 +99,7 @@ class SkeletonView:
     def bodynodes(self):
         """BodyNodeView per skeleton body, in the .skel file's order (``robot_skeleton.bodynodes[i]``)."""
         if self._names is None:
-            from ..model_card import load_model
-            self._names = [b.name for b in load_model(self._env.task.model).bodies]
+            self._names = self._env._body_names()
         return [BodyNodeView(self, i, nm) for i, nm in enumerate(self._names)]
 
     def bodynode(self, name):
@@ -270,6 +269,123 @@ class BatchedDartEnv:
     def state_vector(self):
         q, dq = self._stepper.get_state()
         return np.concatenate([q, dq], axis=1)  # dart_env.py:211-215, one row per env
+
+    def _body_names(self):
+        from ..model_card import load_model
+        return [b.name for b in load_model(self.task.model).bodies]
+
+    def close(self):
+        if self._stepper is not None:
+            self._stepper.close()
+            self._stepper = None
+
+
+class DartEnv:
+    """The reference's ``DartEnv`` base class for user-defined tasks, batched (reference gym/envs/dart/dart_env.py:25-215):
+    same constructor arguments, ``do_simulation(tau, n_frames)``, ``set_state``, ``state_vector``, ``dt``,
+    ``robot_skeleton``, ``seed`` / ``np_random``, ``reset()`` -> ``reset_model()`` -- a subclass written the way the reference's
+    env classes are (hopper.py etc.) runs ``num_envs`` worlds at once with (num_envs, ...) arrays in place of vectors.
+
+    ``model_paths``: a ``.skel`` file (or a list whose last entry is one; absolute, or relative to the working directory --
+    the reference resolves relative names against its own assets directory, dart_env.py:38-44).  The robot is
+    ``skeletons[-1]`` (dart_env.py:62), its finite joint limits are enforced (dart_env.py:64-67), the world runs at ``dt``
+    (dart_env.py:55).  The world lives in HBM behind the C ABI as a physics-only card: action = generalized forces.
+    Only ``obs_type='parameter'`` / ``action_type='continuous'`` (no rendering, SURVEY.md section 8 scope)."""
+
+    _unbatched = False
+
+    def __init__(self, model_paths, frame_skip, observation_size, action_bounds, dt=0.002, obs_type="parameter",
+                 action_type="continuous", visualize=False, disableViewer=True, screen_width=80, screen_height=45,
+                 num_envs=1, device=0, precision=32, collidable_bodies=None, stepper_factory=None):
+        import os
+        from ..skel import parse_skel
+        from ..model_card import build_card
+        if obs_type != "parameter" or action_type != "continuous":
+            raise NotImplementedError("image observations / discrete actions need the renderer (out of scope)")
+        if isinstance(model_paths, str):
+            model_paths = [model_paths]
+        path = model_paths[-1]
+        if not os.path.exists(path):
+            raise IOError("File %s does not exist" % path)      # dart_env.py:43-44
+        self.model = parse_skel(path, dt=dt, collidable_bodies=collidable_bodies)
+        self.card = build_card(self.model, None)
+        self.card.frame_skip = int(frame_skip)
+        self.num_envs, self.frame_skip = int(num_envs), int(frame_skip)
+        self.ndofs = self.card.ndofs
+        self._stepper = (stepper_factory or _st.HipStepper)(self.card, self.num_envs, device, precision)
+        self.robot_skeleton = SkeletonView(self)
+        self._obs_type, self.obs_dim, self.act_dim = obs_type, int(observation_size), len(action_bounds[0])
+        self.action_space = spaces.Box(np.asarray(action_bounds[1], dtype=np.float64), np.asarray(action_bounds[0], dtype=np.float64))
+        self.observation_space = spaces.Box(-np.inf * np.ones(self.obs_dim), np.inf * np.ones(self.obs_dim))   # dart_env.py:97-100
+        self.metadata = {"render.modes": []}
+        self.seed()
+
+    def _body_names(self):
+        return [b.name for b in self.model.bodies]
+
+    def seed(self, seed=None):
+        """int s -> env i seeded s + i (sync_vector_env.py:50-58); each env owns ``seeding.np_random(seed_i)`` (dart_env.py:117-119)."""
+        seeds = [None] * self.num_envs if seed is None else ([int(seed) + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed))
+        pairs = [seeding.np_random(sd) for sd in seeds]
+        self.np_randoms = [p[0] for p in pairs]
+        self.np_random = self.np_randoms[0]
+        return [p[1] for p in pairs]
+
+    def uniform(self, low, high, size):
+        """(num_envs, size): ``self.np_random.uniform(low, high, size)`` of every env's own stream, in env order."""
+        return np.stack([r.uniform(low=low, high=high, size=size) for r in self.np_randoms])
+
+    @property
+    def dt(self):
+        return self.card.dt * self.frame_skip      # dart_env.py:154-156
+
+    def do_simulation(self, tau, n_frames):
+        """``n_frames`` world steps with the generalized forces ``tau`` (num_envs, ndofs) re-applied before each
+        (dart_env.py:158-175).  ``n_frames`` must be a multiple of the constructor's ``frame_skip`` (one launch each)."""
+        k, r = divmod(int(n_frames), self.frame_skip)
+        if r or k < 1:
+            raise ValueError("n_frames must be a positive multiple of frame_skip=%d" % self.frame_skip)
+        tau = np.ascontiguousarray(np.asarray(tau, dtype=np.float32).reshape(self.num_envs, self.ndofs))
+        for _ in range(k):
+            self._stepper.step(tau)
+
+    def set_state(self, qpos, qvel):
+        qpos = np.asarray(qpos, dtype=np.float64); qvel = np.asarray(qvel, dtype=np.float64)
+        assert qpos.shape == (self.num_envs, self.ndofs) and qvel.shape == (self.num_envs, self.ndofs)   # dart_env.py:146
+        self._stepper.set_state(qpos, qvel)
+
+    def set_state_vector(self, state):
+        state = np.asarray(state, dtype=np.float64).reshape(self.num_envs, 2 * self.ndofs)
+        self.set_state(state[:, :self.ndofs], state[:, self.ndofs:])     # dart_env.py:150-152
+
+    def state_vector(self):
+        q, dq = self._stepper.get_state()
+        return np.concatenate([q, dq], axis=1)     # dart_env.py:211-215
+
+    @property
+    def init_qpos(self):
+        return np.tile(np.array([self.card.init_pos[i] for i in range(self.ndofs)]), (self.num_envs, 1))
+
+    @property
+    def init_qvel(self):
+        return np.tile(np.array([self.card.init_vel[i] for i in range(self.ndofs)]), (self.num_envs, 1))
+
+    def enable_contact_report(self, on=True):
+        self._stepper.configure(_st.CFG_CONTACT_REPORT, 1 if on else 0)
+
+    def contacts(self):
+        return self._stepper.contacts()
+
+    def reset_model(self):
+        """Reset the robot degrees of freedom (qpos and qvel); implement this in each subclass (dart_env.py:124-129)."""
+        raise NotImplementedError
+
+    def reset(self):
+        self._stepper.reset(None, None, None, want_obs=False)      # world.reset(): q, dq back to the initial values
+        return self.reset_model()                                   # dart_env.py:140-143
+
+    def step(self, a):
+        raise NotImplementedError
 
     def close(self):
         if self._stepper is not None:

@@ -318,6 +318,7 @@ class DartEnv:
         self.action_space = spaces.Box(np.asarray(action_bounds[1], dtype=np.float64), np.asarray(action_bounds[0], dtype=np.float64))
         self.observation_space = spaces.Box(-np.inf * np.ones(self.obs_dim), np.inf * np.ones(self.obs_dim))   # dart_env.py:97-100
         self.metadata = {"render.modes": []}
+        self._dev = None
         self.seed()
 
     def _body_names(self):
@@ -345,6 +346,21 @@ class DartEnv:
         k, r = divmod(int(n_frames), self.frame_skip)
         if r or k < 1:
             raise ValueError("n_frames must be a positive multiple of frame_skip=%d" % self.frame_skip)
+        if hasattr(tau, "data_ptr") and getattr(tau, "is_cuda", False):
+            # torch tensor resident in HBM: launch on torch's current stream, no host round trip; returns the new state
+            # [q, dq] as a (num_envs, 2 ndofs) float32 tensor (valid until the next call) for a task written in torch
+            import torch
+            t = tau.to(dtype=torch.float32).reshape(self.num_envs, self.ndofs).contiguous()
+            if self._dev is None:
+                self._dev = (torch.empty((self.num_envs, 2 * self.ndofs), dtype=torch.float32, device=t.device),
+                             torch.empty(self.num_envs, dtype=torch.float32, device=t.device),
+                             torch.empty(self.num_envs, dtype=torch.uint8, device=t.device),
+                             torch.empty(self.num_envs, dtype=torch.uint8, device=t.device))
+            st_, rw, dn, tr = self._dev
+            stream = torch.cuda.current_stream(t.device).cuda_stream
+            for _ in range(k):
+                self._stepper.step_device(t.data_ptr(), st_.data_ptr(), rw.data_ptr(), dn.data_ptr(), tr.data_ptr(), stream)
+            return st_
         tau = np.ascontiguousarray(np.asarray(tau, dtype=np.float32).reshape(self.num_envs, self.ndofs))
         for _ in range(k):
             self._stepper.step(tau)

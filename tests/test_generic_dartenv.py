@@ -59,6 +59,20 @@ def test_generic_dartenv_on_gpu_matches_oracle_worlds():
     com = env.robot_skeleton.bodynode("front").com()
     assert com.shape == (n, 3) and np.all(com[:, 1] > 0)
     env.close()
+    # torch tensors resident in HBM: same physics, no host round trip
+    import torch
+    ea, eb = InchwormEnv(num_envs=n, precision=32), InchwormEnv(num_envs=n, precision=32)
+    for e in (ea, eb):
+        e.seed(5); e.reset()
+    for t in range(8):
+        tau = np.zeros((n, 5), dtype=np.float32); tau[:, 3:] = np.clip(actions[t], -1, 1) * [6.0, 4.0]
+        ea.do_simulation(tau, 5)
+        sdev = eb.do_simulation(torch.from_numpy(tau).cuda(), 10 if t == 0 else 5)
+        if t == 0:
+            ea.do_simulation(tau, 5)
+    torch.cuda.synchronize()
+    assert np.array_equal(sdev.cpu().numpy(), ea.state_vector().astype(np.float32)) and np.array_equal(eb.state_vector(), ea.state_vector())
+    ea.close(); eb.close()
     env32 = InchwormEnv(num_envs=n, precision=32)
     env32.seed(5)
     o32 = [env32.reset()]

@@ -271,7 +271,7 @@ def test_classic_env_fp64_matches_oracle(env_id, noise):
                                         ("swingup", "DartCartPoleSwingUp-v1"),
                                         ("doublependulum", "DartDoubleInvertedPendulumEnv-v1"),
                                         ("snake", "DartSnake7Link-v1"), ("reacher3d", "DartReacher3d-v1"),
-                                        ("reacher2d", "DartReacher-v1")])
+                                        ("reacher2d", "DartReacher-v1"), ("dog", "DartDog-v1")])
 def test_classic_env_vector_fixture_and_fp32(tag, env_id):
     """Reference SyncVectorEnv fixture through the default (device MT19937) vector env in fp64; fp32 stays close."""
     import dart_env_amd

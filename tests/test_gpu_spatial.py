@@ -760,3 +760,27 @@ def test_body_poses_match_oracle(env_id):
     assert qq.shape == (nd,) and np.allclose(bn[-1].com(), w.body_com(nb - 1), atol=5e-6) and np.allclose(bn[-1].T, w.body_pose(nb - 1), atol=5e-6)
     assert np.allclose(bn[2].to_world([0.1, 0.2, 0.3]), w.body_pose(2)[:3, :3] @ [0.1, 0.2, 0.3] + w.body_pose(2)[:3, 3], atol=5e-6)
     env.close()
+
+
+@pytest.mark.gpu
+def test_sliding_box_known_answer_on_gpu():
+    """The Coulomb-friction known answer of tests/test_oracle_physics.py (box sliding at 1 m/s decelerates at exactly mu g,
+    sticks after 51 steps) on the kernel itself, without the oracle in between; fp64 and fp32."""
+    from dart_env_amd.stepper import HipStepper, CFG_CONTACT_REPORT
+    from tests.test_oracle_physics import _sled_card, sled_closed_form
+    c = _sled_card()
+    ref = sled_closed_form(80)
+    for prec, tol in ((64, 2e-5), (32, 5e-4)):
+        g = HipStepper(c, 5, precision=prec)
+        g.configure(CFG_CONTACT_REPORT, 1)
+        q0 = np.zeros((5, 3)); q0[:, 0] = [0, 1, -3, 50, 7]          # translation invariance along the way
+        g.set_state(q0, np.tile([1.0, 0.0, 0.0], (5, 1)))
+        for k in range(80):
+            g.step(np.zeros((5, 3), dtype=np.float32))
+            q, dq = g.get_state()
+            assert np.abs(dq[:, 0] - ref[k, 1]).max() < tol and np.abs(q[:, 0] - q0[:, 0] - ref[k, 0]).max() < tol * (1 + 50 * (prec == 32)), (prec, k)
+            cnt, bod, pt, fc = g.contacts()
+            assert np.all(cnt == 4) and np.abs(fc[:, :, 1].sum(axis=1) - 3.5 * 9.81).max() < (2e-2 if prec == 64 else 0.5)
+            if 1 <= k < 50:
+                assert np.allclose(fc[:, :, 0].sum(axis=1), -3.5 * 9.81, rtol=2e-4 if prec == 64 else 5e-3)
+        g.close()

@@ -410,3 +410,48 @@ def test_contact_report_forces_sum_to_the_root_constraint_force(env_id, trans):
     assert seen > 100
     if env_id == "DartWalker3d-v1":
         print("world steps with a link-link contact:", pairs)
+
+
+# ------------------------------------------------------------------ Coulomb friction known answer (own asset: tests/golden/assets/sled.skel)
+def _sled_card():
+    import os
+    from dart_env_amd.skel import parse_skel
+    m = parse_skel(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets", "sled.skel"))
+    c = build_card(m, None)
+    c.contact_cfm = 1e-4            # four coplanar box-face contacts (see dart_model_card.h)
+    return c
+
+
+def sled_closed_form(steps, v0=1.0, mu=1.0, g=9.81, dt=0.002):
+    """Flat box sliding on the floor: v_{k+1} = v_k - mu g dt until the friction impulse can stop it, then it sticks."""
+    v, x, out = v0, 0.0, []
+    for _ in range(steps):
+        v = v - mu * g * dt if v > mu * g * dt else 0.0
+        x += dt * v
+        out.append((x, v))
+    return np.array(out)
+
+
+def test_sliding_box_decelerates_at_mu_g_and_sticks():
+    """3.5 kg box (0.4 x 0.1 x 0.3) sliding at 1 m/s: the friction pyramid along DART's tangent t1 = z x n = -x gives exactly
+    mu g; the two-stage bounds (+-mu * frictionless normal impulse, uniform m g dt / 4 per vertex) cap every vertex at the same
+    friction while the final normals shift forward to balance the friction torque about the COM; after v / (mu g dt) = 51 steps
+    the box sticks."""
+    c = _sled_card()
+    w = OracleWorld(c)
+    w.set_state(np.zeros(3), np.array([1.0, 0.0, 0.0]))
+    ref = sled_closed_form(80)
+    m, g, mu, hl, hh = 3.5, 9.81, c.friction, 0.2, 0.05
+    for k in range(80):
+        w.set_forces(np.zeros(3)); w.step()
+        assert abs(w.dq[0] - ref[k, 1]) < 2e-5 and abs(w.q[0] - ref[k, 0]) < 2e-5, k       # 1e-6 m penetration / ERP transient
+        assert abs(w.q[1]) < 1e-6 and abs(w.q[2]) < 1e-6                                    # stays flat on the floor
+        rep = w.contact_report()
+        assert len(rep) == 4 and np.all(rep[:, 0] == 2) and np.all(rep[:, 1] == -1)
+        assert abs(rep[:, 6].sum() - m * g) < 2e-2                                         # normals carry the weight
+        if 1 <= k < 50:
+            assert np.allclose(rep[:, 5], -mu * m * g / 4, rtol=2e-4)                      # every vertex at its stage-1 bound
+            front = rep[rep[:, 2] > w.q[0]][:, 6].sum(); rear = rep[rep[:, 2] < w.q[0]][:, 6].sum()
+            assert abs((front - rear) * hl - mu * m * g * hh) < 2e-2                       # torque balance about the COM
+        if k > 52:
+            assert np.abs(rep[:, 5]).max() < 1e-3 and w.dq[0] == pytest.approx(0.0, abs=1e-6)   # sticking: no friction needed

@@ -45,6 +45,8 @@ struct Impl {
   virtual int set_task_state(hipStream_t, const uint8_t* /*d_mask*/, const double* /*d_values*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int slots() const = 0;
   virtual int max_contacts() const { return 0; }
+  // device buffers of the implementation that persist between steps (dart_snapshot / dart_restore)
+  virtual void persistent(std::vector<std::pair<void*, size_t>>&, int64_t /*n*/) {}
   virtual int set_contact_report(bool /*on*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int get_contacts(hipStream_t, int64_t /*n*/, int32_t* /*count*/, int32_t* /*bodies*/, double* /*point_force*/, int /*max*/) { return DART_E_UNSUPPORTED; }
   virtual int get_constraint_forces(hipStream_t, int64_t /*n*/, double* /*out*/) { return DART_E_UNSUPPORTED; }
@@ -520,6 +522,10 @@ struct SpatialImplT : Impl {
   hipError_t debug_dump(double* out) override { return dbg ? hipMemcpy(out, dbg, sizeof(double) * 160 * (size_t)nenv, hipMemcpyDeviceToHost) : hipErrorInvalidValue; }
   int slots() const override { return M.maxm; }
   int max_contacts() const override { return M.maxcp; }
+  void persistent(std::vector<std::pair<void*, size_t>>& v, int64_t n) override {
+    if (init_h) v.push_back({init_h, sizeof(Real) * 4 * (size_t)n});          // per-env task state (reach targets, initial head height)
+    if (d_cf) v.push_back({d_cf, sizeof(Real) * (size_t)M.n * (size_t)n});     // SPD: constraint forces carried to the next step
+  }
   Real* d_creport = nullptr; int* d_ccount = nullptr; Real* d_cfrep = nullptr;
   int set_contact_report(bool on, int64_t n) override {
     if (on && !d_creport) {
@@ -1136,6 +1142,59 @@ int dart_get_constraint_forces(DartStepper* h, double* constraint_forces) {
   if (rc == DART_E_INVALID) h->err = "dart_get_constraint_forces: enable DART_CFG_CONTACT_REPORT before stepping";
   if (rc == DART_E_UNSUPPORTED) h->err = "constraint forces: only the generic kernel reports them (card.generic_kernel = 1)";
   return rc;
+}
+
+// everything that persists between steps, in a fixed order
+static void snapshot_buffers(DartStepper* h, std::vector<std::pair<void*, size_t>>& v) {
+  const size_t N = (size_t)h->n, nd = (size_t)h->card.ndofs, rs = h->precision == 32 ? 4 : 8;
+  v.push_back({h->q, rs * nd * N}); v.push_back({h->dq, rs * nd * N});
+  v.push_back({h->elapsed, 4 * N}); v.push_back({h->episode, 4 * N});
+  if (h->mt) { v.push_back({h->mt, 4 * 624 * N}); v.push_back({h->mt_pos, 4 * N}); }
+  if (h->d_ep_ret) {
+    v.push_back({h->d_ep_ret, 8 * N}); v.push_back({h->d_last_ret, 8 * N}); v.push_back({h->d_ep_len, 4 * N});
+    v.push_back({h->d_last_len, 4 * N}); v.push_back({h->d_ep_tot, 8 * 3});
+  }
+  h->impl->persistent(v, h->n);
+}
+
+int dart_snapshot(DartStepper* h, void* buf, uint64_t* nbytes) {
+  if (!h || !nbytes) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  std::vector<std::pair<void*, size_t>> v;
+  snapshot_buffers(h, v);
+  uint64_t total = 16;
+  for (auto& b : v) total += b.second;
+  if (!buf) { *nbytes = total; return DART_OK; }
+  if (*nbytes < total) { h->err = "dart_snapshot: buffer too small"; *nbytes = total; return DART_E_INVALID; }
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  unsigned char* p = (unsigned char*)buf;
+  const uint64_t head[2] = {0x44415254534e4150ull /* "DARTSNAP" */, total};
+  memcpy(p, head, 16); p += 16;
+  for (auto& b : v) { CHK(h, hipMemcpy(p, b.first, b.second, hipMemcpyDeviceToHost)); p += b.second; }
+  *nbytes = total;
+  return DART_OK;
+}
+
+int dart_restore(DartStepper* h, const void* buf, uint64_t nbytes) {
+  if (!h || !buf) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  std::vector<std::pair<void*, size_t>> v;
+  snapshot_buffers(h, v);
+  uint64_t total = 16;
+  for (auto& b : v) total += b.second;
+  uint64_t head[2];
+  if (nbytes < 16) { h->err = "dart_restore: not a snapshot"; return DART_E_INVALID; }
+  memcpy(head, buf, 16);
+  if (head[0] != 0x44415254534e4150ull || head[1] != total || nbytes < total) {
+    h->err = "dart_restore: snapshot of a different handle configuration (model, num_envs, precision, seeding / statistics modes)";
+    return DART_E_INVALID;
+  }
+  CHK(h, hipSetDevice(h->device));
+  CHK(h, hipStreamSynchronize(h->stream));
+  const unsigned char* p = (const unsigned char*)buf + 16;
+  for (auto& b : v) { CHK(h, hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice)); p += b.second; }
+  return DART_OK;
 }
 
 int dart_sync(DartStepper* h) {

@@ -270,6 +270,14 @@ class BatchedDartEnv:
         q, dq = self._stepper.get_state()
         return np.concatenate([q, dq], axis=1)  # dart_env.py:211-215, one row per env
 
+    def snapshot(self):
+        """Exact checkpoint of the device side (state, TimeLimit / episode counters, MT19937 bank, task state) -- with the
+        default device noise the following steps and auto-resets are bitwise those of the original run after restore()."""
+        return self._stepper.snapshot()
+
+    def restore(self, snap):
+        self._stepper.restore(snap)
+
     def _body_names(self):
         from ..model_card import load_model
         return [b.name for b in load_model(self.task.model).bodies]

@@ -28,7 +28,7 @@ SOLVER_BPP, SOLVER_PGS = 0, 1
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses", "dart_snapshot", "dart_restore",
 ]
 
 
@@ -87,6 +87,8 @@ def load_library(path: Optional[str] = None):
     L.dart_get_dynamics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dart_get_contacts.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int32]
     L.dart_get_constraint_forces.argtypes = [vp, C.POINTER(C.c_double)]
+    L.dart_snapshot.argtypes = [vp, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.dart_restore.argtypes = [vp, C.c_void_p, C.c_uint64]
     L.dart_get_body_poses.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dart_set_ext_force.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.dart_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
@@ -194,6 +196,18 @@ class HipStepper:
         cnt = np.empty(n, dtype=np.int32); bod = np.empty((n, k, 2), dtype=np.int32); pf = np.empty((n, k, 6), dtype=np.float64)
         self._check(self.L.dart_get_contacts(self.h, _ptr(cnt, C.c_int32), _ptr(bod, C.c_int32), _ptr(pf, C.c_double), k))
         return cnt, bod, pf[:, :, :3], pf[:, :, 3:]
+
+    def snapshot(self) -> np.ndarray:
+        """Exact checkpoint (state, counters, MT19937 bank, task state, episode statistics) as a uint8 array."""
+        nb = C.c_uint64(0)
+        self._check(self.L.dart_snapshot(self.h, None, C.byref(nb)))
+        buf = np.empty(nb.value, dtype=np.uint8)
+        self._check(self.L.dart_snapshot(self.h, buf.ctypes.data_as(C.c_void_p), C.byref(nb)))
+        return buf
+
+    def restore(self, buf: np.ndarray):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._check(self.L.dart_restore(self.h, buf.ctypes.data_as(C.c_void_p), buf.size))
 
     def body_poses(self):
         """-> rotation (N, nbodies, 3, 3), origin (N, nbodies, 3), com (N, nbodies, 3): pydart2 bodynode.T / .com() of every body."""

@@ -182,6 +182,15 @@ int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* p
  * (N, ndofs).  Recorded together with the contacts: needs DART_CFG_CONTACT_REPORT = 1 before the step. */
 int dart_get_constraint_forces(DartStepper* h, double* constraint_forces);
 
+/* Exact checkpoint of everything that persists between steps: q / dq in the kernel's own precision, TimeLimit and episode
+ * counters, the MT19937 bank, per-env task state (reach targets ...), episode statistics -- the batched form of pickling
+ * a reference env between steps (set_state / get_state are the reference's only checkpoint hooks,
+ * dart_env.py:145-148,211-215; they do not cover np_random or TimeLimit).  dart_snapshot(h, NULL, &n) returns the size;
+ * dart_restore accepts a snapshot of a handle with the same card, num_envs, precision and enabled modes, after which the
+ * following steps (incl. auto-resets) are bitwise those of the original run. */
+int dart_snapshot(DartStepper* h, void* buf, uint64_t* nbytes);
+int dart_restore(DartStepper* h, const void* buf, uint64_t nbytes);
+
 /* Wait for everything enqueued on the handle's stream. */
 int dart_sync(DartStepper* h);
 

@@ -94,3 +94,34 @@ def test_sled_translation_and_batch_invariance_fp32_bitwise():
         s.close()
     for q, dq, off in outs[1:]:
         assert np.array_equal(dq, outs[0][1]) and np.array_equal(q[1:], outs[0][0][1:]) and abs((q[0] - off) - outs[0][0][0]) < 1e-5
+
+
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartHumanWalker-v1", "DartWalker3dSPD-v1"])
+def test_snapshot_restore_resumes_bitwise(env_id):
+    """dart_snapshot / dart_restore: after a restore the next steps -- including on-device auto-resets from the MT19937
+    bank, TimeLimit truncations, episode statistics and the SPD controller's carried constraint forces -- are bitwise those
+    of the uninterrupted run; a snapshot of a different configuration is refused."""
+    import dart_env_amd
+    from dart_env_amd.stepper import StepperError
+    n = 64
+    kw = {}
+    venv = dart_env_amd.vector.make(env_id, n, **kw)
+    venv.seed(7); venv.reset()
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-1, 1, (70, n, venv.single_action_space.shape[0])).astype(np.float32)
+    for t in range(20):
+        venv.step(acts[t])
+    snap = venv.env.snapshot() if hasattr(venv, "env") else venv._env.snapshot()
+    ref = [venv.step(acts[t])[:3] for t in range(20, 70)]
+    if env_id != "DartWalker3dSPD-v1":
+        assert sum(int(r[2].sum()) for r in ref) > 0                  # episodes ended and were reset on the device
+    for t in range(5):
+        venv.step(acts[t])                                            # wander off, then come back
+    (venv.env if hasattr(venv, "env") else venv._env).restore(snap)
+    for t in range(20, 70):
+        ob, r, d, _ = venv.step(acts[t])
+        assert np.array_equal(ob, ref[t - 20][0]) and np.array_equal(r, ref[t - 20][1]) and np.array_equal(d, ref[t - 20][2]), t
+    other = dart_env_amd.vector.make(env_id, n // 2, **kw)
+    with pytest.raises(StepperError):
+        (other.env if hasattr(other, "env") else other._env).restore(snap)
+    other.close(); venv.close()

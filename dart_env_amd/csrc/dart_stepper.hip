@@ -645,6 +645,7 @@ struct DartStepper {
   size_t dyn_lds = 0;
   double *d_dynM = nullptr, *d_dync = nullptr, *d_tstage = nullptr, *d_pose = nullptr;
   bool dyn_free_root = false;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;   // ordering between the handle's stream and a caller-supplied one
   std::string err;
 };
 
@@ -773,6 +774,8 @@ int dart_destroy(DartStepper* h) {
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
+  if (h->ev_in) hipEventDestroy(h->ev_in);
+  if (h->ev_out) hipEventDestroy(h->ev_out);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return DART_OK;
@@ -929,10 +932,27 @@ int dart_reset(DartStepper* h, const uint8_t* mask, const double* qpos_noise, co
   return DART_OK;
 }
 
+// A caller-supplied stream shares the handle's state buffers with the handle's own stream: make it wait for the work already
+// enqueued there (ext_begin) and make the handle's stream wait for what the caller's stream was just given (ext_end).
+static int ext_begin(DartStepper* h, hipStream_t s) {
+  if (s == h->stream) return DART_OK;
+  if (!h->ev_in) { CHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming)); CHK(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming)); }
+  CHK(h, hipEventRecord(h->ev_in, h->stream));
+  CHK(h, hipStreamWaitEvent(s, h->ev_in, 0));
+  return DART_OK;
+}
+static int ext_end(DartStepper* h, hipStream_t s) {
+  if (s == h->stream) return DART_OK;
+  CHK(h, hipEventRecord(h->ev_out, s));
+  CHK(h, hipStreamWaitEvent(h->stream, h->ev_out, 0));
+  return DART_OK;
+}
+
 int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void* hip_stream) {
   if (!h) return DART_E_INVALID;
   CHK(h, hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  { int rc = ext_begin(h, s); if (rc != DART_OK) return rc; }
   const double *dqn = nullptr, *dvn = nullptr;
   if (h->noise_mode == 1) {
     int rc = mt_draw(h, s, d_mask);
@@ -940,7 +960,8 @@ int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void*
     dqn = h->d_qn; dvn = h->d_vn;
   }
   CHK(h, h->impl->reset(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_mask, dqn, dvn, d_obs, h->seed, h->env_offset));
-  return episode_restart(h, s, d_mask);
+  { int rc = episode_restart(h, s, d_mask); if (rc != DART_OK) return rc; }
+  return ext_end(h, s);
 }
 
 static int state_copy(DartStepper* h, double* q, double* dq, int to_device) {
@@ -1026,6 +1047,7 @@ int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float
   if (!h || !d_actions) return DART_E_INVALID;
   CHK(h, hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  { int rc = ext_begin(h, s); if (rc != DART_OK) return rc; }
   const bool mt_reset = h->autoreset && h->noise_mode == 1;
   float* o = d_obs ? d_obs : h->d_obs;
   uint8_t* dn = d_done ? d_done : h->d_done;
@@ -1037,7 +1059,7 @@ int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float
     if (rc != DART_OK) return rc;
     CHK(h, h->impl->reset(s, h->n, h->q, h->dq, h->elapsed, h->episode, dn, h->d_qn, h->d_vn, o, h->seed, h->env_offset, 1));
   }
-  return DART_OK;
+  return ext_end(h, s);
 }
 
 int dart_get_counters(DartStepper* h, int32_t* elapsed, uint32_t* episode) {

@@ -1,0 +1,169 @@
+// spatial_model.hpp -- model constants (SpatialModel), small vector helpers and the per-env LDS block (SpLds) of the tree kernel.
+// Part of the gfx950 tree kernel; overview in spatial_kernel.hpp, design in DESIGN.md section 4.2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "planar_kernel.hpp"  // philox, sincos_, rcp_, tol_
+
+namespace dartk {
+
+constexpr int SP_MAXL = 48;   // expanded 1-dof links
+constexpr int SP_MAXN = 32;   // dofs
+constexpr int SP_MAXS = 16;   // collidable shapes
+// LCP capacity is a property of the model (SpatialModel::maxm / maxcp): 36 rows / 12 contact points by default
+// (HumanWalker peaks at ~31 active rows), 64 rows / 20 points for models with link-link contacts (rows = lanes <= 64)
+constexpr int SP_MAXPAIRS = 40;   // non-adjacent shape pairs tested for link-link contacts
+__device__ __host__ constexpr int sp_tri(int m) { return m * (m + 1) / 2; }   // packed lower triangle of A / LDL workspace
+// The pivoting solver's LDL^T workspace (and its PGS start vector) are live only after the Jacobian rows have been
+// built, the per-link records only before: when the link block is big enough the two share LDS (HumanWalker: 2.8 KB
+// less per workgroup = 10 instead of 8 workgroups per CU).
+__device__ __host__ constexpr bool sp_lw_aliases_links(int nl, int maxm) { return nl * 37 >= sp_tri(maxm) + maxm; }
+__device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+__device__ __host__ constexpr int sp_npad(int n) { return (n + 7) & ~7; }   // H is stored padded with identity rows to a multiple of 8
+__device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
+constexpr int SP_LINKF = 37;  // Reals stored per link in LDS
+constexpr int SP_LCONST = 48;   // Rpre 9, ppre 3, Rpost 9, ppost 3, axis 3, com 3, inertia 9, axr 3, cpost 3 (+3 pad)
+enum { LC_RPRE = 0, LC_PPRE = 9, LC_RPOST = 12, LC_PPOST = 21, LC_AXIS = 24, LC_COM = 27, LC_INERTIA = 30, LC_AXR = 39, LC_CPOST = 42 };
+constexpr int SP_ROUNDS = 6;  // pointer-jumping rounds: trees up to 64 links deep
+
+template <class Real>
+struct SpatialModel {
+  int nl, n, nshapes;
+  int parent[SP_MAXL], jtype[SP_MAXL], dof[SP_MAXL], root_trans[SP_MAXL];
+  int pre_ident[SP_MAXL], post_ident[SP_MAXL];   // 1: the fixed transform is the identity (carriers of expanded joints)
+  int n_root_trans, root_trans_link[8];   // the root-chain prismatic links (floating-base translation)
+  int nrounds;                       // ceil(log2(tree depth)): pointer-jumping rounds of the forward pass
+  int anc[SP_MAXL][SP_ROUNDS];       // anc[i][k] = 2^k-th ancestor of link i, -1 beyond the root
+  // backward pass: links of one expanded joint share their joint origin, so their composite bodies are identical;
+  // only the group's last link (the leader, the one that carries the mass) gathers, level by level over GROUPS
+  int link_is_body[SP_MAXL];                         // 1: the link that carries a card body (last link of its joint)
+  int group_leader[SP_MAXL], group_level[SP_MAXL];   // group_level: depth of the group for leaders, -1 for the others
+  int n_group_levels;
+  // the forward pass re-reads its link's geometry from here every substep (48 contiguous Reals per link, 12 x 16-byte
+  // loads issued together: one L1/L2-resident latency per substep instead of ~45 VGPRs held for the whole kernel)
+  Real lconst[SP_MAXL][SP_LCONST];
+  int child_start[SP_MAXL + 1], child_list[SP_MAXL];            // children of every link
+  Real axis[SP_MAXL][3];
+  Real root_axis_world[SP_MAXL][3];   // world axis of the root-chain prismatic links (constant)
+  Real Rpre[SP_MAXL][9], ppre[SP_MAXL][3];    // joint frame in the parent link frame
+  Real Rpost[SP_MAXL][9], ppost[SP_MAXL][3];  // child link frame in the (moved) joint frame
+  Real mass[SP_MAXL], com[SP_MAXL][3], inertia[SP_MAXL][9];
+  int dof_link[SP_MAXN], limited[SP_MAXN];
+  Real lower[SP_MAXN], upper[SP_MAXN], damp[SP_MAXN], stiff[SP_MAXN], rest[SP_MAXN], q0[SP_MAXN], dq0[SP_MAXN];
+  Real spd_kp[SP_MAXN], spd_kd[SP_MAXN];   // DartWalker3dSPD-v1 stable-PD gains (task 12); act_scale = torque limits
+  Real envdt;                        // dt * frame_skip (the SPD law uses the env step, walker3d_spd.py:41-46)
+  Real* cf_store;                    // [n_envs][n] generalized constraint forces of each env's last world step (task 12)
+  Real jfric_dt[SP_MAXN];            // Coulomb joint friction * dt: impulse bound of the dof's friction row (0 = none)
+  int has_joint_friction;
+  int free_root;                     // 1: body 0 hangs on a DART FreeJoint (public q[0:3] rotation vector, dq[0:6] body twist)
+  int free_link;                     // the last of the six root links (carries the body); its joint rotation is Rz(c) R0
+  int maxm, maxcp;                   // LCP rows / contact points this model's LDS block is carved for
+  int npairs, pair_a[SP_MAXPAIRS], pair_b[SP_MAXPAIRS];   // link-link contact candidates: shape slots, a < b
+  int sh_link[SP_MAXS], sh_type[SP_MAXS];
+  Real sh_R[SP_MAXS][9], sh_p[SP_MAXS][3], sh_size[SP_MAXS][3];
+  Real dt, g[3], ground_y, mu, erp_dt, max_erv, limit_erp_dt, cfm1, ccfm1;   // ccfm1 = 1 + contact_cfm
+  // task
+  int task, frame_skip, act_dim, obs_dim, act_dof0, max_steps;
+  Real act_scale[32], act_lo[32], act_hi[32];
+  int aux_link[4];
+  Real aux_real[8], aux_real2[4];
+  Real s_max, v_clip, noise, noise_v, inv_envdt;
+  int solver_iters, pgs_fallback_sweeps;
+  int ext_at_joint_origin;     // 1: the force acts at the link's joint origin (redirected from a massless carrier body)
+  int ext_link;                // external body force (dart_set_ext_force): link it acts on, at the link frame origin
+  const Real* ext_force;       // [n_envs][3] world-frame force per env, nullptr = none
+  int link_body[SP_MAXL];      // card body carried by a link (-1: carrier link of an expanded joint)
+  Real* creport;               // optional [n_envs][maxcp][8]: contacts of the last world step {body a, body b, point, force on a}
+  int* creport_count;          // [n_envs]
+  Real* cf_report;             // [n_envs][n]: constraint_forces() of the last world step (recorded with the contacts)
+  double* dbg;                 // optional [n_envs][160] dump of the last LCP (debug builds of the tests only)
+  unsigned long long* stats;   // optional [64]: [0..31] pivoting iterations per solve, [32] PGS fallbacks, [33] solves
+};
+
+// ---- tiny 3-vector helpers on registers
+template <class Real> struct V3 { Real x, y, z; };
+template <class Real> __device__ __forceinline__ V3<Real> v3(Real x, Real y, Real z) { return {x, y, z}; }
+template <class Real> __device__ __forceinline__ V3<Real> operator+(V3<Real> a, V3<Real> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class Real> __device__ __forceinline__ V3<Real> operator-(V3<Real> a, V3<Real> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class Real> __device__ __forceinline__ V3<Real> operator*(V3<Real> a, Real s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class Real> __device__ __forceinline__ Real dot(V3<Real> a, V3<Real> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class Real> __device__ __forceinline__ V3<Real> cross(V3<Real> a, V3<Real> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class Real> __device__ __forceinline__ V3<Real> ld3(const Real* p) { return {p[0], p[1], p[2]}; }
+template <class Real> __device__ __forceinline__ void st3(Real* p, V3<Real> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+// y = R x, R row-major 3x3
+template <class Real> __device__ __forceinline__ V3<Real> mulR(const Real* R, V3<Real> x) {
+  return {R[0] * x.x + R[1] * x.y + R[2] * x.z, R[3] * x.x + R[4] * x.y + R[5] * x.z, R[6] * x.x + R[7] * x.y + R[8] * x.z};
+}
+template <class Real> __device__ __forceinline__ void mulRR(const Real* A, const Real* B, Real* C) {  // C = A B
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// LDS layout of one link (offsets in Reals)
+enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_C = 18, LK_F = 21, LK_N = 24, LK_MC = 27, LK_H = 28, LK_IC = 31 };
+
+template <class Real>
+struct SpLds {
+  Real* link;    // [nl][SP_LINKF]
+  Real* q; Real* dq; Real* tau; Real* rhs;   // [n]
+  Real* H;       // [n(n+1)/2] packed lower triangle -> Cholesky factor
+  Real* W;       // [maxm+1][n]: constraint Jacobian rows, then W = L^-1 J^T
+  Real* A;       // [tri(maxm)] packed symmetric
+  Real* Lw;      // [tri(maxm)] packed lower
+  Real* b; Real* lo; Real* hi; Real* x; Real* r; Real* x0;   // [maxm]
+  int* rdof;     // [maxm] limit rows: dof index, contact rows: -1
+  int* rfidx;    // [maxm] friction rows: index of their normal row, else -1
+  Real* cpP;     // [maxcp][4]: contact point (relative coords) + depth
+  Real* cpN;     // [maxcp][3]: contact normal, pointing into the first link (ground: +y)
+  int* cplink;   // [maxcp] first link
+  int* cplinkB;  // [maxcp] second link of a link-link contact, -1 for the ground
+  Real* sinv;    // [n]: 1 / L_jj of the mass-matrix Cholesky factor
+  Real* root;    // [24] free root joint: R (9), p (3), body twist w v (6), Euler X-Y-Z of R (3)
+  Real* cf;      // [n]: J^T lambda / dt of the previous world step (pydart2 constraint_forces(), SPD task only)
+  Real* misc;    // [16]: roff(3), scalars
+  int* imisc;    // [8]: ncp, m, contact flags
+  unsigned long long* ticks;   // [10] phase cycle counters of this env-step (diagnostics, only touched when stats are on)
+  int* topo;     // [nl]: (parent + 1) | (dof + 1) << 8 | jtype << 16 -- ancestor walks read this instead of global memory
+};
+__device__ __forceinline__ int topo_parent(int w) { return (w & 0xff) - 1; }
+__device__ __forceinline__ int topo_dof(int w) { return ((w >> 8) & 0xff) - 1; }
+__device__ __forceinline__ int topo_jtype(int w) { return (w >> 16) & 0xff; }
+
+template <class Real>
+__device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int maxm, int maxcp) {
+  SpLds<Real> S;
+  Real* p = base;
+  S.link = p; p += nl * SP_LINKF;
+  S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n;
+  S.H = p; p += sp_npad(n) * (sp_npad(n) + 1) / 2;
+  S.W = p; p += (maxm + 1) * n;
+  S.A = p; p += sp_tri(maxm);
+  if (sp_lw_aliases_links(nl, maxm)) { S.Lw = S.link; S.x0 = S.link + sp_tri(maxm); }
+  else { S.Lw = p; p += sp_tri(maxm); S.x0 = p; p += maxm; }
+  S.b = p; p += maxm; S.lo = p; p += maxm; S.hi = p; p += maxm; S.x = p; p += maxm; S.r = p; p += maxm;
+  S.cpP = p; p += maxcp * 4;
+  S.cpN = p; p += maxcp * 3;
+  S.misc = p; p += 16;
+  S.sinv = p; p += n;
+  S.cf = p; p += n;
+  S.root = p; p += 24;
+  S.rdof = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
+  S.rfidx = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
+  S.cplink = (int*)p; p += maxcp * sizeof(int) / sizeof(Real) + 1;
+  S.cplinkB = (int*)p; p += maxcp * sizeof(int) / sizeof(Real) + 1;
+  S.imisc = (int*)p;
+  S.topo = S.imisc + 8;
+  S.ticks = (unsigned long long*)(((size_t)(S.topo + nl) + 7) & ~(size_t)7);
+  return S;
+}
+__host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp) {
+  const size_t lw = sp_lw_aliases_links(nl, maxm) ? 0 : (size_t)sp_tri(maxm) + maxm;
+  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(maxm + 1) * n + sp_tri(maxm) + lw + 5 * maxm +
+                 maxcp * 7 + 16 + 24;
+  return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
+}
+
+}  // namespace dartk

@@ -1,0 +1,365 @@
+// spatial_world_step.hpp -- one DART world step of the env owned by a wavefront: dynamics, contact / limit / friction rows, two-stage LCP, velocity and position update, contact report.
+// Part of the gfx950 tree kernel; overview in spatial_kernel.hpp, design in DESIGN.md section 4.2.
+#pragma once
+#include "spatial_dense.hpp"
+#include "spatial_free_root.hpp"
+#include "spatial_box_box.hpp"
+
+namespace dartk {
+
+// ------------------------------------------------------------------ one world step for the env owned by this wavefront
+#define SP_TICK(ph)                                                                              \
+  do {                                                                                            \
+    if (Md.stats && lane == 0) {                                                                  \
+      const unsigned long long t1_ = __builtin_readcyclecounter();                                \
+      S.ticks[ph] += t1_ - t0_;                                                                   \
+      t0_ = t1_;                                                                                  \
+    }                                                                                             \
+  } while (0)
+
+// PAIRS: link-link contacts (box pairs, general contact normals); EXTRAS: snake fluid forces, external body force, Coulomb
+// joint friction rows.  Models that need neither run the lean instantiation (HumanWalker: 8 % faster than the full one).
+template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false>
+__device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, const LinkConst<Real>& lc, SpLds<Real>& S, int lane,
+                                              int* contact_flags, bool report = false) {
+  const int n = Md.n, nl = Md.nl;
+  unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
+  if (EXTRAS && Md.free_root) {
+    if (lane == 0) sp_free_root_to_internal<Real>(S);
+    __syncthreads();
+  }
+  // tree recursions level by level: links of equal depth are independent, one lane each
+  if (lane == 0) sp_root_offset<Real>(Md, S);
+  sp_forward<Real, EXTRAS>(lc, Md, S, lane, (int64_t)blockIdx.x);   // lane i owns link i
+  __syncthreads();
+  for (int lv = Md.n_group_levels - 1; lv >= 0; lv--) {
+    if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);
+    __syncthreads();
+  }
+  if (lane < nl) sp_link_rhs<Real, EXTRAS>(lc, Md, S, lane);
+  __syncthreads();
+  if (EXTRAS && Md.free_root) {
+    if (lane == 0) sp_free_root_velocity_correction<Real>(S, Md.dt);
+    __syncthreads();
+  }
+  SP_TICK(0);
+  if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
+  else if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[TL(lane, k)] = Real(0); S.H[TL(lane, lane)] = Real(1); }
+  __syncthreads();
+  if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
+  SP_TICK(1);
+  sp_cholesky<Real>(S.H, S.sinv, n, lane);
+  SP_TICK(2);
+
+  // ---- contact points and active limits, in parallel: lane s tests collision shape s, lane d tests the limits of
+  // dof d; ballots give every hit its slot (shape order, then vertex order -- the serial order of the oracle)
+  const V3<Real> roff = ld3(S.misc);
+  int ncp, m;
+  {
+    const bool has_shape = lane < Md.nshapes;
+    const int s = has_shape ? lane : 0;
+    const int slink = Md.sh_link[s], stype = Md.sh_type[s];
+    Real sR[9];
+    for (int k = 0; k < 9; k++) sR[k] = Md.sh_R[s][k];
+    const V3<Real> sp = ld3(Md.sh_p[s]), ssz = ld3(Md.sh_size[s]);
+    const Real* L = S.link + slink * SP_LINKF;
+    Real Ts[9];
+    mulRR(L + LK_R, sR, Ts);
+    const V3<Real> pc = ld3(L + LK_P) + mulR(L + LK_R, sp);
+    V3<Real> P[4];
+    Real dep[4];
+    bool hit[4] = {false, false, false, false};
+    if (stype == 0) {   // capsule: lowest segment endpoint, ODE sphere-sphere contact position
+      const Real rad = ssz.x, hl = Real(0.5) * ssz.y;
+      const V3<Real> zc = v3<Real>(Ts[2], Ts[5], Ts[8]);
+      const V3<Real> p1 = pc + zc * hl, p2 = pc - zc * hl;
+      const V3<Real> pe = (p2.y < p1.y) ? p2 : p1;
+      const Real d = pe.y + roff.y - Md.ground_y;
+      hit[0] = has_shape && d <= rad;
+      P[0] = v3<Real>(pe.x, pe.y - Real(0.5) * (rad + d), pe.z); dep[0] = rad - d;
+      for (int v = 1; v < 4; v++) { P[v] = P[0]; dep[v] = Real(0); }
+    } else {            // box: vertices of the face that looks down, the ones below the floor
+      const V3<Real> c0 = v3<Real>(Ts[0], Ts[3], Ts[6]), c1 = v3<Real>(Ts[1], Ts[4], Ts[7]), c2 = v3<Real>(Ts[2], Ts[5], Ts[8]);
+      int k = 0;
+      Real bestv = fabs(c0.y);
+      if (fabs(c1.y) > bestv) { bestv = fabs(c1.y); k = 1; }
+      if (fabs(c2.y) > bestv) k = 2;
+      const V3<Real> ek = k == 0 ? c0 : (k == 1 ? c1 : c2), e1 = k == 0 ? c1 : (k == 1 ? c2 : c0), e2 = k == 0 ? c2 : (k == 1 ? c0 : c1);
+      const Real hk = Real(0.5) * (k == 0 ? ssz.x : (k == 1 ? ssz.y : ssz.z)), h1 = Real(0.5) * (k == 0 ? ssz.y : (k == 1 ? ssz.z : ssz.x)),
+                 h2 = Real(0.5) * (k == 0 ? ssz.z : (k == 1 ? ssz.x : ssz.y));
+      const Real sgn = ek.y > Real(0) ? Real(-1) : Real(1);
+      const V3<Real> base = pc + ek * (sgn * hk);
+      const Real sg1[4] = {1, -1, -1, 1}, sg2[4] = {1, 1, -1, -1};
+      for (int v = 0; v < 4; v++) {
+        P[v] = base + e1 * (sg1[v] * h1) + e2 * (sg2[v] * h2);
+        dep[v] = Md.ground_y - (P[v].y + roff.y);
+        hit[v] = has_shape && dep[v] >= Real(0);
+      }
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint64_t hm[4];
+    int before = 0, total = 0;
+    for (int v = 0; v < 4; v++) { hm[v] = __ballot(hit[v]); before += __popcll(hm[v] & lt); total += __popcll(hm[v]); }
+    int idx = before;
+    for (int v = 0; v < 4; v++) {
+      if (hit[v]) {
+        if (idx < Md.maxcp) {
+          S.cpP[4 * idx + 0] = P[v].x; S.cpP[4 * idx + 1] = P[v].y; S.cpP[4 * idx + 2] = P[v].z; S.cpP[4 * idx + 3] = dep[v];
+          S.cpN[3 * idx + 0] = Real(0); S.cpN[3 * idx + 1] = Real(1); S.cpN[3 * idx + 2] = Real(0);
+          S.cplink[idx] = slink; S.cplinkB[idx] = -1;
+        }
+        idx++;
+      }
+    }
+    ncp = total < Md.maxcp ? total : Md.maxcp;
+    // foot-contact flags of the observation (human_walker.py:97-106): any contact on aux_link[2], aux_link[3]
+    const bool anyhit = hit[0] || hit[1] || hit[2] || hit[3];
+    const uint64_t f0 = __ballot(anyhit && slink == Md.aux_link[2]), f1 = __ballot(anyhit && slink == Md.aux_link[3]);
+    if (lane == 0) { contact_flags[0] = f0 != 0ull; contact_flags[1] = f1 != 0ull; }
+    // link-link contacts (walker3d.py:26): lane p tests shape pair p; the points follow the ground contacts, pair by pair
+    if (PAIRS && Md.npairs > 0) {
+      const bool has_pair = lane < Md.npairs;
+      Real* scratch = S.A + lane * 40;          // A / Lw are idle in this phase: 40 Reals of clipping workspace per lane
+      int k = 0, la = 0, lb = 0;
+      V3<Real> nrm = v3<Real>(0, 1, 0);
+      if (has_pair) k = sp_box_box<Real>(Md, S, Md.pair_a[lane], Md.pair_b[lane], scratch, nrm, la, lb);
+      int before = 0, total = 0;
+      for (int v = 0; v < 8; v++) { const uint64_t hm8 = __ballot(v < k); before += __popcll(hm8 & lt); total += __popcll(hm8); }
+      for (int v = 0; v < k; v++) {
+        const int id2 = ncp + before + v;
+        if (id2 < Md.maxcp) {
+          for (int t = 0; t < 4; t++) S.cpP[4 * id2 + t] = scratch[4 * v + t];
+          S.cpN[3 * id2 + 0] = -nrm.x; S.cpN[3 * id2 + 1] = -nrm.y; S.cpN[3 * id2 + 2] = -nrm.z;   // into the first link
+          S.cplink[id2] = la; S.cplinkB[id2] = lb;
+        }
+      }
+      ncp = (ncp + total) < Md.maxcp ? (ncp + total) : Md.maxcp;
+    }
+    // contact rows: normal, two tangents
+    if (lane < 3 * ncp) { S.rdof[lane] = -1; S.rfidx[lane] = (lane % 3 == 0) ? -1 : (lane - lane % 3); }
+    // joint-limit rows
+    const Real qd = lane < n ? S.q[lane] : Real(0);
+    const bool low = lane < n && lc.d_limited && qd <= lc.d_lower;
+    const bool up = lane < n && lc.d_limited && !low && qd >= lc.d_upper;
+    const uint64_t lm = __ballot(low || up);
+    const int row = 3 * ncp + __popcll(lm & lt);
+    if ((low || up) && row < Md.maxm) {
+      const Real viol = low ? qd - lc.d_lower : qd - lc.d_upper;
+      const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
+      S.rdof[row] = lane; S.rfidx[row] = -1;
+      S.b[row] = bounce - S.dq[lane];   // the dt * W_i . y part (unconstrained acceleration) is added after the W solve
+      S.lo[row] = low ? Real(0) : -inf_<Real>();
+      S.hi[row] = low ? inf_<Real>() : Real(0);
+    }
+    m = 3 * ncp + __popcll(lm);
+    if (EXTRAS && Md.has_joint_friction) {   // DART JointCoulombFrictionConstraint rows: joint velocity -> 0, impulse within +-mu dt
+      const bool fr = lane < n && lc.d_fric > Real(0);
+      const uint64_t fm = __ballot(fr);
+      const int frow = m + __popcll(fm & lt);
+      if (fr && frow < Md.maxm) {
+        S.rdof[frow] = lane; S.rfidx[frow] = -1;
+        S.b[frow] = -S.dq[lane];
+        S.lo[frow] = -lc.d_fric; S.hi[frow] = lc.d_fric;
+      }
+      m += __popcll(fm);
+    }
+    m = m < Md.maxm ? m : Md.maxm;
+  }
+  __syncthreads();
+  SP_TICK(3);
+  {
+    // ---- Jacobian rows (lane per row) + the generalized-force row (index m), bias part of b for contact rows
+    if (lane == m) for (int k = 0; k < n; k++) S.W[m * n + k] = S.rhs[k];
+    if (lane < m) {
+      Real* Jr = S.W + lane * n;
+      for (int k = 0; k < n; k++) Jr[k] = Real(0);
+      const int d = S.rdof[lane];
+      if (d >= 0) {
+        Jr[d] = Real(1);
+      } else {
+        const int cidx = lane / 3, kind = lane % 3;
+        // DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1
+        V3<Real> dir;
+        if (PAIRS) {
+          const V3<Real> nn = ld3(S.cpN + 3 * cidx);
+          V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
+          if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
+          t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
+          dir = kind == 0 ? nn : (kind == 1 ? t1 : cross(nn, t1));
+        } else {   // ground contacts only: n = +y, t1 = z x n = -x, t2 = n x t1 = +z
+          dir = kind == 0 ? v3<Real>(0, 1, 0) : (kind == 1 ? v3<Real>(-1, 0, 0) : v3<Real>(0, 0, 1));
+        }
+        const V3<Real> P = ld3(S.cpP + 4 * cidx);
+        Real rel = Real(0);
+        for (int side = 0; side < (PAIRS ? 2 : 1); side++) {   // J = J_a - J_b for a link-link contact
+          const Real sg = side == 0 ? Real(1) : Real(-1);
+          for (int j = side == 0 ? S.cplink[cidx] : S.cplinkB[cidx]; j >= 0;) {
+            const int w = S.topo[j];
+            const int dj = topo_dof(w), jcur = j;
+            j = topo_parent(w);
+            if (dj < 0) continue;
+            const Real* Lj = S.link + jcur * SP_LINKF;
+            const V3<Real> aj = ld3(Lj + LK_A);
+            const Real v = sg * ((topo_jtype(w) == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj));
+            Jr[dj] += v;
+            rel += v * S.dq[dj];
+          }
+        }
+        const Real depth = S.cpP[4 * cidx + 3];
+        S.b[lane] = (kind == 0 ? fmin(depth * Md.erp_dt, Md.max_erv) : Real(0)) - rel;
+        S.lo[lane] = Real(0);
+        S.hi[lane] = kind == 0 ? inf_<Real>() : Real(0);   // friction rows pinned during the frictionless stage
+      }
+    }
+    __syncthreads();
+    SP_TICK(4);
+    // ---- W = L^-1 [J^T | rhs] : every lane forward-substitutes its own row; row m becomes y = L^-1 rhs
+    // The row lives in registers and both loops are fully unrolled (SP_MAXN x SP_MAXN / 2 predicated steps, uniform
+    // `k < n` branches): every factor entry is one LDS read at an immediate offset, no index arithmetic.
+    if (lane <= m) {
+      Real* yrow = S.W + lane * n;
+      Real y[SP_MAXN];
+#pragma unroll
+      for (int k = 0; k < SP_MAXN; k++) y[k] = (k < n) ? yrow[k] : Real(0);
+#pragma unroll
+      for (int k = 0; k < SP_MAXN; k++) {
+        if (k < n) {
+          Real t = y[k];
+#pragma unroll
+          for (int j = 0; j < k; j++) t -= S.H[TL(k, j)] * y[j];
+          y[k] = t * S.sinv[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < SP_MAXN; k++) if (k < n) yrow[k] = y[k];
+    }
+    __syncthreads();
+    // b_i = bounce_i - J_i (dq + dt H^-1 rhs) = bias_i - dt W_i . y
+    if (lane < m) {
+      const Real* wi = S.W + lane * n;
+      const Real* y = S.W + m * n;
+      Real t = Real(0);
+      for (int k = 0; k < n; k++) t += wi[k] * y[k];
+      S.b[lane] -= Md.dt * t;
+    }
+    __syncthreads();
+    SP_TICK(5);
+  }
+  if (m > 0) {
+    // ---- A = W W^T (lower), cfm on the diagonal.  The m(m+1)/2 entries are dealt round-robin to the 64 lanes
+    // (row-per-lane would leave the last lane with m dot products and the first with one).
+    {
+      const int ntri = m * (m + 1) / 2;
+      const Real cfm1 = Md.cfm1, ccfm1 = Md.ccfm1;
+      int i = 0, base = 0;   // entry e = base + k with base = i(i+1)/2
+      for (int e = lane; e < ntri; e += 64) {
+        while (base + i + 1 <= e) { base += i + 1; i++; }
+        const int k = e - base;
+        const Real* wi = S.W + i * n;
+        const Real* wk = S.W + k * n;
+        Real t = Real(0);
+        for (int j = 0; j < n; j++) t += wi[j] * wk[j];
+        if (k == i) t *= (S.rdof[i] >= 0) ? cfm1 : ccfm1;
+        S.A[e] = t;   // TI(i, k) == e for k <= i
+      }
+    }
+    __syncthreads();
+    SP_TICK(6);
+    // ---- stage 1 (frictionless), stage 2 (friction bounds from the stage-1 normal impulses)
+    uint64_t pinmask = 0, F = 0, U = 0;
+    {
+      Real bm = Real(0);
+      for (int i = 0; i < m; i++) bm = fmax(bm, fabs(S.b[i]));
+      const Real tol0 = tol_<Real>() * (Real(1) + bm);
+      bool pinned = false, upper = false, startf = false;
+      if (lane < m) {
+        pinned = !(S.lo[lane] < S.hi[lane]);
+        upper = !(S.lo[lane] == Real(0));
+        startf = !pinned && (upper ? (S.b[lane] < -tol0) : (S.b[lane] > tol0));
+      }
+      pinmask = __ballot(pinned); F = __ballot(startf); U = __ballot(upper && !startf);
+    }
+    if (lane < m) S.x[lane] = Real(0);
+    __syncthreads();
+    // one inlined copy of the solver serves both stages (instruction-cache footprint)
+    for (int stage = 0; stage < 2; stage++) {
+      if (stage == 1) {
+        SP_TICK(7);
+        if (ncp == 0) break;
+        bool isf = false, pinned = false;
+        if (lane < m && S.rfidx[lane] >= 0) {
+          const Real hb = fabs(Md.mu * S.x[S.rfidx[lane]]);
+          // a direction the skeleton cannot move in (planar model, z tangent) has A_ii = 0: keep that row out
+          isf = true; pinned = !(hb > Real(0)) || !(S.A[TI(lane, lane)] > Real(1e-12));
+          S.hi[lane] = hb; S.lo[lane] = -hb;
+        }
+        __syncthreads();
+        const uint64_t fr = __ballot(isf), pf = __ballot(isf && pinned);
+        pinmask = (pinmask & ~fr) | pf;
+        F = (F & ~fr) | (fr & ~pf);
+        U &= ~fr;
+      }
+      sp_blcp<Real>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction));
+    }
+    SP_TICK(8);
+    if (Md.dbg) {
+      double* D = Md.dbg + (size_t)blockIdx.x * 160;
+      if (lane == 0) { D[0] = m; D[1] = ncp; }
+      if (lane < m) { D[2 + lane] = (double)S.x[lane]; D[42 + lane] = (double)S.b[lane]; D[82 + lane] = (double)S.hi[lane]; D[122 + lane] = (double)S.A[TI(lane, lane)]; }
+    }
+  }
+  if (REPORT && report) {   // world.collision_result.contacts (walker2d.py:38-41, human_walker.py:97-106): point, force on the first body
+    if (lane == 0) Md.creport_count[blockIdx.x] = ncp;
+    if (lane < ncp) {
+      Real* out = Md.creport + ((size_t)blockIdx.x * Md.maxcp + lane) * 8;
+      const V3<Real> nn = ld3(S.cpN + 3 * lane);
+      V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
+      if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
+      t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
+      const V3<Real> t2 = cross(nn, t1);
+      // a tangent the skeleton cannot move along (planar model: z) has A_ii = 0 and stays pinned at a bound: no force
+      const int r1 = 3 * lane + 1, r2 = 3 * lane + 2;
+      const Real l0 = S.x[3 * lane], l1 = S.A[TI(r1, r1)] > Real(1e-12) ? S.x[r1] : Real(0),
+                 l2 = S.A[TI(r2, r2)] > Real(1e-12) ? S.x[r2] : Real(0), idt = Real(1) / Md.dt;
+      const int lb = S.cplinkB[lane];
+      out[0] = (Real)Md.link_body[S.cplink[lane]]; out[1] = lb >= 0 ? (Real)Md.link_body[lb] : Real(-1);
+      st3(out + 2, ld3(S.cpP + 4 * lane) + roff);
+      st3(out + 5, (nn * l0 + t1 * l1 + t2 * l2) * idt);
+    }
+  }
+  // ---- new velocity: vs = dq + L^-T (dt y + W^T lambda)
+  if (lane < n) {
+    Real u = Md.dt * S.W[m * n + lane], ul = Real(0);
+    for (int i = 0; i < m; i++) { const Real t = S.W[i * n + lane] * S.x[i]; u += t; ul += t; }
+    if ((EXTRAS && Md.task == 12) || (REPORT && report)) S.lo[lane] = ul;   // W^T lambda = L^-1 J^T lambda
+    S.rhs[lane] = u;
+  }
+  __syncthreads();
+  if ((EXTRAS && Md.task == 12) || (REPORT && report)) {   // constraint_forces() of this step: J^T lambda / dt = L (W^T lambda) / dt
+    if (lane < n) {
+      Real t = Real(0);
+      for (int k = 0; k <= lane; k++) t += S.H[TL(lane, k)] * S.lo[k];
+      S.cf[lane] = t / Md.dt;
+    }
+    __syncthreads();
+    if (REPORT && report && lane < n) {
+      Real v = S.cf[lane];
+      if (EXTRAS && Md.free_root && lane < 6) {   // internal root coordinates are world-frame, DART's body-frame: tau_b = R^T tau_w
+        const int g = lane < 3 ? 0 : 3, a = lane - g;
+        v = S.root[a] * S.cf[g] + S.root[3 + a] * S.cf[g + 1] + S.root[6 + a] * S.cf[g + 2];
+      }
+      Md.cf_report[(size_t)blockIdx.x * n + lane] = v;
+    }
+  }
+  sp_chol_backsolve<Real>(S.H, S.sinv, n, S.rhs, lane);
+  SP_TICK(9);
+  if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
+  __syncthreads();
+  if (EXTRAS && Md.free_root) {   // the six root entries just advanced are placeholders: the pose lives in S.root
+    if (lane == 0) sp_free_root_advance<Real>(S, Md.dt);
+    __syncthreads();
+  }
+  (void)nl;
+}
+
+}  // namespace dartk

@@ -365,9 +365,16 @@ class DartEnv:
                              torch.empty(self.num_envs, dtype=torch.uint8, device=t.device),
                              torch.empty(self.num_envs, dtype=torch.uint8, device=t.device))
             st_, rw, dn, tr = self._dev
-            stream = torch.cuda.current_stream(t.device).cuda_stream
+            cur = torch.cuda.current_stream(t.device)
+            stream = cur.cuda_stream
+            if stream == 0:
+                # torch's legacy default stream has no handle to pass (NULL means "the stepper's own stream" in the ABI):
+                # order the two streams by hand -- tau must be complete before, the state visible to torch after
+                cur.synchronize()
             for _ in range(k):
                 self._stepper.step_device(t.data_ptr(), st_.data_ptr(), rw.data_ptr(), dn.data_ptr(), tr.data_ptr(), stream)
+            if stream == 0:
+                self._stepper.sync()
             return st_
         tau = np.ascontiguousarray(np.asarray(tau, dtype=np.float32).reshape(self.num_envs, self.ndofs))
         for _ in range(k):

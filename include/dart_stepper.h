@@ -111,7 +111,10 @@ int dart_step_wait(DartStepper* h, float* obs_out, double* reward_out, uint8_t* 
 
 /* Device-resident variant for GPU learners / benchmarks: all pointers are HBM addresses on the handle's device,
  * reward is float32.  Enqueued on `hip_stream` (a hipStream_t, NULL = the handle's own stream); returns
- * without synchronising. */
+ * without synchronising.  A caller-supplied stream is ordered against the handle's own stream with events in both
+ * directions (it waits for work already enqueued on the handle, later calls on the handle wait for it), so mixing this
+ * entry point with the host-buffer calls needs no extra synchronisation; the caller orders its own producers / consumers
+ * of the argument buffers on `hip_stream`. */
 int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done,
                      uint8_t* d_truncated, void* hip_stream);
 int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void* hip_stream);

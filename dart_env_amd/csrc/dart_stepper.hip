@@ -100,7 +100,6 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   if (c.obs_dim != 2 * T::NDOF - 1 && c.task != DART_TASK_NONE) return "obs_dim";
   for (int d = 0; d < c.ndofs; d++) if (c.joint_friction[d] != 0.0) return "joint Coulomb friction";
   if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
-  if (c.contact_cfm != c.cfm) return "contact_cfm differs from cfm";
   // floating base: prismatic x, prismatic y, revolute +-z
   if (c.jtype[0] != DART_JT_PRISMATIC || c.jtype[1] != DART_JT_PRISMATIC || c.parent[0] != -1 || c.parent[1] != 0)
     return "root carriers";
@@ -159,7 +158,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   if (nc != T::NC) return "collidable shape count";
   P.dt = (Real)c.dt; P.ground_y = (Real)c.ground_y; P.g = (Real)(-c.gravity[1]); P.mu = (Real)c.friction;
   P.erp_dt = (Real)(c.erp / c.dt); P.max_erv = (Real)c.max_erv; P.limit_erp_dt = (Real)(c.limit_erp / c.dt);
-  P.cfm1 = (Real)(1.0 + c.cfm);
+  P.cfm1 = (Real)(1.0 + c.cfm); P.ccfm1 = (Real)(1.0 + c.contact_cfm);
   for (int k = 0; k < T::NA; k++) {
     P.act_scale[k] = (Real)c.act_scale[k]; P.act_lo[k] = (Real)c.act_low[k]; P.act_hi[k] = (Real)c.act_high[k];
   }

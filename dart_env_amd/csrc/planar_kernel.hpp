@@ -100,7 +100,8 @@ struct Params {
   using Topo = T;
   static constexpr bool is_static = false;  // static_models.hpp holds the compile-time variants
   __device__ __host__ static constexpr bool zero(int, int) { return false; }
-  Real dt, ground_y, g, mu, erp_dt, max_erv, limit_erp_dt, cfm1;  // cfm1 = 1 + cfm (DART scales diag(A))
+  Real dt, ground_y, g, mu, erp_dt, max_erv, limit_erp_dt, cfm1;  // cfm1 = 1 + cfm (DART scales diag(A)): limit rows
+  Real ccfm1;                                                     // 1 + contact cfm: contact rows (ContactConstraint's own value)
   Real root_x0, root_y0;
   Real sigma[T::NL], mass[T::NL], cx[T::NL], cy[T::NL], izz[T::NL], jx[T::NL], jy[T::NL];
   Real lo[T::NL], hi[T::NL];
@@ -517,7 +518,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     // inactive slots: decouple (unit diagonal keeps the factorisations regular)
     sfor<0, M>([&](auto I) {
       constexpr int i = I;
-      A[tri(i, i)] = act[i] ? A[tri(i, i)] * P.cfm1 : Real(1);
+      A[tri(i, i)] = act[i] ? A[tri(i, i)] * (i < 2 * NC ? P.ccfm1 : P.cfm1) : Real(1);
       sfor<0, i>([&](auto J) { constexpr int j = J; if (!act[i] || !act[j]) A[tri(i, j)] = Real(0); });
     });
 

@@ -94,7 +94,7 @@ class TaskSpec:
     aux_ints: List[int] = field(default_factory=list)   # stored in aux_body[] after the named bodies
     aux_real: List[float] = field(default_factory=list)
     aux_real2: List[float] = field(default_factory=list)
-    contact_cfm: Optional[float] = None   # None -> the model's DART cfm (1e-9)
+    contact_cfm: Optional[float] = None   # None -> the model's (DART ContactConstraint's 1e-5)
     act_low: float = -1.0
     act_high: float = 1.0
     clamp_actions: bool = True            # False: the env passes a[k] * scale on unclamped (cart_pole.py:16)
@@ -126,7 +126,7 @@ HUMANWALKER = TaskSpec(
     max_episode_steps=300, reward_threshold=None, height_body=10, penalty_dof=-1, height_lo=-0.2, height_hi=1.0,
     angle_max=2.0, contact_bodies=["l-foot", "r-foot"], alive_bonus=2.0, ctrl_cost=0.5, limit_penalty=0.0,
     reset_noise=0.005, reset_noise_vel=0.05, aux_body_names=["pelvis", "head", "l-foot", "r-foot"],
-    aux_real=[1.0, 2.0, 0.5, 3.0, -0.2, 1.0, 1.3, 0.4], aux_real2=[0.9], contact_cfm=1e-4, all_bodies_collide=True)
+    aux_real=[1.0, 2.0, 0.5, 3.0, -0.2, 1.0, 1.3, 0.4], aux_real2=[0.9], all_bodies_collide=True)
 
 # DartWalker3d-v1 -- reference gym/envs/dart/walker3d.py:10-15 (15 actions, scale 100 / 150 for the waist / 20 for the
 # ankles, obs 41, frame_skip 4), :45-92 (reward, done; quantities of bodynodes[0] = the translational carrier body),
@@ -136,7 +136,7 @@ WALKER3D = TaskSpec(
     act_scale=[150.0] * 3 + [100.0] * 4 + [20.0] * 2 + [100.0] * 4 + [20.0] * 2,
     max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1, height_lo=1.05, height_hi=2.0,
     angle_max=0.84, contact_bodies=["h_foot", "h_foot_left"], alive_bonus=1.0, ctrl_cost=1e-3, limit_penalty=0.2,
-    aux_body_names=["h_torso_aux"], aux_ints=[18, 12], aux_real=[1e-3], contact_cfm=1e-4, all_bodies_collide=True,
+    aux_body_names=["h_torso_aux"], aux_ints=[18, 12], aux_real=[1e-3], all_bodies_collide=True,
     self_collision=True)
 
 # DartCartPole-v1 -- reference gym/envs/dart/cart_pole.py:6-39 (dt 0.02, frame_skip 2, obs [q, dq], scale 100, no clamp,
@@ -210,7 +210,7 @@ WALKER3D_SPD = TaskSpec(
     act_scale=[100.0] * 3 + [200.0] * 4 + [20.0] * 2 + [200.0] * 4 + [20.0] * 2,
     max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1, height_lo=1.05, height_hi=2.0,
     angle_max=0.54, alive_bonus=1.0, ctrl_cost=1e-2, limit_penalty=0.0, aux_body_names=["h_torso_aux"], aux_ints=[18, 12],
-    aux_real=[0.1, 0.45], contact_cfm=1e-4, all_bodies_collide=True, self_collision=True, spd_kp=_SPD_KP)
+    aux_real=[0.1, 0.45], all_bodies_collide=True, self_collision=True, spd_kp=_SPD_KP)
 
 # DartDog-v1 -- reference gym/envs/dart/dog.py:9-65: quadruped on a FREE root joint (22 dofs), 16 actions x 200 on dofs 6..,
 # reward 0.6 dx/dt + 1 - 1e-3 sum a^2 (:35-37), done on height outside (0.7, 1.8) or |z| >= 0.4 (:40-41), obs q[1:], clip(dq)
@@ -219,7 +219,7 @@ DOG = TaskSpec(
     env_id="DartDog-v1", model="dog", task=TASK_DOG, frame_skip=4, act_dim=16, obs_dim=43, act_dof0=6, act_scale=[200.0] * 16,
     max_episode_steps=1000, reward_threshold=None, height_body=0, penalty_dof=-1, height_lo=0.7, height_hi=1.8,
     angle_max=np.inf, alive_bonus=1.0, ctrl_cost=1e-3, limit_penalty=0.0, aux_body_names=["main_body"], aux_real=[0.6, 0.4],
-    contact_cfm=1e-4, all_bodies_collide=True)
+    all_bodies_collide=True)
 
 TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH, CARTPOLE_SWINGUP,
                                DOUBLE_PENDULUM, SNAKE, REACHER2D, REACHER3D, WALKER3D_SPD, DOG)}
@@ -269,7 +269,7 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         c.damping[i], c.stiffness[i], c.rest[i] = model.damping[i], model.stiffness[i], model.rest[i]
         c.init_pos[i], c.init_vel[i] = model.init_pos[i], model.init_vel[i]
         c.joint_friction[i] = 0.0 if model.joint_friction is None else float(model.joint_friction[i])
-    c.contact_cfm = model.cfm
+    c.contact_cfm = model.contact_cfm
     c.nshapes = len(model.shapes)
     for i, s in enumerate(model.shapes):
         c.shape_body[i], c.shape_type[i], c.shape_collidable[i] = s.body, s.kind, int(s.collidable)

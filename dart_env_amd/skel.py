@@ -153,11 +153,16 @@ class ModelCard:
     init_vel: np.ndarray
     ground_y: float             # top face of the immobile ground box
     friction: float = 1.0       # DART default (no <friction> tags in the assets) (A6)
-    # constraint-solver constants (DART ContactConstraint / JointLimitConstraint defaults, A9)
+    # constraint-solver constants (A9): DART 6's per-constraint-type #defines --
+    #   ContactConstraint.cpp:    DART_ERP 0.01, DART_MAX_ERV 1e-3, DART_CFM 1e-5   (erp, max_erv, contact_cfm)
+    #   JointLimitConstraint.cpp: DART_ERP 0.01, DART_MAX_ERV 1e+1, DART_CFM 1e-9, error allowance 0 -> its correction
+    #                             velocity is identically zero (limit_erp = 0), so its cap never acts       (cfm)
+    #   JointCoulombFrictionConstraint.cpp: DART_CFM 1e-9                                                   (cfm)
     erp: float = 0.01
-    max_erv: float = 10.0
-    cfm: float = 1e-9
+    max_erv: float = 1e-3       # cap of the contact penetration-correction velocity
+    cfm: float = 1e-9           # diagonal scaling (1 + cfm) of joint-limit / joint-friction rows
     limit_erp: float = 0.0      # DART 6 joint-limit rows carry no position correction (allowance 0)
+    contact_cfm: float = 1e-5   # diagonal scaling (1 + cfm) of contact rows
     dof_names: List[str] = field(default_factory=list)
     joint_friction: Optional[np.ndarray] = None   # Coulomb friction per dof (<dynamics><friction>); None = all zero
 
@@ -180,7 +185,7 @@ class ModelCard:
         d = dict(
             format="dart_env_amd.modelcard/1", name=self.name, dt=self.dt, gravity=arr(self.gravity),
             ground_y=self.ground_y, friction=self.friction, erp=self.erp, max_erv=self.max_erv,
-            cfm=self.cfm, limit_erp=self.limit_erp, dof_names=self.dof_names,
+            cfm=self.cfm, limit_erp=self.limit_erp, contact_cfm=self.contact_cfm, dof_names=self.dof_names,
             lower=[None if not np.isfinite(x) else float(x) for x in self.lower],
             upper=[None if not np.isfinite(x) else float(x) for x in self.upper],
             limited=[bool(x) for x in self.limited], damping=arr(self.damping),
@@ -213,7 +218,8 @@ class ModelCard:
             limited=np.asarray(d["limited"], dtype=bool), damping=f(d["damping"]),
             stiffness=f(d["stiffness"]), rest=f(d["rest"]), init_pos=f(d["init_pos"]),
             init_vel=f(d["init_vel"]), ground_y=d["ground_y"], friction=d["friction"], erp=d["erp"],
-            max_erv=d["max_erv"], cfm=d["cfm"], limit_erp=d["limit_erp"], dof_names=d["dof_names"],
+            max_erv=d["max_erv"], cfm=d["cfm"], limit_erp=d["limit_erp"], contact_cfm=d.get("contact_cfm", 1e-5),
+            dof_names=d["dof_names"],
             joint_friction=f(d["joint_friction"]) if "joint_friction" in d else None)
 
 

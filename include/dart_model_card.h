@@ -88,8 +88,8 @@ typedef struct DartModelCard {
   double ground_y;    /* top face of the immobile ground box; -inf = no floor */
   double friction;    /* Coulomb mu of foot/ground pair (DART default 1.0) */
   double erp;         /* contact error-reduction parameter (DART 0.01) */
-  double max_erv;     /* cap of the contact correction velocity (DART 10) */
-  double cfm;         /* constraint force mixing on diag(A) (DART 1e-9) */
+  double max_erv;     /* cap of the contact correction velocity (DART ContactConstraint.cpp: DART_MAX_ERV 1e-3) */
+  double cfm;         /* diag(A) *= 1 + cfm on joint-limit / joint-friction rows (DART JointLimitConstraint.cpp: DART_CFM 1e-9) */
   double limit_erp;   /* joint-limit correction gain (DART 6: effectively 0) */
 
   /* ---- bodies (creation order = joint order in file, parents first) ---- */
@@ -155,10 +155,9 @@ typedef struct DartModelCard {
   int32_t aux_body[4];
   double aux_real[8];
   double aux_real2[4];
-  /* Regularisation of CONTACT rows (normal + friction): diag(A) *= 1 + contact_cfm.  DART's value is `cfm` (1e-9);
-   * models whose feet are boxes produce up to 4 coplanar, redundant contact points per rigid foot, which makes the
-   * Delassus matrix singular up to that 1e-9 -- the split of the normal impulse (and with it the friction bounds) is
-   * then decided by rounding / pivoting order, in DART as much as here.  A larger value makes the LCP well posed. */
+  /* diag(A) *= 1 + contact_cfm on CONTACT rows (normal + friction): DART's ContactConstraint.cpp carries its own
+   * DART_CFM 1e-5 (four orders above the joint-limit value) -- models whose feet are boxes produce up to 4 coplanar,
+   * redundant contact points per rigid foot, and this is what keeps their Delassus matrix regular. */
   double contact_cfm;
   /* 1: link-link contacts between the robot's own collision shapes (boxes) are generated for every pair of bodies
    * that are not parent and child -- `robot_skeleton.set_self_collision_check(True)` (walker3d.py:26) with DART's

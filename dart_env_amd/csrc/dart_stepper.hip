@@ -419,7 +419,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   }
   M.s_max = (Real)c.state_abs_max; M.v_clip = (Real)c.obs_vel_clip; M.noise = (Real)c.reset_noise; M.noise_v = (Real)c.reset_noise_vel;
   M.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip));
-  M.solver_iters = 200; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.dbg = nullptr; M.creport = nullptr; M.creport_count = nullptr; M.cf_report = nullptr;
+  M.solver_iters = 600; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.dbg = nullptr; M.creport = nullptr; M.creport_count = nullptr; M.cf_report = nullptr;
   if (c.task == DART_TASK_NONE && c.obs_dim != 2 * c.ndofs) return "physics-only obs must be [q, dq]";
   return "";
 }
@@ -488,7 +488,7 @@ struct SpatialImplT : Impl {
     // reduced across the wavefront with __shfl_xor); solver 0 = pivoting with the PGS safety net
     (void)it2;
     if (solver == 1) { M.solver_iters = 0; M.pgs_fallback_sweeps = it1 > 0 ? it1 : 30; }
-    else { M.solver_iters = it1 > 0 ? it1 : 200; M.pgs_fallback_sweeps = 600; }
+    else { M.solver_iters = it1 > 0 ? it1 : 600; M.pgs_fallback_sweeps = 600; }
     upload();
   }
   double* dbg = nullptr; int64_t nenv = 0;

@@ -23,6 +23,8 @@
  *      the ODE Dantzig driver DART calls sets lo/hi when it reaches the first
  *      findex row (two-stage solve)
  *   5. qd = qd* + H^-1 J^T lambda ; q += dt qd  (Skeleton::integratePositions)
+ *      constants: ContactConstraint.cpp ERP 0.01 / MAX_ERV 1e-3 / CFM 1e-5, JointLimitConstraint.cpp CFM 1e-9 with an
+ *      error allowance of 0 (no position correction), JointCoulombFrictionConstraint.cpp CFM 1e-9 -- card knobs
  *
  * It is pinned only by known-answer tests (tests/test_oracle_physics.py):
  * closed-form free fall, total mass / standing normal force, M symmetric PD and

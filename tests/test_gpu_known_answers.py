@@ -125,3 +125,25 @@ def test_snapshot_restore_resumes_bitwise(env_id):
     with pytest.raises(StepperError):
         (other.env if hasattr(other, "env") else other._env).restore(snap)
     other.close(); venv.close()
+
+
+@pytest.mark.parametrize("kind", ["damping", "spring", "friction", "limit"])
+def test_single_dof_closed_forms_on_the_kernel(kind):
+    """Implicit joint damping / spring, Coulomb joint friction and an inelastic joint limit on a 1-dof wheel: the kernel against
+    the update rules themselves (tests/test_oracle_physics.py::flywheel_closed_forms), fp64 and fp32, no oracle in between."""
+    from dart_env_amd.stepper import HipStepper
+    from tests.test_oracle_physics import flywheel_card, flywheel_closed_forms
+    card = dict(damping=lambda: flywheel_card(damping=0.7), spring=lambda: flywheel_card(damping=0.3, stiffness=5.0, rest=0.1),
+                friction=lambda: flywheel_card(friction=0.2), limit=lambda: flywheel_card(lower=-1.0, upper=0.05))[kind]()
+    steps = 2700 if kind == "friction" else 600
+    card.frame_skip = 20                                   # 20 world steps per launch
+    ref = flywheel_closed_forms(kind, steps)
+    for prec, tq, tv in ((64, 1e-10, 1e-9), (32, 2e-4, 2e-4)):
+        s = HipStepper(card, 3, precision=prec)
+        s.set_state(np.zeros((3, 1)), np.full((3, 1), 2.0))
+        for j in range(steps // 20):
+            s.step(np.zeros((3, 1), dtype=np.float32))
+            q, dq = s.get_state()
+            k = 20 * (j + 1) - 1
+            assert np.abs(q[:, 0] - ref[k, 0]).max() < tq * (1 + abs(ref[k, 0])) and np.abs(dq[:, 0] - ref[k, 1]).max() < tv, (kind, prec, k)
+        s.close()

@@ -457,3 +457,59 @@ def test_sliding_box_decelerates_at_mu_g_and_sticks():
             assert abs((front - rear) * hl - mu * m * g * hh) < 2e-2                       # torque balance about the COM
         if k > 52:
             assert np.abs(rep[:, 5]).max() < 1e-3 and w.dq[0] == pytest.approx(0.0, abs=1e-6)   # sticking: no friction needed
+
+
+# ------------------------------------------------------------------ single-dof closed forms (own asset: tests/golden/assets/flywheel.skel)
+def flywheel_card(damping=0.0, stiffness=0.0, rest=0.0, friction=0.0, lower=None, upper=None, dt=0.002):
+    import os
+    from dart_env_amd.skel import parse_skel
+    m = parse_skel(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets", "flywheel.skel"), dt=dt)
+    m.damping[:] = damping; m.stiffness[:] = stiffness; m.rest[:] = rest
+    m.joint_friction = np.array([friction])
+    if lower is not None or upper is not None:
+        m.lower[:] = -np.inf if lower is None else lower
+        m.upper[:] = np.inf if upper is None else upper
+        m.limited[:] = True
+    return build_card(m, None)
+
+
+FLY_I = 0.5      # izz of the wheel about its axle
+
+
+def flywheel_closed_forms(kind, steps, dt=0.002):
+    """(q, dq) after every step of the 1-dof wheel, from the update rules DART's semantics imply (A3, A10, joint friction):
+    implicit damping / spring  (I + dt d + dt^2 k) a = tau - d v - k (q + dt v - rest);   Coulomb friction: an impulse within
+    +-mu dt that drives v to zero;   limit: inelastic stop while q >= upper (inclusive) and v > 0, no position correction."""
+    q, v, out = 0.0, 2.0, []
+    d, k, rest, mu, up = dict(damping=(0.7, 0, 0, 0, None), spring=(0.3, 5.0, 0.1, 0, None), friction=(0, 0, 0, 0.2, None),
+                              limit=(0, 0, 0, 0, 0.05))[kind]
+    for _ in range(steps):
+        a = (-d * v - k * (q + dt * v - rest)) / (FLY_I + dt * d + dt * dt * k)
+        vs = v + dt * a
+        if mu:
+            imp = max(-mu * dt, min(mu * dt, -FLY_I * vs / (1 + 1e-9)))   # row: (1 + cfm) imp / I = -vs within +-mu dt
+            vs = vs + imp / FLY_I
+        if up is not None and q >= up and vs > 0:
+            vs = vs - vs / (1 + 1e-9)                                # (1 + cfm) on the diagonal leaves vs cfm / (1 + cfm)
+        v = vs
+        q = q + dt * v
+        out.append((q, v))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("kind", ["damping", "spring", "friction", "limit"])
+def test_single_dof_closed_forms(kind):
+    card = dict(damping=lambda: flywheel_card(damping=0.7), spring=lambda: flywheel_card(damping=0.3, stiffness=5.0, rest=0.1),
+                friction=lambda: flywheel_card(friction=0.2), limit=lambda: flywheel_card(lower=-1.0, upper=0.05))[kind]()
+    w = OracleWorld(card)
+    w.set_state(np.zeros(1), np.array([2.0]))
+    ref = flywheel_closed_forms(kind, 3000)
+    for t in range(3000):
+        w.set_forces(np.zeros(1)); w.step()
+        assert abs(w.q[0] - ref[t, 0]) < 1e-10 and abs(w.dq[0] - ref[t, 1]) < 1e-9, (kind, t, w.q[0], ref[t, 0], w.dq[0], ref[t, 1])
+    if kind == "damping":
+        assert ref[-1, 1] == pytest.approx(2.0 * (FLY_I / (FLY_I + 0.002 * 0.7)) ** 3000, rel=1e-12)
+    if kind == "friction":
+        assert abs(ref[-1, 1]) < 1e-12 and ref[2498, 1] > 0          # stops after v0 I / (mu dt) = 2500 steps, then stays
+    if kind == "limit":
+        assert abs(ref[-1, 1]) < 1e-8 and 0.05 <= ref[-1, 0] < 0.05 + 2.0 * 0.002   # stuck one step beyond the limit: no correction

@@ -147,3 +147,30 @@ def test_single_dof_closed_forms_on_the_kernel(kind):
             k = 20 * (j + 1) - 1
             assert np.abs(q[:, 0] - ref[k, 0]).max() < tq * (1 + abs(ref[k, 0])) and np.abs(dq[:, 0] - ref[k, 1]).max() < tv, (kind, prec, k)
         s.close()
+
+
+def test_landing_is_inelastic_and_recovers_at_the_capped_rate_on_the_kernel():
+    """Box dropped from 1 mm (tests/test_oracle_physics.py: same closed form): after the landing step the vertical velocity is
+    the penetration-correction velocity min(erp depth / dt, max_erv), and the depth decays by exactly that per step."""
+    from dart_env_amd.stepper import HipStepper
+    from tests.test_oracle_physics import _sled_card
+    c = _sled_card()
+    s = HipStepper(c, 2, precision=64)
+    s.set_state(np.tile([0.0, 0.001, 0.0], (2, 1)), np.zeros((2, 3)))
+    g, dt = 9.81, c.dt
+    y, v, landed = 0.001, 0.0, False
+    for k in range(300):
+        s.step(np.zeros((2, 3), dtype=np.float32))
+        q, dq = s.get_state()
+        depth = -y
+        if depth >= 0:
+            v = min(c.erp * depth / dt, c.max_erv); landed = True
+        else:
+            v = v - g * dt
+        y = y + dt * v
+        assert np.abs(dq[:, 1] - v).max() < 3e-6 and np.abs(q[:, 1] - y).max() < 1e-8, (k, q[:, 1], y, dq[:, 1], v)
+        y = q[0, 1]
+        if not landed:
+            v = dq[0, 1]
+    assert landed and -2e-4 < y < 0
+    s.close()

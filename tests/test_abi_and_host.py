@@ -180,3 +180,19 @@ def test_batched_mt_keys_equal_the_per_seed_path():
     for i, s in enumerate(seeds):
         w = seeding.int_list_from_bigint(seeding.hash_seed(seeding.create_seed(s)))
         assert klen[i] == len(w) and list(keys[i, :len(w)]) == w
+
+
+def test_public_headers_are_plain_c():
+    """include/*.h is the C ABI: it must compile as C99 (and as C++) on its own, with no HIP / torch types in it."""
+    import shutil, subprocess, tempfile
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "hc.c")
+        with open(src, "w") as f:
+            f.write('#include "dart_stepper.h"\n#include "dart_model_card.h"\nint main(void) { return (int)sizeof(DartModelCard) == 0; }\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, src])
+        subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", "-I", inc, src])
+    text = open(os.path.join(inc, "dart_stepper.h")).read() + open(os.path.join(inc, "dart_model_card.h")).read()
+    assert "hipStream_t" not in text.replace("(a hipStream_t", "") and "torch" not in text and "at::" not in text

@@ -242,6 +242,42 @@ def main():
                               "envs_same_episode_history": int(same.sum()), "envs": ne, "env_steps": ns},
         }
         small.close()
+        # the same sample spread over the host's cores, one oracle process per core ("1 core, then P
+        # processes"): compute time only, slowest worker; bounded, and never allowed to lose the line
+        try:
+            import subprocess
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:      # a container may be capped below its visible cores (cgroup v2 cpu.max = "<quota> <period>" or "max <period>")
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if quota != "max":
+                    avail = min(avail, max(1, int(float(quota) / float(period) + 0.5)))
+            except (OSError, ValueError):
+                try:  # cgroup v1
+                    quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    if quota > 0:
+                        avail = min(avail, max(1, int(quota / period + 0.5)))
+                except (OSError, ValueError):
+                    pass
+            P = max(1, min(avail, 64, ne))
+            per = ne // P
+            procs = [subprocess.Popen([sys.executable, "-m", "tests.oracle_worker", args.env_id, str(int(args.all_bodies_collide)),
+                                       str(i * per), str(per), str(ns), str(card.act_dim), str(ne)],
+                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(P)]
+            tot, slowest = 0, 0.0
+            deadline = time.time() + 120
+            for pr in procs:
+                out, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+                a, b = out.split()
+                tot += int(a); slowest = max(slowest, float(b))
+            result["cpu_baseline"]["all_cores"] = {"value": tot / slowest, "unit": "env-steps/s", "cores": P,
+                                                   "note": "one oracle process per usable core (affinity / cgroup quota, at most 64) "
+                                                           "on %d of the %d envs each; compute time of the slowest process" % (per, ne)}
+        except Exception as ex:
+            for pr in locals().get("procs", []):
+                if pr.poll() is None:
+                    pr.kill()
+            result["cpu_baseline"]["all_cores"] = {"value": None, "note": "not measured: %r" % (ex,)}
         if args.env_id in ("DartHopper-v1", "DartWalker2d-v1"):
             # The default cards of these two envs test only the feet against the floor (BASELINE config[1]); rerun the
             # CPU sample with EVERY capsule collidable, as DART has it: identical final states = the deviation is

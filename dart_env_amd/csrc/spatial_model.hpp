@@ -121,7 +121,7 @@ struct SpLds {
   int* cplink;   // [maxcp] first link
   int* cplinkB;  // [maxcp] second link of a link-link contact, -1 for the ground
   Real* sinv;    // [n]: 1 / L_jj of the mass-matrix Cholesky factor
-  Real* root;    // [24] free root joint: R (9), p (3), body twist w v (6), Euler X-Y-Z of R (3)
+  Real* root;    // [24] free root joint: R (9), p (3), body twist w v (6); 6 spare
   Real* cf;      // [n]: J^T lambda / dt of the previous world step (pydart2 constraint_forces(), SPD task only)
   Real* misc;    // [16]: roff(3), scalars
   int* imisc;    // [8]: ncp, m, contact flags

@@ -644,6 +644,7 @@ struct DartStepper {
   size_t dyn_lds = 0;
   double *d_dynM = nullptr, *d_dync = nullptr, *d_tstage = nullptr, *d_pose = nullptr;
   bool dyn_free_root = false;
+  double* d_tvals = nullptr;     // reach targets drawn on the device (mt_draw)
   hipEvent_t ev_in = nullptr, ev_out = nullptr;   // ordering between the handle's stream and a caller-supplied one
   std::string err;
 };
@@ -769,7 +770,7 @@ int dart_destroy(DartStepper* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->impl) h->impl->release();
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn_model, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -857,12 +858,20 @@ static int episode_restart(DartStepper* h, hipStream_t s, const uint8_t* d_mask)
 }
 
 // MT19937 mode: draw reference-exact reset noise on the device for the masked envs into d_qn / d_vn
+// reset_model() of the masked envs from the MT19937 bank: the two noise vectors every env draws (hopper.py:78-79) and, for the
+// tasks whose reset_model draws more from the same stream, that as well (swing-up sign, reach targets -> device task state)
 static int mt_draw(DartStepper* h, hipStream_t s, const uint8_t* d_mask) {
   const double r = h->card.reset_noise, rv = h->card.reset_noise_vel;
+  const int extra = h->card.task == DART_TASK_CARTPOLE_SWINGUP ? MT_EXTRA_SWINGUP
+                  : h->card.task == DART_TASK_REACHER2D ? MT_EXTRA_REACHER2D
+                  : h->card.task == DART_TASK_REACHER3D ? MT_EXTRA_REACHER3D : MT_EXTRA_NONE;
+  const bool targets = extra == MT_EXTRA_REACHER2D || extra == MT_EXTRA_REACHER3D;
+  if (targets && !h->d_tvals) CHK(h, hipMalloc((void**)&h->d_tvals, sizeof(double) * 4 * (size_t)h->n));
   dim3 grid((unsigned)((h->n + 127) / 128)), block(128);
   hipLaunchKernelGGL(mt_draw_kernel, grid, block, 0, s, h->n, (int)h->card.ndofs, h->mt, h->mt_pos, d_mask, -r, r - (-r), -rv,
-                     rv - (-rv), h->d_init_pos, h->d_init_vel, h->d_qn, h->d_vn);
+                     rv - (-rv), h->d_init_pos, h->d_init_vel, h->d_qn, h->d_vn, extra, h->d_tvals);
   CHK(h, hipGetLastError());
+  if (targets) return h->impl->set_task_state(s, d_mask, h->d_tvals, h->n);   // before the reset kernel computes the observation
   return DART_OK;
 }
 

@@ -41,6 +41,8 @@ __global__ void mt_seed_kernel(int64_t n_envs, uint32_t* __restrict__ mt, int32_
   pos[e] = 0;     // numpy regenerates before its first draw: the first output is x[624], produced over slot 0
 }
 
+enum { MT_EXTRA_NONE = 0, MT_EXTRA_SWINGUP = 1, MT_EXTRA_REACHER2D = 2, MT_EXTRA_REACHER3D = 3 };
+
 // For every env with mask[e] != 0 (mask == nullptr: all): draw 2*ndofs doubles and emit
 //   qn[e][d] = init_pos[d] + U(-r, r),  vn[e][d] = init_vel[d] + U(-rv, rv)     (row-major doubles, as dart_reset takes them)
 //
@@ -52,7 +54,7 @@ __global__ void mt_seed_kernel(int64_t n_envs, uint32_t* __restrict__ mt, int32_
 __global__ void mt_draw_kernel(int64_t n_envs, int ndofs, uint32_t* __restrict__ mt, int32_t* __restrict__ pos,
                                const uint8_t* __restrict__ mask, double low_q, double range_q, double low_v,
                                double range_v, const double* __restrict__ init_pos, const double* __restrict__ init_vel,
-                               double* __restrict__ qn, double* __restrict__ vn) {
+                               double* __restrict__ qn, double* __restrict__ vn, int extra, double* __restrict__ tvals) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_envs) return;
   if (mask && !mask[e]) return;
@@ -100,6 +102,45 @@ __global__ void mt_draw_kernel(int64_t n_envs, int ndofs, uint32_t* __restrict__
     }
     p += 2 * cnt;
     if (p >= 624) p -= 624;
+  }
+  // ---- what some reset_model()s draw after the two noise vectors, from the same stream, one double at a time
+  if (extra != MT_EXTRA_NONE) {
+    auto next_word = [&]() -> uint32_t {
+      const uint32_t a = M(p), b = M(p + 1);
+      const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+      const uint32_t x = M(p + 397) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      M(p) = x;
+      p = p + 1 >= 624 ? 0 : p + 1;
+      return temper(x);
+    };
+    auto next_double = [&]() -> double {
+      const uint32_t a = next_word() >> 5, b = next_word() >> 6;
+      return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    };
+    if (extra == MT_EXTRA_SWINGUP) {
+      // cartpole_swingup.py:42-45: `if np_random.uniform(0, 1, 1) > 0.5: qpos[1] += pi else: qpos[1] += -pi`
+      const double u = affine(0.0, 0.0, 1.0, next_double());
+      qn[e * ndofs + 1] += (u > 0.5) ? 3.141592653589793 : -3.141592653589793;
+    } else {
+      // reacher2d.py:51-55 / reacher.py:52-54: rejection-sample the target inside a disc / ball
+      const bool planar = extra == MT_EXTRA_REACHER2D;
+      const double low = planar ? -0.2 : -1.0, range = planar ? 0.4 : 2.0, rmax = planar ? 0.2 : 1.5;
+      double t0, t1, t2;
+      for (;;) {
+        t0 = affine(0.0, low, range, next_double());
+        t1 = affine(0.0, low, range, next_double());
+        t2 = affine(0.0, low, range, next_double());
+        if (planar) t1 = 0.0;
+        double ss;
+        {
+#pragma clang fp contract(off)
+          ss = t0 * t0 + t1 * t1 + t2 * t2;
+        }
+        if (sqrt(ss) < rmax) break;
+      }
+      if (planar) t1 = 0.01;
+      tvals[4 * e + 0] = t0; tvals[4 * e + 1] = t1; tvals[4 * e + 2] = t2; tvals[4 * e + 3] = 0.0;
+    }
   }
   pos[e] = p;
 }

@@ -20,7 +20,7 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from .. import seeding, spaces
-from ..model_card import (DartModelCard, HOST_RESET_TASKS, TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D,
+from ..model_card import (DartModelCard, HOST_RESET_TASKS, MT_ONLY_TASKS, TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D,
                           TASK_REACHER3D, TASK_STATE_TASKS, TASKS, card_for)
 from .. import stepper as _st
 
@@ -142,9 +142,9 @@ class BatchedDartEnv:
         self._stepper = factory(self.card, self.num_envs, device, precision)
         if noise == "mt19937" and not hasattr(self._stepper, "seed_mt19937"):
             noise = self.noise = "mt19937-host"     # injected test stepper without a device bank
-        if self.task.task in HOST_RESET_TASKS:      # reset_model draws beyond two uniform vectors: drawn by numpy
-            if noise == "philox":
-                raise ValueError("%s resets with host-drawn noise only (noise='mt19937')" % env_id)
+        if self.task.task in MT_ONLY_TASKS and noise == "philox":   # reset_model draws beyond two uniform vectors
+            raise ValueError("%s resets from the MT19937 streams only (noise='mt19937')" % env_id)
+        if self.task.task in HOST_RESET_TASKS:      # Gaussian draws: numpy on the host
             noise = self.noise = "mt19937-host"
         self.device_noise = noise in ("mt19937", "philox")
         # spaces exactly as DartEnv.__init__ builds them (dart_env.py:85-86, 97-100)

@@ -70,7 +70,15 @@ class Tuple(Space):
         super().__init__(None, None)
 
     def seed(self, seed=None):
-        return [s.seed(seed) for s in self.spaces]
+        # the vector env's action space is Tuple((single_space,) * num_envs): one object repeated -- seeding it once leaves
+        # the same final state as the reference's loop (tuple.py) and keeps a 65 536-env constructor from building 65 536
+        # RandomStates (4 s)
+        done, out = {}, []
+        for s in self.spaces:
+            if id(s) not in done:
+                done[id(s)] = s.seed(seed)
+            out.append(done[id(s)])
+        return out
 
     def sample(self):
         return tuple(s.sample() for s in self.spaces)

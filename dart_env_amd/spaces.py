@@ -81,6 +81,14 @@ class Tuple(Space):
         return out
 
     def sample(self):
+        s0 = self.spaces[0] if self.spaces else None
+        if len(self.spaces) > 1 and isinstance(s0, Box) and all(s is s0 for s in self.spaces) and \
+                bool(np.all(s0.bounded_below & s0.bounded_above)):
+            # one bounded Box repeated (the vector env's action space): the N consecutive uniform(low, high, shape) calls of
+            # the loop below consume the stream exactly like one call of shape (N,) + shape (numpy fills in C order)
+            n = len(self.spaces)
+            out = s0.np_random.uniform(low=s0.low, high=s0.high, size=(n,) + s0.shape).astype(s0.dtype)
+            return tuple(out)
         return tuple(s.sample() for s in self.spaces)
 
     def contains(self, x):

@@ -196,3 +196,20 @@ def test_public_headers_are_plain_c():
         subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", "-I", inc, src])
     text = open(os.path.join(inc, "dart_stepper.h")).read() + open(os.path.join(inc, "dart_model_card.h")).read()
     assert "hipStream_t" not in text.replace("(a hipStream_t", "") and "torch" not in text and "at::" not in text
+
+
+def test_tuple_space_fast_paths_equal_the_reference_loop():
+    """Tuple((box,) * N): seeding the repeated object once and sampling all N in one call give the stream of the reference's
+    per-space loops (gym/spaces/tuple.py, box.py:70-110)."""
+    from dart_env_amd import spaces
+    box = spaces.Box(np.array([-1.0, -2.0, 0.5]), np.array([1.0, 3.0, 0.75]))
+    tup = spaces.Tuple((box,) * 257)
+    tup.seed(11)
+    fast = tup.sample(); fast2 = tup.sample()
+    box.seed(11)
+    slow = [box.sample() for _ in range(257)]; slow2 = [box.sample() for _ in range(257)]
+    assert all(a.dtype == np.float32 and np.array_equal(a, b) for a, b in zip(fast, slow))
+    assert all(np.array_equal(a, b) for a, b in zip(fast2, slow2))
+    mixed = spaces.Tuple((box, spaces.Box(-np.ones(2), np.ones(2))))       # distinct objects: the plain loop
+    mixed.seed(3)
+    assert len(mixed.sample()) == 2

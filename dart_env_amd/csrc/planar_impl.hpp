@@ -1,0 +1,164 @@
+// planar_impl.hpp -- host side of the planar register kernels: card validation -> kernel parameters, launches.
+// Included by planar_f32.hip / planar_f64.hip only (each instantiates the kernels for one precision).
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "impl_iface.hpp"
+#include "planar_kernel.hpp"
+#include "static_models.hpp"
+
+namespace dartk {
+
+template <class Real, class T, class PT = Params<Real, T>>
+struct ImplT : Impl {
+  PT P;
+  hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
+                  float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
+    dim3 grid((unsigned)((n + block_threads - 1) / block_threads)), block(block_threads);
+    hipLaunchKernelGGL((step_kernel<Real, T, PT>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew,
+                       done, trunc, autoreset, seed, off);
+    return hipGetLastError();
+  }
+  hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
+                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off, int obs_masked_only) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((reset_kernel<Real, T, PT>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, mask, qn, vn, obs,
+                       seed, off, obs_masked_only);
+    return hipGetLastError();
+  }
+  hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((state_io_kernel<Real, T::NDOF>), grid, block, 0, s, n, (Real*)q, (Real*)dq, qh, dqh, to_device);
+    return hipGetLastError();
+  }
+  void set_solver(int solver, int it1, int it2) override {   // 0 = default cap
+    P.solver = solver; P.iters1 = it1 > 0 ? it1 : 24; P.iters2 = it2 > 0 ? it2 : 24;
+  }
+  void set_stats(unsigned long long* p) override { P.stats = p; }
+  int slots() const override { return 2 * T::NC + n_limited<T>(); }
+};
+
+static inline bool is_identity3(const double* T16, double tol = 1e-12) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      if (std::fabs(T16[4 * i + j] - (i == j ? 1.0 : 0.0)) > tol) return false;
+  return true;
+}
+
+// Validate the card against topology T and fill the kernel parameters.  Returns "" or the reason it does not fit.
+template <class Real, class T>
+std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
+  constexpr int NL = T::NL;
+  if (c.nbodies != NL + 2 || c.ndofs != T::NDOF) return "body/dof count";
+  if (c.act_dim != T::NA || c.act_dof0 != T::NDOF - T::NA) return "action layout";
+  if (c.obs_dim != 2 * T::NDOF - 1 && c.task != DART_TASK_NONE) return "obs_dim";
+  for (int d = 0; d < c.ndofs; d++) if (c.joint_friction[d] != 0.0) return "joint Coulomb friction";
+  if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
+  // floating base: prismatic x, prismatic y, revolute +-z
+  if (c.jtype[0] != DART_JT_PRISMATIC || c.jtype[1] != DART_JT_PRISMATIC || c.parent[0] != -1 || c.parent[1] != 0)
+    return "root carriers";
+  if (std::fabs(c.axes[0][0] - 1) > 1e-12 || std::fabs(c.axes[1][1] - 1) > 1e-12) return "root prismatic axes";
+  if (c.mass[0] != 0 || c.mass[1] != 0) return "root carriers must be massless";
+  double x0 = 0, y0 = 0;
+  for (int b = 0; b < 3; b++) {
+    if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated root frames";
+    x0 += c.T_pj[b][3] - c.T_cj[b][3];
+    y0 += c.T_pj[b][7] - c.T_cj[b][7];
+    if (c.T_pj[b][11] != 0 || c.T_cj[b][11] != 0) return "root z offset";
+  }
+  P.root_x0 = (Real)x0; P.root_y0 = (Real)y0;
+  for (int k = 0; k < NL; k++) {
+    int b = k + 2;
+    if (c.jtype[b] != DART_JT_REVOLUTE) return "non-revolute link joint";
+    if (std::fabs(std::fabs(c.axes[b][2]) - 1) > 1e-12) return "link axis must be +-z";
+    if (k > 0) {
+      if (c.parent[b] - 2 != T::parent(k)) return "tree shape";
+      if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated joint frames";
+      if (c.T_pj[b][11] != 0 || c.T_cj[b][3] != 0 || c.T_cj[b][7] != 0 || c.T_cj[b][11] != 0) return "joint offsets";
+      P.jx[k] = (Real)c.T_pj[b][3]; P.jy[k] = (Real)c.T_pj[b][7];
+    } else {
+      if (c.parent[b] != 1) return "root link parent";
+      P.jx[0] = 0; P.jy[0] = 0;
+    }
+    if (c.com[b][2] != 0) return "com off plane";
+    P.sigma[k] = (Real)(c.axes[b][2] > 0 ? 1.0 : -1.0);
+    P.mass[k] = (Real)c.mass[b]; P.cx[k] = (Real)c.com[b][0]; P.cy[k] = (Real)c.com[b][1];
+    P.izz[k] = (Real)c.inertia[b][8];
+    int d = 2 + k;
+    if (c.stiffness[d] != 0) return "joint springs";
+    bool lim = c.limited[d] != 0;
+    if (lim && !T::limited(k)) return "limit on unlimited link";
+    P.lo[k] = (Real)(lim ? c.lower[d] : -INFINITY);
+    P.hi[k] = (Real)(lim ? c.upper[d] : INFINITY);
+  }
+  for (int d = 0; d < T::NDOF; d++) {
+    if (d < 2 && (c.limited[d] || c.stiffness[d] != 0)) return "limits/springs on root translation";
+    P.damp[d] = (Real)c.damping[d]; P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
+  }
+  int nc = 0;
+  for (int s = 0; s < c.nshapes; s++) {
+    if (!c.shape_collidable[s]) continue;
+    if (c.shape_type[s] != DART_SH_CAPSULE) return "collidable non-capsule shape";
+    if (nc >= T::NC) return "too many collidable shapes";
+    if (c.shape_body[s] - 2 != T::clink(nc)) return "collidable shape on unexpected link";
+    const double* S = c.shape_pose[s];
+    double hl = 0.5 * c.shape_size[s][1];
+    if (std::fabs(S[10]) > 1e-9 || S[11] != 0) return "capsule axis off plane";
+    P.e1x[nc] = (Real)(S[3] + hl * S[2]); P.e1y[nc] = (Real)(S[7] + hl * S[6]);
+    P.e2x[nc] = (Real)(S[3] - hl * S[2]); P.e2y[nc] = (Real)(S[7] - hl * S[6]);
+    P.rad[nc] = (Real)c.shape_size[s][0];
+    nc++;
+  }
+  if (nc != T::NC) return "collidable shape count";
+  P.dt = (Real)c.dt; P.ground_y = (Real)c.ground_y; P.g = (Real)(-c.gravity[1]); P.mu = (Real)c.friction;
+  P.erp_dt = (Real)(c.erp / c.dt); P.max_erv = (Real)c.max_erv; P.limit_erp_dt = (Real)(c.limit_erp / c.dt);
+  P.cfm1 = (Real)(1.0 + c.cfm); P.ccfm1 = (Real)(1.0 + c.contact_cfm);
+  for (int k = 0; k < T::NA; k++) {
+    P.act_scale[k] = (Real)c.act_scale[k]; P.act_lo[k] = (Real)c.act_low[k]; P.act_hi[k] = (Real)c.act_high[k];
+  }
+  P.alive = (Real)c.alive_bonus; P.ctrl_cost = (Real)c.ctrl_cost; P.pen_each = (Real)(c.limit_penalty * 1.5);
+  P.pen_margin = (Real)c.penalty_margin; P.h_lo = (Real)c.height_lo; P.h_hi = (Real)c.height_hi;
+  P.ang_max = (Real)c.angle_max; P.s_max = (Real)c.state_abs_max; P.v_clip = (Real)c.obs_vel_clip;
+  P.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip)); P.noise = (Real)c.reset_noise; P.noise_v = (Real)c.reset_noise_vel;
+  P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task;
+  P.penalty_link = c.penalty_dof >= 2 ? c.penalty_dof - 2 : -1;
+  if (c.task != DART_TASK_NONE && c.height_body != 2) return "height body must be the root link";
+  P.solver = 0; P.iters1 = 24; P.iters2 = 24; P.stats = nullptr;
+  return "";
+}
+
+// generic (runtime-parameter) kernel, or the compile-time specialisation when the card is bit-identical to a baked one
+template <class Real, class T, class Static>
+std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why, bool allow_static) {
+  Params<Real, T> R;
+  std::string w = fill_params<Real, T>(c, R);
+  if (!w.empty()) { why += w; return nullptr; }
+  if constexpr (!std::is_void<Static>::value) {
+    if (allow_static && Static::matches(R)) {
+      auto p = std::make_unique<ImplT<Real, T, Static>>();
+      p->P.max_steps = R.max_steps; p->P.solver = R.solver; p->P.iters1 = R.iters1; p->P.iters2 = R.iters2;
+      p->P.stats = nullptr;
+      p->is_static = true;
+      return p;
+    }
+  }
+  auto p = std::make_unique<ImplT<Real, T>>();
+  p->P = R;
+  return p;
+}
+
+template <class Real>
+std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool allow_static) {
+  why += "hopper-chain: ";
+  if (auto p = make_for_topology<Real, HopperTopo, HopperStatic<Real>>(c, why, allow_static)) return p;
+  why += "; hopper-chain, all capsules: ";
+  if (auto p = make_for_topology<Real, HopperAllTopo, void>(c, why, allow_static)) return p;
+  why += "; walker2d-tree: ";
+  if (auto p = make_for_topology<Real, Walker2dTopo, Walker2dStatic<Real>>(c, why, allow_static)) return p;
+  return nullptr;
+}
+
+}  // namespace dartk

@@ -492,7 +492,7 @@ static void rnea(OracleWorld* w, const double* dq, const double* ddq, int with_g
 
 /* CRBA -> dense M (n x n) */
 static void crba(OracleWorld* w, double* M) {
-  static double Ic[MAXL][36];
+  static __thread double Ic[MAXL][36];
   int n = w->n;
   memset(M, 0, n * n * sizeof(double));
   for (int i = 0; i < w->nl; i++) memcpy(Ic[i], w->L[i].I, 36 * sizeof(double));
@@ -745,7 +745,7 @@ static int blcp_exact(const double* A, const double* b, const double* lo, const 
   for (int iter = 0; iter < 4000; iter++) {
     int fi[MAXM], nf = 0;
     for (int i = 0; i < m; i++) if (set[i] == 0) fi[nf++] = i;
-    static double AF[MAXM * MAXM];
+    static __thread double AF[MAXM * MAXM];
     double rhs[MAXM];
     for (int a = 0; a < nf; a++) {
       int ga = idx[fi[a]];
@@ -807,7 +807,7 @@ int oracle_step(OracleWorld* w) {
   crba(w, w->M);
   rnea(w, w->dqi, NULL, 1, w->C);
   /* H = M + dt D + dt^2 K ; rhs = tau - C - D dq - K (q + dt dq - rest) */
-  static double H[MAXN * MAXN];
+  static __thread double H[MAXN * MAXN];
   double rhs[MAXN];
   memcpy(H, w->M, n * n * sizeof(double));
   for (int i = 0; i < n; i++) {
@@ -854,7 +854,7 @@ int oracle_step(OracleWorld* w) {
   }
 
   /* ---- constraints at q_t ---- */
-  static double J[MAXM][MAXN], Y[MAXM][MAXN], A[MAXM * MAXM];
+  static __thread double J[MAXM][MAXN], Y[MAXM][MAXN], A[MAXM * MAXM];
   double b[MAXM], lo[MAXM], hi[MAXM], x[MAXM];
   int findex[MAXM];
   int m = 0;
@@ -1464,7 +1464,7 @@ static void spd_torque(OracleWorld* w, const double* target, double* tau) {
   const DartModelCard* c = &w->card;
   int n = w->n;
   double envdt = c->dt * c->frame_skip;
-  static double A2[MAXN * MAXN];
+  static __thread double A2[MAXN * MAXN];
   double rhs2[MAXN], p[MAXN], d[MAXN], cb[MAXN];
   kinematics(w);
   crba(w, w->M);
@@ -1702,6 +1702,58 @@ int64_t oracle_rollout(const DartModelCard* card, int solver, int64_t n_envs, in
     if (episode_out) episode_out[e] = ep;
     if (elapsed_out) elapsed_out[e] = elapsed;
     if (reward_sum_out) reward_sum_out[e] = rs;
+  }
+  oracle_destroy(w);
+  return count;
+}
+
+/* Auto-resetting rollout of env range [0, n_envs) with a trace: the done flag of every env-step (before the reset it causes)
+ * and the PRE-RESET state after the steps listed in snap_steps (1-based step counts, ascending).  Thread-safe (one world per
+ * call, thread-local scratch): the parity harness runs one call per host core.  actions are [steps][act_stride_envs][act]
+ * with this call's envs starting at column act_env0. */
+int64_t oracle_rollout_trace(const DartModelCard* card, int solver, int64_t n_envs, int steps, const float* actions,
+                             int64_t act_stride_envs, int64_t act_env0, uint64_t seed, uint64_t env_offset, int n_snap,
+                             const int32_t* snap_steps, double* q_snap, double* dq_snap, uint8_t* done_trace,
+                             int64_t trace_stride_envs, uint32_t* episode_out, int32_t* elapsed_out) {
+  OracleWorld* w = oracle_create(card);
+  if (!w) return -1;
+  w->solver = solver;
+  int n = w->n, na = card->act_dim;
+  int64_t count = 0;
+  double obs[2 * MAXN + 8], a[DART_MAX_ACTIONS];
+  for (int64_t e = 0; e < n_envs; e++) {
+    uint32_t ep = 1;
+    int elapsed = 0, si = 0;
+    double qn[MAXN], vn[MAXN];
+    oracle_reset(w);
+    oracle_philox_noise(seed, env_offset + (uint64_t)e, ep, card->reset_noise, card->reset_noise_vel, n, qn, vn);
+    for (int i = 0; i < n; i++) { w->q[i] += qn[i]; w->dq[i] += vn[i]; }
+    oracle_env_after_reset(w);
+    for (int t = 0; t < steps; t++) {
+      const float* at = actions + ((size_t)t * act_stride_envs + act_env0 + e) * na;
+      for (int k = 0; k < na; k++) a[k] = (double)at[k];
+      double r;
+      int done = oracle_env_step(w, a, obs, &r);
+      elapsed++;
+      count++;
+      if (card->max_episode_steps > 0 && elapsed >= card->max_episode_steps) done = 1;
+      if (done_trace) done_trace[(size_t)t * trace_stride_envs + act_env0 + e] = (uint8_t)(done ? 1 : 0);
+      if (si < n_snap && snap_steps[si] == t + 1) {
+        memcpy(q_snap + ((size_t)si * trace_stride_envs + act_env0 + e) * n, w->q, n * sizeof(double));
+        memcpy(dq_snap + ((size_t)si * trace_stride_envs + act_env0 + e) * n, w->dq, n * sizeof(double));
+        si++;
+      }
+      if (done) {
+        ep++;
+        oracle_reset(w);
+        oracle_philox_noise(seed, env_offset + (uint64_t)e, ep, card->reset_noise, card->reset_noise_vel, n, qn, vn);
+        for (int i = 0; i < n; i++) { w->q[i] += qn[i]; w->dq[i] += vn[i]; }
+        oracle_env_after_reset(w);
+        elapsed = 0;
+      }
+    }
+    if (episode_out) episode_out[act_env0 + e] = ep;
+    if (elapsed_out) elapsed_out[act_env0 + e] = elapsed;
   }
   oracle_destroy(w);
   return count;

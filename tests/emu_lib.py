@@ -1,0 +1,111 @@
+"""ctypes binding of tests/kernel_emu/libdart_planar_emu.so -- TEST INFRASTRUCTURE ONLY.
+
+The planar device kernels (dart_env_amd/csrc/planar_kernel.hpp) compiled for the host by g++ against a stand-in
+<hip/hip_runtime.h>, one lane at a time.  It exists so that the kernels' arithmetic can be held against the fp64 oracle in
+the GPU-less development container (`pytest -m "not gpu"`); nothing under dart_env_amd/ loads it and the product library has
+no CPU path.  `EmuStepper` mirrors the subset of `dart_env_amd.stepper.HipStepper` the parity helpers use.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dart_env_amd.model_card import DartModelCard
+from dart_env_amd import stepper as st
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_emu")
+_LIB = os.path.join(_DIR, "libdart_planar_emu.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-s", "-C", _DIR])
+        L = C.CDLL(_LIB)
+        vp, dp, fp, u8 = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+        L.emu_create.restype = vp
+        L.emu_create.argtypes = [C.POINTER(DartModelCard), C.c_int64, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.emu_destroy.argtypes = [vp]
+        L.emu_is_static.argtypes = [vp]
+        L.emu_slots.argtypes = [vp]
+        L.emu_set_solver.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.emu_enable_stats.argtypes = [vp, C.c_int]
+        L.emu_get_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.emu_reset.argtypes = [vp, u8, dp, dp, fp, C.c_uint64, C.c_uint64, C.c_int]
+        L.emu_step.argtypes = [vp, fp, fp, fp, u8, u8, C.c_int, C.c_uint64, C.c_uint64]
+        L.emu_state.argtypes = [vp, dp, dp, C.c_int]
+        L.emu_counters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+class EmuStepper:
+    def __init__(self, card, num_envs, precision=64, allow_static=True):
+        self.L = lib()
+        self.card, self.n, self.precision = card, int(num_envs), precision
+        why = C.create_string_buffer(512)
+        self.h = self.L.emu_create(C.byref(card), self.n, precision, int(allow_static), why, 512)
+        if not self.h:
+            raise RuntimeError("no planar kernel for this card: " + why.value.decode())
+        self.autoreset, self.seed, self.env_offset = 0, 0, 0
+        self.nd, self.na, self.no = card.ndofs, card.act_dim, card.obs_dim
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.emu_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def is_static(self):
+        return bool(self.L.emu_is_static(self.h))
+
+    def configure(self, key, value):
+        if key == st.CFG_AUTORESET: self.autoreset = int(value != 0)
+        elif key == st.CFG_SEED: self.seed = int(value)
+        elif key == st.CFG_ENV_OFFSET: self.env_offset = int(value)
+        elif key == st.CFG_SOLVER: self._solver = int(value); self.L.emu_set_solver(self.h, self._solver, 0, 0)
+        elif key == st.CFG_STATS: self.L.emu_enable_stats(self.h, int(value != 0))
+        else: raise ValueError(key)
+
+    def solver_stats(self):
+        h = np.zeros(64, dtype=np.uint64)
+        self.L.emu_get_stats(self.h, _p(h, C.c_uint64))
+        return h[:32], h[32:]
+
+    def reset(self, mask=None, qpos_noise=None, qvel_noise=None, want_obs=True):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        qn = None if qpos_noise is None else np.ascontiguousarray(qpos_noise, dtype=np.float64)
+        vn = None if qvel_noise is None else np.ascontiguousarray(qvel_noise, dtype=np.float64)
+        obs = np.zeros((self.n, self.no), dtype=np.float32) if want_obs else None
+        self.L.emu_reset(self.h, _p(m, C.c_uint8), _p(qn, C.c_double), _p(vn, C.c_double), _p(obs, C.c_float), self.seed, self.env_offset, 0)
+        return obs
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        obs = np.zeros((self.n, self.no), dtype=np.float32); rew = np.zeros(self.n, dtype=np.float32)
+        done = np.zeros(self.n, dtype=np.uint8); trunc = np.zeros(self.n, dtype=np.uint8)
+        self.L.emu_step(self.h, _p(a, C.c_float), _p(obs, C.c_float), _p(rew, C.c_float), _p(done, C.c_uint8), _p(trunc, C.c_uint8),
+                        self.autoreset, self.seed, self.env_offset)
+        return obs, rew.astype(np.float64), done.astype(bool), trunc.astype(bool)
+
+    def get_state(self):
+        q = np.zeros((self.n, self.nd)); dq = np.zeros((self.n, self.nd))
+        self.L.emu_state(self.h, _p(q, C.c_double), _p(dq, C.c_double), 0)
+        return q, dq
+
+    def set_state(self, q, dq):
+        q = np.ascontiguousarray(q, dtype=np.float64); dq = np.ascontiguousarray(dq, dtype=np.float64)
+        self.L.emu_state(self.h, _p(q, C.c_double), _p(dq, C.c_double), 1)
+
+    def counters(self):
+        el = np.zeros(self.n, dtype=np.int32); ep = np.zeros(self.n, dtype=np.uint32)
+        self.L.emu_counters(self.h, _p(el, C.c_int32), _p(ep, C.c_uint32))
+        return el, ep

@@ -1,0 +1,69 @@
+// TEST INFRASTRUCTURE -- the planar register kernels compiled for the host (see fake_include/hip/hip_runtime.h) behind a
+// minimal C interface: create / reset / step / state on host arrays laid out exactly like the device buffers.
+// Built by tests/kernel_emu/Makefile into libdart_planar_emu.so; loaded only by tests/emu_lib.py.
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "planar_impl.hpp"
+
+using namespace dartk;
+
+namespace dartk {   // the spatial factories live in TUs this library does not build
+std::unique_ptr<Impl> make_planar_impl_f32(const DartModelCard& c, std::string& why, bool s) { return make_planar<float>(c, why, s); }
+std::unique_ptr<Impl> make_planar_impl_f64(const DartModelCard& c, std::string& why, bool s) { return make_planar<double>(c, why, s); }
+}
+
+struct Emu {
+  DartModelCard card;
+  int64_t n; int precision;
+  std::unique_ptr<Impl> impl;
+  std::vector<unsigned char> q, dq;
+  std::vector<int32_t> elapsed; std::vector<uint32_t> episode;
+  std::vector<double> qn, vn;
+  std::vector<unsigned long long> stats;
+  std::string err;
+};
+
+extern "C" {
+const char* emu_last_error(Emu* h) { static std::string g; return h ? h->err.c_str() : g.c_str(); }
+Emu* emu_create(const DartModelCard* card, int64_t n, int precision, int allow_static, char* why_out, int why_len) {
+  std::string why;
+  auto impl = precision == 32 ? make_planar_impl_f32(*card, why, allow_static != 0) : make_planar_impl_f64(*card, why, allow_static != 0);
+  if (!impl) { if (why_out) snprintf(why_out, why_len, "%s", why.c_str()); return nullptr; }
+  auto* h = new Emu();
+  h->card = *card; h->n = n; h->precision = precision; h->impl = std::move(impl);
+  h->impl->set_solver(0, 0, 0);
+  const size_t rs = precision == 32 ? 4 : 8, nd = card->ndofs;
+  h->q.assign(rs * nd * n, 0); h->dq.assign(rs * nd * n, 0);
+  h->elapsed.assign(n, 0); h->episode.assign(n, 0);
+  h->qn.resize(nd * n); h->vn.resize(nd * n);
+  for (int64_t i = 0; i < n; i++) for (size_t d = 0; d < nd; d++) { h->qn[i * nd + d] = card->init_pos[d]; h->vn[i * nd + d] = card->init_vel[d]; }
+  h->impl->state_io(nullptr, n, h->q.data(), h->dq.data(), h->qn.data(), h->vn.data(), 1);
+  return h;
+}
+void emu_destroy(Emu* h) { delete h; }
+int emu_is_static(Emu* h) { return h->impl->is_static ? 1 : 0; }
+int emu_slots(Emu* h) { return h->impl->slots(); }
+void emu_set_solver(Emu* h, int solver, int it1, int it2) { h->impl->set_solver(solver, it1, it2); }
+void emu_enable_stats(Emu* h, int on) { h->stats.assign(64, 0); h->impl->set_stats(on ? h->stats.data() : nullptr); }
+void emu_get_stats(Emu* h, unsigned long long* out64) { memcpy(out64, h->stats.data(), 64 * sizeof(unsigned long long)); }
+// mask: n bytes or NULL; noise rows (n, ndofs) doubles or NULL (Philox with `seed`, `env_offset`)
+void emu_reset(Emu* h, const uint8_t* mask, const double* qnoise, const double* vnoise, float* obs, uint64_t seed, uint64_t off, int obs_masked_only) {
+  const size_t nd = h->card.ndofs;
+  const double *qn = nullptr, *vn = nullptr;
+  if (qnoise) {
+    for (int64_t i = 0; i < h->n; i++) {
+      if (mask && !mask[i]) continue;
+      for (size_t d = 0; d < nd; d++) { h->qn[i * nd + d] = h->card.init_pos[d] + qnoise[i * nd + d]; h->vn[i * nd + d] = h->card.init_vel[d] + vnoise[i * nd + d]; }
+    }
+    qn = h->qn.data(); vn = h->vn.data();
+  }
+  h->impl->reset(nullptr, h->n, h->q.data(), h->dq.data(), h->elapsed.data(), h->episode.data(), mask, qn, vn, obs, seed, off, obs_masked_only);
+}
+void emu_step(Emu* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) {
+  h->impl->step(nullptr, h->n, h->q.data(), h->dq.data(), h->elapsed.data(), h->episode.data(), actions, obs, rew, done, trunc, autoreset, seed, off);
+}
+void emu_state(Emu* h, double* q, double* dq, int to_device) { h->impl->state_io(nullptr, h->n, h->q.data(), h->dq.data(), q, dq, to_device); }
+void emu_counters(Emu* h, int32_t* el, uint32_t* ep) { memcpy(el, h->elapsed.data(), 4 * h->n); memcpy(ep, h->episode.data(), 4 * h->n); }
+}

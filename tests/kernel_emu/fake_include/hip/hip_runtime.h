@@ -1,0 +1,48 @@
+// TEST INFRASTRUCTURE -- a stand-in for <hip/hip_runtime.h> that lets g++ compile the planar DEVICE code
+// (dart_env_amd/csrc/planar_kernel.hpp + planar_impl.hpp) for the host, one lane at a time.
+//
+// Why: the development container has no GPU; this makes the arithmetic of the one-env-per-lane kernels checkable against
+// the fp64 oracle with `pytest -m "not gpu"`.  A lane of those kernels never reads another lane's data (wave votes only
+// decide when a loop stops), so running the lanes one after the other is the same computation.
+// Nothing under dart_env_amd/ includes or loads this; the product library is built by hipcc against the real header and
+// has no CPU path.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define DART_PIN_VGPR(x) asm volatile("" : "+x"(x))   // the device build pins the value in a VGPR
+
+using std::fabs; using std::fmax; using std::fmin; using std::isfinite; using std::sqrt;
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+
+inline bool __all(bool p) { return p; }
+inline bool __any(bool p) { return p; }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+// hardware approximations: model them a few bits short of exact so the Newton refinements in the kernels are exercised
+inline float __builtin_amdgcn_rcpf(float x) { return (1.0f / x) * (1.0f + 5.9e-8f); }
+inline float __builtin_amdgcn_rsqf(float x) { return (1.0f / sqrtf(x)) * (1.0f - 5.9e-8f); }
+inline double __builtin_amdgcn_rcp(double x) { return (double)(float)(1.0 / x); }
+inline double __builtin_amdgcn_rsq(double x) { return (double)(float)(1.0 / std::sqrt(x)); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+
+// a kernel launch = the kernel body called for every (block, thread) in turn
+template <class F> inline void emu_launch_(dim3 g, dim3 b, F&& f) {
+  gridDim = g; blockDim = b;
+  for (unsigned bx = 0; bx < g.x; bx++) for (unsigned tx = 0; tx < b.x; tx++) { blockIdx.x = bx; threadIdx.x = tx; f(); }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu_launch_(grid, block, [&]() { kernel(__VA_ARGS__); })

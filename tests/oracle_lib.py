@@ -68,6 +68,10 @@ def lib():
         L.oracle_rollout.restype = C.c_int64
         L.oracle_rollout.argtypes = [C.POINTER(DartModelCard), C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float),
                                      C.c_uint64, C.c_uint64, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), dp]
+        L.oracle_rollout_trace.restype = C.c_int64
+        L.oracle_rollout_trace.argtypes = [C.POINTER(DartModelCard), C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_int64,
+                                           C.c_int64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int32), dp, dp,
+                                           C.POINTER(C.c_uint8), C.c_int64, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
         L.oracle_philox_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_int, dp, dp]
         _lib = L
     return _lib
@@ -235,6 +239,59 @@ def rollout(card, actions, seed=0, env_offset=0, solver=0):
                                env_offset, _p(q), _p(dq), ep.ctypes.data_as(C.POINTER(C.c_uint32)),
                                el.ctypes.data_as(C.POINTER(C.c_int32)), _p(rs))
     return dict(q=q, dq=dq, episode=ep, elapsed=el, reward_sum=rs, env_steps=cnt)
+
+
+def usable_cores():
+    """cores this process may use: affinity mask capped by the cgroup quota (the GPU box grants 16 of its 256)"""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:      # cgroup v2: "<quota> <period>" or "max <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            avail = min(avail, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                avail = min(avail, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, avail)
+
+
+def rollout_trace(card, actions, snap_steps, seed=0, env_offset=0, solver=0, threads=None):
+    """Auto-resetting (Philox) rollout of actions[steps][n][act] on the fp64 oracle, spread over host threads (ctypes drops
+    the GIL; the oracle's scratch is thread-local).  Returns dict(done[steps][n] u8 -- the flag of every env-step BEFORE
+    the reset it causes, q/dq[len(snap_steps)][n][nd] -- PRE-RESET states after the listed step counts, episode, elapsed,
+    env_steps, seconds = wall time, cpu_seconds = sum of the threads' times)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    actions = np.ascontiguousarray(actions, dtype=np.float32)
+    steps, n, _ = actions.shape
+    nd = card.ndofs
+    snaps = np.ascontiguousarray(sorted(int(x) for x in snap_steps), dtype=np.int32)
+    q = np.zeros((len(snaps), n, nd)); dq = np.zeros((len(snaps), n, nd))
+    done = np.zeros((steps, n), dtype=np.uint8)
+    ep = np.zeros(n, dtype=np.uint32); el = np.zeros(n, dtype=np.int32)
+    L = lib()
+    T = max(1, min(threads or usable_cores(), n))
+    bounds = [(n * i) // T for i in range(T + 1)]
+
+    def work(i):
+        lo, hi = bounds[i], bounds[i + 1]
+        t0 = time.perf_counter()
+        cnt = L.oracle_rollout_trace(C.byref(card), solver, hi - lo, steps, actions.ctypes.data_as(C.POINTER(C.c_float)), n, lo,
+                                     seed, env_offset + lo, len(snaps), snaps.ctypes.data_as(C.POINTER(C.c_int32)), _p(q), _p(dq),
+                                     done.ctypes.data_as(C.POINTER(C.c_uint8)), n, ep.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                     el.ctypes.data_as(C.POINTER(C.c_int32)))
+        return cnt, time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(T) as ex:
+        res = list(ex.map(work, range(T)))
+    wall = time.perf_counter() - t0
+    return dict(done=done, q=q, dq=dq, snap_steps=snaps, episode=ep, elapsed=el, env_steps=sum(r[0] for r in res),
+                seconds=wall, cpu_seconds=sum(r[1] for r in res), threads=T)
 
 
 def philox_noise(seed, gid, ep, r, rv, n):

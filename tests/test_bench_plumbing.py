@@ -1,0 +1,106 @@
+"""bench.py's N > 1 plumbing on CPU: rank / env_offset sharding, max-over-ranks timing, JSON assembly, the rollout gather and
+the refusal of a WORLD_SIZE that contradicts --gpus.  The GPU shard is replaced by a numpy stand-in on the planar kernel
+emulator (tests/emu_lib.py) injected through bench.main(env_factory=...), the collective backend is gloo."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class EmuBenchEnv:
+    """stand-in for bench.HipBenchEnv: same surface, host arrays, device kernels compiled for the host"""
+
+    def __init__(self, env_id, n, local_rank, precision, env_offset, ring=16, ring_seed=1234, all_bodies_collide=None, configure=()):
+        from dart_env_amd import stepper as st
+        from dart_env_amd.model_card import card_for
+        from tests.emu_lib import EmuStepper
+        self.card = card_for(env_id)
+        self.n, self.ring_len, self.env_offset = n, ring, env_offset
+        self.env = EmuStepper(self.card, n, precision=precision)
+        self.env.configure(st.CFG_AUTORESET, 1); self.env.configure(st.CFG_SEED, 0); self.env.configure(st.CFG_ENV_OFFSET, env_offset)
+        self.ring = np.random.RandomState(ring_seed).uniform(-1, 1, (ring, n, self.card.act_dim)).astype(np.float32)
+        self.last = None
+
+    def reset(self):
+        self.env.reset()
+
+    def run(self, k, base=0):
+        for i in range(k):
+            self.last = self.env.step(self.ring[(base + i) % self.ring_len])
+
+    def timed_steps(self, k):
+        t0 = time.perf_counter()
+        self.run(k)
+        return (time.perf_counter() - t0) / k * 1e3
+
+    def sync(self):
+        pass
+
+    def done_fraction(self):
+        return float(self.last[2].mean())
+
+    def packed_last(self):
+        o, r, d, _ = self.last
+        return torch.from_numpy(np.concatenate([o.reshape(-1), r.astype(np.float32), d.astype(np.float32)]))
+
+    def is_static(self):
+        return self.env.is_static
+
+    def close(self):
+        self.env.close()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    from tests.test_bench_plumbing import EmuBenchEnv as E
+    res = bench.main(["--gpus", str(world), "--envs", "64", "--steps", "3", "--warmup", "1"], env_factory=E, dist_backend="gloo")
+    q.put((rank, res))
+
+
+def test_two_rank_bench_line():
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=300) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got[1] is None                       # only rank 0 reports
+    r = got[0]
+    json.dumps(r)
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["higher_is_better"] is True
+    assert r["config"]["env_offsets"] == [0, 64]                      # disjoint contiguous shards keyed by rank
+    assert r["config"]["envs_per_gpu"] == 64 and "DartHopper-v1" in r["config"]["workload"]
+    assert abs(r["value"] - 2 * 64 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]   # whole-job aggregate over the slowest rank
+    assert r["gather_ms"] > 0 and "gather_note" not in r
+    assert r["roofline"]["algorithmic_bytes_per_env_step"] == 157 and r["vs_baseline"] is None
+    assert "cpu_baseline" not in r and "other_configs" not in r      # N = 1 extras only
+
+
+def test_world_size_mismatch_is_fatal(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "8"], env_factory=EmuBenchEnv, dist_backend="gloo")
+    assert "WORLD_SIZE" in str(e.value)
+
+
+def test_shards_are_contiguous_and_disjoint():
+    sys.path.insert(0, ROOT)
+    import bench
+    spans = [bench.shard_of(r, 65536) for r in range(8)]
+    assert spans[0] == (0, 65536) and spans[7] == (7 * 65536, 65536)
+    assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(7))
+    assert bench.default_envs("DartHumanWalker-v1") == 16384 and bench.default_envs("DartHopper-v1") == 65536

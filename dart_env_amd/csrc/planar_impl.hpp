@@ -38,6 +38,7 @@ struct ImplT : Impl {
     P.solver = solver; P.iters1 = it1 > 0 ? it1 : 24; P.iters2 = it2 > 0 ? it2 : 24;
   }
   void set_stats(unsigned long long* p) override { P.stats = p; }
+  void set_force_slow(int on) override { P.force_slow = on; }
   int slots() const override { return 2 * T::NC + n_limited<T>(); }
 };
 
@@ -126,7 +127,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task;
   P.penalty_link = c.penalty_dof >= 2 ? c.penalty_dof - 2 : -1;
   if (c.task != DART_TASK_NONE && c.height_body != 2) return "height body must be the root link";
-  P.solver = 0; P.iters1 = 24; P.iters2 = 24; P.stats = nullptr;
+  P.solver = 0; P.iters1 = 24; P.iters2 = 24; P.stats = nullptr; P.force_slow = 0;
   return "";
 }
 
@@ -140,7 +141,7 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
     if (allow_static && Static::matches(R)) {
       auto p = std::make_unique<ImplT<Real, T, Static>>();
       p->P.max_steps = R.max_steps; p->P.solver = R.solver; p->P.iters1 = R.iters1; p->P.iters2 = R.iters2;
-      p->P.stats = nullptr;
+      p->P.stats = nullptr; p->P.force_slow = 0;
       p->is_static = true;
       return p;
     }
@@ -152,12 +153,14 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
 
 template <class Real>
 std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool allow_static) {
-  why += "hopper-chain: ";
+  why += "hopper-chain, feet only: ";
   if (auto p = make_for_topology<Real, HopperTopo, HopperStatic<Real>>(c, why, allow_static)) return p;
   why += "; hopper-chain, all capsules: ";
-  if (auto p = make_for_topology<Real, HopperAllTopo, void>(c, why, allow_static)) return p;
-  why += "; walker2d-tree: ";
+  if (auto p = make_for_topology<Real, HopperAllTopo, HopperAllStatic<Real>>(c, why, allow_static)) return p;
+  why += "; walker2d-tree, feet only: ";
   if (auto p = make_for_topology<Real, Walker2dTopo, Walker2dStatic<Real>>(c, why, allow_static)) return p;
+  why += "; walker2d-tree, all capsules: ";
+  if (auto p = make_for_topology<Real, Walker2dAllTopo, Walker2dAllStatic<Real>>(c, why, allow_static)) return p;
   return nullptr;
 }
 

@@ -55,25 +55,36 @@ __device__ __host__ constexpr int tri(int i, int j) { return i >= j ? i * (i + 1
 
 // ------------------------------------------------------------------ topologies
 // Link 0 is the floating root (dofs 0,1,2 = x, y, rot); link k>=1 hangs on a revolute joint (dof 2+k).
-struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - shin - foot
-  static constexpr int NL = 4, NDOF = NL + 2, NC = 1, NA = 3;
+// NC = CANDIDATE capsules (each tested against the floor every substep).  The constraint phase works on compacted contact
+// SLOTS: TIER0 slots in the first register path, TIER1 (0 = none) in a second one chosen by a wave vote when some lane has
+// more contacts, and a lane with more contacts than the last tier is served alone by a loop-based solver in LDS
+// (slow_constraints) -- exact for any number of contacts, and never on the path of a workload that stays within the tiers.
+struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - shin - foot; ONLY the foot collides (BASELINE config[1])
+  static constexpr int NL = 4, NDOF = NL + 2, NC = 1, NA = 3, TIER0 = 1, TIER1 = 0;
   static constexpr bool WARM = false;  // warm-started active sets: measured -4 % here (short, violent episodes)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
-struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour; 11 LCP rows instead of 5)
-  static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3;
+struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour, the default card)
+  static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2;
   static constexpr bool WARM = false;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
-struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin foot) x 2
-  static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6;
+struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin foot) x 2; only the feet collide
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6, TIER0 = 2, TIER1 = 0;
   static constexpr bool WARM = true;   // measured +26 % (persistent double-support contacts)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3, 6}; return L[c]; }
+  __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
+};
+struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the floor (DART's behaviour, the default card)
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0;
+  static constexpr bool WARM = true;
+  __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
+  __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3, 4, 5, 6}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
 
@@ -91,11 +102,29 @@ __device__ __host__ constexpr int n_limited() {
   for (int k = 0; k < T::NL; k++) n += T::limited(k) ? 1 : 0;
   return n;
 }
-template <class T>
-__device__ __host__ constexpr int limit_slot(int k) {  // LCP slot of link k's limit row
-  int s = 2 * T::NC;
+template <class T, int NCA>
+__device__ __host__ constexpr int limit_slot(int k) {  // LCP slot of link k's limit row when NCA contact slots precede the limits
+  int s = 2 * NCA;
   for (int j = 0; j < k; j++) s += T::limited(j) ? 1 : 0;
   return s;
+}
+template <class T> __device__ __host__ constexpr int last_tier() { return T::TIER1 > 0 ? T::TIER1 : T::TIER0; }
+template <class T> __device__ __host__ constexpr bool has_slow_path() { return T::NC > last_tier<T>(); }
+template <class T> __device__ __host__ constexpr int max_rows() { return 2 * T::NC + n_limited<T>(); }
+// ancestor-or-self sets of all links, 8 bits per link (NL <= 8): bit j of byte k = is_anc(j, k)
+template <class T>
+__device__ __host__ constexpr unsigned long long anc_table() {
+  static_assert(T::NL <= 8, "ancestor table packs 8 links");
+  unsigned long long t = 0;
+  for (int k = 0; k < T::NL; k++)
+    for (int j = 0; j < T::NL; j++) if (is_anc<T>(j, k)) t |= 1ull << (8 * k + j);
+  return t;
+}
+// LDS words of the single-lane fallback solver (slow_constraints): H^-1 full, kinematics, candidates, rows
+template <class T>
+__device__ __host__ constexpr int slow_words() {
+  constexpr int N = T::NDOF, M = max_rows<T>();
+  return N * N + 3 * T::NL + N + 4 * T::NC + 3 * T::NL + 2 * M * N + 2 * (M * (M + 1) / 2) + 8 * M + 16;
 }
 
 // ------------------------------------------------------------------ runtime parameters (kernel argument -> SGPRs)
@@ -115,6 +144,7 @@ struct Params {
   Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise, noise_v;
   int frame_skip, max_steps, penalty_link, task;
   int solver, iters1, iters2;  // solver 0: block principal pivoting (exact); 1: PGS sweeps
+  int force_slow;              // debug / test knob: every lane with a contact takes the single-lane fallback solver
   unsigned long long* stats;   // optional [2][32] histogram of wave-level pivoting iterations per stage (debug), or null
 };
 
@@ -358,16 +388,394 @@ __device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const
 // Active sets of the previous substep (registers, per lane): contacts and limits persist over the frame_skip substeps,
 // so the pivoting solver usually starts on the right set.  Any start gives the same (unique) LCP solution.
 struct WarmSets {
+  uint32_t cid = 0;                // candidate capsule held by each contact slot (4 bits per slot)
   uint32_t sig = 0, up = 0;        // which rows were active / which of them rested on their upper bound
   uint32_t F1 = 0, U1 = 0;         // final sets of the frictionless stage
   uint32_t F2 = 0, U2 = 0;         // final sets of the friction stage
 };
 
+// ------------------------------------------------------------------ constraint phase on NCA compacted contact slots
+// Inputs: H^-1 (packed, reversed dof order), link origins px / py, the unconstrained velocity vs (in/out), the candidate
+// contacts (con / cPx / cPy / cdep over the T::NC capsules) and the state q (limits).  A lane with `off` set takes no part
+// (it is served by slow_constraints): all its rows are inactive and its vs comes back unchanged.
+template <class Real, class T, class PT, int NCA>
+__device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T::NDOF], const Real (&H)[T::NDOF * (T::NDOF + 1) / 2],
+                                                 const Real (&px)[T::NL], const Real (&py)[T::NL], Real (&vs)[T::NDOF],
+                                                 const bool (&con)[T::NC], const Real (&cPx)[T::NC], const Real (&cPy)[T::NC],
+                                                 const Real (&cdep)[T::NC], bool off, WarmSets& warm) {
+  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * NCA + n_limited<T>();
+  constexpr bool IDENT = (NCA == NC);   // slot s IS candidate s: links are compile-time constants
+  // ---- compaction: slot s takes the s-th touching capsule (capsule order = the oracle's serial order)
+  bool son[NCA];
+  Real sPx[NCA], sPy[NCA], sdep[NCA];
+  uint32_t samask[NCA];   // ancestor-or-self set of the slot's link (bit j = link j moves the contact point)
+  uint32_t cid = 0;
+  if constexpr (IDENT) {
+    sfor<0, NCA>([&](auto S) {
+      constexpr int sl = S;
+      son[sl] = con[sl] && !off; sPx[sl] = cPx[sl]; sPy[sl] = cPy[sl]; sdep[sl] = cdep[sl];
+      samask[sl] = (uint32_t)((anc_table<T>() >> (8 * T::clink(sl))) & 0xffull);
+    });
+  } else {
+    sfor<0, NCA>([&](auto S) { son[S] = false; sPx[S] = Real(0); sPy[S] = Real(0); sdep[S] = Real(0); samask[S] = 0u; });
+    int rank = 0;
+    sfor<0, NC>([&](auto Cc) {
+      constexpr int c = Cc;
+      const bool hit = con[c] && !off;
+      sfor<0, NCA>([&](auto S) {
+        constexpr int sl = S;
+        const bool take = hit && rank == sl;
+        son[sl] = son[sl] || take;
+        sPx[sl] = take ? cPx[c] : sPx[sl]; sPy[sl] = take ? cPy[c] : sPy[sl]; sdep[sl] = take ? cdep[c] : sdep[sl];
+        samask[sl] = take ? (uint32_t)((anc_table<T>() >> (8 * T::clink(c))) & 0xffull) : samask[sl];
+        cid = take ? (cid | ((uint32_t)c << (4 * sl))) : cid;
+      });
+      rank += hit ? 1 : 0;
+    });
+  }
+  Real A[M * (M + 1) / 2], b[M], lo[M], hi[M], x[M];
+  bool act[M];
+  Real Jn[NCA][N], Jt[NCA][N], Yn[NCA][N], Yt[NCA][N];
+  bool any = false;
+  sfor<0, NCA>([&](auto S) {
+    constexpr int sl = S;
+    Jn[sl][0] = Real(0); Jn[sl][1] = Real(1);
+    Jt[sl][0] = Real(-1); Jt[sl][1] = Real(0);
+    sfor<0, NL>([&](auto J) {
+      constexpr int j = J;
+      if constexpr (IDENT) {
+        if constexpr (is_anc<T>(j, T::clink(sl))) {
+          Jn[sl][2 + j] = P.sigma[j] * (sPx[sl] - px[j]);
+          Jt[sl][2 + j] = P.sigma[j] * (sPy[sl] - py[j]);
+        } else {
+          Jn[sl][2 + j] = Real(0); Jt[sl][2 + j] = Real(0);
+        }
+      } else {
+        const bool a = (samask[sl] >> j) & 1u;
+        Jn[sl][2 + j] = a ? P.sigma[j] * (sPx[sl] - px[j]) : Real(0);
+        Jt[sl][2 + j] = a ? P.sigma[j] * (sPy[sl] - py[j]) : Real(0);
+      }
+    });
+    Real rn = Real(0), rt = Real(0);
+    sfor<0, N>([&](auto I) { constexpr int i = I; rn += Jn[sl][i] * vs[i]; rt += Jt[sl][i] * vs[i]; });
+    const Real bounce = fmin(sdep[sl] * P.erp_dt, P.max_erv);
+    constexpr int sn = 2 * sl, stt = 2 * sl + 1;
+    const bool on = son[sl];
+    act[sn] = on; act[stt] = on;
+    b[sn] = on ? (bounce - rn) : Real(0);
+    b[stt] = on ? -rt : Real(0);
+    lo[sn] = Real(0); hi[sn] = on ? inf_<Real>() : Real(0);
+    lo[stt] = Real(0); hi[stt] = Real(0);  // friction rows are pinned at 0 during stage 1
+    any = any || on;
+  });
+  sfor<0, NL>([&](auto K) {
+    constexpr int k = K;
+    if constexpr (T::limited(k)) {
+      constexpr int sl = limit_slot<T, NCA>(k), i = 2 + k;
+      const bool low = !off && q[i] <= P.lo[k], up = !off && (!low) && (q[i] >= P.hi[k]);
+      const Real viol = low ? (q[i] - P.lo[k]) : (q[i] - P.hi[k]);
+      const Real bounce = fmin(fmax(-viol * P.limit_erp_dt, -P.max_erv), P.max_erv);
+      const bool on = low || up;
+      act[sl] = on;
+      b[sl] = on ? (bounce - vs[i]) : Real(0);
+      lo[sl] = low ? Real(0) : (up ? -inf_<Real>() : Real(0));
+      hi[sl] = low ? inf_<Real>() : Real(0);
+      any = any || on;
+    }
+  });
+  if (!__any(any)) return;
+
+  // Y = H^-1 J^T for contact rows (limit rows: columns of H^-1), Delassus matrix A = J H^-1 J^T
+  sfor<0, NCA>([&](auto S) {
+    constexpr int sl = S;
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      Real a = Real(0), t = Real(0);
+      sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(rev<N>(i), rev<N>(j))] * Jn[sl][j]; t += H[tri(rev<N>(i), rev<N>(j))] * Jt[sl][j]; });
+      Yn[sl][i] = a; Yt[sl][i] = t;
+    });
+  });
+  sfor<0, NCA>([&](auto Ca) {
+    constexpr int a = Ca;
+    sfor<0, a + 1>([&](auto Cb) {
+      constexpr int bb = Cb;
+      Real nn = Real(0), nt = Real(0), tn = Real(0), ttv = Real(0);
+      sfor<0, N>([&](auto I) {
+        constexpr int i = I;
+        nn += Jn[a][i] * Yn[bb][i]; nt += Jn[a][i] * Yt[bb][i];
+        tn += Jt[a][i] * Yn[bb][i]; ttv += Jt[a][i] * Yt[bb][i];
+      });
+      A[tri(2 * a, 2 * bb)] = nn;
+      A[tri(2 * a + 1, 2 * bb + 1)] = ttv;
+      A[tri(2 * a + 1, 2 * bb)] = tn;
+      if constexpr (a != bb) A[tri(2 * a, 2 * bb + 1)] = nt;
+    });
+  });
+  sfor<0, NL>([&](auto K) {
+    constexpr int k = K;
+    if constexpr (T::limited(k)) {
+      constexpr int sl = limit_slot<T, NCA>(k), i = 2 + k;
+      sfor<0, NCA>([&](auto S) {
+        constexpr int cs = S;
+        A[tri(sl, 2 * cs)] = Yn[cs][i];
+        A[tri(sl, 2 * cs + 1)] = Yt[cs][i];
+      });
+      sfor<0, k + 1>([&](auto J) {
+        constexpr int j = J;
+        if constexpr (T::limited(j)) A[tri(sl, limit_slot<T, NCA>(j))] = H[tri(rev<N>(i), rev<N>(2 + j))];
+      });
+    }
+  });
+  // inactive slots: decouple (unit diagonal keeps the factorisations regular)
+  sfor<0, M>([&](auto I) {
+    constexpr int i = I;
+    A[tri(i, i)] = act[i] ? A[tri(i, i)] * (i < 2 * NCA ? P.ccfm1 : P.cfm1) : Real(1);
+    sfor<0, i>([&](auto J) { constexpr int j = J; if (!act[i] || !act[j]) A[tri(i, j)] = Real(0); });
+  });
+
+  // initial active set: every row at its finite bound, except rows that x = 0 already violates (w = -b has the
+  // wrong sign) -- those start free, which is what the first pivoting iteration would have found
+  uint32_t pinmask = 0, F = 0, U = 0, sig = 0, up = 0;
+  bool has_contact = false;
+  Real bmax0 = Real(0);
+  sfor<0, M>([&](auto I) { bmax0 = fmax(bmax0, fabs(b[I])); });
+  const Real tol0 = tol_<Real>() * (Real(1) + bmax0);
+  sfor<0, M>([&](auto I) {
+    constexpr int i = I;
+    x[i] = Real(0);
+    const bool pinned = !(lo[i] < hi[i]);
+    const bool upper = !(lo[i] == Real(0));   // (-inf, 0] rows rest on their upper bound
+    const bool start_free = !pinned && (upper ? (b[i] < -tol0) : (b[i] > tol0));
+    pinmask |= pinned ? (1u << i) : 0u;
+    F |= start_free ? (1u << i) : 0u;
+    U |= (upper && !start_free) ? (1u << i) : 0u;
+    sig |= act[i] ? (1u << i) : 0u;
+    up |= (act[i] && upper) ? (1u << i) : 0u;
+  });
+  sfor<0, NCA>([&](auto S) { has_contact = has_contact || act[2 * S]; });
+  // rows that were active on the same side in the previous substep (contact slots: and hold the same capsule) inherit
+  // that substep's final set
+  uint32_t keep = ~0u;
+  if constexpr (!IDENT) {
+    sfor<0, NCA>([&](auto S) {
+      constexpr int sl = S;
+      const bool same_capsule = ((warm.cid >> (4 * sl)) & 15u) == ((cid >> (4 * sl)) & 15u);
+      keep = same_capsule ? keep : (keep & ~(3u << (2 * sl)));
+    });
+  }
+  const uint32_t same = T::WARM ? (sig & warm.sig & ~(up ^ warm.up) & ~pinmask & keep) : 0u;
+  F = (F & ~same) | (warm.F1 & same);
+  U = (U & ~same) | (warm.U1 & same);
+
+  if (P.solver == 0) blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
+  else {
+    bool skip[M];
+    sfor<0, M>([&](auto I) { skip[I] = (pinmask >> I) & 1u; });
+    blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters1);
+  }
+
+  warm.F1 = F; warm.U1 = U;
+  if (__any(has_contact)) {
+    // ODE/DART friction bounds: +-mu * (normal impulse of the frictionless solve), then the full problem
+    uint32_t fric = 0;
+    sfor<0, NCA>([&](auto S) {
+      constexpr int sn = 2 * S, stt = 2 * S + 1;
+      Real hb = act[sn] ? fabs(P.mu * x[sn]) : Real(0);
+      hi[stt] = hb; lo[stt] = -hb;
+      const bool pinned = !(hb > Real(0));
+      pinmask = pinned ? (pinmask | (1u << stt)) : (pinmask & ~(1u << stt));
+      F = pinned ? (F & ~(1u << stt)) : (F | (1u << stt));   // friction rows start free
+      U &= ~(1u << stt);
+      fric |= pinned ? 0u : (1u << stt);
+    });
+    // ... unless the same contact was sliding/sticking a substep ago: start from that state
+    const uint32_t samef = fric & (same << 1);   // friction row of a contact whose normal row persisted
+    F = (F & ~samef) | (warm.F2 & samef);
+    U = (U & ~samef) | (warm.U2 & samef);
+    if (P.solver == 0) blcp_bpp<Real, M, false>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr);
+    else {
+      bool skip[M];
+      sfor<0, M>([&](auto I) { skip[I] = !has_contact; });   // per-env semantics: no contact -> no second stage
+      blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters2);
+    }
+    warm.F2 = F; warm.U2 = U;
+  }
+  warm.sig = sig; warm.up = up; warm.cid = cid;
+  // velocity change  H^-1 J^T lambda
+  sfor<0, N>([&](auto I) {
+    constexpr int i = I;
+    Real dv = Real(0);
+    sfor<0, NCA>([&](auto S) { constexpr int cs = S; dv += Yn[cs][i] * x[2 * cs] + Yt[cs][i] * x[2 * cs + 1]; });
+    sfor<0, NL>([&](auto K) {
+      constexpr int k = K;
+      if constexpr (T::limited(k)) dv += H[tri(rev<N>(i), rev<N>(2 + k))] * x[limit_slot<T, NCA>(k)];
+    });
+    vs[i] += dv;
+  });
+}
+
+// ------------------------------------------------------------------ single-lane fallback: any number of contacts, loops over LDS
+// Executed by ONE lane at a time (the others of its wave wait) for an env with more touching capsules than the register
+// tiers hold -- the robot lying on the floor.  Same LCP, same two-stage pivoting with the same start sets and tolerances
+// as blcp_bpp, written as plain loops over arrays in `mem` (slow_words<T>() Reals of LDS).  Speed is irrelevant here.
+template <class Real>
+__device__ inline void slow_masked_solve(int m, const Real* A, uint32_t F, Real* x, Real* L, Real* invd, Real* W) {
+  for (int j = 0; j < m; j++) {
+    const Real fj0 = ((F >> j) & 1u) ? Real(1) : Real(0);
+    Real d = fj0 * A[tri(j, j)] + (Real(1) - fj0);
+    for (int k = 0; k < j; k++) { W[k] = L[tri(j, k)] * L[tri(k, k)]; d -= L[tri(j, k)] * W[k]; }
+    L[tri(j, j)] = d;
+    invd[j] = rcp_<Real>(d);
+    const Real fj = fj0 * invd[j];
+    for (int i = j + 1; i < m; i++) {
+      Real t = ((F >> i) & 1u) ? A[tri(i, j)] : Real(0);
+      for (int k = 0; k < j; k++) t -= L[tri(i, k)] * W[k];
+      L[tri(i, j)] = t * fj;
+    }
+  }
+  for (int i = 0; i < m; i++) for (int k = 0; k < i; k++) x[i] -= L[tri(i, k)] * x[k];
+  for (int i = 0; i < m; i++) x[i] *= invd[i];
+  for (int i = m - 1; i >= 0; i--) for (int k = i + 1; k < m; k++) x[i] -= L[tri(k, i)] * x[k];
+}
+template <class Real>
+__device__ inline void slow_blcp(int m, const Real* A, const Real* b, const Real* lo, const Real* hi, uint32_t pinmask, uint32_t& F,
+                                 uint32_t& U, Real* x, int max_iter, bool zero_bounds, Real* L, Real* invd, Real* W, Real* r, Real* xb) {
+  Real bmax = Real(0);
+  for (int i = 0; i < m; i++) bmax = fmax(bmax, fabs(b[i]));
+  const Real tol = tol_<Real>() * (Real(1) + bmax);
+  int best = m + 1, patience = 3;
+  bool conv = false;
+  for (int it = 0; it < max_iter && !conv; ++it) {
+    for (int i = 0; i < m; i++) {
+      const bool f = (F >> i) & 1u, u = (U >> i) & 1u;
+      xb[i] = f ? Real(0) : (u ? hi[i] : lo[i]);
+    }
+    for (int i = 0; i < m; i++) {
+      Real t = b[i];
+      if (!zero_bounds) for (int j = 0; j < m; j++) t -= A[tri(i, j)] * xb[j];
+      r[i] = ((F >> i) & 1u) ? t : xb[i];
+    }
+    slow_masked_solve<Real>(m, A, F, r, L, invd, W);
+    uint32_t B = 0, GT = 0;
+    for (int i = 0; i < m; i++) {
+      Real w = -b[i];
+      for (int j = 0; j < m; j++) w += A[tri(i, j)] * r[j];
+      const bool f = (F >> i) & 1u, u = (U >> i) & 1u, pinned = (pinmask >> i) & 1u;
+      const bool over = r[i] > hi[i] + tol * (Real(1) + fabs(hi[i]));
+      const bool under = r[i] < lo[i] - tol * (Real(1) + fabs(lo[i]));
+      const bool wbad = u ? (w > tol) : (w < -tol);
+      const bool inf = f ? (over || under) : (wbad && !pinned);
+      B |= inf ? (1u << i) : 0u;
+      GT |= (r[i] > hi[i]) ? (1u << i) : 0u;
+    }
+    for (int i = 0; i < m; i++) x[i] = r[i];
+    conv = (B == 0u);
+    if (conv) break;
+    const int ninf = __popc(B);
+    const bool improved = ninf < best;
+    const bool single = !improved && patience == 0;
+    best = improved ? ninf : best;
+    patience = improved ? 3 : (patience > 0 ? patience - 1 : 0);
+    const uint32_t Bs = single ? (1u << (31 - __clz((int)B))) : B;
+    const uint32_t toBound = Bs & F, toFree = Bs & ~F;
+    F = (F & ~toBound) | toFree;
+    U = (U & ~(toFree | toBound)) | (toBound & GT);
+  }
+  for (int i = 0; i < m; i++) x[i] = fmin(fmax(x[i], lo[i]), hi[i]);
+}
+
+template <class Real, class T, class PT>
+__device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* mem) {
+  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, MM = max_rows<T>();
+  // layout written by the caller: Hi[N*N], px[NL], py[NL], sg[NL], vs[N], con[NC], cPx[NC], cPy[NC], cdep[NC], lim[NL] (-1 low, +1 up, 0),
+  // viol[NL], clk[NL] scratch
+  Real* Hi = mem; Real* px = Hi + N * N; Real* py = px + NL; Real* sg = py + NL; Real* vs = sg + NL;
+  Real* con = vs + N; Real* cPx = con + NC; Real* cPy = cPx + NC; Real* cdep = cPy + NC;
+  Real* lim = cdep + NC; Real* viol = lim + NL; Real* spare = viol + NL;
+  Real* J = spare + NL; Real* Y = J + MM * N; Real* A = Y + MM * N; Real* L = A + MM * (MM + 1) / 2;
+  Real* b = L + MM * (MM + 1) / 2; Real* lo = b + MM; Real* hi = lo + MM; Real* x = hi + MM; Real* r = x + MM; Real* xb = r + MM;
+  Real* invd = xb + MM; Real* W = invd + MM;
+  int m = 0, ncont = 0;
+  uint32_t limrows = 0;
+  for (int c = 0; c < NC; c++) {
+    if (con[c] == Real(0)) continue;
+    const uint32_t am = (uint32_t)((anc_table<T>() >> (8 * T::clink(c))) & 0xffull);
+    Real* jn = J + m * N; Real* jt = J + (m + 1) * N;
+    jn[0] = Real(0); jn[1] = Real(1); jt[0] = Real(-1); jt[1] = Real(0);
+    for (int j = 0; j < NL; j++) {
+      const bool a = (am >> j) & 1u;
+      jn[2 + j] = a ? sg[j] * (cPx[c] - px[j]) : Real(0);
+      jt[2 + j] = a ? sg[j] * (cPy[c] - py[j]) : Real(0);
+    }
+    Real rn = Real(0), rt = Real(0);
+    for (int i = 0; i < N; i++) { rn += jn[i] * vs[i]; rt += jt[i] * vs[i]; }
+    b[m] = fmin(cdep[c] * P.erp_dt, P.max_erv) - rn; lo[m] = Real(0); hi[m] = inf_<Real>();
+    b[m + 1] = -rt; lo[m + 1] = Real(0); hi[m + 1] = Real(0);
+    m += 2; ncont++;
+  }
+  for (int k = 0; k < NL; k++) {
+    if (lim[k] == Real(0)) continue;
+    Real* jl = J + m * N;
+    for (int i = 0; i < N; i++) jl[i] = Real(0);
+    jl[2 + k] = Real(1);
+    const bool low = lim[k] < Real(0);
+    b[m] = fmin(fmax(-viol[k] * P.limit_erp_dt, -P.max_erv), P.max_erv) - vs[2 + k];
+    lo[m] = low ? Real(0) : -inf_<Real>(); hi[m] = low ? inf_<Real>() : Real(0);
+    limrows |= 1u << m;
+    m++;
+  }
+  if (m == 0) return;
+  for (int rr = 0; rr < m; rr++)
+    for (int i = 0; i < N; i++) {
+      Real t = Real(0);
+      for (int j = 0; j < N; j++) t += Hi[i * N + j] * J[rr * N + j];
+      Y[rr * N + i] = t;
+    }
+  for (int rr = 0; rr < m; rr++)
+    for (int cc = 0; cc <= rr; cc++) {
+      Real t = Real(0);
+      for (int i = 0; i < N; i++) t += J[rr * N + i] * Y[cc * N + i];
+      if (rr == cc) t *= ((limrows >> rr) & 1u) ? P.cfm1 : P.ccfm1;
+      A[tri(rr, cc)] = t;
+    }
+  uint32_t pinmask = 0, F = 0, U = 0;
+  Real bmax0 = Real(0);
+  for (int i = 0; i < m; i++) bmax0 = fmax(bmax0, fabs(b[i]));
+  const Real tol0 = tol_<Real>() * (Real(1) + bmax0);
+  for (int i = 0; i < m; i++) {
+    x[i] = Real(0);
+    const bool pinned = !(lo[i] < hi[i]);
+    const bool upper = !(lo[i] == Real(0));
+    const bool start_free = !pinned && (upper ? (b[i] < -tol0) : (b[i] > tol0));
+    pinmask |= pinned ? (1u << i) : 0u;
+    F |= start_free ? (1u << i) : 0u;
+    U |= (upper && !start_free) ? (1u << i) : 0u;
+  }
+  slow_blcp<Real>(m, A, b, lo, hi, pinmask, F, U, x, 4 * P.iters1 + 64, true, L, invd, W, r, xb);
+  if (ncont > 0) {
+    for (int c = 0; c < ncont; c++) {
+      const int sn = 2 * c, stt = 2 * c + 1;
+      const Real hb = fabs(P.mu * x[sn]);
+      hi[stt] = hb; lo[stt] = -hb;
+      const bool pinned = !(hb > Real(0));
+      pinmask = pinned ? (pinmask | (1u << stt)) : (pinmask & ~(1u << stt));
+      F = pinned ? (F & ~(1u << stt)) : (F | (1u << stt));
+      U &= ~(1u << stt);
+    }
+    slow_blcp<Real>(m, A, b, lo, hi, pinmask, F, U, x, 4 * P.iters2 + 64, false, L, invd, W, r, xb);
+  }
+  for (int i = 0; i < N; i++) {
+    Real dv = Real(0);
+    for (int rr = 0; rr < m; rr++) dv += Y[rr * N + i] * x[rr];
+    vs[i] += dv;
+  }
+}
+
 // ------------------------------------------------------------------ one World::step (dt) for one env
 template <class Real, class T, class PT>
 __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
-                                           const Real (&tau)[T::NDOF], WarmSets& warm) {
-  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * T::NC + n_limited<T>();
+                                           const Real (&tau)[T::NDOF], WarmSets& warm, Real* slow_mem) {
+  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC;
   Real c[NL], s[NL], px[NL], py[NL], lx[NL], ly[NL], om[NL];
   Real apx[NL], apy[NL];
   // composite-body quantities, each expressed about the link's OWN joint origin (no large-offset cancellation in
@@ -458,11 +866,11 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     vs[i] = dq[i] + P.dt * a;
   });
 
-  // ---- constraints at q_t
-  Real A[M * (M + 1) / 2], b[M], lo[M], hi[M], x[M];
-  bool act[M];
-  Real Jn[NC][N], Jt[NC][N], Yn[NC][N], Yt[NC][N];
-  bool any = false;
+  // ---- candidate contacts at q_t: every capsule's lowest segment endpoint against the floor (ODE capsule-plane as DART
+  // uses it: one contact, position in the middle of the penetration)
+  bool con[NC];
+  Real cPx[NC], cPy[NC], cdep[NC];
+  int nact = 0;
   sfor<0, NC>([&](auto Cc) {
     constexpr int cidx = Cc, k = T::clink(cidx);
     Real x1 = px[k] + c[k] * P.e1x[cidx] - s[k] * P.e1y[cidx], y1 = py[k] + s[k] * P.e1x[cidx] + c[k] * P.e1y[cidx];
@@ -470,166 +878,52 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     bool second = y2 < y1;  // lowest endpoint; exact tie -> first (+axis) end
     Real ex = second ? x2 : x1, ey = second ? y2 : y1;
     Real d = (P.root_y0 + q[1] + ey) - P.ground_y;
-    bool on = d <= P.rad[cidx];
-    Real depth = P.rad[cidx] - d;
-    Real Px = ex, Py = ey - Real(0.5) * (P.rad[cidx] + d);  // ODE sphere-sphere contact position
-    Jn[cidx][0] = Real(0); Jn[cidx][1] = Real(1);
-    Jt[cidx][0] = Real(-1); Jt[cidx][1] = Real(0);
-    sfor<0, NL>([&](auto J) {
-      constexpr int j = J;
-      if constexpr (is_anc<T>(j, k)) {
-        Jn[cidx][2 + j] = P.sigma[j] * (Px - px[j]);
-        Jt[cidx][2 + j] = P.sigma[j] * (Py - py[j]);
-      } else {
-        Jn[cidx][2 + j] = Real(0); Jt[cidx][2 + j] = Real(0);
-      }
-    });
-    Real rn = Real(0), rt = Real(0);
-    sfor<0, N>([&](auto I) { constexpr int i = I; rn += Jn[cidx][i] * vs[i]; rt += Jt[cidx][i] * vs[i]; });
-    Real bounce = fmin(depth * P.erp_dt, P.max_erv);
-    constexpr int sn = 2 * cidx, stt = 2 * cidx + 1;
-    act[sn] = on; act[stt] = on;
-    b[sn] = on ? (bounce - rn) : Real(0);
-    b[stt] = on ? -rt : Real(0);
-    lo[sn] = Real(0); hi[sn] = on ? inf_<Real>() : Real(0);
-    lo[stt] = Real(0); hi[stt] = Real(0);  // friction rows are pinned at 0 during stage 1
-    any = any || on;
-  });
-  sfor<0, NL>([&](auto K) {
-    constexpr int k = K;
-    if constexpr (T::limited(k)) {
-      constexpr int sl = limit_slot<T>(k), i = 2 + k;
-      bool low = q[i] <= P.lo[k], up = (!low) && (q[i] >= P.hi[k]);
-      Real viol = low ? (q[i] - P.lo[k]) : (q[i] - P.hi[k]);
-      Real bounce = fmin(fmax(-viol * P.limit_erp_dt, -P.max_erv), P.max_erv);
-      bool on = low || up;
-      act[sl] = on;
-      b[sl] = on ? (bounce - vs[i]) : Real(0);
-      lo[sl] = low ? Real(0) : (up ? -inf_<Real>() : Real(0));
-      hi[sl] = low ? inf_<Real>() : Real(0);
-      any = any || on;
-    }
+    con[cidx] = d <= P.rad[cidx];
+    cdep[cidx] = P.rad[cidx] - d;
+    cPx[cidx] = ex; cPy[cidx] = ey - Real(0.5) * (P.rad[cidx] + d);  // ODE sphere-sphere contact position
+    nact += con[cidx] ? 1 : 0;
   });
 
-  if (__any(any)) {
-    // Y = H^-1 J^T for contact rows (limit rows: columns of H^-1), Delassus matrix A = J H^-1 J^T
-    sfor<0, NC>([&](auto Cc) {
-      constexpr int cidx = Cc;
-      sfor<0, N>([&](auto I) {
-        constexpr int i = I;
-        Real a = Real(0), t = Real(0);
-        sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(rev<N>(i), rev<N>(j))] * Jn[cidx][j]; t += H[tri(rev<N>(i), rev<N>(j))] * Jt[cidx][j]; });
-        Yn[cidx][i] = a; Yt[cidx][i] = t;
-      });
-    });
-    sfor<0, NC>([&](auto Ca) {
-      constexpr int a = Ca;
-      sfor<0, a + 1>([&](auto Cb) {
-        constexpr int bb = Cb;
-        Real nn = Real(0), nt = Real(0), tn = Real(0), ttv = Real(0);
-        sfor<0, N>([&](auto I) {
-          constexpr int i = I;
-          nn += Jn[a][i] * Yn[bb][i]; nt += Jn[a][i] * Yt[bb][i];
-          tn += Jt[a][i] * Yn[bb][i]; ttv += Jt[a][i] * Yt[bb][i];
-        });
-        A[tri(2 * a, 2 * bb)] = nn;
-        A[tri(2 * a + 1, 2 * bb + 1)] = ttv;
-        A[tri(2 * a + 1, 2 * bb)] = tn;
-        if constexpr (a != bb) A[tri(2 * a, 2 * bb + 1)] = nt;
-      });
-    });
-    sfor<0, NL>([&](auto K) {
-      constexpr int k = K;
-      if constexpr (T::limited(k)) {
-        constexpr int sl = limit_slot<T>(k), i = 2 + k;
-        sfor<0, NC>([&](auto Cc) {
-          constexpr int cidx = Cc;
-          A[tri(sl, 2 * cidx)] = Yn[cidx][i];
-          A[tri(sl, 2 * cidx + 1)] = Yt[cidx][i];
-        });
-        sfor<0, k + 1>([&](auto J) {
-          constexpr int j = J;
-          if constexpr (T::limited(j)) A[tri(sl, limit_slot<T>(j))] = H[tri(rev<N>(i), rev<N>(2 + j))];
-        });
+  bool slow = false;
+  if constexpr (has_slow_path<T>()) {
+    slow = nact > last_tier<T>() || (P.force_slow != 0 && nact > 0);
+    if (__any(slow)) {
+      // the rare lanes whose env touches the floor with more capsules than the tiers hold: one after the other, alone
+      for (int turn = 0; turn < 64; ++turn) {
+        if (slow && (int)(threadIdx.x & 63) == turn) {
+          Real* m = slow_mem;
+          sfor<0, N>([&](auto I) { constexpr int i = I; sfor<0, N>([&](auto J) { constexpr int j = J; m[i * N + j] = H[tri(rev<N>(i), rev<N>(j))]; }); });
+          m += N * N;
+          sfor<0, NL>([&](auto K) { m[K] = px[K]; m[NL + K] = py[K]; m[2 * NL + K] = P.sigma[K]; });
+          m += 3 * NL;
+          sfor<0, N>([&](auto I) { m[I] = vs[I]; });
+          Real* mvs = m;
+          m += N;
+          sfor<0, NC>([&](auto Cc) { m[Cc] = con[Cc] ? Real(1) : Real(0); m[NC + Cc] = cPx[Cc]; m[2 * NC + Cc] = cPy[Cc]; m[3 * NC + Cc] = cdep[Cc]; });
+          m += 4 * NC;
+          sfor<0, NL>([&](auto K) {
+            constexpr int k = K;
+            Real lim = Real(0), viol = Real(0);
+            if constexpr (T::limited(k)) {
+              const bool low = q[2 + k] <= P.lo[k], up = (!low) && (q[2 + k] >= P.hi[k]);
+              lim = low ? Real(-1) : (up ? Real(1) : Real(0));
+              viol = low ? (q[2 + k] - P.lo[k]) : (q[2 + k] - P.hi[k]);
+            }
+            m[k] = lim; m[NL + k] = viol;
+          });
+          slow_constraints<Real, T, PT>(P, slow_mem);
+          sfor<0, N>([&](auto I) { vs[I] = mvs[I]; });
+        }
       }
-    });
-    // inactive slots: decouple (unit diagonal keeps the factorisations regular)
-    sfor<0, M>([&](auto I) {
-      constexpr int i = I;
-      A[tri(i, i)] = act[i] ? A[tri(i, i)] * (i < 2 * NC ? P.ccfm1 : P.cfm1) : Real(1);
-      sfor<0, i>([&](auto J) { constexpr int j = J; if (!act[i] || !act[j]) A[tri(i, j)] = Real(0); });
-    });
-
-    // initial active set: every row at its finite bound, except rows that x = 0 already violates (w = -b has the
-    // wrong sign) -- those start free, which is what the first pivoting iteration would have found
-    uint32_t pinmask = 0, F = 0, U = 0, sig = 0, up = 0;
-    bool has_contact = false;
-    Real bmax0 = Real(0);
-    sfor<0, M>([&](auto I) { bmax0 = fmax(bmax0, fabs(b[I])); });
-    const Real tol0 = tol_<Real>() * (Real(1) + bmax0);
-    sfor<0, M>([&](auto I) {
-      constexpr int i = I;
-      x[i] = Real(0);
-      const bool pinned = !(lo[i] < hi[i]);
-      const bool upper = !(lo[i] == Real(0));   // (-inf, 0] rows rest on their upper bound
-      const bool start_free = !pinned && (upper ? (b[i] < -tol0) : (b[i] > tol0));
-      pinmask |= pinned ? (1u << i) : 0u;
-      F |= start_free ? (1u << i) : 0u;
-      U |= (upper && !start_free) ? (1u << i) : 0u;
-      sig |= act[i] ? (1u << i) : 0u;
-      up |= (act[i] && upper) ? (1u << i) : 0u;
-    });
-    sfor<0, NC>([&](auto Cc) { has_contact = has_contact || act[2 * Cc]; });
-    // rows that were active on the same side in the previous substep inherit that substep's final set
-    const uint32_t same = T::WARM ? (sig & warm.sig & ~(up ^ warm.up) & ~pinmask) : 0u;
-    F = (F & ~same) | (warm.F1 & same);
-    U = (U & ~same) | (warm.U1 & same);
-
-    if (P.solver == 0) blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
-    else {
-      bool skip[M];
-      sfor<0, M>([&](auto I) { skip[I] = (pinmask >> I) & 1u; });
-      blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters1);
     }
-
-    warm.F1 = F; warm.U1 = U;
-    if (__any(has_contact)) {
-      // ODE/DART friction bounds: +-mu * (normal impulse of the frictionless solve), then the full problem
-      uint32_t fric = 0;
-      sfor<0, NC>([&](auto Cc) {
-        constexpr int sn = 2 * Cc, stt = 2 * Cc + 1;
-        Real hb = act[sn] ? fabs(P.mu * x[sn]) : Real(0);
-        hi[stt] = hb; lo[stt] = -hb;
-        const bool pinned = !(hb > Real(0));
-        pinmask = pinned ? (pinmask | (1u << stt)) : (pinmask & ~(1u << stt));
-        F = pinned ? (F & ~(1u << stt)) : (F | (1u << stt));   // friction rows start free
-        U &= ~(1u << stt);
-        fric |= pinned ? 0u : (1u << stt);
-      });
-      // ... unless the same contact was sliding/sticking a substep ago: start from that state
-      const uint32_t samef = fric & (same << 1);   // friction row of a contact whose normal row persisted
-      F = (F & ~samef) | (warm.F2 & samef);
-      U = (U & ~samef) | (warm.U2 & samef);
-      if (P.solver == 0) blcp_bpp<Real, M, false>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr);
-      else {
-        bool skip[M];
-        sfor<0, M>([&](auto I) { skip[I] = !has_contact; });   // per-env semantics: no contact -> no second stage
-        blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters2);
-      }
-      warm.F2 = F; warm.U2 = U;
-    }
-    warm.sig = sig; warm.up = up;
-    // velocity change  H^-1 J^T lambda
-    sfor<0, N>([&](auto I) {
-      constexpr int i = I;
-      Real dv = Real(0);
-      sfor<0, NC>([&](auto Cc) { constexpr int cidx = Cc; dv += Yn[cidx][i] * x[2 * cidx] + Yt[cidx][i] * x[2 * cidx + 1]; });
-      sfor<0, NL>([&](auto K) {
-        constexpr int k = K;
-        if constexpr (T::limited(k)) dv += H[tri(rev<N>(i), rev<N>(2 + k))] * x[limit_slot<T>(k)];
-      });
-      vs[i] += dv;
-    });
+  }
+  // ---- register tiers: the smallest one that holds every (remaining) lane's contacts
+  const int nreg = slow ? 0 : nact;
+  if constexpr (T::TIER1 > 0) {
+    if (__any(nreg > T::TIER0)) constraint_phase<Real, T, PT, T::TIER1>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm);
+    else constraint_phase<Real, T, PT, T::TIER0>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm);
+  } else {
+    constraint_phase<Real, T, PT, T::TIER0>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm);
   }
   sfor<0, N>([&](auto I) { constexpr int i = I; dq[i] = vs[i]; q[i] += P.dt * vs[i]; });
 }
@@ -714,9 +1008,11 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   Real x_before = q[0];
   Real dx = Real(0);
   WarmSets warm;
+  // LDS of the single-lane fallback solver (only topologies with more candidate capsules than tier slots have one)
+  __shared__ Real slow_lds[has_slow_path<T>() ? slow_words<T>() : 1];
 #pragma unroll 1
   for (int f = 0; f < P.frame_skip; ++f) {
-    world_step<Real, T, PT>(P, q, dq, tau, warm);
+    world_step<Real, T, PT>(P, q, dq, tau, warm, slow_lds);
     dx += P.dt * dq[0];
   }
   (void)x_before;

@@ -28,7 +28,7 @@ class ShardedDartVectorEnv:
     """This rank's shard of a `total_envs` batch; Philox reset streams are keyed by the GLOBAL env index, so the
     union of all shards is bit-identical to one big single-GPU batch."""
 
-    def __init__(self, env_id, total_envs, rank=None, world_size=None, device=None, precision=32, seed=0,
+    def __init__(self, env_id, total_envs, rank=None, world_size=None, device=None, precision=64, seed=0,
                  stepper_factory=None):
         from .vector import DartVectorEnv
         r, lr, w = env_rank_info()

@@ -124,7 +124,7 @@ class BatchedDartEnv:
 
     metadata = {"render.modes": []}
 
-    def __init__(self, env_id: str, num_envs: int = 1, device: int = 0, precision: int = 32, noise: str = "mt19937",
+    def __init__(self, env_id: str, num_envs: int = 1, device: int = 0, precision: int = 64, noise: str = "mt19937",
                  max_episode_steps: Optional[int] = None, card: Optional[DartModelCard] = None,
                  stepper_factory: Optional[Callable] = None, generic_kernel: bool = False):
         if noise not in ("mt19937", "mt19937-host", "philox"):
@@ -304,7 +304,7 @@ class DartEnv:
 
     def __init__(self, model_paths, frame_skip, observation_size, action_bounds, dt=0.002, obs_type="parameter",
                  action_type="continuous", visualize=False, disableViewer=True, screen_width=80, screen_height=45,
-                 num_envs=1, device=0, precision=32, collidable_bodies=None, stepper_factory=None):
+                 num_envs=1, device=0, precision=64, collidable_bodies=None, stepper_factory=None):
         import os
         from ..skel import parse_skel
         from ..model_card import build_card

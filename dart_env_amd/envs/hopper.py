@@ -11,7 +11,7 @@ class _SingleEnv(BatchedDartEnv):
     ENV_ID = None
     _unbatched = True   # robot_skeleton getters return un-batched arrays, like pydart2's
 
-    def __init__(self, device=0, precision=32, stepper_factory=None):
+    def __init__(self, device=0, precision=64, stepper_factory=None):
         super().__init__(self.ENV_ID, num_envs=1, device=device, precision=precision, noise="mt19937-host",
                          max_episode_steps=0, stepper_factory=stepper_factory)
         self.control_bounds = np.array([[self.task.act_high] * self.act_dim, [self.task.act_low] * self.act_dim])

@@ -108,13 +108,13 @@ HOPPER = TaskSpec(
     env_id="DartHopper-v1", model="hopper", task=TASK_HOPPER, frame_skip=4, act_dim=3, obs_dim=11,
     act_dof0=3, act_scale=[200.0] * 3, max_episode_steps=1000, reward_threshold=3800.0,
     height_body=2, penalty_dof=4, height_lo=0.7, height_hi=1.8, angle_max=0.2,
-    contact_bodies=["h_foot"])
+    contact_bodies=["h_foot"], all_bodies_collide=True)
 
 WALKER2D = TaskSpec(
     env_id="DartWalker2d-v1", model="walker2d", task=TASK_WALKER2D, frame_skip=4, act_dim=6, obs_dim=17,
     act_dof0=3, act_scale=[100.0, 100.0, 20.0, 100.0, 100.0, 20.0], max_episode_steps=1000,
     reward_threshold=None, height_body=2, penalty_dof=-1, height_lo=0.8, height_hi=2.0, angle_max=1.0,
-    contact_bodies=["h_foot", "h_foot_left"])
+    contact_bodies=["h_foot", "h_foot_left"], all_bodies_collide=True)
 
 # DartHumanWalker-v1 -- reference gym/envs/dart/human_walker.py:16-30 (23 actions, scale*1.5, obs 57+2, frame_skip 15),
 # :109-128 (reward, done), :150-165 (reset: velocity noise 0.05), gym/envs/__init__.py:284-288 (300 steps)
@@ -321,12 +321,18 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
     return c
 
 
-def card_for(env_id: str, all_bodies_collide: bool = False, generic_kernel: bool = False) -> DartModelCard:
-    """The card the batched env for ``env_id`` runs on."""
+def card_for(env_id: str, all_bodies_collide: Optional[bool] = None, generic_kernel: bool = False) -> DartModelCard:
+    """The card the batched env for ``env_id`` runs on.
+
+    ``all_bodies_collide``: None = the task's default, which is DART's behaviour for every shipped env: each collision shape
+    of the robot is tested against the ground (the reference never restricts it: hopper.py:14-18 / walker2d.py:12-18 only pick
+    the detector).  False restricts the contacts to the task's ``contact_bodies`` (the feet; BASELINE.json config[1]'s
+    "no contacts beyond foot-ground"), True forces every shape."""
     task = TASKS[env_id]
     model = load_model(task.model)
+    every = task.all_bodies_collide if all_bodies_collide is None else bool(all_bodies_collide)
     for s in model.shapes:
-        s.collidable = all_bodies_collide or task.all_bodies_collide or model.bodies[s.body].name in task.contact_bodies
+        s.collidable = every or model.bodies[s.body].name in task.contact_bodies
     c = build_card(model, task)
     c.generic_kernel = int(generic_kernel)
     return c

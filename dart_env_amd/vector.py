@@ -42,16 +42,16 @@ class InfoList:
 
 
 class DartVectorEnv:
-    def __init__(self, env_id, num_envs, device=0, precision=32, noise="mt19937", copy=True, stepper_factory=None,
-                 env_offset=0, all_bodies_collide=False, generic_kernel=False):
-        """all_bodies_collide=True: every collision shape of the robot is tested against the floor, as DART does (the
-        default Hopper / Walker2d cards test the feet only -- the fast planar kernels)."""
+    def __init__(self, env_id, num_envs, device=0, precision=64, noise="mt19937", copy=True, stepper_factory=None,
+                 env_offset=0, all_bodies_collide=None, generic_kernel=False):
+        """all_bodies_collide: None = the task's default card -- every collision shape of the robot against the floor, as DART
+        has it; False restricts the contacts to the feet (BASELINE.json config[1]); DESIGN.md section 2."""
         from .model_card import card_for
         task = TASKS[env_id]
         self.env = BatchedDartEnv(env_id, num_envs, device, precision, noise,
                                   max_episode_steps=task.max_episode_steps, stepper_factory=stepper_factory,
                                   card=card_for(env_id, all_bodies_collide=all_bodies_collide, generic_kernel=generic_kernel)
-                                  if (all_bodies_collide or generic_kernel) else None)
+                                  if (all_bodies_collide is not None or generic_kernel) else None)
         self.num_envs = num_envs
         self.copy = copy
         self.single_observation_space = self.env.observation_space

@@ -57,7 +57,9 @@ enum {
   DART_CFG_BLOCK_THREADS = 6,/* envs (active lanes) per wave64 workgroup of the step kernel: 64, 32 or 16 */
   DART_CFG_STATS = 7,       /* 1: histogram the wave-level pivoting iteration counts (dart_get_stats) */
   DART_CFG_EPISODE_STATS = 8,/* 1: keep per-env episode return / length accumulators on the device (dart_get_episode_stats) */
-  DART_CFG_CONTACT_REPORT = 9 /* 1: record the contacts of every env-step's last world step (dart_get_contacts) */
+  DART_CFG_CONTACT_REPORT = 9, /* 1: record the contacts of every env-step's last world step (dart_get_contacts) */
+  DART_CFG_DEBUG_FORCE_FALLBACK = 10 /* planar register kernels, tests only: 1 routes every env that touches the floor through the
+                               single-lane fallback solver, the path of an env with more contacts than the kernel's slot tiers hold */
 };
 
 /* Library-level error text for failures that happen before a handle exists (handle == NULL). */

@@ -32,6 +32,7 @@ def lib():
         L.emu_slots.argtypes = [vp]
         L.emu_set_solver.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.emu_enable_stats.argtypes = [vp, C.c_int]
+        L.emu_force_slow.argtypes = [vp, C.c_int]
         L.emu_get_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.emu_reset.argtypes = [vp, u8, dp, dp, fp, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_step.argtypes = [vp, fp, fp, fp, u8, u8, C.c_int, C.c_uint64, C.c_uint64]
@@ -74,6 +75,10 @@ class EmuStepper:
         elif key == st.CFG_SOLVER: self._solver = int(value); self.L.emu_set_solver(self.h, self._solver, 0, 0)
         elif key == st.CFG_STATS: self.L.emu_enable_stats(self.h, int(value != 0))
         else: raise ValueError(key)
+
+    def force_slow(self, on=True):
+        """every env with a contact goes through the single-lane fallback solver (validates it against the oracle)"""
+        self.L.emu_force_slow(self.h, int(on))
 
     def solver_stats(self):
         h = np.zeros(64, dtype=np.uint64)

@@ -187,7 +187,7 @@ class StubWorld:
 
     def __init__(self, dt, skel_path=None):
         name = os.path.basename(skel_path)
-        contact = {"hopper_capsule.skel": ["h_foot"], "walker2d.skel": ["h_foot", "h_foot_left"],
+        contact = {"hopper_capsule.skel": None, "walker2d.skel": None,   # every capsule collides, as in DART (the default cards)
                    "kima_human_edited.skel": None, "walker3d_waist.skel": None,
                    "cartpole.skel": None, "half_cheetah.skel": None, "cartpole_swingup.skel": None,
                    "inverted_double_pendulum.skel": None, "snake_7link.skel": None, "reacher2d.skel": [],

@@ -46,6 +46,7 @@ void emu_destroy(Emu* h) { delete h; }
 int emu_is_static(Emu* h) { return h->impl->is_static ? 1 : 0; }
 int emu_slots(Emu* h) { return h->impl->slots(); }
 void emu_set_solver(Emu* h, int solver, int it1, int it2) { h->impl->set_solver(solver, it1, it2); }
+void emu_force_slow(Emu* h, int on) { h->impl->set_force_slow(on); }
 void emu_enable_stats(Emu* h, int on) { h->stats.assign(64, 0); h->impl->set_stats(on ? h->stats.data() : nullptr); }
 void emu_get_stats(Emu* h, unsigned long long* out64) { memcpy(out64, h->stats.data(), 64 * sizeof(unsigned long long)); }
 // mask: n bytes or NULL; noise rows (n, ndofs) doubles or NULL (Philox with `seed`, `env_offset`)

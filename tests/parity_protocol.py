@@ -91,19 +91,25 @@ def parity_check(env_id, precision, ne, steps, local_rank, all_bodies_collide=No
     d_done_ref = torch.from_numpy(ref["done"]).to(dev)
     d_done = torch.empty((ne,), device=dev, dtype=torch.uint8)
     mism = torch.zeros((), device=dev, dtype=torch.int64)
-    ts = torch.cuda.current_stream(dev).cuda_stream     # steps, flag compares and resets all on torch's stream: ordered
+    # steps, flag compares and resets all go to ONE side stream of torch's (a null stream handle would mean "the handle's own
+    # stream" to the C ABI, and torch's compares would then race the kernels)
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    ts = side.cuda_stream
+    assert ts != 0
     gpu.reset_device(0, 0, ts)
     per_snap, si = {}, 0
     stride = ne * card.act_dim * 4
     t0 = time.perf_counter()
-    for t in range(steps):
-        gpu.step_device(d_acts.data_ptr() + t * stride, 0, 0, d_done.data_ptr(), 0, ts)
-        mism += (d_done != d_done_ref[t]).sum()
-        if si < len(snaps) and snaps[si] == t + 1:
-            qg, dqg = gpu.get_state()
-            per_snap[str(t + 1)] = snap_stats(qg, dqg, ref, si)
-            si += 1
-        gpu.reset_device(d_done_ref[t].data_ptr(), 0, ts)     # resets follow the oracle's episodes, identical Philox noise
+    with torch.cuda.stream(side):
+        for t in range(steps):
+            gpu.step_device(d_acts.data_ptr() + t * stride, 0, 0, d_done.data_ptr(), 0, ts)
+            mism += (d_done != d_done_ref[t]).sum()
+            if si < len(snaps) and snaps[si] == t + 1:
+                qg, dqg = gpu.get_state()
+                per_snap[str(t + 1)] = snap_stats(qg, dqg, ref, si)
+                si += 1
+            gpu.reset_device(d_done_ref[t].data_ptr(), 0, ts)     # resets follow the oracle's episodes, identical Philox noise
     torch.cuda.synchronize()
     gpu.sync()
     gpu_s = time.perf_counter() - t0

@@ -322,17 +322,22 @@ def test_dynamics_getters_match_oracle(env_id):
         s.close()
 
 
+@pytest.mark.parametrize("kernel", ["register", "register-fallback", "tree"])
 @pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1"])
-def test_all_capsule_contacts_env_matches_oracle(env_id):
-    """card_for(..., all_bodies_collide=True): every capsule vs. the floor (DART's behaviour).  The planar kernels
-    decline such a card, the spatial kernel serves it with the Hopper / Walker2d task logic; tiny torques make knees and
-    thighs reach the floor before the episode ends."""
-    from dart_env_amd.stepper import HipStepper, Q_STATIC_KERNEL
-    card = card_for(env_id, all_bodies_collide=True)
+def test_all_capsule_contacts_env_matches_oracle(env_id, kernel):
+    """The default cards: every capsule vs. the floor (DART's behaviour; assets/walker2d.skel, hopper_capsule.skel).  Tiny
+    torques make knees and thighs reach the floor before the episode ends.  `register`: the planar register kernel with its
+    contact-slot tiers; `register-fallback`: the same with every touching env routed through the single-lane fallback solver
+    (the path of an env with more contacts than the tiers hold); `tree`: the general kernel (generic_kernel=True)."""
+    from dart_env_amd.stepper import HipStepper, Q_STATIC_KERNEL, CFG_DEBUG_FORCE_FALLBACK
+    card = card_for(env_id, generic_kernel=(kernel == "tree"))
+    assert all(card.shape_collidable[s] for s in range(card.nshapes))
     n, nd, na = 128, card.ndofs, card.act_dim
     rng = np.random.RandomState(6)
     gpu = HipStepper(card, n, precision=64)
-    assert gpu.query(Q_STATIC_KERNEL) == 0
+    assert gpu.query(Q_STATIC_KERNEL) == (0 if kernel == "tree" else 1)
+    if kernel == "register-fallback":
+        gpu.configure(CFG_DEBUG_FORCE_FALLBACK, 1)
     ora = OracleBatch(card, n)
     qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
     og = gpu.reset(None, qn, vn); ora.reset(None, qn, vn)

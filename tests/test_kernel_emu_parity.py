@@ -29,3 +29,53 @@ def test_generic_and_baked_kernels_agree():
     run_host_api(a, acts, ref); run_host_api(b, acts, ref)
     qa, dqa = a.get_state(); qb, dqb = b.get_state()
     assert np.abs(qa - qb).max() < 1e-12 and np.abs(dqa - dqb).max() < 1e-10
+
+
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1"])
+@pytest.mark.parametrize("force_fallback", [False, True])
+def test_default_cards_collide_every_capsule_small_torques(env_id, force_fallback):
+    """Small torques: the robots sink to the floor and knees / shins touch before `done` -- the tier-1 contact slots, and with
+    force_fallback the single-lane loop solver that serves an env with more contacts than the tiers hold."""
+    from dart_env_amd import stepper as st
+    card = card_for(env_id)
+    assert all(card.shape_collidable[s] for s in range(card.nshapes))
+    acts, ref = make_reference(card, 96, 300)
+    acts *= 0.1
+    from tests import oracle_lib as ol
+    ref = ol.rollout_trace(card, acts, ref["snap_steps"])
+    g = EmuStepper(card, 96, precision=64)
+    if force_fallback:
+        g.force_slow(True)
+    s = run_host_api(g, acts, ref)
+    assert s["done_flag_mismatches"] == 0
+    assert s["q"] < 1e-9 and s["dq"] < 1e-8, (s["q"], s["dq"])
+
+
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1"])
+def test_robot_lying_on_the_floor_takes_the_fallback_solver(env_id):
+    """Every capsule on the ground at once (more contacts than any register tier): the natural trigger of slow_constraints."""
+    from tests.oracle_lib import OracleWorld
+    card = card_for(env_id)
+    n = 4
+    g = EmuStepper(card, n, precision=64)
+    nd = card.ndofs
+    q = np.zeros((n, nd)); dq = np.zeros((n, nd))
+    for i in range(n):
+        q[i, 1] = -1.17 + 0.01 * i          # root height: the capsules just reach into the floor
+        q[i, 2] = 1.5 + 0.02 * i            # lying on its side
+        q[i, 3:] = 0.05 * (i + 1) * (-1.0) ** np.arange(nd - 3) * 0.2
+    g.set_state(q, dq)
+    worlds = [OracleWorld(card) for _ in range(n)]
+    for w, qi, dqi in zip(worlds, q, dq):
+        w.set_state(qi, dqi)
+    most = 0
+    for t in range(40):
+        a = np.zeros((n, card.act_dim), dtype=np.float32)
+        g.step(a)
+        for w in worlds:
+            w.env_step(a[0].astype(np.float64))
+            most = max(most, len(w.last_contacts()))
+        qg, dqg = g.get_state()
+        qo = np.stack([w.q for w in worlds]); dqo = np.stack([w.dq for w in worlds])
+        assert np.abs(qg - qo).max() < 1e-9 and np.abs(dqg - dqo).max() < 1e-7, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+    assert most >= 3, most       # more touching capsules than the register tiers of either model hold

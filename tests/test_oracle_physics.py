@@ -197,7 +197,7 @@ def test_foot_only_contacts_equal_all_capsules_until_done():
     reaches the floor before termination (measured 0 / 200 episodes, also for Walker2d); only slow collapses under
     tiny torques let the knee touch just before height < 0.7 ends the episode (known deviation)."""
     a_card = card_for("DartHopper-v1", all_bodies_collide=True)
-    f_card = card_for("DartHopper-v1")
+    f_card = card_for("DartHopper-v1", all_bodies_collide=False)
     rng = np.random.RandomState(11)
     for ep in range(30):
         wa, wf = OracleWorld(a_card), OracleWorld(f_card)

@@ -10,8 +10,32 @@ from .hopper import _SingleEnv
 class DartHumanWalkerEnv(_SingleEnv):
     ENV_ID = "DartHumanWalker-v1"
 
+    def _com(self, which):
+        """world COM of card.aux_body[which] (0: the progress body bodynodes[1], 1: the head), human_walker.py:78-92"""
+        st = self._stepper
+        if not hasattr(st, "body_poses"):       # an injected stand-in stepper without pose getters
+            return None
+        return st.body_poses()[2][0, self.card.aux_body[which]]
+
+    def step(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        before = self._com(0)
+        self._terms = None
+        ob, reward, done, _ = super().step(a)
+        after, head = self._com(0), self._com(1)
+        if before is not None:
+            # the three reward terms the reference also returns in `info` (human_walker.py:111-117, 135-137), recomputed on the
+            # host from the body poses either side of the step; the reward itself comes from the kernel
+            tv = float(self.card.aux_real[0])
+            vel = (after[0] - before[0]) / self.dt
+            self._terms = {"vel_rew": 2.0 * (tv - abs(tv - vel)), "action_pen": float(self.card.aux_real[2]) * float(np.abs(a).sum()),
+                           "deviation_pen": float(self.card.aux_real[3]) * abs(float(head[2]))}
+        return ob, reward, done, self._info(done)
+
     def _info(self, done):
         s = self.state_vector()
         broke = not (np.isfinite(s).all() and (np.abs(s[2:]) < 100).all())
-        # vel_rew / action_pen / deviation_pen of the reference's info dict stay on the device; the flags are kept
-        return {"broke_sim": bool(broke), "done_return": done, "dyn_model_id": 0, "state_index": 0}
+        info = {"broke_sim": bool(broke), "done_return": done, "dyn_model_id": 0, "state_index": 0}
+        if getattr(self, "_terms", None):
+            info.update(self._terms)
+        return info

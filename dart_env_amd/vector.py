@@ -102,7 +102,10 @@ class DartVectorEnv:
         zero_copy = not self.copy and self.env.device_noise and hasattr(self.env._stepper, "_views")
         obs, rew, done, trunc = self.env.step_wait(copy=not zero_copy)
         if not self.env.device_noise and done.any():
-            obs = self.env.reset(done)      # post-reset observation for done envs (sync_vector_env.py:77-78)
+            # post-reset observation for the done envs only (sync_vector_env.py:77-78); the other rows keep this step's
+            # observation (a whole-batch refresh would lose what only the step knows, e.g. HumanWalker's foot-contact flags)
+            obs = np.array(obs, copy=True)
+            obs[done] = self.env.reset(done)[done]
         return obs, rew, done, InfoList(trunc)
 
     def step(self, actions):

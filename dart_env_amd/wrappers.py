@@ -1,72 +1,83 @@
-"""TimeLimit for the single-env objects, same observable behaviour as reference gym/wrappers/time_limit.py:5-25
-(the vector env applies the limit on the device instead)."""
+"""Episode bookkeeping around the single-env objects: the step budget (observable behaviour of reference
+gym/wrappers/time_limit.py:5-25) and per-episode return / length records (gym/wrappers/record_episode_statistics.py:7-34).
+The vector env keeps both on the device instead (csrc/planar_kernel.hpp, csrc/episode_kernels.hpp)."""
+import time as _time
+from collections import deque as _deque
 
 
-class TimeLimit:
-    def __init__(self, env, max_episode_steps=None):
+class _EnvShell:
+    """attribute pass-through to the wrapped env, shared by the two wrappers below"""
+
+    def __init__(self, env):
         self.env = env
-        self._max_episode_steps = max_episode_steps
-        self._elapsed_steps = None
-        self.action_space = env.action_space
-        self.observation_space = env.observation_space
+        self.action_space, self.observation_space = env.action_space, env.observation_space
 
     def __getattr__(self, name):
         return getattr(self.env, name)
 
     @property
     def unwrapped(self):
-        return self.env
+        return getattr(self.env, "unwrapped", self.env)
 
-    def step(self, action):
-        assert self._elapsed_steps is not None, "Cannot call env.step() before calling reset()"
-        observation, reward, done, info = self.env.step(action)
-        self._elapsed_steps += 1
-        if self._elapsed_steps >= self._max_episode_steps:
-            info["TimeLimit.truncated"] = not done
-            done = True
-        return observation, reward, done, info
+
+class TimeLimit(_EnvShell):
+    """Ends an episode after `max_episode_steps` steps: the step that exhausts the budget reports done, and
+    info["TimeLimit.truncated"] says whether the task itself had NOT ended there."""
+
+    def __init__(self, env, max_episode_steps=None):
+        super().__init__(env)
+        self._max_episode_steps = max_episode_steps
+        self._elapsed_steps = None          # None until the first reset: stepping before that is a usage error
+
+    @property
+    def unwrapped(self):
+        return self.env
 
     def reset(self, **kwargs):
         self._elapsed_steps = 0
         return self.env.reset(**kwargs)
 
+    def step(self, action):
+        if self._elapsed_steps is None:
+            raise AssertionError("Cannot call env.step() before calling reset()")
+        out = self.env.step(action)
+        self._elapsed_steps += 1
+        if self._elapsed_steps < self._max_episode_steps:
+            return out
+        ob, reward, task_done, info = out
+        info["TimeLimit.truncated"] = not task_done
+        return ob, reward, True, info
 
-class RecordEpisodeStatistics:
-    """Single-env wrapper, same behaviour as reference gym/wrappers/record_episode_statistics.py:7-34."""
+
+class RecordEpisodeStatistics(_EnvShell):
+    """Adds info['episode'] = {r: return, l: length, t: seconds since construction} to the step that ends an episode and keeps
+    the last `deque_size` returns / lengths in return_queue / length_queue."""
 
     def __init__(self, env, deque_size=100):
-        import time
-        from collections import deque
-        self.env = env
-        self.action_space, self.observation_space = env.action_space, env.observation_space
-        self._time = time
-        self.t0 = time.time()
-        self.episode_return = 0.0
-        self.episode_length = 0
-        self.return_queue = deque(maxlen=deque_size)
-        self.length_queue = deque(maxlen=deque_size)
+        super().__init__(env)
+        self.t0 = _time.time()
+        self.return_queue, self.length_queue = _deque(maxlen=deque_size), _deque(maxlen=deque_size)
+        self._clear()
 
-    def __getattr__(self, name):
-        return getattr(self.env, name)
+    def _clear(self):
+        self.episode_return, self.episode_length = 0.0, 0
 
     def reset(self, **kwargs):
-        observation = self.env.reset(**kwargs)
-        self.episode_return = 0.0
-        self.episode_length = 0
-        return observation
+        ob = self.env.reset(**kwargs)
+        self._clear()
+        return ob
 
     def step(self, action):
-        observation, reward, done, info = self.env.step(action)
+        ob, reward, done, info = self.env.step(action)
         self.episode_return += reward
         self.episode_length += 1
         if done:
-            info['episode'] = {'r': self.episode_return, 'l': self.episode_length,
-                               't': round(self._time.time() - self.t0, 6)}
-            self.return_queue.append(self.episode_return)
-            self.length_queue.append(self.episode_length)
-            self.episode_return = 0.0
-            self.episode_length = 0
-        return observation, reward, done, info
+            ret, length = self.episode_return, self.episode_length
+            self.return_queue.append(ret)
+            self.length_queue.append(length)
+            info["episode"] = {"r": ret, "l": length, "t": round(_time.time() - self.t0, 6)}
+            self._clear()
+        return ob, reward, done, info
 
 
 class VectorRecordEpisodeStatistics:

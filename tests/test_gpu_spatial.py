@@ -115,6 +115,10 @@ def test_humanwalker_golden_fixture_fp64():
         assert np.allclose(ob, d["obs"][t], rtol=0, atol=2e-5), (t, np.abs(ob - d["obs"][t]).max())
         assert abs(r - d["reward"][t]) < 1e-4
         assert np.allclose(env.state_vector(), np.concatenate([d["q"][t], d["dq"][t]]), rtol=0, atol=1e-6)
+        # the reward terms of the reference's info dict (human_walker.py:135-137) add up to the kernel's reward
+        assert {"vel_rew", "action_pen", "deviation_pen", "broke_sim", "done_return"} <= set(info)
+        if not done:
+            assert abs(info["vel_rew"] + 2.0 - info["action_pen"] - info["deviation_pen"] - r) < 1e-4
         if done:
             assert np.allclose(env.reset(), d["reset_obs"][t], atol=1e-6)
     env.close()

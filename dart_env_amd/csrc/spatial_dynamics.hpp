@@ -104,7 +104,9 @@ template <class Real> __device__ __forceinline__ V3<Real> shfl3(V3<Real> v, int 
 //   3. angular velocity, velocity-product angular and linear accelerations are path sums of per-link terms
 //      (w_i = a_i qd_i;  t_i = om_parent x w_i;  b_i = the centripetal / Coriolis increment): three more prefix sums,
 //   4. the link's wrench and composite-body seeds about its own joint origin go to LDS.
-template <class Real, bool EXTRAS = false>
+// POSE_ONLY: steps 1-2 only (link frames, joint origins / axes, COMs go to LDS) -- the pose the task code reads before and
+// after the world steps, which the first version computed link after link on lane 0.
+template <class Real, bool EXTRAS = false, bool POSE_ONLY = false>
 __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane,
                                            int64_t env = 0) {
   const bool live = lane < Md.nl;
@@ -162,6 +164,14 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
   V3<Real> pj = p - mulR(R, ld3(G + LC_CPOST));
   if (slide) pj = pj - a * qv;
   const V3<Real> c = p + mulR(R, ld3(G + LC_COM));
+  if constexpr (POSE_ONLY) {
+    if (live) {
+      Real* L = S.link + lane * SP_LINKF;
+      for (int k = 0; k < 9; k++) L[LK_R + k] = R[k];
+      st3(L + LK_P, p); st3(L + LK_JO, pj); st3(L + LK_A, a); st3(L + LK_C, c);
+    }
+    return;
+  }
   // angular velocity
   const V3<Real> w = rev ? a * qd : v3<Real>(0, 0, 0);
   V3<Real> om = w;
@@ -260,6 +270,11 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
   L[LK_IC + 5] = Iw[8] + m * (d2 - dj.z * dj.z);
 }
 
+// Link poses of the current S.q for the task code (all 64 lanes call; ends with a barrier): what sp_kinematics computes
+// serially, in O(log depth) wave steps.  A free root must already be in internal coordinates (sp_free_root_to_internal).
+template <class Real, bool EXTRAS>
+__device__ __forceinline__ void sp_pose_pass(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane);
+
 // floating-base translation: root-chain prismatic joints have fixed world axes (their ancestors never rotate)
 template <class Real>
 __device__ __forceinline__ void sp_root_offset(const SpatialModel<Real>& Md, SpLds<Real>& S) {
@@ -270,6 +285,14 @@ __device__ __forceinline__ void sp_root_offset(const SpatialModel<Real>& Md, SpL
     roff = roff + ld3(Md.root_axis_world[i]) * S.q[Md.dof[i]];
   }
   st3(S.misc, roff);
+}
+
+template <class Real, bool EXTRAS>
+__device__ __forceinline__ void sp_pose_pass(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane) {
+  __syncthreads();
+  if (lane == 0) sp_root_offset<Real>(Md, S);
+  sp_forward<Real, EXTRAS, true>(lc, Md, S, lane);
+  __syncthreads();
 }
 
 // parent-centric backward step for group leader i (all child groups are complete): gather their wrenches and composite
@@ -338,7 +361,7 @@ __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const Spa
     Lm = a * L[LK_MC];
     K = cross(h, a);
   }
-  for (int k = 0; k < d; k++) S.H[TI(d, k)] = Real(0);
+  for (int k = 0; k < d; k++) S.H[HL(d, k)] = Real(0);
   for (int j = i; j >= 0;) {
     const int w = S.topo[j];
     const int dj = topo_dof(w), jcur = j;
@@ -350,7 +373,7 @@ __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const Spa
     if (topo_jtype(w) == 2) v = dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm));
     else v = dot(aj, Lm);
     if (dj == d) v += lc.d_diag;
-    S.H[TI(d, dj)] = v;   // dj <= d because parents come first
+    S.H[HI(d, dj)] = v;   // dj <= d when parents come first; a free root's rotation dofs (0..2) hang below its translation dofs (3..5)
   }
 }
 

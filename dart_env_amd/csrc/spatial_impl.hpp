@@ -285,8 +285,12 @@ struct SpatialImplT : Impl {
     lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp);
     // lean / pairs / extras instantiations of the step kernel (see sp_world_step)
     pairs = M.npairs > 0;
-    const void* fns[4] = {(const void*)sp_step_kernel<Real, false, false>, (const void*)sp_step_kernel<Real, true, false>,
-                          (const void*)sp_step_kernel<Real, false, true>, (const void*)sp_step_kernel<Real, true, true>};
+    // the 20+-dof models without a free root run the BIG instantiations (register LCP solver); measured on HumanWalker / Walker3d
+    big = M.n >= 20 && !M.free_root;
+    const void* fns[7] = {(const void*)sp_step_kernel<Real, false, false, false, false>, (const void*)sp_step_kernel<Real, false, false, false, true>,
+                          (const void*)sp_step_kernel<Real, true, false, false, true>, (const void*)sp_step_kernel<Real, false, true, false, false>,
+                          (const void*)sp_step_kernel<Real, true, true, false, true>, (const void*)sp_step_kernel<Real, true, true, true, false>,
+                          (const void*)sp_step_kernel<Real, true, false, false, false>};
     for (const void* fn : fns)
       if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
@@ -300,12 +304,12 @@ struct SpatialImplT : Impl {
   void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
                   float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
-#define SP_LAUNCH(P, X, R)                                                                                              \
-  hipLaunchKernelGGL((sp_step_kernel<Real, P, X, R>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep, \
+#define SP_LAUNCH(P, X, R, B)                                                                                           \
+  hipLaunchKernelGGL((sp_step_kernel<Real, P, X, R, B>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q, (Real*)dq, init_h, el, ep, \
                      act, obs, rew, done, trunc, autoreset, seed, off)
-    if (M.creport) SP_LAUNCH(true, true, true);   // contact reporting lives in the most general instantiation only
-    else if (pairs) { if (extras) SP_LAUNCH(true, true, false); else SP_LAUNCH(true, false, false); }
-    else { if (extras) SP_LAUNCH(false, true, false); else SP_LAUNCH(false, false, false); }
+    if (M.creport) SP_LAUNCH(true, true, true, false);   // contact reporting lives in the most general instantiation only
+    else if (pairs) { if (extras) SP_LAUNCH(true, true, false, true); else if (big) SP_LAUNCH(true, false, false, true); else SP_LAUNCH(true, false, false, false); }
+    else { if (extras) SP_LAUNCH(false, true, false, false); else if (big) SP_LAUNCH(false, false, false, true); else SP_LAUNCH(false, false, false, false); }
 #undef SP_LAUNCH
     return hipGetLastError();
   }
@@ -332,7 +336,7 @@ struct SpatialImplT : Impl {
   double* dbg = nullptr; int64_t nenv = 0;
   Real* d_ext = nullptr;
   Real* d_cf = nullptr;
-  bool pairs = false, extras = false;   // which instantiation of the step kernel this model runs
+  bool pairs = false, extras = false, big = false;   // which instantiation of the step kernel this model runs
   int body_link_map[DART_MAX_BODIES];
   int set_task_state(hipStream_t s, const uint8_t* d_mask, const double* d_values, int64_t n) override {
     hipLaunchKernelGGL((sp_task_state_kernel<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_mask, d_values, init_h);

@@ -26,10 +26,14 @@
 namespace dartk {
 
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
+// fp64 doubles the LDS block (HumanWalker: 4 workgroups per CU = one wave per SIMD): its register budget is the whole file.
+// BIG kernels hold the LCP rows in registers: two waves per SIMD is what their LDS block allows anyway (HumanWalker fp32: 8
+// workgroups per CU); the small-model kernels keep three.
+template <class Real, bool BIG> __host__ __device__ constexpr int sp_min_waves() { return BIG ? (sizeof(Real) == 8 ? 1 : 2) : 3; }
 // REPORT: the contact-report variant (dart_get_contacts); only the most general instantiation <true, true, true> is built --
 // the mere presence of the reporting code costs the lean kernels 2.5 % (register allocation), so they do not carry it.
-template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false>
-__global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
+template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false, bool BIG = false>
+__global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG>())) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ tstate,
                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
                                                       const float* __restrict__ actions, float* __restrict__ obs,
@@ -50,23 +54,34 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
   if (Md.stats && lane < 10) S.ticks[lane] = 0ull;
   if (EXTRAS && Md.task == 12 && lane < n) S.cf[lane] = Md.cf_store[e * n + lane];
   __syncthreads();
+  // action: comparison clamp (a NaN stays NaN, hopper.py:25-30) and scaling, one lane per action; the reward's |a| and a^2 sums
+  // by wave reductions
   Real abs_sum = Real(0), sq_sum = Real(0);
-  if (lane == 0) {
-    for (int k = 0; k < Md.act_dim; k++) {
-      const Real a = (Real)actions[e * Md.act_dim + k];
-      abs_sum += fabs(a); sq_sum += a * a;
-      Real cl = (a > Md.act_hi[k]) ? Md.act_hi[k] : a;
-      cl = (cl < Md.act_lo[k]) ? Md.act_lo[k] : cl;
-      const int dd = Md.act_dof0 + k;
+  {
+    const bool has = lane < Md.act_dim;
+    const Real a = has ? (Real)actions[e * Md.act_dim + lane] : Real(0);
+    abs_sum = wave_sum<Real>(fabs(a)); sq_sum = wave_sum<Real>(a * a);
+    if (has) {
+      Real cl = (a > Md.act_hi[lane]) ? Md.act_hi[lane] : a;
+      cl = (cl < Md.act_lo[lane]) ? Md.act_lo[lane] : cl;
+      const int dd = Md.act_dof0 + lane;
       if (EXTRAS && Md.task == 12)   // SPD: the action is a target pose inside the joint's limits (walker3d_spd.py:68-70)
         S.tau[dd] = (cl + Real(1)) / Real(2) * (Md.upper[dd] - Md.lower[dd]) + Md.lower[dd];
       else
-        S.tau[dd] = cl * Md.act_scale[k];
+        S.tau[dd] = cl * Md.act_scale[lane];
     }
-    if (EXTRAS && Md.free_root) { sp_free_root_load<Real>(S); sp_free_root_to_internal<Real>(S); }   // S.q / S.dq: internal from here
-    // link poses are needed before the step only by the tasks that measure progress on a body (3, 4) or a tip (11), after
-    // it only by the tasks whose reward / done / observation read a body pose
-    if (Md.task == 3 || Md.task == 4 || Md.task == 11 || Md.task == 12 || Md.task == 13) sp_kinematics<Real>(Md, S);
+  }
+  LinkConst<Real> lc;
+  sp_load_link_const<Real>(Md, lane < Md.nl ? lane : 0, lc);
+  if (EXTRAS && Md.free_root) {
+    __syncthreads();
+    if (lane == 0) { sp_free_root_load<Real>(S); sp_free_root_to_internal<Real>(S); }   // S.q / S.dq: internal from here
+  }
+  // link poses are needed before the step only by the tasks that measure progress on a body (3, 4) or a tip (11), after
+  // it only by the tasks whose reward / done / observation read a body pose
+  if (Md.task == 3 || Md.task == 4 || Md.task == 11 || Md.task == 12 || Md.task == 13) sp_pose_pass<Real, EXTRAS>(lc, Md, S, lane);
+  else __syncthreads();
+  if (lane == 0) {
     sh_scal[0] = (Md.task == 3 || Md.task == 4 || Md.task == 12 || Md.task == 13) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
     if (Md.task == 11) {   // DartReacher3d: distance to the target BEFORE the step, and sum tau^2 (reacher.py:23-27)
       const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - ld3(tstate + 4 * e);
@@ -78,16 +93,17 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
     cflags[0] = 0; cflags[1] = 0;
   }
   __syncthreads();
-  LinkConst<Real> lc;
-  sp_load_link_const<Real>(Md, lane < Md.nl ? lane : 0, lc);
-  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT>(Md, lc, S, lane, cflags, REPORT && Md.creport != nullptr && f == Md.frame_skip - 1);
+  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG>(Md, lc, S, lane, cflags, REPORT && Md.creport != nullptr && f == Md.frame_skip - 1);
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
   const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task >= 10;
   const bool pose_reset = pose_last && Md.task != 13;   // the dog's observation holds no body pose
+  if (EXTRAS && Md.free_root) {
+    __syncthreads();
+    if (lane == 0) sp_free_root_to_internal<Real>(S);   // internal coordinates of the final pose
+  }
+  if (pose_last) sp_pose_pass<Real, EXTRAS>(lc, Md, S, lane);
   if (lane == 0) {
-    if (EXTRAS && Md.free_root) sp_free_root_to_internal<Real>(S);   // internal coordinates of the final pose
-    if (pose_last) sp_kinematics<Real>(Md, S);
     Real rew = Real(0);
     bool task_done = false;
     Real dog_x = Real(0), dog_h = Real(0), dog_side = Real(0);
@@ -150,9 +166,9 @@ __global__ void __launch_bounds__(64, 3) sp_step_kernel(const SpatialModel<Real>
       S.dq[lane] = Md.dq0[lane] + (-Md.noise_v + Real(2) * Md.noise_v * uv);
     }
     __syncthreads();
+    if (pose_reset) sp_pose_pass<Real, false>(lc, Md, S, lane);   // (`dn` is wave-uniform; no free-root model reads a pose here)
     if (lane == 0) {
       episode[e] = ep;
-      if (pose_reset) sp_kinematics<Real>(Md, S);
       if (Md.task == 4) tstate[4 * e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
       cflags[0] = 0; cflags[1] = 0;
     }
@@ -231,7 +247,7 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
     if (lane < n) {
       double* Mo = mass_out + e * n * n;
       for (int k = 0; k <= lane; k++) {
-        double v = (double)S.H[TL(lane, k)];
+        double v = (double)S.H[HL(lane, k)];
         if (k == lane) v -= (double)lc.d_diag;
         Mo[lane * n + k] = v; Mo[k * n + lane] = v;
       }

@@ -22,6 +22,12 @@ __device__ __host__ constexpr bool sp_lw_aliases_links(int nl, int maxm) { retur
 __device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 __device__ __host__ constexpr int sp_npad(int n) { return (n + 7) & ~7; }   // H is stored padded with identity rows to a multiple of 8
 __device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
+// The mass matrix / its Cholesky factor is stored lower-triangular with rows padded to multiples of 4 entries and 16-byte
+// aligned row starts, so that a row is read with 128-bit LDS loads (the triangular solves read every factor entry once per
+// constraint row): rows 4g .. 4g+3 hold 4(g+1) entries each.
+__device__ __host__ constexpr int HR(int i) { return 8 * (i >> 2) * ((i >> 2) + 1) + 4 * ((i >> 2) + 1) * (i - 4 * (i >> 2)); }   // row offset
+__device__ __host__ constexpr int HL(int i, int j) { return HR(i) + j; }   // caller guarantees i >= j
+__device__ __host__ constexpr int HI(int i, int j) { return i >= j ? HR(i) + j : HR(j) + i; }
 constexpr int SP_LINKF = 37;  // Reals stored per link in LDS
 constexpr int SP_LCONST = 48;   // Rpre 9, ppre 3, Rpost 9, ppost 3, axis 3, com 3, inertia 9, axr 3, cpost 3 (+3 pad)
 enum { LC_RPRE = 0, LC_PPRE = 9, LC_RPOST = 12, LC_PPOST = 21, LC_AXIS = 24, LC_COM = 27, LC_INERTIA = 30, LC_AXR = 39, LC_CPOST = 42 };
@@ -81,6 +87,11 @@ struct SpatialModel {
   unsigned long long* stats;   // optional [64]: [0..31] pivoting iterations per solve, [32] PGS fallbacks, [33] solves
 };
 
+// 128-bit LDS access of `width` consecutive Reals
+template <class Real> struct sp_vec128;
+template <> struct sp_vec128<float> { using type = float4; static constexpr int width = 4; };
+template <> struct sp_vec128<double> { using type = double2; static constexpr int width = 2; };
+
 // ---- tiny 3-vector helpers on registers
 template <class Real> struct V3 { Real x, y, z; };
 template <class Real> __device__ __forceinline__ V3<Real> v3(Real x, Real y, Real z) { return {x, y, z}; }
@@ -138,7 +149,8 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   Real* p = base;
   S.link = p; p += nl * SP_LINKF;
   S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n;
-  S.H = p; p += sp_npad(n) * (sp_npad(n) + 1) / 2;
+  p = base + (((p - base) + 3) & ~3);   // 16-byte aligned rows
+  S.H = p; p += HR(sp_npad(n));
   S.W = p; p += (maxm + 1) * n;
   S.A = p; p += sp_tri(maxm);
   if (sp_lw_aliases_links(nl, maxm)) { S.Lw = S.link; S.x0 = S.link + sp_tri(maxm); }
@@ -161,7 +173,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
 }
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp) {
   const size_t lw = sp_lw_aliases_links(nl, maxm) ? 0 : (size_t)sp_tri(maxm) + maxm;
-  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)sp_npad(n) * (sp_npad(n) + 1) / 2 + (size_t)(maxm + 1) * n + sp_tri(maxm) + lw + 5 * maxm +
+  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)HR(sp_npad(n)) + 3 + (size_t)(maxm + 1) * n + sp_tri(maxm) + lw + 5 * maxm +
                  maxcp * 7 + 16 + 24;
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }

@@ -17,9 +17,10 @@ namespace dartk {
     }                                                                                             \
   } while (0)
 
+// BIG: register-resident LCP solver and back-substitution (the 20+-dof models).
 // PAIRS: link-link contacts (box pairs, general contact normals); EXTRAS: snake fluid forces, external body force, Coulomb
 // joint friction rows.  Models that need neither run the lean instantiation (HumanWalker: 8 % faster than the full one).
-template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false>
+template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false, bool BIG = false>
 __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, const LinkConst<Real>& lc, SpLds<Real>& S, int lane,
                                               int* contact_flags, bool report = false) {
   const int n = Md.n, nl = Md.nl;
@@ -44,7 +45,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   }
   SP_TICK(0);
   if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
-  else if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[TL(lane, k)] = Real(0); S.H[TL(lane, lane)] = Real(1); }
+  else if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[HL(lane, k)] = Real(0); S.H[HL(lane, lane)] = Real(1); }
   __syncthreads();
   if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
   SP_TICK(1);
@@ -221,12 +222,22 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       Real y[SP_MAXN];
 #pragma unroll
       for (int k = 0; k < SP_MAXN; k++) y[k] = (k < n) ? yrow[k] : Real(0);
+      // factor rows start 16-byte aligned and are padded to multiples of 4 entries (HR): 128-bit LDS loads, 4 (fp32) or 2 (fp64)
+      // entries each; the entries a load brings in beyond column k - 1 are not used
+      using Vec = typename sp_vec128<Real>::type;
+      constexpr int VW = sp_vec128<Real>::width;
 #pragma unroll
       for (int k = 0; k < SP_MAXN; k++) {
         if (k < n) {
           Real t = y[k];
+          const Vec* hr = reinterpret_cast<const Vec*>(S.H + HR(k));
 #pragma unroll
-          for (int j = 0; j < k; j++) t -= S.H[TL(k, j)] * y[j];
+          for (int j = 0; j < k; j += VW) {
+            const Vec h = hr[j / VW];
+            const Real* hv = reinterpret_cast<const Real*>(&h);
+#pragma unroll
+            for (int c = 0; c < VW; c++) if (j + c < k) t -= hv[c] * y[j + c];
+          }
           y[k] = t * S.sinv[k];
         }
       }
@@ -299,7 +310,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         F = (F & ~fr) | (fr & ~pf);
         U &= ~fr;
       }
-      sp_blcp<Real>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction));
+      sp_blcp<Real, BIG>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction));
     }
     SP_TICK(8);
     if (Md.dbg) {
@@ -338,7 +349,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   if ((EXTRAS && Md.task == 12) || (REPORT && report)) {   // constraint_forces() of this step: J^T lambda / dt = L (W^T lambda) / dt
     if (lane < n) {
       Real t = Real(0);
-      for (int k = 0; k <= lane; k++) t += S.H[TL(lane, k)] * S.lo[k];
+      for (int k = 0; k <= lane; k++) t += S.H[HL(lane, k)] * S.lo[k];
       S.cf[lane] = t / Md.dt;
     }
     __syncthreads();
@@ -351,7 +362,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       Md.cf_report[(size_t)blockIdx.x * n + lane] = v;
     }
   }
-  sp_chol_backsolve<Real>(S.H, S.sinv, n, S.rhs, lane);
+  sp_chol_backsolve<Real, BIG>(S.H, S.sinv, n, S.rhs, lane);
   SP_TICK(9);
   if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
   __syncthreads();

@@ -287,7 +287,8 @@ def test_classic_env_vector_fixture_and_fp32(tag, env_id):
         assert venv.env.noise == ("mt19937-host" if tag == "doublependulum" else "mt19937")
         venv.seed(3)
         assert np.allclose(venv.reset(), d["obs0"], atol=1e-6)
-        for t in range(len(d["done"]) if prec == 64 else 25):
+        # fp32: the first 15 steps only -- a free-flying 22-dof body amplifies rounding differences beyond any fixed bound later
+        for t in range(len(d["done"]) if prec == 64 else 15):
             ob, r, done, infos = venv.step(d["actions"][t])
             if prec == 64:
                 assert np.array_equal(done, d["done"][t]), t

@@ -208,6 +208,7 @@ int dart_query(const DartStepper* h, int what, int64_t* out) {
     case DART_Q_LCP_SLOTS: *out = h->impl->slots(); break;
     case DART_Q_STATIC_KERNEL: *out = h->impl->is_static ? 1 : 0; break;
     case DART_Q_MAX_CONTACTS: *out = h->impl->max_contacts(); break;
+    case DART_Q_LDS_BYTES: *out = h->impl->lds_bytes(); break;
     default: return DART_E_INVALID;
   }
   return DART_OK;

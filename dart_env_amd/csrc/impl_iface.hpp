@@ -32,6 +32,7 @@ struct Impl {
   virtual int set_task_state(hipStream_t, const uint8_t* /*d_mask*/, const double* /*d_values*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int slots() const = 0;
   virtual int max_contacts() const { return 0; }
+  virtual int64_t lds_bytes() const { return 0; }
   // device buffers of the implementation that persist between steps (dart_snapshot / dart_restore)
   virtual void persistent(std::vector<std::pair<void*, size_t>>&, int64_t /*n*/) {}
   virtual int set_contact_report(bool /*on*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }

@@ -40,6 +40,7 @@ struct ImplT : Impl {
   void set_stats(unsigned long long* p) override { P.stats = p; }
   void set_force_slow(int on) override { P.force_slow = on; }
   int slots() const override { return 2 * T::NC + n_limited<T>(); }
+  int64_t lds_bytes() const override { return has_slow_path<T>() ? (int64_t)(slow_words<T>() * sizeof(Real)) : 0; }
 };
 
 static inline bool is_identity3(const double* T16, double tol = 1e-12) {

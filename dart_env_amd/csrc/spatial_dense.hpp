@@ -414,6 +414,7 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
   BlcpSets r;
   if (m <= 16) r = sp_blcp_t<Real, 16>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
   else if (m <= 24) r = sp_blcp_t<Real, 24>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (m <= 32) r = sp_blcp_t<Real, 32>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
 #if SP_BLCP_MAXREG > 24
   else r = sp_blcp_t<Real, 40>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
 #else

@@ -282,24 +282,34 @@ struct SpatialImplT : Impl {
       M.cf_store = d_cf;
       if ((e = hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice)) != hipSuccess) return e;
     }
-    lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp);
-    // lean / pairs / extras instantiations of the step kernel (see sp_world_step)
     pairs = M.npairs > 0;
-    // the 20+-dof models without a free root run the BIG instantiations (register LCP solver); measured on HumanWalker / Walker3d
     big = M.n >= 20 && !M.free_root;
+    choose_lds();
+    (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice);
+    const size_t lds_max = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp, 0);
+    // the 20+-dof models without a free root run the BIG instantiations (register LCP solver); measured on HumanWalker / Walker3d
     const void* fns[7] = {(const void*)sp_step_kernel<Real, false, false, false, false>, (const void*)sp_step_kernel<Real, false, false, false, true>,
                           (const void*)sp_step_kernel<Real, true, false, false, true>, (const void*)sp_step_kernel<Real, false, true, false, false>,
                           (const void*)sp_step_kernel<Real, true, true, false, true>, (const void*)sp_step_kernel<Real, true, true, true, false>,
                           (const void*)sp_step_kernel<Real, true, false, false, false>};
     for (const void* fn : fns)
-      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max)) != hipSuccess) return e;
     return hipSuccess;
   }
   void release() override {
     if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); if (d_ext) (void)hipFree(d_ext); if (d_cf) (void)hipFree(d_cf);
     if (d_creport) (void)hipFree(d_creport); if (d_ccount) (void)hipFree(d_ccount); if (d_cfrep) (void)hipFree(d_cfrep); d_creport = nullptr; d_ccount = nullptr; d_cfrep = nullptr;
     dM = nullptr; init_h = nullptr; d_ext = nullptr; d_cf = nullptr;
+  }
+  // register-LCP models without contact reporting drop the LDS solver's workspace (sp_carve): smaller block, more workgroups per CU
+  bool uses_big() const {   // which step-kernel instantiation step() launches
+    if (M.creport) return false;
+    return pairs ? (extras || big) : (!extras && big);
+  }
+  void choose_lds() {
+    M.reg_lcp = (uses_big() && M.npairs == 0 && M.maxm <= 40) ? 1 : 0;
+    lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp, M.reg_lcp);
   }
   void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
@@ -363,6 +373,7 @@ struct SpatialImplT : Impl {
   hipError_t debug_dump(double* out) override { return dbg ? hipMemcpy(out, dbg, sizeof(double) * 160 * (size_t)nenv, hipMemcpyDeviceToHost) : hipErrorInvalidValue; }
   int slots() const override { return M.maxm; }
   int max_contacts() const override { return M.maxcp; }
+  int64_t lds_bytes() const override { return (int64_t)lds; }
   void persistent(std::vector<std::pair<void*, size_t>>& v, int64_t n) override {
     if (init_h) v.push_back({init_h, sizeof(Real) * 4 * (size_t)n});          // per-env task state (reach targets, initial head height)
     if (d_cf) v.push_back({d_cf, sizeof(Real) * (size_t)M.n * (size_t)n});     // SPD: constraint forces carried to the next step
@@ -377,6 +388,7 @@ struct SpatialImplT : Impl {
       (void)hipMemset(d_cfrep, 0, sizeof(Real) * (size_t)M.n * (size_t)n);
     }
     M.creport = on ? d_creport : nullptr; M.creport_count = on ? d_ccount : nullptr; M.cf_report = on ? d_cfrep : nullptr;
+    choose_lds();
     upload();
     return DART_OK;
   }
@@ -428,7 +440,7 @@ int dyn_prepare(const DartModelCard& c, DynModel& out, std::string& err) {
   out.free_root = M->free_root != 0;
   if (hipMalloc(&out.dev, sizeof(SpatialModel<Real>)) != hipSuccess) { err = "hipMalloc(dynamics model)"; return DART_E_HIP; }
   if (hipMemcpy(out.dev, M.get(), sizeof(SpatialModel<Real>), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy(dynamics model)"; return DART_E_HIP; }
-  out.lds = sp_lds_bytes(M->nl, M->n, sizeof(Real), M->maxm, M->maxcp);
+  out.lds = sp_lds_bytes(M->nl, M->n, sizeof(Real), M->maxm, M->maxcp, 0);
   if (hipFuncSetAttribute((const void*)sp_dynamics_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)out.lds) != hipSuccess) {
     err = "hipFuncSetAttribute(sp_dynamics_kernel)"; return DART_E_HIP;
   }

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG>())) sp_step_kerne
   const int64_t e = blockIdx.x;
   if (e >= n_envs) return;
   const int n = Md.n;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp, Md.reg_lcp);
   int* cflags = S.imisc + 2;
   Real* sh_scal = S.misc + 8;
   if (lane < n) { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; S.tau[lane] = Real(0); }
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
   const int64_t e = blockIdx.x;
   if (e >= n_envs) return;
   const int n = Md.n, nl = Md.nl;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl, n, Md.maxm, Md.maxcp);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl, n, Md.maxm, Md.maxcp, Md.reg_lcp);
   if (lane < n) {
     const int64_t at = soa ? (int64_t)lane * n_envs + e : e * n + lane;
     S.q[lane] = qs[at]; S.dq[lane] = dqs[at]; S.tau[lane] = Real(0);
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
   const int64_t e = blockIdx.x;
   if (e >= n_envs) return;
   const int n = Md.n;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp, Md.reg_lcp);
   int* cflags = S.imisc + 2;
   const bool m = (mask == nullptr) || mask[e];
   if (lane < n) {

@@ -65,6 +65,8 @@ struct SpatialModel {
   int free_root;                     // 1: body 0 hangs on a DART FreeJoint (public q[0:3] rotation vector, dq[0:6] body twist)
   int free_link;                     // the last of the six root links (carries the body); its joint rotation is Rz(c) R0
   int maxm, maxcp;                   // LCP rows / contact points this model's LDS block is carved for
+  int reg_lcp;                       // 1: the model runs the BIG kernels with <= 40 LCP rows and no link-link contacts: the LDS solver's
+                                     // workspace is never touched and A (written after the link records' last use) takes its alias slot
   int npairs, pair_a[SP_MAXPAIRS], pair_b[SP_MAXPAIRS];   // link-link contact candidates: shape slots, a < b
   int sh_link[SP_MAXS], sh_type[SP_MAXS];
   Real sh_R[SP_MAXS][9], sh_p[SP_MAXS][3], sh_size[SP_MAXS][3];
@@ -144,7 +146,7 @@ __device__ __forceinline__ int topo_dof(int w) { return ((w >> 8) & 0xff) - 1; }
 __device__ __forceinline__ int topo_jtype(int w) { return (w >> 16) & 0xff; }
 
 template <class Real>
-__device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int maxm, int maxcp) {
+__device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int maxm, int maxcp, int reg_lcp) {
   SpLds<Real> S;
   Real* p = base;
   S.link = p; p += nl * SP_LINKF;
@@ -152,9 +154,13 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   p = base + (((p - base) + 3) & ~3);   // 16-byte aligned rows
   S.H = p; p += HR(sp_npad(n));
   S.W = p; p += (maxm + 1) * n;
-  S.A = p; p += sp_tri(maxm);
-  if (sp_lw_aliases_links(nl, maxm)) { S.Lw = S.link; S.x0 = S.link + sp_tri(maxm); }
-  else { S.Lw = p; p += sp_tri(maxm); S.x0 = p; p += maxm; }
+  const bool alias = sp_lw_aliases_links(nl, maxm);
+  if (reg_lcp && alias) { S.A = S.link; S.x0 = S.link + sp_tri(maxm); S.Lw = nullptr; }
+  else {
+    S.A = p; p += sp_tri(maxm);
+    if (alias) { S.Lw = S.link; S.x0 = S.link + sp_tri(maxm); }
+    else { S.Lw = p; p += sp_tri(maxm); S.x0 = p; p += maxm; }
+  }
   S.b = p; p += maxm; S.lo = p; p += maxm; S.hi = p; p += maxm; S.x = p; p += maxm; S.r = p; p += maxm;
   S.cpP = p; p += maxcp * 4;
   S.cpN = p; p += maxcp * 3;
@@ -171,9 +177,11 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   S.ticks = (unsigned long long*)(((size_t)(S.topo + nl) + 7) & ~(size_t)7);
   return S;
 }
-__host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp) {
-  const size_t lw = sp_lw_aliases_links(nl, maxm) ? 0 : (size_t)sp_tri(maxm) + maxm;
-  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)HR(sp_npad(n)) + 3 + (size_t)(maxm + 1) * n + sp_tri(maxm) + lw + 5 * maxm +
+__host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp, int reg_lcp) {
+  const bool alias = sp_lw_aliases_links(nl, maxm);
+  const size_t lw = alias ? 0 : (size_t)sp_tri(maxm) + maxm;
+  const size_t a = (reg_lcp && alias) ? 0 : (size_t)sp_tri(maxm);
+  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)HR(sp_npad(n)) + 3 + (size_t)(maxm + 1) * n + a + lw + 5 * maxm +
                  maxcp * 7 + 16 + 24;
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }

@@ -51,12 +51,15 @@ static inline bool is_identity3(const double* T16, double tol = 1e-12) {
 }
 
 // Validate the card against topology T and fill the kernel parameters.  Returns "" or the reason it does not fit.
+// Bodies on weld joints (half_cheetah.skel's head) are folded into the link they are welded to: mass, COM, inertia and
+// collision shapes; a moving joint on a welded body is declined.
 template <class Real, class T>
 std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   constexpr int NL = T::NL;
-  if (c.nbodies != NL + 2 || c.ndofs != T::NDOF) return "body/dof count";
+  if (c.ndofs != T::NDOF || c.nbodies < NL + 2) return "body/dof count";
   if (c.act_dim != T::NA || c.act_dof0 != T::NDOF - T::NA) return "action layout";
   if (c.obs_dim != 2 * T::NDOF - 1 && c.task != DART_TASK_NONE) return "obs_dim";
+  if (c.task != DART_TASK_NONE && c.task != DART_TASK_HOPPER && c.task != DART_TASK_WALKER2D && c.task != DART_TASK_HALFCHEETAH) return "task";
   for (int d = 0; d < c.ndofs; d++) if (c.joint_friction[d] != 0.0) return "joint Coulomb friction";
   if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
   // floating base: prismatic x, prismatic y, revolute +-z
@@ -72,12 +75,33 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
     if (c.T_pj[b][11] != 0 || c.T_cj[b][11] != 0) return "root z offset";
   }
   P.root_x0 = (Real)x0; P.root_y0 = (Real)y0;
+  // bodies -> links (welded bodies share their parent's link, shifted by the weld offset)
+  int link_of_body[DART_MAX_BODIES], body_of_link[NL], nl = 0;
+  double wx[DART_MAX_BODIES], wy[DART_MAX_BODIES];   // origin of the body frame in its link frame
+  for (int b = 0; b < c.nbodies; b++) { link_of_body[b] = -1; wx[b] = 0; wy[b] = 0; }
+  for (int b = 2; b < c.nbodies; b++) {
+    if (c.jtype[b] == DART_JT_WELD) {
+      const int pb = c.parent[b];
+      if (b == 2 || pb < 2 || link_of_body[pb] < 0) return "weld without a link to hold it";
+      if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated weld";
+      if (c.T_pj[b][11] != 0 || c.T_cj[b][11] != 0) return "weld off plane";
+      link_of_body[b] = link_of_body[pb];
+      wx[b] = wx[pb] + c.T_pj[b][3] - c.T_cj[b][3]; wy[b] = wy[pb] + c.T_pj[b][7] - c.T_cj[b][7];
+      continue;
+    }
+    if (nl >= NL) return "body/dof count";
+    body_of_link[nl] = b; link_of_body[b] = nl++;
+  }
+  if (nl != NL) return "body/dof count";
+  double lm[NL], lcx[NL], lcy[NL], lizz[NL];
   for (int k = 0; k < NL; k++) {
-    int b = k + 2;
+    const int b = body_of_link[k];
     if (c.jtype[b] != DART_JT_REVOLUTE) return "non-revolute link joint";
     if (std::fabs(std::fabs(c.axes[b][2]) - 1) > 1e-12) return "link axis must be +-z";
     if (k > 0) {
-      if (c.parent[b] - 2 != T::parent(k)) return "tree shape";
+      const int pb = c.parent[b];
+      if (pb < 2 || link_of_body[pb] != T::parent(k)) return "tree shape";
+      if (c.jtype[pb] == DART_JT_WELD) return "joint on a welded body";
       if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated joint frames";
       if (c.T_pj[b][11] != 0 || c.T_cj[b][3] != 0 || c.T_cj[b][7] != 0 || c.T_cj[b][11] != 0) return "joint offsets";
       P.jx[k] = (Real)c.T_pj[b][3]; P.jy[k] = (Real)c.T_pj[b][7];
@@ -87,30 +111,42 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
     }
     if (c.com[b][2] != 0) return "com off plane";
     P.sigma[k] = (Real)(c.axes[b][2] > 0 ? 1.0 : -1.0);
-    P.mass[k] = (Real)c.mass[b]; P.cx[k] = (Real)c.com[b][0]; P.cy[k] = (Real)c.com[b][1];
-    P.izz[k] = (Real)c.inertia[b][8];
-    int d = 2 + k;
-    if (c.stiffness[d] != 0) return "joint springs";
+    lm[k] = c.mass[b]; lcx[k] = c.com[b][0]; lcy[k] = c.com[b][1]; lizz[k] = c.inertia[b][8];
+    const int d = c.dof_offset[b];
+    if (d != 2 + k) return "dof order";
     bool lim = c.limited[d] != 0;
     if (lim && !T::limited(k)) return "limit on unlimited link";
     P.lo[k] = (Real)(lim ? c.lower[d] : -INFINITY);
     P.hi[k] = (Real)(lim ? c.upper[d] : INFINITY);
   }
+  for (int b = 2; b < c.nbodies; b++) {   // fold the welded bodies in: composite mass, COM, inertia about the new COM
+    if (c.jtype[b] != DART_JT_WELD || c.mass[b] == 0) continue;
+    if (c.com[b][2] != 0) return "com off plane";
+    const int k = link_of_body[b];
+    const double mb = c.mass[b], bx = wx[b] + c.com[b][0], by = wy[b] + c.com[b][1];
+    const double m = lm[k] + mb, nx = (lm[k] * lcx[k] + mb * bx) / m, ny = (lm[k] * lcy[k] + mb * by) / m;
+    lizz[k] = lizz[k] + lm[k] * ((lcx[k] - nx) * (lcx[k] - nx) + (lcy[k] - ny) * (lcy[k] - ny)) + c.inertia[b][8] +
+              mb * ((bx - nx) * (bx - nx) + (by - ny) * (by - ny));
+    lm[k] = m; lcx[k] = nx; lcy[k] = ny;
+  }
+  for (int k = 0; k < NL; k++) { P.mass[k] = (Real)lm[k]; P.cx[k] = (Real)lcx[k]; P.cy[k] = (Real)lcy[k]; P.izz[k] = (Real)lizz[k]; }
   for (int d = 0; d < T::NDOF; d++) {
     if (d < 2 && (c.limited[d] || c.stiffness[d] != 0)) return "limits/springs on root translation";
     P.damp[d] = (Real)c.damping[d]; P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
+    P.stiff[d] = (Real)c.stiffness[d]; P.rest[d] = (Real)c.rest[d];
   }
   int nc = 0;
   for (int s = 0; s < c.nshapes; s++) {
     if (!c.shape_collidable[s]) continue;
     if (c.shape_type[s] != DART_SH_CAPSULE) return "collidable non-capsule shape";
     if (nc >= T::NC) return "too many collidable shapes";
-    if (c.shape_body[s] - 2 != T::clink(nc)) return "collidable shape on unexpected link";
+    const int sb = c.shape_body[s];
+    if (sb < 2 || link_of_body[sb] != T::clink(nc)) return "collidable shape on unexpected link";
     const double* S = c.shape_pose[s];
     double hl = 0.5 * c.shape_size[s][1];
     if (std::fabs(S[10]) > 1e-9 || S[11] != 0) return "capsule axis off plane";
-    P.e1x[nc] = (Real)(S[3] + hl * S[2]); P.e1y[nc] = (Real)(S[7] + hl * S[6]);
-    P.e2x[nc] = (Real)(S[3] - hl * S[2]); P.e2y[nc] = (Real)(S[7] - hl * S[6]);
+    P.e1x[nc] = (Real)(wx[sb] + S[3] + hl * S[2]); P.e1y[nc] = (Real)(wy[sb] + S[7] + hl * S[6]);
+    P.e2x[nc] = (Real)(wx[sb] + S[3] - hl * S[2]); P.e2y[nc] = (Real)(wy[sb] + S[7] - hl * S[6]);
     P.rad[nc] = (Real)c.shape_size[s][0];
     nc++;
   }
@@ -162,6 +198,8 @@ std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool
   if (auto p = make_for_topology<Real, Walker2dTopo, Walker2dStatic<Real>>(c, why, allow_static)) return p;
   why += "; walker2d-tree, all capsules: ";
   if (auto p = make_for_topology<Real, Walker2dAllTopo, Walker2dAllStatic<Real>>(c, why, allow_static)) return p;
+  why += "; half-cheetah: ";
+  if (auto p = make_for_topology<Real, CheetahTopo, void>(c, why, allow_static)) return p;
   return nullptr;
 }
 

@@ -88,6 +88,14 @@ struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the flo
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
 
+struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded head) - (thigh shin foot) x 2, eight capsules, joint springs
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4;   // a thrashing cheetah rests on 3-4 capsules in half of the waves
+  static constexpr bool WARM = true;
+  __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
+  __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 0, 1, 2, 3, 4, 5, 6}; return L[c]; }
+  __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
+};
+
 template <class T>
 __device__ __host__ constexpr bool is_anc(int j, int k) {  // j ancestor-or-self of k
   while (k >= 0) {
@@ -139,6 +147,7 @@ struct Params {
   Real sigma[T::NL], mass[T::NL], cx[T::NL], cy[T::NL], izz[T::NL], jx[T::NL], jy[T::NL];
   Real lo[T::NL], hi[T::NL];
   Real damp[T::NDOF], q0[T::NDOF], dq0[T::NDOF];  // joint damping; world.reset() state
+  Real stiff[T::NDOF], rest[T::NDOF];             // joint springs (implicit: H += dt^2 K, rhs -= K (q + dt dq - rest))
   Real e1x[T::NC], e1y[T::NC], e2x[T::NC], e2y[T::NC], rad[T::NC];
   Real act_scale[T::NA], act_lo[T::NA], act_hi[T::NA];
   Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise, noise_v;
@@ -150,7 +159,7 @@ struct Params {
 
 // compile-time "is this model parameter exactly zero" (always false for the runtime block): lets the specialised
 // kernels drop whole terms without asking the compiler for non-IEEE x*0 folding
-enum { ZF_jx = 0, ZF_jy = 1, ZF_cx = 2, ZF_cy = 3, ZF_damp = 4 };
+enum { ZF_jx = 0, ZF_jy = 1, ZF_cx = 2, ZF_cy = 3, ZF_damp = 4, ZF_stiff = 5 };
 #define DART_ZERO(PT, field, k) (PT::zero(ZF_##field, k))
 
 // ------------------------------------------------------------------ math helpers
@@ -837,6 +846,8 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   rhs[1] = tau[1] - Fy[0];
   if constexpr (!DART_ZERO(PT, damp, 0)) rhs[0] -= P.damp[0] * dq[0];
   if constexpr (!DART_ZERO(PT, damp, 1)) rhs[1] -= P.damp[1] * dq[1];
+  if constexpr (!DART_ZERO(PT, stiff, 0)) rhs[0] -= P.stiff[0] * (q[0] + P.dt * dq[0] - P.rest[0]);
+  if constexpr (!DART_ZERO(PT, stiff, 1)) rhs[1] -= P.stiff[1] * (q[1] + P.dt * dq[1] - P.rest[1]);
   sfor<0, NL>([&](auto K) {
     constexpr int k = K, i = 2 + k;
     H[tri(rev<N>(i), rev<N>(0))] = -P.sigma[k] * dcy[k];
@@ -852,10 +863,12 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     });
     rhs[i] = tau[i] - P.sigma[k] * Nz[k];
     if constexpr (!DART_ZERO(PT, damp, i)) rhs[i] -= P.damp[i] * dq[i];
+    if constexpr (!DART_ZERO(PT, stiff, i)) rhs[i] -= P.stiff[i] * (q[i] + P.dt * dq[i] - P.rest[i]);
   });
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
     if constexpr (!DART_ZERO(PT, damp, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.damp[i];
+    if constexpr (!DART_ZERO(PT, stiff, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.dt * P.stiff[i];
   });
   spd_inverse<Real, N>(H);  // H now holds H^-1 (reversed dof order)
   Real vs[N];
@@ -1035,6 +1048,10 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     ok = ok && isfinite(q[i]) && isfinite(dq[i]) && (fabs(dq[i]) < P.s_max);
     if constexpr (i >= 2) ok = ok && (fabs(q[i]) < P.s_max);
   });
+  if (P.task == 6) {   // half_cheetah.py:50-63: the reward is zeroed when the state broke; the observation starts with q[1] itself
+    rew = ok ? rew : Real(0);
+    height = q[1];
+  }
   ok = ok && (height > P.h_lo) && (height < P.h_hi) && (fabs(ang) < P.ang_max);
   bool task_done = (P.task != 0) && !ok;
   int el = elapsed[ec] + 1;
@@ -1045,7 +1062,7 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, P.noise_v, q, dq);
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
     el = 0;
-    height = root_height<Real, T, PT>(P, q);
+    height = (P.task == 6) ? q[1] : root_height<Real, T, PT>(P, q);
     if (valid) episode[e] = ep;
   }
   if (valid) {
@@ -1085,7 +1102,7 @@ __global__ void __launch_bounds__(256) reset_kernel(PT P, int64_t n_envs, Real* 
   } else {
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + e]; dq[i] = dqs[(int64_t)i * n_envs + e]; });
   }
-  if (obs && (m || !obs_masked_only)) write_obs<Real, T, PT>(P, q, dq, root_height<Real, T, PT>(P, q), obs + e * (2 * N - 1));
+  if (obs && (m || !obs_masked_only)) write_obs<Real, T, PT>(P, q, dq, (P.task == 6) ? q[1] : root_height<Real, T, PT>(P, q), obs + e * (2 * N - 1));
 }
 
 // (N, n) row-major doubles  <->  SoA state, for set_state / get_state (dart_env.py:145-148, 211-215)

@@ -18,8 +18,12 @@ struct ImplT : Impl {
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
                   float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
     dim3 grid((unsigned)((n + block_threads - 1) / block_threads)), block(block_threads);
-    hipLaunchKernelGGL((step_kernel<Real, T, PT>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew,
-                       done, trunc, autoreset, seed, off);
+    if (P.ex.ext_force != nullptr || P.ex.creport != nullptr)
+      hipLaunchKernelGGL((step_kernel<Real, T, PT, true>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew,
+                         done, trunc, autoreset, seed, off);
+    else
+      hipLaunchKernelGGL((step_kernel<Real, T, PT, false>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew,
+                         done, trunc, autoreset, seed, off);
     return hipGetLastError();
   }
   hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
@@ -39,8 +43,65 @@ struct ImplT : Impl {
   }
   void set_stats(unsigned long long* p) override { P.stats = p; }
   void set_force_slow(int on) override { P.force_slow = on; }
+  // ---- optional extras: external body force, contact report (see Extras in planar_kernel.hpp)
+  int link_body[T::NL] = {};                 // card body of each link (welded bodies have no link of their own)
+  Real* d_ext = nullptr; Real* d_rec = nullptr; int* d_cnt = nullptr; Real* d_cf = nullptr;
+  void release() override {
+    if (d_ext) (void)hipFree(d_ext); if (d_rec) (void)hipFree(d_rec); if (d_cnt) (void)hipFree(d_cnt); if (d_cf) (void)hipFree(d_cf);
+    d_ext = nullptr; d_rec = nullptr; d_cnt = nullptr; d_cf = nullptr;
+  }
+  int set_ext_force(int body, const double* host_force, int64_t n) override {
+    if (!host_force) { P.ex.ext_force = nullptr; return DART_OK; }
+    int link = -1;
+    for (int k = 0; k < T::NL; k++) if (link_body[k] == body) link = k;
+    if (link < 0) return DART_E_UNSUPPORTED;   // a root carrier or a welded body: the tree kernel serves those (generic_kernel)
+    if (!d_ext && hipMalloc((void**)&d_ext, sizeof(Real) * 3 * (size_t)n) != hipSuccess) return DART_E_HIP;
+    std::vector<Real> tmp(3 * (size_t)n);
+    for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (Real)host_force[i];
+    if (hipMemcpy(d_ext, tmp.data(), sizeof(Real) * tmp.size(), hipMemcpyHostToDevice) != hipSuccess) return DART_E_HIP;
+    P.ex.ext_force = d_ext; P.ex.ext_link = link;
+    return DART_OK;
+  }
+  int max_contacts() const override { return T::NC; }
+  int set_contact_report(bool on, int64_t n) override {
+    if (on && !d_rec) {
+      if (hipMalloc((void**)&d_rec, sizeof(Real) * 8 * T::NC * (size_t)n) != hipSuccess) return DART_E_HIP;
+      if (hipMalloc((void**)&d_cnt, sizeof(int) * (size_t)n) != hipSuccess) return DART_E_HIP;
+      if (hipMalloc((void**)&d_cf, sizeof(Real) * T::NDOF * (size_t)n) != hipSuccess) return DART_E_HIP;
+      (void)hipMemset(d_cnt, 0, sizeof(int) * (size_t)n); (void)hipMemset(d_cf, 0, sizeof(Real) * T::NDOF * (size_t)n);
+    }
+    P.ex.creport = on ? d_rec : nullptr; P.ex.creport_count = on ? d_cnt : nullptr; P.ex.cf_report = on ? d_cf : nullptr;
+    return DART_OK;
+  }
+  int get_contacts(hipStream_t s, int64_t n, int32_t* count, int32_t* bodies, double* point_force, int maxc) override {
+    if (!P.ex.creport) return DART_E_INVALID;
+    if (hipStreamSynchronize(s) != hipSuccess) return DART_E_HIP;
+    std::vector<Real> rec(8 * (size_t)T::NC * (size_t)n);
+    std::vector<int> cnt((size_t)n);
+    if (hipMemcpy(rec.data(), d_rec, sizeof(Real) * rec.size(), hipMemcpyDeviceToHost) != hipSuccess) return DART_E_HIP;
+    if (hipMemcpy(cnt.data(), d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost) != hipSuccess) return DART_E_HIP;
+    for (int64_t e = 0; e < n; e++) {
+      const int k = cnt[(size_t)e] < maxc ? cnt[(size_t)e] : maxc;
+      count[e] = cnt[(size_t)e];
+      for (int c = 0; c < maxc; c++) {
+        const bool live = c < k && c < T::NC;
+        const Real* r = rec.data() + ((size_t)e * T::NC + (live ? c : 0)) * 8;
+        if (bodies) { bodies[((size_t)e * maxc + c) * 2] = live ? (int32_t)r[0] : -1; bodies[((size_t)e * maxc + c) * 2 + 1] = -1; }
+        if (point_force) for (int a = 0; a < 6; a++) point_force[((size_t)e * maxc + c) * 6 + a] = live ? (double)r[2 + a] : 0.0;
+      }
+    }
+    return DART_OK;
+  }
+  int get_constraint_forces(hipStream_t s, int64_t n, double* out) override {
+    if (!P.ex.cf_report) return DART_E_INVALID;
+    if (hipStreamSynchronize(s) != hipSuccess) return DART_E_HIP;
+    std::vector<Real> tmp((size_t)T::NDOF * (size_t)n);
+    if (hipMemcpy(tmp.data(), d_cf, sizeof(Real) * tmp.size(), hipMemcpyDeviceToHost) != hipSuccess) return DART_E_HIP;
+    for (size_t i = 0; i < tmp.size(); i++) out[i] = (double)tmp[i];
+    return DART_OK;
+  }
   int slots() const override { return 2 * T::NC + n_limited<T>(); }
-  int64_t lds_bytes() const override { return has_slow_path<T>() ? (int64_t)(slow_words<T>() * sizeof(Real)) : 0; }
+  int64_t lds_bytes() const override { return has_slow_path<T, Real>() ? (int64_t)(slow_words<T>() * sizeof(Real)) : 0; }
 };
 
 static inline bool is_identity3(const double* T16, double tol = 1e-12) {
@@ -148,6 +209,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
     P.e1x[nc] = (Real)(wx[sb] + S[3] + hl * S[2]); P.e1y[nc] = (Real)(wy[sb] + S[7] + hl * S[6]);
     P.e2x[nc] = (Real)(wx[sb] + S[3] - hl * S[2]); P.e2y[nc] = (Real)(wy[sb] + S[7] - hl * S[6]);
     P.rad[nc] = (Real)c.shape_size[s][0];
+    P.cbody[nc] = sb;
     nc++;
   }
   if (nc != T::NC) return "collidable shape count";
@@ -164,7 +226,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task;
   P.penalty_link = c.penalty_dof >= 2 ? c.penalty_dof - 2 : -1;
   if (c.task != DART_TASK_NONE && c.height_body != 2) return "height body must be the root link";
-  P.solver = 0; P.iters1 = 24; P.iters2 = 24; P.stats = nullptr; P.force_slow = 0;
+  P.solver = 0; P.iters1 = 24; P.iters2 = 24; P.stats = nullptr; P.force_slow = 0; P.ex = Extras<Real>();
   return "";
 }
 
@@ -178,13 +240,15 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
     if (allow_static && Static::matches(R)) {
       auto p = std::make_unique<ImplT<Real, T, Static>>();
       p->P.max_steps = R.max_steps; p->P.solver = R.solver; p->P.iters1 = R.iters1; p->P.iters2 = R.iters2;
-      p->P.stats = nullptr; p->P.force_slow = 0;
+      p->P.stats = nullptr; p->P.force_slow = 0; p->P.ex = Extras<Real>();
+      for (int b = 2, k = 0; b < c.nbodies && k < T::NL; b++) if (c.jtype[b] != DART_JT_WELD) p->link_body[k++] = b;
       p->is_static = true;
       return p;
     }
   }
   auto p = std::make_unique<ImplT<Real, T>>();
   p->P = R;
+  for (int b = 2, k = 0; b < c.nbodies && k < T::NL; b++) if (c.jtype[b] != DART_JT_WELD) p->link_body[k++] = b;
   return p;
 }
 

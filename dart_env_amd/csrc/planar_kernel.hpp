@@ -60,28 +60,28 @@ __device__ __host__ constexpr int tri(int i, int j) { return i >= j ? i * (i + 1
 // more contacts, and a lane with more contacts than the last tier is served alone by a loop-based solver in LDS
 // (slow_constraints) -- exact for any number of contacts, and never on the path of a workload that stays within the tiers.
 struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - shin - foot; ONLY the foot collides (BASELINE config[1])
-  static constexpr int NL = 4, NDOF = NL + 2, NC = 1, NA = 3, TIER0 = 1, TIER1 = 0;
+  static constexpr int NL = 4, NDOF = NL + 2, NC = 1, NA = 3, TIER0 = 1, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool WARM = false;  // warm-started active sets: measured -4 % here (short, violent episodes)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
 struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour, the default card)
-  static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2;
+  static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2, TIER1_F64 = 2;
   static constexpr bool WARM = false;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
 struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin foot) x 2; only the feet collide
-  static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6, TIER0 = 2, TIER1 = 0;
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool WARM = true;   // measured +26 % (persistent double-support contacts)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3, 6}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
 struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the floor (DART's behaviour, the default card)
-  static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0;
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool WARM = true;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3, 4, 5, 6}; return L[c]; }
@@ -89,7 +89,12 @@ struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the flo
 };
 
 struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded head) - (thigh shin foot) x 2, eight capsules, joint springs
-  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4;   // a thrashing cheetah rests on 3-4 capsules in half of the waves
+  // a thrashing cheetah rests on 3 capsules in half of the waves, on 4 in 6 % of them (1 % / 0.1 % of the envs): fp32 runs a
+  // 4-slot second tier.  fp64 does not: register tiers of 12 and 14 LCP rows (312 / 420 VGPRs of matrix, 3-5 KB of scratch
+  // per lane) produced wrong states on gfx950 / ROCm 7.2 in some instantiations while the same source is right in fp32, on
+  // the host and with <= 10 rows (Walker2d: 4 M env-steps at 1e-13 of the oracle) -- fp64 keeps the 2-slot tier and sends
+  // the envs with more contacts through the fallback solver (1.7 ms instead of 1.0 ms per batched step at 65 536 envs).
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4, TIER1_F64 = 0;
   static constexpr bool WARM = true;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 0, 1, 2, 3, 4, 5, 6}; return L[c]; }
@@ -116,8 +121,9 @@ __device__ __host__ constexpr int limit_slot(int k) {  // LCP slot of link k's l
   for (int j = 0; j < k; j++) s += T::limited(j) ? 1 : 0;
   return s;
 }
-template <class T> __device__ __host__ constexpr int last_tier() { return T::TIER1 > 0 ? T::TIER1 : T::TIER0; }
-template <class T> __device__ __host__ constexpr bool has_slow_path() { return T::NC > last_tier<T>(); }
+template <class T, class Real> __device__ __host__ constexpr int tier1() { return sizeof(Real) == 8 ? T::TIER1_F64 : T::TIER1; }
+template <class T, class Real> __device__ __host__ constexpr int last_tier() { return tier1<T, Real>() > 0 ? tier1<T, Real>() : T::TIER0; }
+template <class T, class Real> __device__ __host__ constexpr bool has_slow_path() { return T::NC > last_tier<T, Real>(); }
 template <class T> __device__ __host__ constexpr int max_rows() { return 2 * T::NC + n_limited<T>(); }
 // ancestor-or-self sets of all links, 8 bits per link (NL <= 8): bit j of byte k = is_anc(j, k)
 template <class T>
@@ -134,6 +140,24 @@ __device__ __host__ constexpr int slow_words() {
   constexpr int N = T::NDOF, M = max_rows<T>();
   return N * N + 3 * T::NL + N + 4 * T::NC + 3 * T::NL + 2 * M * N + 2 * (M * (M + 1) / 2) + 8 * M + 16;
 }
+
+// Optional per-launch extras of both parameter flavours (all null / off by default):
+//   ext_force      [n_envs][3] world-frame force added at link ext_link's frame origin before every world step --
+//                  bodynodes[b].add_ext_force(F), reference dart_env.py:159-172
+//   creport        [n_envs][NC][8] contacts of the env-step's LAST world step {body, -1, point xyz, force on the body xyz} --
+//                  world.collision_result.contacts as walker2d.py:38-41 reads it; creport_count [n_envs]; cf_report [n_envs][NDOF] =
+//                  skel.constraint_forces() of that step (J^T lambda / dt)
+template <class Real>
+struct Extras {
+  const Real* ext_force = nullptr;
+  int ext_link = 0;
+  Real* creport = nullptr;
+  int* creport_count = nullptr;
+  Real* cf_report = nullptr;
+};
+// where a world step reports to (null record pointer: nothing to report)
+template <class Real>
+struct ReportTo { Real* rec = nullptr; int* count = nullptr; Real* cf = nullptr; };
 
 // ------------------------------------------------------------------ runtime parameters (kernel argument -> SGPRs)
 template <class Real, class T>
@@ -155,6 +179,8 @@ struct Params {
   int solver, iters1, iters2;  // solver 0: block principal pivoting (exact); 1: PGS sweeps
   int force_slow;              // debug / test knob: every lane with a contact takes the single-lane fallback solver
   unsigned long long* stats;   // optional [2][32] histogram of wave-level pivoting iterations per stage (debug), or null
+  int cbody[T::NC];            // card body index of each candidate capsule (contact report)
+  Extras<Real> ex;
 };
 
 // compile-time "is this model parameter exactly zero" (always false for the runtime block): lets the specialised
@@ -398,6 +424,7 @@ __device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const
 // so the pivoting solver usually starts on the right set.  Any start gives the same (unique) LCP solution.
 struct WarmSets {
   uint32_t cid = 0;                // candidate capsule held by each contact slot (4 bits per slot)
+  uint32_t nca = 0;                // contact slots of the tier that wrote these sets (row positions differ between tiers)
   uint32_t sig = 0, up = 0;        // which rows were active / which of them rested on their upper bound
   uint32_t F1 = 0, U1 = 0;         // final sets of the frictionless stage
   uint32_t F2 = 0, U2 = 0;         // final sets of the friction stage
@@ -407,11 +434,11 @@ struct WarmSets {
 // Inputs: H^-1 (packed, reversed dof order), link origins px / py, the unconstrained velocity vs (in/out), the candidate
 // contacts (con / cPx / cPy / cdep over the T::NC capsules) and the state q (limits).  A lane with `off` set takes no part
 // (it is served by slow_constraints): all its rows are inactive and its vs comes back unchanged.
-template <class Real, class T, class PT, int NCA>
+template <class Real, class T, class PT, int NCA, bool EXTRAS>
 __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T::NDOF], const Real (&H)[T::NDOF * (T::NDOF + 1) / 2],
                                                  const Real (&px)[T::NL], const Real (&py)[T::NL], Real (&vs)[T::NDOF],
                                                  const bool (&con)[T::NC], const Real (&cPx)[T::NC], const Real (&cPy)[T::NC],
-                                                 const Real (&cdep)[T::NC], bool off, WarmSets& warm) {
+                                                 const Real (&cdep)[T::NC], bool off, WarmSets& warm, const ReportTo<Real>& rp) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * NCA + n_limited<T>();
   constexpr bool IDENT = (NCA == NC);   // slot s IS candidate s: links are compile-time constants
   // ---- compaction: slot s takes the s-th touching capsule (capsule order = the oracle's serial order)
@@ -564,7 +591,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   sfor<0, NCA>([&](auto S) { has_contact = has_contact || act[2 * S]; });
   // rows that were active on the same side in the previous substep (contact slots: and hold the same capsule) inherit
   // that substep's final set
-  uint32_t keep = ~0u;
+  uint32_t keep = (warm.nca == (uint32_t)NCA) ? ~0u : 0u;
   if constexpr (!IDENT) {
     sfor<0, NCA>([&](auto S) {
       constexpr int sl = S;
@@ -609,7 +636,32 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     }
     warm.F2 = F; warm.U2 = U;
   }
-  warm.sig = sig; warm.up = up; warm.cid = cid;
+  warm.sig = sig; warm.up = up; warm.cid = cid; warm.nca = (uint32_t)NCA;
+  if (EXTRAS && rp.rec != nullptr && !off) {   // contact records in capsule order, constraint forces J^T lambda / dt
+    const Real idt = Real(1) / P.dt;
+    int r = 0;
+    sfor<0, NCA>([&](auto S) {
+      constexpr int sl = S;
+      if (son[sl]) {
+        int body = 0;
+        if constexpr (IDENT) body = P.cbody[sl];
+        else sfor<0, NC>([&](auto Cc) { body = (((cid >> (4 * sl)) & 15u) == (uint32_t)Cc) ? P.cbody[Cc] : body; });
+        Real* o = rp.rec + 8 * r;
+        o[0] = (Real)body; o[1] = Real(-1);
+        o[2] = P.root_x0 + q[0] + sPx[sl]; o[3] = P.root_y0 + q[1] + sPy[sl]; o[4] = Real(0);
+        o[5] = -x[2 * sl + 1] * idt; o[6] = x[2 * sl] * idt; o[7] = Real(0);   // n = +y, t1 = z x n = -x (DART's tangent basis)
+        r++;
+      }
+    });
+    *rp.count = r;
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      Real f = Real(0);
+      sfor<0, NCA>([&](auto S) { constexpr int cs = S; f += Jn[cs][i] * x[2 * cs] + Jt[cs][i] * x[2 * cs + 1]; });
+      if constexpr (i >= 3) { if constexpr (T::limited(i - 2)) f += x[limit_slot<T, NCA>(i - 2)]; }
+      rp.cf[i] = f * idt;
+    });
+  }
   // velocity change  H^-1 J^T lambda
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
@@ -693,8 +745,8 @@ __device__ inline void slow_blcp(int m, const Real* A, const Real* b, const Real
   for (int i = 0; i < m; i++) x[i] = fmin(fmax(x[i], lo[i]), hi[i]);
 }
 
-template <class Real, class T, class PT>
-__device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* mem) {
+template <class Real, class T, class PT, bool EXTRAS>
+__device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* mem, Real qx, Real qy, const ReportTo<Real>& rp) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, MM = max_rows<T>();
   // layout written by the caller: Hi[N*N], px[NL], py[NL], sg[NL], vs[N], con[NC], cPx[NC], cPy[NC], cdep[NC], lim[NL] (-1 low, +1 up, 0),
   // viol[NL], clk[NL] scratch
@@ -778,12 +830,31 @@ __device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* me
     for (int rr = 0; rr < m; rr++) dv += Y[rr * N + i] * x[rr];
     vs[i] += dv;
   }
+  if (EXTRAS && rp.rec != nullptr) {
+    const Real idt = Real(1) / P.dt;
+    int r = 0;
+    for (int c = 0; c < NC; c++) {
+      if (con[c] == Real(0)) continue;
+      Real* o = rp.rec + 8 * r;
+      o[0] = (Real)P.cbody[c]; o[1] = Real(-1);
+      o[2] = P.root_x0 + qx + cPx[c]; o[3] = P.root_y0 + qy + cPy[c]; o[4] = Real(0);
+      o[5] = -x[2 * r + 1] * idt; o[6] = x[2 * r] * idt; o[7] = Real(0);
+      r++;
+    }
+    *rp.count = r;
+    for (int i = 0; i < N; i++) {
+      Real f = Real(0);
+      for (int rr = 0; rr < m; rr++) f += J[rr * N + i] * x[rr];
+      rp.cf[i] = f * idt;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ one World::step (dt) for one env
-template <class Real, class T, class PT>
+template <class Real, class T, class PT, bool EXTRAS>
 __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
-                                           const Real (&tau)[T::NDOF], WarmSets& warm, Real* slow_mem) {
+                                           const Real (&tau)[T::NDOF], WarmSets& warm, Real* slow_mem, int64_t env,
+                                           const ReportTo<Real>& rp) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC;
   Real c[NL], s[NL], px[NL], py[NL], lx[NL], ly[NL], om[NL];
   Real apx[NL], apy[NL];
@@ -865,6 +936,18 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     if constexpr (!DART_ZERO(PT, damp, i)) rhs[i] -= P.damp[i] * dq[i];
     if constexpr (!DART_ZERO(PT, stiff, i)) rhs[i] -= P.stiff[i] * (q[i] + P.dt * dq[i] - P.rest[i]);
   });
+  if (EXTRAS && P.ex.ext_force != nullptr) {   // external force at the frame origin (= joint origin) of link ext_link: generalized force J^T f
+    const Real fx = P.ex.ext_force[env * 3], fy = P.ex.ext_force[env * 3 + 1];
+    rhs[0] += fx; rhs[1] += fy;
+    sfor<0, NL>([&](auto K) {
+      constexpr int k = K;
+      if (P.ex.ext_link == k)
+        sfor<0, k + 1>([&](auto J) {
+          constexpr int j = J;
+          if constexpr (is_anc<T>(j, k)) rhs[2 + j] += P.sigma[j] * ((px[k] - px[j]) * fy - (py[k] - py[j]) * fx);
+        });
+    });
+  }
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
     if constexpr (!DART_ZERO(PT, damp, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.damp[i];
@@ -897,9 +980,13 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     nact += con[cidx] ? 1 : 0;
   });
 
+  if (EXTRAS && rp.rec != nullptr) {   // nothing touching, no limit active: an empty report
+    *rp.count = 0;
+    sfor<0, N>([&](auto I) { rp.cf[I] = Real(0); });
+  }
   bool slow = false;
-  if constexpr (has_slow_path<T>()) {
-    slow = nact > last_tier<T>() || (P.force_slow != 0 && nact > 0);
+  if constexpr (has_slow_path<T, Real>()) {
+    slow = nact > last_tier<T, Real>() || (P.force_slow != 0 && nact > 0);
     if (__any(slow)) {
       // the rare lanes whose env touches the floor with more capsules than the tiers hold: one after the other, alone
       for (int turn = 0; turn < 64; ++turn) {
@@ -924,7 +1011,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
             }
             m[k] = lim; m[NL + k] = viol;
           });
-          slow_constraints<Real, T, PT>(P, slow_mem);
+          slow_constraints<Real, T, PT, EXTRAS>(P, slow_mem, q[0], q[1], rp);
           sfor<0, N>([&](auto I) { vs[I] = mvs[I]; });
         }
       }
@@ -932,11 +1019,11 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   }
   // ---- register tiers: the smallest one that holds every (remaining) lane's contacts
   const int nreg = slow ? 0 : nact;
-  if constexpr (T::TIER1 > 0) {
-    if (__any(nreg > T::TIER0)) constraint_phase<Real, T, PT, T::TIER1>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm);
-    else constraint_phase<Real, T, PT, T::TIER0>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm);
+  if constexpr (tier1<T, Real>() > 0) {
+    if (__any(nreg > T::TIER0)) constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
+    else constraint_phase<Real, T, PT, T::TIER0, EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
   } else {
-    constraint_phase<Real, T, PT, T::TIER0>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm);
+    constraint_phase<Real, T, PT, T::TIER0, EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
   }
   sfor<0, N>([&](auto I) { constexpr int i = I; dq[i] = vs[i]; q[i] += P.dt * vs[i]; });
 }
@@ -995,7 +1082,9 @@ __device__ __forceinline__ void write_obs(const PT& P, const Real (&q)[T::NDOF],
 // ------------------------------------------------------------------ kernels
 // One batched env.step(): clamp+scale action, frame_skip world steps, reward, done, TimeLimit, observation,
 // optional on-device auto-reset (post-reset observation is returned, as SyncVectorEnv does).
-template <class Real, class T, class PT>
+// EXTRAS: the instantiation that serves an external body force and / or the contact report (Extras); the lean one carries
+// none of that code (measured: its mere presence cost the fp64 Walker2d kernel 22 %).
+template <class Real, class T, class PT, bool EXTRAS = false>
 __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __restrict__ qs,
                                                    Real* __restrict__ dqs, int32_t* __restrict__ elapsed,
                                                    uint32_t* __restrict__ episode, const float* __restrict__ actions,
@@ -1022,10 +1111,14 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   Real dx = Real(0);
   WarmSets warm;
   // LDS of the single-lane fallback solver (only topologies with more candidate capsules than tier slots have one)
-  __shared__ Real slow_lds[has_slow_path<T>() ? slow_words<T>() : 1];
+  __shared__ Real slow_lds[has_slow_path<T, Real>() ? slow_words<T>() : 1];
 #pragma unroll 1
   for (int f = 0; f < P.frame_skip; ++f) {
-    world_step<Real, T, PT>(P, q, dq, tau, warm, slow_lds);
+    ReportTo<Real> rp;
+    if (EXTRAS && P.ex.creport != nullptr && f == P.frame_skip - 1 && valid) {
+      rp.rec = P.ex.creport + (size_t)e * T::NC * 8; rp.count = P.ex.creport_count + e; rp.cf = P.ex.cf_report + (size_t)e * N;
+    }
+    world_step<Real, T, PT, EXTRAS>(P, q, dq, tau, warm, slow_lds, ec, rp);
     dx += P.dt * dq[0];
   }
   (void)x_before;

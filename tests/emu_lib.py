@@ -33,6 +33,11 @@ def lib():
         L.emu_set_solver.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.emu_enable_stats.argtypes = [vp, C.c_int]
         L.emu_force_slow.argtypes = [vp, C.c_int]
+        L.emu_set_ext_force.argtypes = [vp, C.c_int, dp]
+        L.emu_contact_report.argtypes = [vp, C.c_int]
+        L.emu_max_contacts.argtypes = [vp]
+        L.emu_get_contacts.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, C.c_int]
+        L.emu_get_constraint_forces.argtypes = [vp, dp]
         L.emu_get_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.emu_reset.argtypes = [vp, u8, dp, dp, fp, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_step.argtypes = [vp, fp, fp, fp, u8, u8, C.c_int, C.c_uint64, C.c_uint64]
@@ -75,6 +80,26 @@ class EmuStepper:
         elif key == st.CFG_SOLVER: self._solver = int(value); self.L.emu_set_solver(self.h, self._solver, 0, 0)
         elif key == st.CFG_STATS: self.L.emu_enable_stats(self.h, int(value != 0))
         else: raise ValueError(key)
+
+    def set_ext_force(self, body, force):
+        f = None if force is None else np.ascontiguousarray(force, dtype=np.float64)
+        rc = self.L.emu_set_ext_force(self.h, int(body), _p(f, C.c_double))
+        if rc != 0:
+            raise RuntimeError("set_ext_force rc=%d" % rc)
+
+    def enable_contact_report(self, on=True):
+        assert self.L.emu_contact_report(self.h, int(on)) == 0
+
+    def contacts(self):
+        K = self.L.emu_max_contacts(self.h)
+        cnt = np.zeros(self.n, dtype=np.int32); bod = np.zeros((self.n, K, 2), dtype=np.int32); pf = np.zeros((self.n, K, 6))
+        assert self.L.emu_get_contacts(self.h, _p(cnt, C.c_int32), _p(bod, C.c_int32), _p(pf, C.c_double), K) == 0
+        return cnt, bod, pf[:, :, :3], pf[:, :, 3:]
+
+    def constraint_forces(self):
+        cf = np.zeros((self.n, self.nd))
+        assert self.L.emu_get_constraint_forces(self.h, _p(cf, C.c_double)) == 0
+        return cf
 
     def force_slow(self, on=True):
         """every env with a contact goes through the single-lane fallback solver (validates it against the oracle)"""

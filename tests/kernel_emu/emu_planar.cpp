@@ -42,10 +42,15 @@ Emu* emu_create(const DartModelCard* card, int64_t n, int precision, int allow_s
   h->impl->state_io(nullptr, n, h->q.data(), h->dq.data(), h->qn.data(), h->vn.data(), 1);
   return h;
 }
-void emu_destroy(Emu* h) { delete h; }
+void emu_destroy(Emu* h) { if (h) { h->impl->release(); delete h; } }
 int emu_is_static(Emu* h) { return h->impl->is_static ? 1 : 0; }
 int emu_slots(Emu* h) { return h->impl->slots(); }
 void emu_set_solver(Emu* h, int solver, int it1, int it2) { h->impl->set_solver(solver, it1, it2); }
+int emu_set_ext_force(Emu* h, int body, const double* force) { return h->impl->set_ext_force(body, force, h->n); }
+int emu_contact_report(Emu* h, int on) { return h->impl->set_contact_report(on != 0, h->n); }
+int emu_max_contacts(Emu* h) { return h->impl->max_contacts(); }
+int emu_get_contacts(Emu* h, int32_t* count, int32_t* bodies, double* point_force, int maxc) { return h->impl->get_contacts(nullptr, h->n, count, bodies, point_force, maxc); }
+int emu_get_constraint_forces(Emu* h, double* out) { return h->impl->get_constraint_forces(nullptr, h->n, out); }
 void emu_force_slow(Emu* h, int on) { h->impl->set_force_slow(on); }
 void emu_enable_stats(Emu* h, int on) { h->stats.assign(64, 0); h->impl->set_stats(on ? h->stats.data() : nullptr); }
 void emu_get_stats(Emu* h, unsigned long long* out64) { memcpy(out64, h->stats.data(), 64 * sizeof(unsigned long long)); }

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -29,9 +30,19 @@ typedef int hipError_t;
 typedef void* hipStream_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
+// "device" memory is host memory here
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
 inline bool __all(bool p) { return p; }
-inline bool __any(bool p) { return p; }
+// a lane's wave neighbours may vote a lane into the larger tier / the friction stage / the constraint phase although it
+// has nothing there itself: DART_EMU_ANY=1 makes every __any() vote true so that those paths are exercised lane by lane
+inline bool emu_any_true_() { static const bool v = getenv("DART_EMU_ANY") && getenv("DART_EMU_ANY")[0] == '1'; return v; }
+inline bool __any(bool p) { return p || emu_any_true_(); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 // hardware approximations: model them a few bits short of exact so the Newton refinements in the kernels are exercised

@@ -438,11 +438,14 @@ def test_spatial_pgs_solver_converges_to_pivoting_solver(force_spatial):
     assert np.median(e400) < 1e-6 and np.median(e400) < 0.1 * np.median(e30) + 1e-12
 
 
-@pytest.mark.parametrize("env_id,body", [("DartHopper-v1", 3), ("DartHumanWalker-v1", 9), ("DartWalker3d-v1", 0)])  # 0: massless carrier
-def test_external_body_force_matches_oracle(env_id, body):
-    """dart_set_ext_force = bodynodes[b].add_ext_force(F) before every world step (perturbation branch, dart_env.py:159-172)."""
+@pytest.mark.parametrize("env_id,body,generic", [("DartHopper-v1", 3, True), ("DartHopper-v1", 3, False), ("DartWalker2d-v1", 5, False),
+                                                 ("DartHalfCheetah-v1", 6, False), ("DartHumanWalker-v1", 9, True),
+                                                 ("DartWalker3d-v1", 0, True)])  # 0: massless carrier
+def test_external_body_force_matches_oracle(env_id, body, generic):
+    """dart_set_ext_force = bodynodes[b].add_ext_force(F) before every world step (perturbation branch, dart_env.py:159-172):
+    on the tree kernel (generic) and on the planar register kernels (Hopper, Walker2d, HalfCheetah default cards)."""
     from dart_env_amd.stepper import HipStepper, StepperError
-    card = card_for(env_id, generic_kernel=True)
+    card = card_for(env_id, generic_kernel=generic)
     n, nd, na = 32, card.ndofs, card.act_dim
     rng = np.random.RandomState(9)
     gpu = HipStepper(card, n, precision=64)
@@ -468,10 +471,10 @@ def test_external_body_force_matches_oracle(env_id, body):
         assert np.abs(qg - qo).max() < 1e-7 and np.abs(dqg - dqo).max() < 1e-5, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
     assert np.abs(plain.get_state()[0] - gpu.get_state()[0]).max() > 1e-3       # the push did something
     gpu.close(); plain.close()
-    if env_id == "DartHopper-v1":                      # the specialised planar kernel declines, loudly
+    if env_id == "DartHopper-v1" and not generic:      # a force on a root carrier body has no link in the planar kernel: declined, loudly
         fast = HipStepper(card_for(env_id), n, precision=64)
         with pytest.raises(StepperError):
-            fast.set_ext_force(body, F)
+            fast.set_ext_force(0, F)
         fast.close()
 
 
@@ -691,18 +694,16 @@ def test_free_root_chart_has_no_singular_heading():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartHumanWalker-v1", "DartWalker3d-v1", "DartDog-v1"])
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1", "DartHopper-v1/tree", "DartHumanWalker-v1",
+                                    "DartWalker3d-v1", "DartDog-v1"])
 def test_contact_report_matches_oracle(env_id):
-    """dart_get_contacts (pydart2 collision_result.contacts of the last world step): bodies, points and forces equal the
-    oracle's, fp64; fp32 close; the planar register kernels refuse (generic_kernel routes Hopper through the tree kernel)."""
-    from dart_env_amd.stepper import HipStepper, StepperError, CFG_CONTACT_REPORT, Q_MAX_CONTACTS
-    planar = env_id == "DartHopper-v1"
-    if planar:
-        g = HipStepper(card_for(env_id), 4, precision=64)
-        with pytest.raises(StepperError):
-            g.configure(CFG_CONTACT_REPORT, 1)
-        g.close()
-    card = card_for(env_id, generic_kernel=True) if planar else card_for(env_id)
+    """dart_get_contacts (pydart2 collision_result.contacts of the last world step, walker2d.py:38-41): bodies, points and forces
+    equal the oracle's, fp64; fp32 close.  The planar register kernels (Hopper, Walker2d, HalfCheetah default cards) report from
+    their contact slots; `/tree` routes the Hopper through the tree kernel (generic_kernel)."""
+    from dart_env_amd.stepper import HipStepper, StepperError, CFG_CONTACT_REPORT, Q_MAX_CONTACTS, Q_STATIC_KERNEL
+    tree = env_id.endswith("/tree")
+    env_id = env_id.split("/")[0]
+    card = card_for(env_id, generic_kernel=tree)
     n, nd, na = 24, card.ndofs, card.act_dim
     rng = np.random.RandomState(4)
     ora = OracleBatch(card, n)
@@ -714,6 +715,8 @@ def test_contact_report_matches_oracle(env_id):
         g.reset(None, qn, vn)
     K = gpus[64].query(Q_MAX_CONTACTS)
     assert K >= 4
+    if env_id in ("DartHopper-v1", "DartWalker2d-v1") and not tree:
+        assert gpus[64].query(Q_STATIC_KERNEL) == 1        # the baked register kernel itself reports
     with_contacts = pair_contacts = borderline = 0
     for t in range(40):
         a = rng.uniform(-1, 1, (n, na)).astype(np.float32)

@@ -79,3 +79,50 @@ def test_robot_lying_on_the_floor_takes_the_fallback_solver(env_id):
         qo = np.stack([w.q for w in worlds]); dqo = np.stack([w.dq for w in worlds])
         assert np.abs(qg - qo).max() < 1e-9 and np.abs(dqg - dqo).max() < 1e-7, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
     assert most >= 3, most       # more touching capsules than the register tiers of either model hold
+
+
+@pytest.mark.parametrize("env_id,body", [("DartHopper-v1", 3), ("DartWalker2d-v1", 5), ("DartHalfCheetah-v1", 6)])
+@pytest.mark.parametrize("force_fallback", [False, True])
+def test_contact_report_constraint_forces_and_external_force(env_id, body, force_fallback):
+    """What walker2d.py:38-41 reads (collision_result.contacts: body, point, force), skel.constraint_forces() and the
+    perturbation branch of do_simulation (add_ext_force, dart_env.py:159-172) on the planar register kernels' code."""
+    from tests.batch_oracle import OracleBatch
+    card = card_for(env_id); n = 16; nd, na = card.ndofs, card.act_dim
+    rng = np.random.RandomState(4)
+    g = EmuStepper(card, n, precision=64); o = OracleBatch(card, n)
+    if force_fallback:
+        g.force_slow(True)
+    g.enable_contact_report(True)
+    F = rng.uniform(-30, 30, (n, 3)); F[:, 2] = 0
+    g.set_ext_force(body, F)
+    for i, w in enumerate(o.worlds):
+        w.set_ext_force(body, F[i])
+    qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+    g.reset(None, qn, vn); o.reset(None, qn, vn)
+    seen = 0
+    for t in range(50):
+        a = (rng.uniform(-1, 1, (n, na)) * 0.3).astype(np.float32)
+        g.step(a); _, _, do, _ = o.step(a)
+        cnt, bod, pt, fc = g.contacts(); cf = g.constraint_forces()
+        qg, dqg = g.get_state(); qo, dqo = o.state()
+        assert np.abs(qg - qo).max() < 1e-9 and np.abs(dqg - dqo).max() < 1e-7
+        for i, w in enumerate(o.worlds):
+            rep = w.contact_report(); k = len(rep)
+            assert cnt[i] == k
+            assert np.abs(cf[i] - w.constraint_forces()).max() < 1e-6
+            if k:
+                seen += k
+                assert np.array_equal(bod[i, :k, 0], rep[:, 0].astype(np.int32)) and np.all(bod[i, :k, 1] == -1)
+                assert np.abs(pt[i, :k] - rep[:, 2:5]).max() < 1e-9 and np.abs(fc[i, :k] - rep[:, 5:8]).max() < 1e-6
+        if do.any():
+            qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+            g.reset(do.astype(np.uint8), qn, vn, want_obs=False); o.reset(do, qn, vn)
+    assert seen > 100
+
+
+def test_half_cheetah_on_the_register_kernel():
+    """half_cheetah.skel: welded head folded into the torso link, joint springs, eight capsules (tiers of 2 / 4 contact slots)"""
+    card = card_for("DartHalfCheetah-v1")
+    acts, ref = make_reference(card, 64, 200)
+    s = run_host_api(EmuStepper(card, 64, precision=64), acts, ref)
+    assert s["done_flag_mismatches"] == 0 and s["q"] < 1e-9 and s["dq"] < 1e-8, (s["q"], s["dq"])

@@ -407,3 +407,87 @@ def test_vector_env_copy_false_returns_views_with_the_same_values():
             assert prev is ob or np.shares_memory(prev, ob)        # the same pinned buffer every step
         prev = ob
     va.close(); vb.close()
+
+
+# ---------------------------------------------------------------- the same properties at BASELINE configs 3 and 4
+@pytest.mark.parametrize("env_id,n_full,steps", [("DartWalker2d-v1", 65536, 10), ("DartHumanWalker-v1", 16384, 4)])
+def test_other_configs_full_batch_determinism_and_batch_independence(env_id, n_full, steps):
+    """BASELINE.json configs 3 (DartWalker2d-v1 @ 65 536) and 4 (DartHumanWalker-v1 @ 16 384) at full size, product precision:
+    bitwise run-to-run determinism, every env's trajectory independent of the batch around it (ragged sub-batch), finite
+    states, and episodes that end and restart on the device."""
+    def run(n):
+        card = card_for(env_id)
+        s = st.HipStepper(card, n, precision=64)
+        s.configure(st.CFG_AUTORESET, 1); s.configure(st.CFG_SEED, 9)
+        s.reset(None, None, None, want_obs=False)
+        rng = np.random.RandomState(1)
+        outs = []
+        for t in range(steps):
+            a = rng.uniform(-1, 1, (n_full, card.act_dim)).astype(np.float32)[:n]
+            outs.append(s.step(a))
+        q, dq = s.get_state(); el, ep = s.counters()
+        s.close()
+        return outs, q, dq, el, ep
+    o1, q1, dq1, el1, ep1 = run(n_full)
+    o2, q2, dq2, el2, ep2 = run(n_full)
+    assert np.array_equal(q1, q2) and np.array_equal(dq1, dq2) and np.array_equal(ep1, ep2) and np.array_equal(el1, el2)
+    for a, b in zip(o1, o2):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    o3, q3, dq3, el3, ep3 = run(1000)                    # ragged: not a multiple of 64
+    assert np.array_equal(q1[:1000], q3) and np.array_equal(dq1[:1000], dq3) and np.array_equal(ep1[:1000], ep3)
+    assert np.isfinite(q1).all() and np.isfinite(dq1).all()
+    assert ep1.min() >= 1 and (ep1.max() > 1 or env_id == "DartHumanWalker-v1")
+
+
+def test_walker2d_full_batch_outputs_are_consistent():
+    """obs / reward / done of DartWalker2d-v1 at N = 65 536 obey walker2d.py:43-74: obs = [height, q[2:], clip(dq)],
+    reward dx/dt + 1 - 1e-3 sum a^2, done outside 0.8 < h < 2.0, |ang| < 1.0."""
+    card = card_for("DartWalker2d-v1")
+    s = st.HipStepper(card, N_FULL, precision=64)
+    s.configure(st.CFG_SEED, 3)
+    s.reset(None, None, None, want_obs=False)
+    rng = np.random.RandomState(2)
+    n_done = 0
+    for t in range(8):
+        a = rng.uniform(-1.5, 1.5, (N_FULL, 6)).astype(np.float32)
+        q0, _ = s.get_state()
+        ob, r, done, trunc = s.step(a)
+        q, dq = s.get_state()
+        assert np.allclose(ob[:, 0], 1.25 + q[:, 1], atol=1e-5) and np.allclose(ob[:, 1:8], q[:, 2:], atol=1e-5)
+        assert np.allclose(ob[:, 8:], np.clip(dq, -10, 10), atol=1e-4)
+        rew = (q[:, 0] - q0[:, 0]) / 0.008 + 1.0 - 1e-3 * np.sum(a.astype(np.float64) ** 2, axis=1)
+        assert np.allclose(r, rew, atol=1e-5)
+        ok = np.isfinite(q).all(1) & np.isfinite(dq).all(1) & (np.abs(q[:, 2:]) < 100).all(1) & (np.abs(dq) < 100).all(1) & \
+            (ob[:, 0] > .8) & (ob[:, 0] < 2.0) & (np.abs(q[:, 2]) < 1.0)
+        border = (np.abs(ob[:, 0] - .8) < 1e-6) | (np.abs(np.abs(q[:, 2]) - 1.0) < 1e-6)
+        assert np.array_equal(done[~border], ~ok[~border])
+        n_done += int(done.sum())
+        if done.any():
+            s.reset(done.astype(np.uint8), None, None, want_obs=False)
+    assert n_done > 100
+    s.close()
+
+
+def test_humanwalker_full_batch_outputs_are_consistent():
+    """DartHumanWalker-v1 at N = 16 384 (BASELINE config 4): observation = [q[1:], clip(dq), two foot-contact flags in {0, 1}]
+    (human_walker.py:140-149), a done env earns reward 0 (:127-128), episodes end under random actions."""
+    card = card_for("DartHumanWalker-v1")
+    n = 16384
+    s = st.HipStepper(card, n, precision=64)
+    s.configure(st.CFG_SEED, 5)
+    s.reset(None, None, None, want_obs=False)
+    rng = np.random.RandomState(3)
+    n_done = touched = 0
+    for t in range(6):
+        a = rng.uniform(-1, 1, (n, 23)).astype(np.float32)
+        ob, r, done, trunc = s.step(a)
+        q, dq = s.get_state()
+        assert ob.shape == (n, 59) and np.isfinite(ob).all()
+        assert np.allclose(ob[:, :28], q[:, 1:], atol=1e-5) and np.allclose(ob[:, 28:57], np.clip(dq, -10, 10), atol=1e-4)
+        assert np.isin(ob[:, 57:], (0.0, 1.0)).all()
+        assert np.all(r[done] == 0.0) and np.all(np.abs(r[~done]) < 100.0)
+        touched += int(ob[:, 57:].sum()); n_done += int(done.sum())
+        if done.any():
+            s.reset(done.astype(np.uint8), None, None, want_obs=False)
+    assert touched > n and n_done > 0
+    s.close()

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Regenerate profiles/pmc_traffic.json from a rocprof summary (tools/summarize_rocprof.py output of tools/profile_round.sh).
+
+    python tools/update_pmc_traffic.py gpurun_out/<tag>_rocprof.txt [profiles/<committed copy>.txt]
+
+For every `<cfg>_pmc_fetch` / `<cfg>_pmc_write` / `<cfg>_pmc_sq` section triple it takes the step kernel's per-dispatch averages:
+HBM bytes per launch = 2 x FETCH_SIZE (MI355X_MICROARCH.md: gfx950's FETCH_SIZE reports half of a wide coalesced read) +
+WRITE_SIZE, both in KB; and the issue statistics of the SQ pass.  bench.py copies the entry of the configuration it runs
+into `roofline.traffic` / `roofline.valu_issue`; keys are "<env id>/<envs>/<dtype>" as bench.py builds them (the section name
+encodes them: e.g. hopper_f64 -> DartHopper-v1/65536/f64).
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = {"hopper": ("DartHopper-v1", 65536), "walker2d": ("DartWalker2d-v1", 65536), "humanwalker": ("DartHumanWalker-v1", 16384)}
+
+
+def parse(path):
+    sections, cur = {}, None
+    for line in open(path):
+        m = re.match(r"^## (\S+)", line)
+        if m:
+            cur = m.group(1); sections[cur] = {}
+            continue
+        m = re.match(r"^(\S.*?)\s+([A-Z][A-Z0-9_]+)\s+(\d+)\s+([0-9.]+)\s*$", line)
+        if m and cur and "step_kernel" in m.group(1):
+            sections[cur].setdefault(m.group(2), (int(m.group(3)), float(m.group(4)), m.group(1).strip()))
+    return sections
+
+
+def main():
+    src = sys.argv[1]
+    cite = sys.argv[2] if len(sys.argv) > 2 else src
+    S = parse(src)
+    out = {}
+    for name in S:
+        m = re.match(r"^(\w+?)_(f32|f64)_pmc_fetch$", name)
+        if not m or m.group(1) not in CFG:
+            continue
+        cfg, dt = m.group(1), m.group(2)
+        fetch = S[name].get("FETCH_SIZE"); write = S.get("%s_%s_pmc_write" % (cfg, dt), {}).get("WRITE_SIZE")
+        if not fetch or not write:
+            continue
+        env_id, n = CFG[cfg]
+        entry = {"bytes_per_launch": int(round((2 * fetch[1] + write[1]) * 1024)), "fetch_size_kb_raw": fetch[1], "write_size_kb_raw": write[1],
+                 "kernel": fetch[2],
+                 "source": "%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, avg of %d dispatches; FETCH_SIZE x2 per "
+                           "MI355X_MICROARCH.md gfx950 note (written by tools/update_pmc_traffic.py)" % (os.path.relpath(cite, ROOT), fetch[0])}
+        sq = S.get("%s_%s_pmc_sq" % (cfg, dt), {})
+        if "SQ_WAVE_CYCLES" in sq and "SQ_WAVES" in sq:
+            waves = sq["SQ_WAVES"][1]
+            entry["valu_issue"] = {
+                "SQ_INSTS_VALU_per_wave": sq.get("SQ_INSTS_VALU", (0, 0))[1] / waves,
+                "SQ_INSTS_SALU_per_wave": sq.get("SQ_INSTS_SALU", (0, 0))[1] / waves,
+                "SQ_ACTIVE_INST_ANY_over_SQ_WAVE_CYCLES": sq.get("SQ_ACTIVE_INST_ANY", (0, 0))[1] / sq["SQ_WAVE_CYCLES"][1],
+                "SQ_WAIT_ANY_over_SQ_WAVE_CYCLES": sq.get("SQ_WAIT_ANY", (0, 0))[1] / sq["SQ_WAVE_CYCLES"][1],
+                "wave_cycles_per_wave": 4 * sq["SQ_WAVE_CYCLES"][1] / waves,
+                "source": "%s %s_%s_pmc_sq (SQ_* count quad-cycles)" % (os.path.relpath(cite, ROOT), cfg, dt)}
+        out["%s/%d/%s" % (env_id, n, dt)] = entry
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path, "keys", sorted(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -620,8 +620,14 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       hi[stt] = hb; lo[stt] = -hb;
       const bool pinned = !(hb > Real(0));
       pinmask = pinned ? (pinmask | (1u << stt)) : (pinmask & ~(1u << stt));
-      F = pinned ? (F & ~(1u << stt)) : (F | (1u << stt));   // friction rows start free
-      U &= ~(1u << stt);
+      // start of the friction row: the impulse that would stop the tangential velocity left by the frictionless solve, with
+      // every other row held -- inside the bounds the row starts free (sticking), beyond them on that bound (sliding)
+      Real wt = -b[stt];
+      sfor<0, M>([&](auto J) { constexpr int j = J; wt += A[tri(stt, j)] * x[j]; });
+      const Real xe = -wt * rcp_<Real>(A[tri(stt, stt)]);
+      const bool up = xe > hb, dn = xe < -hb;
+      F = (pinned || up || dn) ? (F & ~(1u << stt)) : (F | (1u << stt));
+      U = (!pinned && up) ? (U | (1u << stt)) : (U & ~(1u << stt));
       fric |= pinned ? 0u : (1u << stt);
     });
     // ... unless the same contact was sliding/sticking a substep ago: start from that state

@@ -28,7 +28,7 @@ SOLVER_BPP, SOLVER_PGS = 0, 1
 EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
-    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses", "dart_snapshot", "dart_restore",
+    "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses", "dart_snapshot", "dart_restore", "dart_timer_mark", "dart_timer_elapsed",
 ]
 
 
@@ -99,6 +99,8 @@ def load_library(path: Optional[str] = None):
     L.dart_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.dart_get_counters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
     L.dart_time_steps.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, dp]
+    L.dart_timer_mark.argtypes = [vp, C.c_int]
+    L.dart_timer_elapsed.argtypes = [vp, dp]
     for name in EXPORTS:
         if name != "dart_last_error":
             getattr(L, name).restype = C.c_int
@@ -316,6 +318,15 @@ class HipStepper:
 
     def sync(self):
         self._check(self.L.dart_sync(self.h))
+
+    def timer_mark(self, which: int):
+        """enqueue HIP event `which` (0 start, 1 stop) on the handle's stream"""
+        self._check(self.L.dart_timer_mark(self.h, int(which)))
+
+    def timer_elapsed(self) -> float:
+        ms = C.c_double(0)
+        self._check(self.L.dart_timer_elapsed(self.h, C.byref(ms)))
+        return ms.value
 
     def time_steps(self, d_actions, action_batches, steps, d_obs=0, d_reward=0, d_done=0, d_truncated=0) -> float:
         ms = C.c_double(0)

@@ -206,6 +206,12 @@ int dart_sync(DartStepper* h);
 int dart_time_steps(DartStepper* h, const float* d_actions, int action_batches, float* d_obs, float* d_reward,
                     uint8_t* d_done, uint8_t* d_truncated, int steps, double* ms_per_step);
 
+/* The same stopwatch in two halves, for a caller that brackets its own wall-clock region around the launches (bench.py):
+ * dart_timer_mark(h, 0) / (h, 1) enqueue a HIP event on the handle's stream before / after the work (no wait);
+ * dart_timer_elapsed waits for the second event and returns the milliseconds between the two. */
+int dart_timer_mark(DartStepper* h, int which);
+int dart_timer_elapsed(DartStepper* h, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,15 @@ class EmuBenchEnv:
         self.run(k)
         return (time.perf_counter() - t0) / k * 1e3
 
+    def mark(self, which):
+        if which == 0:
+            self._t0 = time.perf_counter()
+        else:
+            self._t1 = time.perf_counter()
+
+    def elapsed_ms(self):
+        return (self._t1 - self._t0) * 1e3
+
     def sync(self):
         pass
 

@@ -377,6 +377,7 @@ static int ext_end(DartStepper* h, hipStream_t s) {
 
 int dart_reset_device(DartStepper* h, const uint8_t* d_mask, float* d_obs, void* hip_stream) {
   if (!h) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
   CHK(h, hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   { int rc = ext_begin(h, s); if (rc != DART_OK) return rc; }
@@ -472,6 +473,7 @@ int dart_step(DartStepper* h, const float* actions, float* obs_out, double* rewa
 int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done,
                      uint8_t* d_truncated, void* hip_stream) {
   if (!h || !d_actions) return DART_E_INVALID;
+  if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
   CHK(h, hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   { int rc = ext_begin(h, s); if (rc != DART_OK) return rc; }
@@ -605,20 +607,37 @@ static void snapshot_buffers(DartStepper* h, std::vector<std::pair<void*, size_t
   h->impl->persistent(v, h->n);
 }
 
+// snapshot header: what a snapshot must share with the handle it is restored into
+struct SnapHeader {
+  uint64_t magic, total;
+  int64_t n;
+  int32_t ndofs, precision, noise_mode, autoreset;
+  uint64_t seed, env_offset;
+  char name[32];
+};
+static SnapHeader snapshot_header(const DartStepper* h, uint64_t total) {
+  SnapHeader s;
+  memset(&s, 0, sizeof(s));
+  s.magic = 0x44415254534e4150ull /* "DARTSNAP" */; s.total = total; s.n = h->n; s.ndofs = h->card.ndofs; s.precision = h->precision;
+  s.noise_mode = h->noise_mode; s.autoreset = h->autoreset; s.seed = h->seed; s.env_offset = h->env_offset;
+  memcpy(s.name, h->card.name, sizeof(s.name));
+  return s;
+}
+
 int dart_snapshot(DartStepper* h, void* buf, uint64_t* nbytes) {
   if (!h || !nbytes) return DART_E_INVALID;
   if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
   std::vector<std::pair<void*, size_t>> v;
   snapshot_buffers(h, v);
-  uint64_t total = 16;
+  uint64_t total = sizeof(SnapHeader);
   for (auto& b : v) total += b.second;
   if (!buf) { *nbytes = total; return DART_OK; }
   if (*nbytes < total) { h->err = "dart_snapshot: buffer too small"; *nbytes = total; return DART_E_INVALID; }
   CHK(h, hipSetDevice(h->device));
   CHK(h, hipStreamSynchronize(h->stream));
   unsigned char* p = (unsigned char*)buf;
-  const uint64_t head[2] = {0x44415254534e4150ull /* "DARTSNAP" */, total};
-  memcpy(p, head, 16); p += 16;
+  const SnapHeader head = snapshot_header(h, total);
+  memcpy(p, &head, sizeof(head)); p += sizeof(head);
   for (auto& b : v) { CHK(h, hipMemcpy(p, b.first, b.second, hipMemcpyDeviceToHost)); p += b.second; }
   *nbytes = total;
   return DART_OK;
@@ -629,18 +648,24 @@ int dart_restore(DartStepper* h, const void* buf, uint64_t nbytes) {
   if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
   std::vector<std::pair<void*, size_t>> v;
   snapshot_buffers(h, v);
-  uint64_t total = 16;
+  uint64_t total = sizeof(SnapHeader);
   for (auto& b : v) total += b.second;
-  uint64_t head[2];
-  if (nbytes < 16) { h->err = "dart_restore: not a snapshot"; return DART_E_INVALID; }
-  memcpy(head, buf, 16);
-  if (head[0] != 0x44415254534e4150ull || head[1] != total || nbytes < total) {
-    h->err = "dart_restore: snapshot of a different handle configuration (model, num_envs, precision, seeding / statistics modes)";
+  SnapHeader got;
+  if (nbytes < sizeof(SnapHeader)) { h->err = "dart_restore: not a snapshot"; return DART_E_INVALID; }
+  memcpy(&got, buf, sizeof(got));
+  const SnapHeader want = snapshot_header(h, total);
+  if (got.magic != want.magic) { h->err = "dart_restore: not a snapshot"; return DART_E_INVALID; }
+  // model, batch, precision, reset-noise mode and Philox stream identity must match: the bytes would otherwise restore silently
+  // into a handle that continues differently
+  if (memcmp(got.name, want.name, sizeof(want.name)) != 0 || got.n != want.n || got.ndofs != want.ndofs || got.precision != want.precision ||
+      got.noise_mode != want.noise_mode || got.seed != want.seed || got.env_offset != want.env_offset || got.total != total || nbytes < total) {
+    h->err = "dart_restore: snapshot of a different handle configuration (model, num_envs, precision, noise mode, seed, env offset, "
+             "statistics modes)";
     return DART_E_INVALID;
   }
   CHK(h, hipSetDevice(h->device));
   CHK(h, hipStreamSynchronize(h->stream));
-  const unsigned char* p = (const unsigned char*)buf + 16;
+  const unsigned char* p = (const unsigned char*)buf + sizeof(SnapHeader);
   for (auto& b : v) { CHK(h, hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice)); p += b.second; }
   return DART_OK;
 }

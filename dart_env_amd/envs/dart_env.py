@@ -172,22 +172,21 @@ class BatchedDartEnv:
         elif isinstance(seeds, (int, np.integer)):
             seeds = [int(seeds) + i for i in range(self.num_envs)]
         assert len(seeds) == self.num_envs
-        self._pending_seeds = list(seeds)
+        for sd in seeds:
+            if sd is not None and not (isinstance(sd, (int, np.integer)) and 0 <= sd):
+                raise seeding.SeedError("Seed must be a non-negative integer or omitted, not %r" % (sd,))
+        # the seeds actually used (None -> OS entropy, resolved here once), returned like DartEnv.seed's [seed] (dart_env.py:117-119)
+        used = [seeding.create_seed(None if sd is None else int(sd)) for sd in seeds]
+        self._pending_seeds = list(used)
+        self._seeds = list(used)
         self._rngs = [None] * self.num_envs   # RandomStates are built lazily, on an env's first reset
         if self.noise == "philox":
-            s0 = seeding.create_seed(seeds[0])
-            self._stepper.configure(_st.CFG_SEED, float(s0 % (1 << 53)))
+            self._stepper.configure(_st.CFG_SEED, float(used[0] % (1 << 53)))
         elif self.noise == "mt19937":
             # the words numpy's RandomState.seed(list) receives in seeding.np_random (gym/utils/seeding.py:17-18)
-            used = []
-            for sd in seeds:
-                if sd is not None and not (isinstance(sd, (int, np.integer)) and 0 <= sd):
-                    raise seeding.SeedError("Seed must be a non-negative integer or omitted, not %r" % (sd,))
-                used.append(seeding.create_seed(sd))
             keys, klen = seeding.mt_keys(used)
             self._stepper.seed_mt19937(keys, klen)
-            self._seeds = used
-        return list(seeds)
+        return list(used)
 
     def _rng(self, i):
         if self._rngs[i] is None:

@@ -344,6 +344,28 @@ def parse_skel(path: str, dt: Optional[float] = None, skeleton_index: int = -1,
                 ground_y = top if ground_y is None else max(ground_y, top)
     if ground_y is None:
         ground_y = -np.inf  # no floor (e.g. reacher)
+    # everything else that is static or a second skeleton is NOT simulated: say so instead of letting a robot fall through a
+    # floor that is not the >= 100 m slab, or pass through an obstacle
+    import warnings
+    ignored = []
+    for si, sk in enumerate(skels):
+        if si == (skeleton_index % len(skels)):
+            continue
+        mob = sk.find("mobile")
+        static = mob is not None and mob.text.strip().lower() == "false"
+        for b in sk.findall("body"):
+            for cs in b.findall("collision_shape"):
+                s = _shape_from_xml(cs, 0, os.path.dirname(path))
+                if s is None:
+                    continue
+                if static and s.kind == SH_BOX and s.size[0] >= 100.0:
+                    continue      # the ground slab, simulated as the plane y = ground_y
+                ignored.append("%s/%s" % (sk.get("name", "skeleton %d" % si), b.get("name", "body")))
+    if ignored:
+        warnings.warn("parse_skel(%s): collision shapes outside the robot skeleton are not simulated (only a static box of >= 100 m is "
+                      "taken as the ground plane): %s%s" % (os.path.basename(path), ", ".join(sorted(set(ignored))[:6]),
+                                                            "" if ground_y > -np.inf else " -- and NO ground plane was found"),
+                      stacklevel=2)
 
     sk = skels[skeleton_index]
     T_sk = np.eye(4)

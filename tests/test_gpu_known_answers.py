@@ -124,7 +124,22 @@ def test_snapshot_restore_resumes_bitwise(env_id):
     other = dart_env_amd.vector.make(env_id, n // 2, **kw)
     with pytest.raises(StepperError):
         (other.env if hasattr(other, "env") else other._env).restore(snap)
-    other.close(); venv.close()
+    other.close()
+    # same size in bytes, different identity: another precision of half the batch (fp64 state of n / 2 envs = fp32 state of n) or
+    # another Philox shard offset is refused by the snapshot header, not restored silently
+    if env_id == "DartHopper-v1":
+        from dart_env_amd.stepper import HipStepper, CFG_ENV_OFFSET
+        from dart_env_amd.model_card import card_for
+        a = HipStepper(card_for(env_id), 32, precision=64); b = HipStepper(card_for(env_id), 32, precision=64)
+        b.configure(CFG_ENV_OFFSET, 32)
+        sa = a.snapshot()
+        b.configure(CFG_ENV_OFFSET, 32)
+        with pytest.raises(StepperError):
+            b.restore(sa)
+        b.configure(CFG_ENV_OFFSET, 0)
+        b.restore(sa)
+        a.close(); b.close()
+    venv.close()
 
 
 @pytest.mark.parametrize("kind", ["damping", "spring", "friction", "limit"])

@@ -9,6 +9,7 @@
 #include "impl_iface.hpp"
 #include "planar_kernel.hpp"
 #include "static_models.hpp"
+#include "cart_kernel.hpp"
 
 namespace dartk {
 
@@ -252,6 +253,121 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
   return p;
 }
 
+// ------------------------------------------------------------------ cart + pendulum chains (cart_kernel.hpp)
+template <class Real, int NP>
+struct CartImplT : Impl {
+  CartParams<Real, NP> P;
+  hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
+                  float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
+    dim3 grid((unsigned)((n + block_threads - 1) / block_threads)), block(block_threads);
+    hipLaunchKernelGGL((cart_step_kernel<Real, NP>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew, done, trunc,
+                       autoreset, seed, off);
+    return hipGetLastError();
+  }
+  hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
+                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off, int obs_masked_only) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((cart_reset_kernel<Real, NP>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, mask, qn, vn, obs, seed, off,
+                       obs_masked_only);
+    return hipGetLastError();
+  }
+  hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((state_io_kernel<Real, 1 + NP>), grid, block, 0, s, n, (Real*)q, (Real*)dq, qh, dqh, to_device);
+    return hipGetLastError();
+  }
+  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : 24; }   // limits only: one exact (pivoting) stage
+  void set_stats(unsigned long long*) override {}
+  int slots() const override { return 1 + NP; }
+};
+
+// cart (prismatic along x, body 0) + NP links on revolute +-z joints in a chain; welded bodies (the weights) fold into their link
+template <class Real, int NP>
+std::string fill_cart(const DartModelCard& c, CartParams<Real, NP>& P) {
+  constexpr int N = 1 + NP;
+  if (c.ndofs != N || c.nbodies < N) return "body/dof count";
+  if (c.task != DART_TASK_CARTPOLE && c.task != DART_TASK_CARTPOLE_SWINGUP && c.task != DART_TASK_DOUBLE_PENDULUM) return "task";
+  if (c.act_dim != 1 || c.act_dof0 != 0) return "action layout";
+  if (c.obs_dim != cart_obs_dim<NP>(c.task)) return "obs_dim";
+  if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
+  for (int d = 0; d < c.ndofs; d++) if (c.joint_friction[d] != 0.0) return "joint Coulomb friction";
+  for (int s = 0; s < c.nshapes; s++) if (c.shape_collidable[s]) return "collidable shapes";
+  if (c.jtype[0] != DART_JT_PRISMATIC || c.parent[0] != -1 || std::fabs(c.axes[0][0] - 1) > 1e-12) return "slider root";
+  if (!is_identity3(c.T_pj[0]) || !is_identity3(c.T_cj[0]) || c.T_cj[0][3] != 0 || c.T_cj[0][7] != 0) return "rotated slider frames";
+  int link_of_body[DART_MAX_BODIES], body_of_link[N], nl = 1;
+  double wx[DART_MAX_BODIES], wy[DART_MAX_BODIES];
+  for (int b = 0; b < c.nbodies; b++) { link_of_body[b] = -1; wx[b] = 0; wy[b] = 0; }
+  link_of_body[0] = 0; body_of_link[0] = 0;
+  for (int b = 1; b < c.nbodies; b++) {
+    const int pb = c.parent[b];
+    if (pb < 0 || link_of_body[pb] < 0) return "tree shape";
+    if (c.jtype[b] == DART_JT_WELD) {
+      if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b]) || c.T_pj[b][11] != 0 || c.T_cj[b][11] != 0) return "rotated weld";
+      link_of_body[b] = link_of_body[pb];
+      wx[b] = wx[pb] + c.T_pj[b][3] - c.T_cj[b][3]; wy[b] = wy[pb] + c.T_pj[b][7] - c.T_cj[b][7];
+      continue;
+    }
+    if (nl >= N) return "body/dof count";
+    if (c.jtype[b] != DART_JT_REVOLUTE || std::fabs(std::fabs(c.axes[b][2]) - 1) > 1e-12) return "link joint must be revolute about +-z";
+    if (link_of_body[pb] != nl - 1 || c.jtype[pb] == DART_JT_WELD) return "not a chain";
+    if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b]) || c.T_cj[b][3] != 0 || c.T_cj[b][7] != 0 || c.T_pj[b][11] != 0) return "joint frames";
+    if (c.dof_offset[b] != nl) return "dof order";
+    body_of_link[nl] = b; link_of_body[b] = nl++;
+  }
+  if (nl != N) return "body/dof count";
+  double lm[N], lcx[N], lcy[N], lizz[N];
+  for (int k = 0; k < N; k++) {
+    const int b = body_of_link[k];
+    if (c.com[b][2] != 0) return "com off plane";
+    lm[k] = c.mass[b]; lcx[k] = c.com[b][0]; lcy[k] = c.com[b][1]; lizz[k] = c.inertia[b][8];
+  }
+  P.tipx = 0; P.tipy = 0;
+  for (int b = 1; b < c.nbodies; b++) {
+    if (c.jtype[b] != DART_JT_WELD) continue;
+    const int k = link_of_body[b];
+    if (c.task == DART_TASK_DOUBLE_PENDULUM && b == c.aux_body[1]) {
+      if (k != N - 1) return "weight must hang on the last link";
+      P.tipx = (Real)wx[b]; P.tipy = (Real)wy[b];
+    }
+    if (c.mass[b] == 0) continue;
+    const double mb = c.mass[b], bx = wx[b] + c.com[b][0], by = wy[b] + c.com[b][1];
+    const double m = lm[k] + mb, nx = (lm[k] * lcx[k] + mb * bx) / m, ny = (lm[k] * lcy[k] + mb * by) / m;
+    lizz[k] = lizz[k] + lm[k] * ((lcx[k] - nx) * (lcx[k] - nx) + (lcy[k] - ny) * (lcy[k] - ny)) + c.inertia[b][8] +
+              mb * ((bx - nx) * (bx - nx) + (by - ny) * (by - ny));
+    lm[k] = m; lcx[k] = nx; lcy[k] = ny;
+  }
+  if (c.task == DART_TASK_DOUBLE_PENDULUM && (c.aux_body[0] != 0 || c.aux_body[1] < 0 || c.aux_body[1] >= c.nbodies ||
+                                              link_of_body[c.aux_body[1]] != N - 1)) return "double pendulum bodies";
+  P.cart_mass = (Real)lm[0];
+  for (int k = 1; k < N; k++) {
+    const int b = body_of_link[k], i = k - 1;
+    P.sigma[i] = (Real)(c.axes[b][2] > 0 ? 1.0 : -1.0);
+    P.mass[i] = (Real)lm[k]; P.cx[i] = (Real)lcx[k]; P.cy[i] = (Real)lcy[k]; P.izz[i] = (Real)lizz[k];
+    P.jx[i] = (Real)c.T_pj[b][3]; P.jy[i] = (Real)c.T_pj[b][7];
+  }
+  for (int d = 0; d < N; d++) {
+    P.lo[d] = (Real)(c.limited[d] ? c.lower[d] : -INFINITY); P.hi[d] = (Real)(c.limited[d] ? c.upper[d] : INFINITY);
+    P.damp[d] = (Real)c.damping[d]; P.stiff[d] = (Real)c.stiffness[d]; P.rest[d] = (Real)c.rest[d];
+    P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
+  }
+  P.dt = (Real)c.dt; P.g = (Real)(-c.gravity[1]); P.limit_erp_dt = (Real)(c.limit_erp / c.dt); P.max_erv = (Real)c.max_erv;
+  P.cfm1 = (Real)(1.0 + c.cfm);
+  P.act_scale = (Real)c.act_scale[0]; P.act_lo = (Real)c.act_low[0]; P.act_hi = (Real)c.act_high[0];
+  for (int k = 0; k < 8; k++) P.aux[k] = (Real)c.aux_real[k];
+  if (c.task == DART_TASK_CARTPOLE) { P.aux[0] = (Real)c.alive_bonus; P.aux[1] = (Real)c.ctrl_cost; }
+  P.angle_max = (Real)c.angle_max; P.s_max = (Real)c.state_abs_max; P.noise = (Real)c.reset_noise; P.noise_v = (Real)c.reset_noise_vel;
+  P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task; P.iters = 24;
+  return "";
+}
+
+template <class Real, int NP>
+std::unique_ptr<Impl> make_cart(const DartModelCard& c, std::string& why) {
+  auto p = std::make_unique<CartImplT<Real, NP>>();
+  std::string w = fill_cart<Real, NP>(c, p->P);
+  if (!w.empty()) { why += w; return nullptr; }
+  return p;
+}
+
 template <class Real>
 std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool allow_static) {
   why += "hopper-chain, feet only: ";
@@ -264,6 +380,10 @@ std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool
   if (auto p = make_for_topology<Real, Walker2dAllTopo, Walker2dAllStatic<Real>>(c, why, allow_static)) return p;
   why += "; half-cheetah: ";
   if (auto p = make_for_topology<Real, CheetahTopo, void>(c, why, allow_static)) return p;
+  why += "; cart + 1 link: ";
+  if (auto p = make_cart<Real, 1>(c, why)) return p;
+  why += "; cart + 2 links: ";
+  if (auto p = make_cart<Real, 2>(c, why)) return p;
   return nullptr;
 }
 

@@ -61,6 +61,7 @@ __device__ __host__ constexpr int tri(int i, int j) { return i >= j ? i * (i + 1
 // (slow_constraints) -- exact for any number of contacts, and never on the path of a workload that stays within the tiers.
 struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - shin - foot; ONLY the foot collides (BASELINE config[1])
   static constexpr int NL = 4, NDOF = NL + 2, NC = 1, NA = 3, TIER0 = 1, TIER1 = 0, TIER1_F64 = 0;
+  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = false;  // warm-started active sets: measured -4 % here (short, violent episodes)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3}; return L[c]; }
@@ -68,6 +69,7 @@ struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - s
 };
 struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour, the default card)
   static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2, TIER1_F64 = 2;
+  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = false;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3}; return L[c]; }
@@ -75,6 +77,7 @@ struct HopperAllTopo {  // the same chain with EVERY capsule tested against the 
 };
 struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin foot) x 2; only the feet collide
   static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
+  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;   // measured +26 % (persistent double-support contacts)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3, 6}; return L[c]; }
@@ -82,6 +85,7 @@ struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin f
 };
 struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the floor (DART's behaviour, the default card)
   static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
+  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3, 4, 5, 6}; return L[c]; }
@@ -89,12 +93,16 @@ struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the flo
 };
 
 struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded head) - (thigh shin foot) x 2, eight capsules, joint springs
-  // a thrashing cheetah rests on 3 capsules in half of the waves, on 4 in 6 % of them (1 % / 0.1 % of the envs): fp32 runs a
-  // 4-slot second tier.  fp64 does not: register tiers of 12 and 14 LCP rows (312 / 420 VGPRs of matrix, 3-5 KB of scratch
-  // per lane) produced wrong states on gfx950 / ROCm 7.2 in some instantiations while the same source is right in fp32, on
-  // the host and with <= 10 rows (Walker2d: 4 M env-steps at 1e-13 of the oracle) -- fp64 keeps the 2-slot tier and sends
-  // the envs with more contacts through the fallback solver (1.7 ms instead of 1.0 ms per batched step at 65 536 envs).
-  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4, TIER1_F64 = 0;
+  // A thrashing cheetah rests on 3 capsules in half of the waves and on 4 in 6 % of them (1 % / 0.1 % of the envs), so a second
+  // register tier of 4 (fp32) / 3 (fp64) slots pays: 0.36 / 1.2 ms per batched step at 65 536 envs against 1.6 / 1.7 with one tier.
+  // That tier is 12 / 14 LCP rows (312 / 420 registers of matrix per lane, KBs of scratch).  INLINED into the step kernel it was
+  // NOT TRUSTWORTHY on gfx950 / ROCm 7.2: some instantiations (fp64 lean 3-slot, fp64 and fp32 reporting 4-slot) produced states
+  // that differed from the host build of the same source, from the fp64 oracle and -- the fp32 reporting kernel -- between the
+  // first and every later launch of one process.  As a real call on copies of its inputs (ISOLATED_TIER1, constraint_phase_call)
+  // every instantiation is bitwise repeatable and 3e-13 (fp64) / 6e-7 (fp32) per step from the oracle with all four slots in
+  // use; tests/test_gpu_repeatability.py and tools/gpu/determinism.py keep watching it.
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4, TIER1_F64 = 3;
+  static constexpr bool ISOLATED_TIER1 = true;
   static constexpr bool WARM = true;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 0, 1, 2, 3, 4, 5, 6}; return L[c]; }
@@ -681,6 +689,19 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   });
 }
 
+// A tier as a real function call on copies of its inputs (topologies with ISOLATED_TIER1).
+template <class Real, class T>
+struct TierIO {
+  Real q[T::NDOF], H[T::NDOF * (T::NDOF + 1) / 2], px[T::NL], py[T::NL], vs[T::NDOF], cPx[T::NC], cPy[T::NC], cdep[T::NC];
+  bool con[T::NC], off;
+  WarmSets warm;
+  ReportTo<Real> rp;
+};
+template <class Real, class T, class PT, int NCA, bool EXTRAS>
+__device__ __attribute__((noinline)) void constraint_phase_call(PT P, TierIO<Real, T>& io) {
+  constraint_phase<Real, T, PT, NCA, EXTRAS>(P, io.q, io.H, io.px, io.py, io.vs, io.con, io.cPx, io.cPy, io.cdep, io.off, io.warm, io.rp);
+}
+
 // ------------------------------------------------------------------ single-lane fallback: any number of contacts, loops over LDS
 // Executed by ONE lane at a time (the others of its wave wait) for an env with more touching capsules than the register
 // tiers hold -- the robot lying on the floor.  Same LCP, same two-stage pivoting with the same start sets and tolerances
@@ -1026,7 +1047,21 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   // ---- register tiers: the smallest one that holds every (remaining) lane's contacts
   const int nreg = slow ? 0 : nact;
   if constexpr (tier1<T, Real>() > 0) {
-    if (__any(nreg > T::TIER0)) constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
+    if (__any(nreg > T::TIER0)) {
+      if constexpr (T::ISOLATED_TIER1) {   // a real call on copies of the inputs: the big tier gets a register allocation of its own
+        TierIO<Real, T> io;
+        sfor<0, N>([&](auto I) { io.q[I] = q[I]; io.vs[I] = vs[I]; });
+        sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = H[I]; });
+        sfor<0, NL>([&](auto K) { io.px[K] = px[K]; io.py[K] = py[K]; });
+        sfor<0, NC>([&](auto Cc) { io.con[Cc] = con[Cc]; io.cPx[Cc] = cPx[Cc]; io.cPy[Cc] = cPy[Cc]; io.cdep[Cc] = cdep[Cc]; });
+        io.off = slow; io.warm = warm; io.rp = rp;
+        constraint_phase_call<Real, T, PT, tier1<T, Real>(), EXTRAS>(P, io);
+        sfor<0, N>([&](auto I) { vs[I] = io.vs[I]; });
+        warm = io.warm;
+      } else {
+        constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
+      }
+    }
     else constraint_phase<Real, T, PT, T::TIER0, EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
   } else {
     constraint_phase<Real, T, PT, T::TIER0, EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);

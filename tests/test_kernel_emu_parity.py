@@ -126,3 +126,32 @@ def test_half_cheetah_on_the_register_kernel():
     acts, ref = make_reference(card, 64, 200)
     s = run_host_api(EmuStepper(card, 64, precision=64), acts, ref)
     assert s["done_flag_mismatches"] == 0 and s["q"] < 1e-9 and s["dq"] < 1e-8, (s["q"], s["dq"])
+
+
+@pytest.mark.parametrize("env_id,qnoise,vnoise", [("DartCartPole-v1", 0.01, 0.01), ("DartCartPoleSwingUp-v1", 0.1, 0.01),
+                                                   ("DartDoubleInvertedPendulumEnv-v1", 0.1, 0.1)])
+def test_cart_family_on_the_lane_kernel(env_id, qnoise, vnoise):
+    """csrc/cart_kernel.hpp: slider + one or two hinged poles, joint limits through the pivoting LCP, tasks 5 / 7 / 8 -- state,
+    observation, reward and done flags against the oracle with resets on the oracle's flags"""
+    from tests.batch_oracle import OracleBatch
+    card = card_for(env_id); n = 64; nd, na = card.ndofs, card.act_dim
+    rng = np.random.RandomState(3)
+    g = EmuStepper(card, n, precision=64); o = OracleBatch(card, n)
+    qn = rng.uniform(-qnoise, qnoise, (n, nd)); vn = rng.uniform(-vnoise, vnoise, (n, nd))
+    og = g.reset(None, qn, vn); o.reset(None, qn, vn)
+    assert np.allclose(og, o.obs(), atol=1e-6)
+    worst = dict(q=0.0, dq=0.0, obs=0.0, rew=0.0); dones = 0
+    for t in range(150):
+        a = rng.uniform(-1.5, 1.5, (n, na)).astype(np.float32)
+        ob, r, d, _ = g.step(a); oo, ro, do, _ = o.step(a)
+        assert np.array_equal(d.astype(bool), do.astype(bool)), t
+        qg, dqg = g.get_state(); qo, dqo = o.state()
+        for key, x, y in (("q", qg, qo), ("dq", dqg, dqo), ("obs", ob, oo), ("rew", r, ro)):
+            worst[key] = max(worst[key], float(np.abs(np.asarray(x, dtype=np.float64) - y).max()))
+        dones += int(do.sum())
+        if do.any():
+            qn = rng.uniform(-qnoise, qnoise, (n, nd)); vn = rng.uniform(-vnoise, vnoise, (n, nd))
+            g.reset(do.astype(np.uint8), qn, vn, want_obs=False); o.reset(do, qn, vn)
+    assert worst["q"] < 1e-9 and worst["dq"] < 1e-8 and worst["obs"] < 1e-5 and worst["rew"] < 5e-6, worst       # obs and reward cross the ABI as float32
+    if env_id != "DartCartPoleSwingUp-v1":
+        assert dones > 0

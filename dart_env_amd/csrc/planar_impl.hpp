@@ -118,23 +118,31 @@ static inline bool is_identity3(const double* T16, double tol = 1e-12) {
 template <class Real, class T>
 std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   constexpr int NL = T::NL;
+  // plane of motion: x-y (rotations about +-z, gravity along -y) or, for topologies with PLANE_XZ, the horizontal x-z plane
+  // (rotations about +-y -- a turn about +y is clockwise seen in (x, z) coordinates, hence the opposite sigma; gravity is normal
+  // to the plane and drops out).  V = index of the second in-plane coordinate, W = the normal one.
+  constexpr bool XZ = topo_plane_xz<T>::value;
+  constexpr int V = XZ ? 2 : 1, W = XZ ? 1 : 2;
   if (c.ndofs != T::NDOF || c.nbodies < NL + 2) return "body/dof count";
   if (c.act_dim != T::NA || c.act_dof0 != T::NDOF - T::NA) return "action layout";
   if (c.obs_dim != 2 * T::NDOF - 1 && c.task != DART_TASK_NONE) return "obs_dim";
-  if (c.task != DART_TASK_NONE && c.task != DART_TASK_HOPPER && c.task != DART_TASK_WALKER2D && c.task != DART_TASK_HALFCHEETAH) return "task";
+  if (XZ != (c.task == DART_TASK_SNAKE)) return "task";
+  if (c.task != DART_TASK_NONE && c.task != DART_TASK_HOPPER && c.task != DART_TASK_WALKER2D && c.task != DART_TASK_HALFCHEETAH &&
+      c.task != DART_TASK_SNAKE) return "task";
   for (int d = 0; d < c.ndofs; d++) if (c.joint_friction[d] != 0.0) return "joint Coulomb friction";
   if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
   // floating base: prismatic x, prismatic y, revolute +-z
   if (c.jtype[0] != DART_JT_PRISMATIC || c.jtype[1] != DART_JT_PRISMATIC || c.parent[0] != -1 || c.parent[1] != 0)
     return "root carriers";
-  if (std::fabs(c.axes[0][0] - 1) > 1e-12 || std::fabs(c.axes[1][1] - 1) > 1e-12) return "root prismatic axes";
+  if (std::fabs(c.axes[0][0] - 1) > 1e-12 || std::fabs(c.axes[1][V] - 1) > 1e-12) return "root prismatic axes";
   if (c.mass[0] != 0 || c.mass[1] != 0) return "root carriers must be massless";
-  double x0 = 0, y0 = 0;
+  double x0 = 0, y0 = 0, y_plane = 0;   // y_plane: height of an x-z plane of motion
   for (int b = 0; b < 3; b++) {
     if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated root frames";
+    y_plane += c.T_pj[b][7] - c.T_cj[b][7];
     x0 += c.T_pj[b][3] - c.T_cj[b][3];
-    y0 += c.T_pj[b][7] - c.T_cj[b][7];
-    if (c.T_pj[b][11] != 0 || c.T_cj[b][11] != 0) return "root z offset";
+    y0 += c.T_pj[b][3 + 4 * V] - c.T_cj[b][3 + 4 * V];
+    if (!XZ && (c.T_pj[b][3 + 4 * W] != 0 || c.T_cj[b][3 + 4 * W] != 0)) return "root offset out of the plane";
   }
   P.root_x0 = (Real)x0; P.root_y0 = (Real)y0;
   // bodies -> links (welded bodies share their parent's link, shifted by the weld offset)
@@ -146,9 +154,9 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
       const int pb = c.parent[b];
       if (b == 2 || pb < 2 || link_of_body[pb] < 0) return "weld without a link to hold it";
       if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated weld";
-      if (c.T_pj[b][11] != 0 || c.T_cj[b][11] != 0) return "weld off plane";
+      if (c.T_pj[b][3 + 4 * W] != 0 || c.T_cj[b][3 + 4 * W] != 0) return "weld off plane";
       link_of_body[b] = link_of_body[pb];
-      wx[b] = wx[pb] + c.T_pj[b][3] - c.T_cj[b][3]; wy[b] = wy[pb] + c.T_pj[b][7] - c.T_cj[b][7];
+      wx[b] = wx[pb] + c.T_pj[b][3] - c.T_cj[b][3]; wy[b] = wy[pb] + c.T_pj[b][3 + 4 * V] - c.T_cj[b][3 + 4 * V];
       continue;
     }
     if (nl >= NL) return "body/dof count";
@@ -159,21 +167,21 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   for (int k = 0; k < NL; k++) {
     const int b = body_of_link[k];
     if (c.jtype[b] != DART_JT_REVOLUTE) return "non-revolute link joint";
-    if (std::fabs(std::fabs(c.axes[b][2]) - 1) > 1e-12) return "link axis must be +-z";
+    if (std::fabs(std::fabs(c.axes[b][W]) - 1) > 1e-12) return "link axis must be normal to the plane";
     if (k > 0) {
       const int pb = c.parent[b];
       if (pb < 2 || link_of_body[pb] != T::parent(k)) return "tree shape";
       if (c.jtype[pb] == DART_JT_WELD) return "joint on a welded body";
       if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated joint frames";
-      if (c.T_pj[b][11] != 0 || c.T_cj[b][3] != 0 || c.T_cj[b][7] != 0 || c.T_cj[b][11] != 0) return "joint offsets";
-      P.jx[k] = (Real)c.T_pj[b][3]; P.jy[k] = (Real)c.T_pj[b][7];
+      if (c.T_pj[b][3 + 4 * W] != 0 || c.T_cj[b][3] != 0 || c.T_cj[b][7] != 0 || c.T_cj[b][11] != 0) return "joint offsets";
+      P.jx[k] = (Real)c.T_pj[b][3]; P.jy[k] = (Real)c.T_pj[b][3 + 4 * V];
     } else {
       if (c.parent[b] != 1) return "root link parent";
       P.jx[0] = 0; P.jy[0] = 0;
     }
-    if (c.com[b][2] != 0) return "com off plane";
-    P.sigma[k] = (Real)(c.axes[b][2] > 0 ? 1.0 : -1.0);
-    lm[k] = c.mass[b]; lcx[k] = c.com[b][0]; lcy[k] = c.com[b][1]; lizz[k] = c.inertia[b][8];
+    if (c.com[b][W] != 0) return "com off plane";
+    P.sigma[k] = (Real)((c.axes[b][W] > 0) != XZ ? 1.0 : -1.0);
+    lm[k] = c.mass[b]; lcx[k] = c.com[b][0]; lcy[k] = c.com[b][V]; lizz[k] = c.inertia[b][4 * W];
     const int d = c.dof_offset[b];
     if (d != 2 + k) return "dof order";
     bool lim = c.limited[d] != 0;
@@ -183,11 +191,11 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   }
   for (int b = 2; b < c.nbodies; b++) {   // fold the welded bodies in: composite mass, COM, inertia about the new COM
     if (c.jtype[b] != DART_JT_WELD || c.mass[b] == 0) continue;
-    if (c.com[b][2] != 0) return "com off plane";
+    if (c.com[b][W] != 0) return "com off plane";
     const int k = link_of_body[b];
-    const double mb = c.mass[b], bx = wx[b] + c.com[b][0], by = wy[b] + c.com[b][1];
+    const double mb = c.mass[b], bx = wx[b] + c.com[b][0], by = wy[b] + c.com[b][V];
     const double m = lm[k] + mb, nx = (lm[k] * lcx[k] + mb * bx) / m, ny = (lm[k] * lcy[k] + mb * by) / m;
-    lizz[k] = lizz[k] + lm[k] * ((lcx[k] - nx) * (lcx[k] - nx) + (lcy[k] - ny) * (lcy[k] - ny)) + c.inertia[b][8] +
+    lizz[k] = lizz[k] + lm[k] * ((lcx[k] - nx) * (lcx[k] - nx) + (lcy[k] - ny) * (lcy[k] - ny)) + c.inertia[b][4 * W] +
               mb * ((bx - nx) * (bx - nx) + (by - ny) * (by - ny));
     lm[k] = m; lcx[k] = nx; lcy[k] = ny;
   }
@@ -198,6 +206,18 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
     P.stiff[d] = (Real)c.stiffness[d]; P.rest[d] = (Real)c.rest[d];
   }
   int nc = 0;
+  if constexpr (!topo_contacts<T>::value) {
+    // the robot slides in a horizontal plane: its joints cannot bring a shape to the floor, so a shape that clears it now always will
+    for (int s = 0; s < c.nshapes; s++) {
+      if (!c.shape_collidable[s]) continue;
+      const double reach = c.shape_type[s] == DART_SH_CAPSULE ? c.shape_size[s][0] + 0.5 * c.shape_size[s][1]
+                                                               : 0.5 * std::sqrt(c.shape_size[s][0] * c.shape_size[s][0] + c.shape_size[s][1] * c.shape_size[s][1] + c.shape_size[s][2] * c.shape_size[s][2]);
+      const double clear = c.shape_type[s] == DART_SH_CAPSULE && std::fabs(c.shape_pose[s][4 + 2]) < 1e-9 ? c.shape_size[s][0] : reach;
+      if (y_plane + c.shape_pose[s][7] - clear <= c.ground_y) return "a shape reaches the floor";
+    }
+    for (int k = 0; k < T::NC; k++) { P.e1x[k] = P.e1y[k] = P.e2x[k] = P.e2y[k] = 0; P.rad[k] = (Real)-INFINITY; P.cbody[k] = 0; }
+    nc = T::NC;
+  } else
   for (int s = 0; s < c.nshapes; s++) {
     if (!c.shape_collidable[s]) continue;
     if (c.shape_type[s] != DART_SH_CAPSULE) return "collidable non-capsule shape";
@@ -214,7 +234,8 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
     nc++;
   }
   if (nc != T::NC) return "collidable shape count";
-  P.dt = (Real)c.dt; P.ground_y = (Real)c.ground_y; P.g = (Real)(-c.gravity[1]); P.mu = (Real)c.friction;
+  (void)y_plane;
+  P.dt = (Real)c.dt; P.ground_y = (Real)c.ground_y; P.g = (Real)(XZ ? 0.0 : -c.gravity[1]); P.mu = (Real)c.friction;
   P.erp_dt = (Real)(c.erp / c.dt); P.max_erv = (Real)c.max_erv; P.limit_erp_dt = (Real)(c.limit_erp / c.dt);
   P.cfm1 = (Real)(1.0 + c.cfm); P.ccfm1 = (Real)(1.0 + c.contact_cfm);
   for (int k = 0; k < T::NA; k++) {
@@ -228,6 +249,11 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   P.penalty_link = c.penalty_dof >= 2 ? c.penalty_dof - 2 : -1;
   if (c.task != DART_TASK_NONE && c.height_body != 2) return "height body must be the root link";
   P.solver = 0; P.iters1 = 24; P.iters2 = 24; P.stats = nullptr; P.force_slow = 0; P.ex = Extras<Real>();
+  P.fluid_k = 0; P.dev_cost = 0;
+  if (c.task == DART_TASK_SNAKE) {   // aux_real = {alive bonus, control cost, deviation cost, fluid coefficient} (model_card.py SNAKE)
+    P.alive = (Real)c.aux_real[0]; P.ctrl_cost = (Real)c.aux_real[1]; P.dev_cost = (Real)c.aux_real[2]; P.fluid_k = (Real)c.aux_real[3];
+    P.pen_each = 0; P.penalty_link = -1;
+  }
   return "";
 }
 
@@ -380,6 +406,8 @@ std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool
   if (auto p = make_for_topology<Real, Walker2dAllTopo, Walker2dAllStatic<Real>>(c, why, allow_static)) return p;
   why += "; half-cheetah: ";
   if (auto p = make_for_topology<Real, CheetahTopo, void>(c, why, allow_static)) return p;
+  why += "; snake chain in the x-z plane: ";
+  if (auto p = make_for_topology<Real, SnakeTopo, void>(c, why, allow_static)) return p;
   why += "; cart + 1 link: ";
   if (auto p = make_cart<Real, 1>(c, why)) return p;
   why += "; cart + 2 links: ";

@@ -109,6 +109,26 @@ struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded hea
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
 
+struct SnakeTopo {  // reference assets/snake_7link.skel: seven links in a chain, sliding in the horizontal x-z plane 1 mm above the floor
+  // Gravity is normal to the plane of motion and nothing can reach the floor: no contact rows at all (NC = 1 is a placeholder that
+  // is never tested, TIER0 = 0), six limit rows, and the fluid force of snake_7link.py:37-47 on every body before every world step.
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 1, NA = 6, TIER0 = 0, TIER1 = 0, TIER1_F64 = 0;
+  static constexpr bool ISOLATED_TIER1 = false;
+  static constexpr bool WARM = true;
+  static constexpr bool CONTACTS = false, FLUID = true, PLANE_XZ = true;
+  __device__ __host__ static constexpr int parent(int k) { return k - 1; }
+  __device__ __host__ static constexpr int clink(int) { return 0; }
+  __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
+};
+
+// optional traits (default: a robot in the vertical x-y plane with capsules that can touch the floor, no fluid)
+template <class T, class = void> struct topo_contacts { static constexpr bool value = true; };
+template <class T> struct topo_contacts<T, decltype((void)T::CONTACTS)> { static constexpr bool value = T::CONTACTS; };
+template <class T, class = void> struct topo_fluid { static constexpr bool value = false; };
+template <class T> struct topo_fluid<T, decltype((void)T::FLUID)> { static constexpr bool value = T::FLUID; };
+template <class T, class = void> struct topo_plane_xz { static constexpr bool value = false; };
+template <class T> struct topo_plane_xz<T, decltype((void)T::PLANE_XZ)> { static constexpr bool value = T::PLANE_XZ; };
+
 template <class T>
 __device__ __host__ constexpr bool is_anc(int j, int k) {  // j ancestor-or-self of k
   while (k >= 0) {
@@ -131,7 +151,7 @@ __device__ __host__ constexpr int limit_slot(int k) {  // LCP slot of link k's l
 }
 template <class T, class Real> __device__ __host__ constexpr int tier1() { return sizeof(Real) == 8 ? T::TIER1_F64 : T::TIER1; }
 template <class T, class Real> __device__ __host__ constexpr int last_tier() { return tier1<T, Real>() > 0 ? tier1<T, Real>() : T::TIER0; }
-template <class T, class Real> __device__ __host__ constexpr bool has_slow_path() { return T::NC > last_tier<T, Real>(); }
+template <class T, class Real> __device__ __host__ constexpr bool has_slow_path() { return topo_contacts<T>::value && T::NC > last_tier<T, Real>(); }
 template <class T> __device__ __host__ constexpr int max_rows() { return 2 * T::NC + n_limited<T>(); }
 // ancestor-or-self sets of all links, 8 bits per link (NL <= 8): bit j of byte k = is_anc(j, k)
 template <class T>
@@ -189,6 +209,8 @@ struct Params {
   unsigned long long* stats;   // optional [2][32] histogram of wave-level pivoting iterations per stage (debug), or null
   int cbody[T::NC];            // card body index of each candidate capsule (contact report)
   Extras<Real> ex;
+  Real fluid_k;                // topologies with FLUID: force -k (v_com . n) n on every body, n = the body's in-plane normal
+  Real dev_cost;               // task 9 (snake): reward -= dev_cost |q[2]|
 };
 
 // compile-time "is this model parameter exactly zero" (always false for the runtime block): lets the specialised
@@ -449,10 +471,11 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
                                                  const Real (&cdep)[T::NC], bool off, WarmSets& warm, const ReportTo<Real>& rp) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * NCA + n_limited<T>();
   constexpr bool IDENT = (NCA == NC);   // slot s IS candidate s: links are compile-time constants
+  constexpr int NS = NCA > 0 ? NCA : 1;   // array extent of the slot arrays (a tier without contact slots still declares them)
   // ---- compaction: slot s takes the s-th touching capsule (capsule order = the oracle's serial order)
-  bool son[NCA];
-  Real sPx[NCA], sPy[NCA], sdep[NCA];
-  uint32_t samask[NCA];   // ancestor-or-self set of the slot's link (bit j = link j moves the contact point)
+  bool son[NS];
+  Real sPx[NS], sPy[NS], sdep[NS];
+  uint32_t samask[NS];   // ancestor-or-self set of the slot's link (bit j = link j moves the contact point)
   uint32_t cid = 0;
   if constexpr (IDENT) {
     sfor<0, NCA>([&](auto S) {
@@ -479,7 +502,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   }
   Real A[M * (M + 1) / 2], b[M], lo[M], hi[M], x[M];
   bool act[M];
-  Real Jn[NCA][N], Jt[NCA][N], Yn[NCA][N], Yt[NCA][N];
+  Real Jn[NS][N], Jt[NS][N], Yn[NS][N], Yt[NS][N];
   bool any = false;
   sfor<0, NCA>([&](auto S) {
     constexpr int sl = S;
@@ -926,6 +949,21 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       Fx[k] = fx; Fy[k] = fy; Nz[k] = ox * fy - oy * fx;
     }
   });
+  if constexpr (topo_fluid<T>::value) {
+    // Fluid model of snake_7link.py:37-47: every body is pushed by -k (v_com . n) n at its frame origin (= its joint origin), n =
+    // the body's local z axis, which lies in the plane of motion; the +-0.05 (w x n) terms of the reference drop out of the dot
+    // product.  The carrier of the second root translation takes the same force: a drag on that translation alone.
+    Real vpx[NL], vpy[NL];   // velocity of the link's joint origin
+    sfor<0, NL>([&](auto K) {
+      constexpr int k = K;
+      if constexpr (k == 0) { vpx[0] = dq[0]; vpy[0] = dq[1]; }
+      else { constexpr int p = T::parent(k); vpx[k] = vpx[p] - om[p] * ly[k]; vpy[k] = vpy[p] + om[p] * lx[k]; }
+      const Real ox = c[k] * P.cx[k] - s[k] * P.cy[k], oy = s[k] * P.cx[k] + c[k] * P.cy[k];
+      const Real vn = -(vpx[k] - om[k] * oy) * s[k] + (vpy[k] + om[k] * ox) * c[k];
+      const Real f = -P.fluid_k * vn;
+      Fx[k] += f * s[k]; Fy[k] -= f * c[k];    // F holds inertial minus applied force; the force is f * n, n = (-s, c)
+    });
+  }
   // ---- backward pass: fold each composite into its parent, shifting the reference point by the link vector
   sfor_rev<1, NL>([&](auto K) {
     constexpr int k = K, p = T::parent(k);
@@ -942,6 +980,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   H[tri(rev<N>(0), rev<N>(0))] = mc[0]; H[tri(rev<N>(1), rev<N>(0))] = Real(0); H[tri(rev<N>(1), rev<N>(1))] = mc[0];
   rhs[0] = tau[0] - Fx[0];
   rhs[1] = tau[1] - Fy[0];
+  if constexpr (topo_fluid<T>::value) rhs[1] -= P.fluid_k * dq[1];
   if constexpr (!DART_ZERO(PT, damp, 0)) rhs[0] -= P.damp[0] * dq[0];
   if constexpr (!DART_ZERO(PT, damp, 1)) rhs[1] -= P.damp[1] * dq[1];
   if constexpr (!DART_ZERO(PT, stiff, 0)) rhs[0] -= P.stiff[0] * (q[0] + P.dt * dq[0] - P.rest[0]);
@@ -964,7 +1003,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     if constexpr (!DART_ZERO(PT, stiff, i)) rhs[i] -= P.stiff[i] * (q[i] + P.dt * dq[i] - P.rest[i]);
   });
   if (EXTRAS && P.ex.ext_force != nullptr) {   // external force at the frame origin (= joint origin) of link ext_link: generalized force J^T f
-    const Real fx = P.ex.ext_force[env * 3], fy = P.ex.ext_force[env * 3 + 1];
+    const Real fx = P.ex.ext_force[env * 3], fy = P.ex.ext_force[env * 3 + (topo_plane_xz<T>::value ? 2 : 1)];
     rhs[0] += fx; rhs[1] += fy;
     sfor<0, NL>([&](auto K) {
       constexpr int k = K;
@@ -994,7 +1033,8 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   bool con[NC];
   Real cPx[NC], cPy[NC], cdep[NC];
   int nact = 0;
-  sfor<0, NC>([&](auto Cc) {
+  if constexpr (!topo_contacts<T>::value) { sfor<0, NC>([&](auto Cc) { con[Cc] = false; cPx[Cc] = Real(0); cPy[Cc] = Real(0); cdep[Cc] = Real(0); }); }
+  else sfor<0, NC>([&](auto Cc) {
     constexpr int cidx = Cc, k = T::clink(cidx);
     Real x1 = px[k] + c[k] * P.e1x[cidx] - s[k] * P.e1y[cidx], y1 = py[k] + s[k] * P.e1x[cidx] + c[k] * P.e1y[cidx];
     Real x2 = px[k] + c[k] * P.e2x[cidx] - s[k] * P.e2y[cidx], y2 = py[k] + s[k] * P.e2x[cidx] + c[k] * P.e2y[cidx];
@@ -1182,6 +1222,9 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     ok = ok && isfinite(q[i]) && isfinite(dq[i]) && (fabs(dq[i]) < P.s_max);
     if constexpr (i >= 2) ok = ok && (fabs(q[i]) < P.s_max);
   });
+  if constexpr (topo_fluid<T>::value) {   // snake_7link.py:72-84: deviation cost on the heading, observation q[1:], dq
+    if (P.task == 9) { rew -= P.dev_cost * fabs(q[2]); height = q[1]; }
+  }
   if (P.task == 6) {   // half_cheetah.py:50-63: the reward is zeroed when the state broke; the observation starts with q[1] itself
     rew = ok ? rew : Real(0);
     height = q[1];
@@ -1196,7 +1239,7 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, P.noise_v, q, dq);
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
     el = 0;
-    height = (P.task == 6) ? q[1] : root_height<Real, T, PT>(P, q);
+    height = (P.task == 6 || P.task == 9) ? q[1] : root_height<Real, T, PT>(P, q);
     if (valid) episode[e] = ep;
   }
   if (valid) {
@@ -1236,7 +1279,7 @@ __global__ void __launch_bounds__(256) reset_kernel(PT P, int64_t n_envs, Real* 
   } else {
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + e]; dq[i] = dqs[(int64_t)i * n_envs + e]; });
   }
-  if (obs && (m || !obs_masked_only)) write_obs<Real, T, PT>(P, q, dq, (P.task == 6) ? q[1] : root_height<Real, T, PT>(P, q), obs + e * (2 * N - 1));
+  if (obs && (m || !obs_masked_only)) write_obs<Real, T, PT>(P, q, dq, (P.task == 6 || P.task == 9) ? q[1] : root_height<Real, T, PT>(P, q), obs + e * (2 * N - 1));
 }
 
 // (N, n) row-major doubles  <->  SoA state, for set_state / get_state (dart_env.py:145-148, 211-215)

@@ -155,3 +155,28 @@ def test_cart_family_on_the_lane_kernel(env_id, qnoise, vnoise):
     assert worst["q"] < 1e-9 and worst["dq"] < 1e-8 and worst["obs"] < 1e-5 and worst["rew"] < 5e-6, worst       # obs and reward cross the ABI as float32
     if env_id != "DartCartPoleSwingUp-v1":
         assert dones > 0
+
+
+def test_snake_on_the_register_kernel():
+    """snake_7link.skel on SnakeTopo: motion in the horizontal x-z plane (rotations about +y = clockwise in (x, z)), no contact
+    rows, six limit rows, the fluid force on every body before every world step, deviation cost and |q[2]| >= 1.5 ending"""
+    from tests.batch_oracle import OracleBatch
+    card = card_for("DartSnake7Link-v1"); n = 64; nd, na = card.ndofs, card.act_dim
+    rng = np.random.RandomState(3)
+    g = EmuStepper(card, n, precision=64); o = OracleBatch(card, n)
+    qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+    og = g.reset(None, qn, vn); o.reset(None, qn, vn)
+    assert np.allclose(og, o.obs(), atol=1e-6)
+    dones = 0
+    for t in range(200):
+        a = rng.uniform(-1.5, 1.5, (n, na)).astype(np.float32)
+        ob, r, d, _ = g.step(a); oo, ro, do, _ = o.step(a)
+        assert np.array_equal(d.astype(bool), do.astype(bool)), t
+        qg, dqg = g.get_state(); qo, dqo = o.state()
+        assert np.abs(qg - qo).max() < 1e-10 and np.abs(dqg - dqo).max() < 1e-9, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        assert np.allclose(ob, oo, atol=1e-5) and np.allclose(r, ro, atol=5e-6)
+        dones += int(do.sum())
+        if do.any():
+            qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
+            g.reset(do.astype(np.uint8), qn, vn, want_obs=False); o.reset(do, qn, vn)
+    assert dones > 10

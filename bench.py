@@ -168,6 +168,8 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     ap.add_argument("--stats", action="store_true", help="print wave-level pivoting iteration histograms")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline, fast_mode parity and other_configs parity")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no steady_state / fast_mode / other_configs")
+    ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (RCCL process group, barriers, max-over-ranks, rollout "
+                    "all_gather) even with one rank: the only way to execute it on a 1-GPU box (tests/test_gpu_bench_dist.py)")
     ap.add_argument("--parity-steps", type=int, default=1000)
     ap.add_argument("--parity-budget", type=float, default=12.0, help="seconds of oracle wall time per parity sample")
     args = ap.parse_args(argv)
@@ -180,9 +182,11 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
                          "(one rank per GPU)" % (args.gpus, world, args.gpus))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if dist_backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -119,23 +119,23 @@ template <class Real>
 __device__ __forceinline__ void sp_spd_torque(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane) {
   const int n = Md.n, np = sp_npad(n);
   Real pd = Real(0), kd = Real(0);
-  if (lane < np) {
-    for (int k = 0; k <= lane; k++) S.A[HL(lane, k)] = S.H[HL(lane, k)];
-    if (lane < n) {
-      kd = Md.spd_kd[lane];
-      S.A[HL(lane, lane)] += kd * Md.envdt - lc.d_diag;
-      const Real p = -Md.spd_kp[lane] * (S.q[lane] + S.dq[lane] * Md.envdt - S.tau[lane]);
-      const Real d = -kd * S.dq[lane];
-      pd = p + d;
-      S.lo[lane] = -S.b[lane] + p + d + S.cf[lane];
-    }
+  if (lane < np) for (int k = 0; k <= lane; k++) S.A[HL(lane, k)] = S.H[HL(lane, k)];
+  __syncthreads();
+  if (lane < n) {   // dof `lane` sits at row n-1-lane of the factor's storage order (sp_mass_row)
+    const int rv = n - 1 - lane;
+    kd = Md.spd_kd[lane];
+    S.A[HL(rv, rv)] += kd * Md.envdt - lc.d_diag;
+    const Real p = -Md.spd_kp[lane] * (S.q[lane] + S.dq[lane] * Md.envdt - S.tau[lane]);
+    const Real d = -kd * S.dq[lane];
+    pd = p + d;
+    S.lo[rv] = -S.b[lane] + p + d + S.cf[lane];
   }
   __syncthreads();
   sp_cholesky<Real>(S.A, S.r, n, lane);
   sp_chol_fwdsolve<Real>(S.A, S.r, n, S.lo, lane);
   sp_chol_backsolve<Real>(S.A, S.r, n, S.lo, lane);
   if (lane < n) {
-    Real tq = pd - kd * S.lo[lane] * Md.envdt;
+    Real tq = pd - kd * S.lo[n - 1 - lane] * Md.envdt;
     const int k = lane - Md.act_dof0;
     if (k < 0 || k >= Md.act_dim) tq = Real(0);
     else if (fabs(tq) > Md.act_scale[k]) tq = (tq > Real(0) ? Real(1) : Real(-1)) * Md.act_scale[k];

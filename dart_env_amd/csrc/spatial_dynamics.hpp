@@ -346,7 +346,10 @@ __device__ __forceinline__ void sp_link_rhs(const LinkConst<Real>& lc, const Spa
   }
 }
 
-// row `d` of the mass matrix (lower part): one lane per dof walks its ancestor chain
+// Entries (d, ancestors of d) of the mass matrix: one lane per dof walks its ancestor chain.  STORAGE ORDER IS REVERSED: dof d lives
+// at row / column n-1-d of S.H, so that the Cholesky factor eliminates leaves first and the trunk last (Featherstone's LTL order:
+// no fill-in, L_ij != 0 only where dof(i) is an ancestor of dof(j)); everything between the Jacobian rows and the final
+// back-substitution works in storage order.  The caller has zero-filled S.H (and barriered) before.
 template <class Real>
 __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int d) {
   const int i = lc.d_link;
@@ -361,7 +364,7 @@ __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const Spa
     Lm = a * L[LK_MC];
     K = cross(h, a);
   }
-  for (int k = 0; k < d; k++) S.H[HL(d, k)] = Real(0);
+  const int n1 = Md.n - 1;
   for (int j = i; j >= 0;) {
     const int w = S.topo[j];
     const int dj = topo_dof(w), jcur = j;
@@ -373,7 +376,7 @@ __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const Spa
     if (topo_jtype(w) == 2) v = dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm));
     else v = dot(aj, Lm);
     if (dj == d) v += lc.d_diag;
-    S.H[HI(d, dj)] = v;   // dj <= d when parents come first; a free root's rotation dofs (0..2) hang below its translation dofs (3..5)
+    S.H[HI(n1 - d, n1 - dj)] = v;   // symmetric index: a free root's rotation dofs (0..2) hang below its translation dofs (3..5)
   }
 }
 

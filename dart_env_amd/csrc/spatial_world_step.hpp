@@ -44,8 +44,9 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     __syncthreads();
   }
   SP_TICK(0);
-  if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
-  else if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[HL(lane, k)] = Real(0); S.H[HL(lane, lane)] = Real(1); }
+  if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[HL(lane, k)] = Real(0); if (lane >= n) S.H[HL(lane, lane)] = Real(1); }
+  __syncthreads();
+  if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);   // scatters into other lanes' rows (reversed storage order, see there)
   __syncthreads();
   if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
   SP_TICK(1);
@@ -170,13 +171,14 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   SP_TICK(3);
   {
     // ---- Jacobian rows (lane per row) + the generalized-force row (index m), bias part of b for contact rows
-    if (lane == m) for (int k = 0; k < n; k++) S.W[m * n + k] = S.rhs[k];
+    // columns of W follow the factor's storage order: dof d sits in column n-1-d
+    if (lane == m) for (int k = 0; k < n; k++) S.W[m * n + (n - 1 - k)] = S.rhs[k];
     if (lane < m) {
       Real* Jr = S.W + lane * n;
       for (int k = 0; k < n; k++) Jr[k] = Real(0);
       const int d = S.rdof[lane];
       if (d >= 0) {
-        Jr[d] = Real(1);
+        Jr[n - 1 - d] = Real(1);
       } else {
         const int cidx = lane / 3, kind = lane % 3;
         // DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1
@@ -202,7 +204,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
             const Real* Lj = S.link + jcur * SP_LINKF;
             const V3<Real> aj = ld3(Lj + LK_A);
             const Real v = sg * ((topo_jtype(w) == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj));
-            Jr[dj] += v;
+            Jr[n - 1 - dj] += v;
             rel += v * S.dq[dj];
           }
         }
@@ -338,7 +340,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       st3(out + 5, (nn * l0 + t1 * l1 + t2 * l2) * idt);
     }
   }
-  // ---- new velocity: vs = dq + L^-T (dt y + W^T lambda)
+  // ---- new velocity: vs = dq + L^-T (dt y + W^T lambda)   (storage order until the back-substitution is done)
   if (lane < n) {
     Real u = Md.dt * S.W[m * n + lane], ul = Real(0);
     for (int i = 0; i < m; i++) { const Real t = S.W[i * n + lane] * S.x[i]; u += t; ul += t; }
@@ -350,7 +352,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     if (lane < n) {
       Real t = Real(0);
       for (int k = 0; k <= lane; k++) t += S.H[HL(lane, k)] * S.lo[k];
-      S.cf[lane] = t / Md.dt;
+      S.cf[n - 1 - lane] = t / Md.dt;
     }
     __syncthreads();
     if (REPORT && report && lane < n) {
@@ -364,7 +366,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   }
   sp_chol_backsolve<Real, BIG>(S.H, S.sinv, n, S.rhs, lane);
   SP_TICK(9);
-  if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
+  if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[n - 1 - lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
   __syncthreads();
   if (EXTRAS && Md.free_root) {   // the six root entries just advanced are placeholders: the pose lives in S.root
     if (lane == 0) sp_free_root_advance<Real>(S, Md.dt);

@@ -2,6 +2,7 @@
 // Part of the gfx950 tree kernel; overview in spatial_kernel.hpp, design in DESIGN.md section 4.2.
 #pragma once
 #include "spatial_dynamics.hpp"
+#include "tree_patterns.hpp"
 
 namespace dartk {
 
@@ -22,7 +23,9 @@ template <> __device__ __forceinline__ double readlane_<double>(double x, int l)
 // and no barrier inside the factorisation.  Per column j: d_j = readlane(row[j], j); L_rj = row[j] / sqrt(d_j);
 // row[k] -= L_rj L_kj for k > j.  Updates beyond a lane's diagonal are garbage that nothing reads (kept finite by the
 // identity padding).  The factor is written back to LDS once at the end, with sinv[j] = 1 / L_jj.
-template <class Real, int NP>
+// PAT (tree_patterns.hpp): compile-time sparsity of the factor -- the update of row k by column j is skipped where L_kj is
+// structurally zero (the entry stays the exact 0 the zero-filled H holds).
+template <class Real, int NP, class PAT = DensePattern>
 __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int lane) {
   const int r = lane < NP ? lane : 0;   // spare lanes shadow lane 0 (convergent code, results discarded)
   const int rb = HR(r);
@@ -37,7 +40,7 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
     row[j] = lrj;
     if (lane == j) sinv[j] = sj;
 #pragma unroll
-    for (int k = j + 1; k < NP; k++) row[k] -= lrj * readlane_<Real>(lrj, k);
+    for (int k = j + 1; k < NP; k++) if (PAT::nz(k, j)) row[k] -= lrj * readlane_<Real>(lrj, k);
   }
   if (lane < n) {
 #pragma unroll
@@ -46,8 +49,9 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
   __syncthreads();
 }
 // one straight-line variant per padded size (only the one a model uses ever enters the instruction cache)
-template <class Real>
+template <class Real, class PAT = DensePattern>
 __device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane) {
+  if constexpr (!PAT::dense) { sp_cholesky_t<Real, sp_npad(PAT::n), PAT>(M, sinv, n, lane); return; }
   const int np = sp_npad(n);
   if (np <= 8) sp_cholesky_t<Real, 8>(M, sinv, n, lane);
   else if (np <= 16) sp_cholesky_t<Real, 16>(M, sinv, n, lane);

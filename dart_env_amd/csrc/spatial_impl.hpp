@@ -284,14 +284,16 @@ struct SpatialImplT : Impl {
     }
     pairs = M.npairs > 0;
     big = M.n >= 20 && !M.free_root;
+    pattern = matches_pattern<HumanWalkerPattern>() ? 1 : 0;
     choose_lds();
     (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice);
     const size_t lds_max = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp, 0);
     // the 20+-dof models without a free root run the BIG instantiations (register LCP solver); measured on HumanWalker / Walker3d
-    const void* fns[7] = {(const void*)sp_step_kernel<Real, false, false, false, false>, (const void*)sp_step_kernel<Real, false, false, false, true>,
+    const void* fns[8] = {(const void*)sp_step_kernel<Real, false, false, false, false>, (const void*)sp_step_kernel<Real, false, false, false, true>,
                           (const void*)sp_step_kernel<Real, true, false, false, true>, (const void*)sp_step_kernel<Real, false, true, false, false>,
                           (const void*)sp_step_kernel<Real, true, true, false, true>, (const void*)sp_step_kernel<Real, true, true, true, false>,
-                          (const void*)sp_step_kernel<Real, true, false, false, false>};
+                          (const void*)sp_step_kernel<Real, true, false, false, false>,
+                          (const void*)sp_step_kernel<Real, false, false, false, true, HumanWalkerPattern>};
     for (const void* fn : fns)
       if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)sp_reset_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max)) != hipSuccess) return e;
@@ -301,6 +303,30 @@ struct SpatialImplT : Impl {
     if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); if (d_ext) (void)hipFree(d_ext); if (d_cf) (void)hipFree(d_cf);
     if (d_creport) (void)hipFree(d_creport); if (d_ccount) (void)hipFree(d_ccount); if (d_cfrep) (void)hipFree(d_cfrep); d_creport = nullptr; d_ccount = nullptr; d_cfrep = nullptr;
     dM = nullptr; init_h = nullptr; d_ext = nullptr; d_cf = nullptr;
+  }
+  // Sparsity of this model's mass-matrix factor in storage order (row n-1-d = dof d; symbolic elimination of the ancestor
+  // relation), compared with a baked pattern: only an exact match may run that pattern's kernel.
+  template <class PAT>
+  bool matches_pattern() const {
+    const int n = M.n;
+    if (n != PAT::n || n > 32) return false;
+    uint32_t low[32] = {};
+    for (int i = 0; i < M.nl; i++) {
+      const int d = M.dof[i];
+      if (d < 0) continue;
+      for (int j = M.parent[i]; j >= 0; j = M.parent[j]) {
+        const int a = M.dof[j];
+        if (a < 0 || a == d) continue;
+        const int r = n - 1 - a, c = n - 1 - d;
+        if (r > c) low[r] |= 1u << c; else low[c] |= 1u << r;
+      }
+    }
+    for (int j = 0; j < n; j++)
+      for (int a = j + 1; a < n; a++)
+        if ((low[a] >> j) & 1u)
+          for (int b = j + 1; b < a; b++) if ((low[b] >> j) & 1u) low[a] |= 1u << b;
+    for (int i = 0; i < n; i++) if (low[i] != PAT::row(i)) return false;
+    return true;
   }
   // register-LCP models without contact reporting drop the LDS solver's workspace (sp_carve): smaller block, more workgroups per CU
   bool uses_big() const {   // which step-kernel instantiation step() launches
@@ -319,7 +345,12 @@ struct SpatialImplT : Impl {
                      act, obs, rew, done, trunc, autoreset, seed, off)
     if (M.creport) SP_LAUNCH(true, true, true, false);   // contact reporting lives in the most general instantiation only
     else if (pairs) { if (extras) SP_LAUNCH(true, true, false, true); else if (big) SP_LAUNCH(true, false, false, true); else SP_LAUNCH(true, false, false, false); }
-    else { if (extras) SP_LAUNCH(false, true, false, false); else if (big) SP_LAUNCH(false, false, false, true); else SP_LAUNCH(false, false, false, false); }
+    else if (extras) SP_LAUNCH(false, true, false, false);
+    else if (big && pattern == 1)   // the factor's sparsity is known at compile time (tree_patterns.hpp)
+      hipLaunchKernelGGL((sp_step_kernel<Real, false, false, false, true, HumanWalkerPattern>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q,
+                         (Real*)dq, init_h, el, ep, act, obs, rew, done, trunc, autoreset, seed, off);
+    else if (big) SP_LAUNCH(false, false, false, true);
+    else SP_LAUNCH(false, false, false, false);
 #undef SP_LAUNCH
     return hipGetLastError();
   }
@@ -347,6 +378,7 @@ struct SpatialImplT : Impl {
   Real* d_ext = nullptr;
   Real* d_cf = nullptr;
   bool pairs = false, extras = false, big = false;   // which instantiation of the step kernel this model runs
+  int pattern = 0;                                   // 1: HumanWalkerPattern (lean BIG kernel only)
   int body_link_map[DART_MAX_BODIES];
   int set_task_state(hipStream_t s, const uint8_t* d_mask, const double* d_values, int64_t n) override {
     hipLaunchKernelGGL((sp_task_state_kernel<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_mask, d_values, init_h);

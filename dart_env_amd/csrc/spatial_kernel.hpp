@@ -32,7 +32,7 @@ namespace dartk {
 template <class Real, bool BIG> __host__ __device__ constexpr int sp_min_waves() { return BIG ? (sizeof(Real) == 8 ? 1 : 2) : 3; }
 // REPORT: the contact-report variant (dart_get_contacts); only the most general instantiation <true, true, true> is built --
 // the mere presence of the reporting code costs the lean kernels 2.5 % (register allocation), so they do not carry it.
-template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false, bool BIG = false>
+template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false, bool BIG = false, class PAT = DensePattern>
 __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG>())) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ tstate,
                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG>())) sp_step_kerne
     cflags[0] = 0; cflags[1] = 0;
   }
   __syncthreads();
-  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG>(Md, lc, S, lane, cflags, REPORT && Md.creport != nullptr && f == Md.frame_skip - 1);
+  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG, PAT>(Md, lc, S, lane, cflags, REPORT && Md.creport != nullptr && f == Md.frame_skip - 1);
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
   const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task >= 10;

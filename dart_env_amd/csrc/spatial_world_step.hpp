@@ -20,7 +20,8 @@ namespace dartk {
 // BIG: register-resident LCP solver and back-substitution (the 20+-dof models).
 // PAIRS: link-link contacts (box pairs, general contact normals); EXTRAS: snake fluid forces, external body force, Coulomb
 // joint friction rows.  Models that need neither run the lean instantiation (HumanWalker: 8 % faster than the full one).
-template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false, bool BIG = false>
+// PAT: compile-time sparsity of the mass-matrix factor (tree_patterns.hpp; DensePattern = any model).
+template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false, bool BIG = false, class PAT = DensePattern>
 __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, const LinkConst<Real>& lc, SpLds<Real>& S, int lane,
                                               int* contact_flags, bool report = false) {
   const int n = Md.n, nl = Md.nl;
@@ -50,7 +51,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   __syncthreads();
   if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
   SP_TICK(1);
-  sp_cholesky<Real>(S.H, S.sinv, n, lane);
+  sp_cholesky<Real, PAT>(S.H, S.sinv, n, lane);
   SP_TICK(2);
 
   // ---- contact points and active limits, in parallel: lane s tests collision shape s, lane d tests the limits of
@@ -235,10 +236,11 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
           const Vec* hr = reinterpret_cast<const Vec*>(S.H + HR(k));
 #pragma unroll
           for (int j = 0; j < k; j += VW) {
+            if (((PAT::row(k) >> j) & ((1u << VW) - 1u)) == 0u) continue;   // a chunk of structural zeros: not even loaded
             const Vec h = hr[j / VW];
             const Real* hv = reinterpret_cast<const Real*>(&h);
 #pragma unroll
-            for (int c = 0; c < VW; c++) if (j + c < k) t -= hv[c] * y[j + c];
+            for (int c = 0; c < VW; c++) if (j + c < k && PAT::nz(k, j + c)) t -= hv[c] * y[j + c];
           }
           y[k] = t * S.sinv[k];
         }

@@ -3,6 +3,7 @@ without a GPU (no CPU fallback), the model compiler's cards are sane, and the ho
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -79,6 +80,22 @@ def test_model_compiler_reproduces_committed_cards():
     from dart_env_amd.skel import parse_skel
     a = parse_skel("/root/reference/gym/envs/dart/assets/hopper_capsule.skel", dt=0.002)
     assert a.to_json() == load_model("hopper").to_json()
+
+
+def test_generated_kernel_headers_are_current():
+    """csrc/static_models.hpp and csrc/tree_patterns.hpp are generated from the committed model cards: regenerating must give the
+    committed text, and the HumanWalker factor pattern must be the no-fill pattern of its tree (ancestor pairs only)"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tree_patterns.py")], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(ROOT, "dart_env_amd", "csrc", "tree_patterns.hpp")).read()
+    before = open(os.path.join(ROOT, "dart_env_amd", "csrc", "static_models.hpp")).read()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_static_models.py")], capture_output=True, text=True, check=True).stdout
+    assert "wrote" not in out and before == open(os.path.join(ROOT, "dart_env_amd", "csrc", "static_models.hpp")).read()   # rewrites only when stale
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_tree_patterns import factor_pattern
+    rows = factor_pattern(card_for("DartHumanWalker-v1"))
+    assert len(rows) == 29 and sum(bin(r).count("1") for r in rows) == 222
+    assert rows[28] == (1 << 28) - 1                       # the first root dof (last storage row) couples with everything
 
 
 def test_vector_env_api_errors_and_shapes():

@@ -25,13 +25,17 @@ template <> __device__ __forceinline__ double readlane_<double>(double x, int l)
 // identity padding).  The factor is written back to LDS once at the end, with sinv[j] = 1 / L_jj.
 // PAT (tree_patterns.hpp): compile-time sparsity of the factor -- the update of row k by column j is skipped where L_kj is
 // structurally zero (the entry stays the exact 0 the zero-filled H holds).
+// W != nullptr: the forward substitution W_i <- L^-1 W_i of rows 0..m of W (lane per row, stride n) follows while the factor
+// is still in registers: L_kj reaches the row's lane through v_readlane from lane k, so the 220-400 factor entries a row needs
+// cost no LDS access at all (first version: ~110 128-bit LDS loads per row, the phase was LDS-latency bound at 2 waves / SIMD).
 template <class Real, int NP, class PAT = DensePattern>
-__device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int lane) {
+__device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1) {
   const int r = lane < NP ? lane : 0;   // spare lanes shadow lane 0 (convergent code, results discarded)
   const int rb = HR(r);
   Real row[NP];
 #pragma unroll
   for (int k = 0; k < NP; k++) row[k] = (k <= r) ? M[rb + k] : Real(0);
+  Real sown = Real(1);                  // lane j: 1 / L_jj
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     const Real dj = readlane_<Real>(row[j], j);
@@ -39,6 +43,7 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
     const Real lrj = (r >= j) ? row[j] * sj : Real(0);   // lanes above the diagonal contribute nothing
     row[j] = lrj;
     if (lane == j) sinv[j] = sj;
+    sown = (lane == j) ? sj : sown;
 #pragma unroll
     for (int k = j + 1; k < NP; k++) if (PAT::nz(k, j)) row[k] -= lrj * readlane_<Real>(lrj, k);
   }
@@ -46,17 +51,37 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
 #pragma unroll
     for (int k = 0; k < NP; k++) if (k <= lane) M[rb + k] = row[k];
   }
+  if (W != nullptr) {   // wave-uniform
+    const bool has = lane <= m;
+    Real* yrow = W + (has ? lane : 0) * n;
+    Real y[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) y[k] = (k < n) ? yrow[k] : Real(0);
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      if (k < n) {
+        Real t = y[k];
+#pragma unroll
+        for (int j = 0; j < k; j++) if (PAT::nz(k, j)) t -= readlane_<Real>(row[j], k) * y[j];
+        y[k] = t * readlane_<Real>(sown, k);
+      }
+    }
+    if (has) {
+#pragma unroll
+      for (int k = 0; k < NP; k++) if (k < n) yrow[k] = y[k];
+    }
+  }
   __syncthreads();
 }
 // one straight-line variant per padded size (only the one a model uses ever enters the instruction cache)
 template <class Real, class PAT = DensePattern>
-__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane) {
-  if constexpr (!PAT::dense) { sp_cholesky_t<Real, sp_npad(PAT::n), PAT>(M, sinv, n, lane); return; }
+__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1) {
+  if constexpr (!PAT::dense) { sp_cholesky_t<Real, sp_npad(PAT::n), PAT>(M, sinv, n, lane, W, m); return; }
   const int np = sp_npad(n);
-  if (np <= 8) sp_cholesky_t<Real, 8>(M, sinv, n, lane);
-  else if (np <= 16) sp_cholesky_t<Real, 16>(M, sinv, n, lane);
-  else if (np <= 24) sp_cholesky_t<Real, 24>(M, sinv, n, lane);
-  else sp_cholesky_t<Real, 32>(M, sinv, n, lane);
+  if (np <= 8) sp_cholesky_t<Real, 8>(M, sinv, n, lane, W, m);
+  else if (np <= 16) sp_cholesky_t<Real, 16>(M, sinv, n, lane, W, m);
+  else if (np <= 24) sp_cholesky_t<Real, 24>(M, sinv, n, lane, W, m);
+  else sp_cholesky_t<Real, 32>(M, sinv, n, lane, W, m);
 }
 // x <- L^-T x (backward) for one vector in LDS, column-oriented, lanes own entries
 template <class Real>

@@ -29,11 +29,24 @@ namespace dartk {
 // fp64 doubles the LDS block (HumanWalker: 4 workgroups per CU = one wave per SIMD): its register budget is the whole file.
 // BIG kernels hold the LCP rows in registers: two waves per SIMD is what their LDS block allows anyway (HumanWalker fp32: 8
 // workgroups per CU); the small-model kernels keep three.
-template <class Real, bool BIG> __host__ __device__ constexpr int sp_min_waves() { return BIG ? (sizeof(Real) == 8 ? 1 : 2) : 3; }
+// Waves per SIMD the register allocation is bounded for.  Small models: 3 (168 VGPRs).  BIG (register LCP solver): 2 in fp32 / 1 in
+// fp64 -- except the lean kernel of a model with a compile-time factor pattern (HumanWalker), which is short enough for 3 in fp32
+// (measured 6.19 -> 5.84 ms; the PAIRS kernel of Walker3d got 13 % slower at 3).
+#ifndef SP_PAT_F32_WAVES
+#define SP_PAT_F32_WAVES 3
+#endif
+#ifndef SP_PAT_F64_WAVES
+#define SP_PAT_F64_WAVES 1
+#endif
+template <class Real, bool BIG, class PAT = DensePattern> __host__ __device__ constexpr int sp_min_waves() {
+  if (!BIG) return 3;
+  if (!PAT::dense) return sizeof(Real) == 8 ? SP_PAT_F64_WAVES : SP_PAT_F32_WAVES;
+  return sizeof(Real) == 8 ? 1 : 2;
+}
 // REPORT: the contact-report variant (dart_get_contacts); only the most general instantiation <true, true, true> is built --
 // the mere presence of the reporting code costs the lean kernels 2.5 % (register allocation), so they do not carry it.
 template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false, bool BIG = false, class PAT = DensePattern>
-__global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG>())) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
+__global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_kernel(const SpatialModel<Real>* __restrict__ Mp, int64_t n_envs,
                                                       Real* __restrict__ qs, Real* __restrict__ dqs, Real* __restrict__ tstate,
                                                       int32_t* __restrict__ elapsed, uint32_t* __restrict__ episode,
                                                       const float* __restrict__ actions, float* __restrict__ obs,

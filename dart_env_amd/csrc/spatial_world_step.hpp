@@ -51,8 +51,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   __syncthreads();
   if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
   SP_TICK(1);
-  sp_cholesky<Real, PAT>(S.H, S.sinv, n, lane);
-  SP_TICK(2);
+  if constexpr (PAT::dense) { sp_cholesky<Real, PAT>(S.H, S.sinv, n, lane); SP_TICK(2); }   // pattern kernels factor later (below)
 
   // ---- contact points and active limits, in parallel: lane s tests collision shape s, lane d tests the limits of
   // dof d; ballots give every hit its slot (shape order, then vertex order -- the serial order of the oracle)
@@ -218,37 +217,44 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     __syncthreads();
     SP_TICK(4);
     // ---- W = L^-1 [J^T | rhs] : every lane forward-substitutes its own row; row m becomes y = L^-1 rhs
-    // The row lives in registers and both loops are fully unrolled (SP_MAXN x SP_MAXN / 2 predicated steps, uniform
-    // `k < n` branches): every factor entry is one LDS read at an immediate offset, no index arithmetic.
-    if (lane <= m) {
-      Real* yrow = S.W + lane * n;
-      Real y[SP_MAXN];
+    if constexpr (!PAT::dense) {
+      // Pattern kernels (HumanWalker): the factorisation sits here, after the Jacobian rows it does not depend on, and the
+      // substitution follows while the factor is still in registers -- L_kj reaches a row's lane through v_readlane
+      // (sp_cholesky_t).  Measured 6.36 -> 6.19 ms; the dense kernels got slower with it (Walker3d +4 %) and keep the LDS reads.
+      sp_cholesky<Real, PAT>(S.H, S.sinv, n, lane, S.W, m);
+      SP_TICK(2);
+    } else {
+      // The row lives in registers and both loops are fully unrolled (SP_MAXN x SP_MAXN / 2 predicated steps, uniform
+      // `k < n` branches): every factor entry is one LDS read at an immediate offset, no index arithmetic.
+      if (lane <= m) {
+        Real* yrow = S.W + lane * n;
+        Real y[SP_MAXN];
 #pragma unroll
-      for (int k = 0; k < SP_MAXN; k++) y[k] = (k < n) ? yrow[k] : Real(0);
-      // factor rows start 16-byte aligned and are padded to multiples of 4 entries (HR): 128-bit LDS loads, 4 (fp32) or 2 (fp64)
-      // entries each; the entries a load brings in beyond column k - 1 are not used
-      using Vec = typename sp_vec128<Real>::type;
-      constexpr int VW = sp_vec128<Real>::width;
+        for (int k = 0; k < SP_MAXN; k++) y[k] = (k < n) ? yrow[k] : Real(0);
+        // factor rows start 16-byte aligned and are padded to multiples of 4 entries (HR): 128-bit LDS loads, 4 (fp32) or 2 (fp64)
+        // entries each; the entries a load brings in beyond column k - 1 are not used
+        using Vec = typename sp_vec128<Real>::type;
+        constexpr int VW = sp_vec128<Real>::width;
 #pragma unroll
-      for (int k = 0; k < SP_MAXN; k++) {
-        if (k < n) {
-          Real t = y[k];
-          const Vec* hr = reinterpret_cast<const Vec*>(S.H + HR(k));
+        for (int k = 0; k < SP_MAXN; k++) {
+          if (k < n) {
+            Real t = y[k];
+            const Vec* hr = reinterpret_cast<const Vec*>(S.H + HR(k));
 #pragma unroll
-          for (int j = 0; j < k; j += VW) {
-            if (((PAT::row(k) >> j) & ((1u << VW) - 1u)) == 0u) continue;   // a chunk of structural zeros: not even loaded
-            const Vec h = hr[j / VW];
-            const Real* hv = reinterpret_cast<const Real*>(&h);
+            for (int j = 0; j < k; j += VW) {
+              const Vec h = hr[j / VW];
+              const Real* hv = reinterpret_cast<const Real*>(&h);
 #pragma unroll
-            for (int c = 0; c < VW; c++) if (j + c < k && PAT::nz(k, j + c)) t -= hv[c] * y[j + c];
+              for (int c = 0; c < VW; c++) if (j + c < k) t -= hv[c] * y[j + c];
+            }
+            y[k] = t * S.sinv[k];
           }
-          y[k] = t * S.sinv[k];
         }
-      }
 #pragma unroll
-      for (int k = 0; k < SP_MAXN; k++) if (k < n) yrow[k] = y[k];
+        for (int k = 0; k < SP_MAXN; k++) if (k < n) yrow[k] = y[k];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // b_i = bounce_i - J_i (dq + dt H^-1 rhs) = bias_i - dt W_i . y
     if (lane < m) {
       const Real* wi = S.W + lane * n;

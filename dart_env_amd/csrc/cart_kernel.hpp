@@ -164,10 +164,13 @@ __global__ void __launch_bounds__(64) cart_step_kernel(CartParams<Real, NP> P, i
   const int64_t ec = valid ? e : n_envs - 1;   // tail lanes shadow the last env so wave votes stay uniform
   Real q[N], dq[N];
   sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + ec]; dq[i] = dqs[(int64_t)i * n_envs + ec]; });
+  int el_in = elapsed[ec];            // fetched with the state: a load issued in the epilogue would be a bare HBM round trip
+  uint32_t ep_in = episode[ec];
   const Real a = (Real)actions[ec];
   Real cl = (a > P.act_hi) ? P.act_hi : a;      // comparison clamp; these three tasks leave act_lo / act_hi at -/+inf
   cl = (cl < P.act_lo) ? P.act_lo : cl;
   const Real tau_x = cl * P.act_scale;
+  DART_PIN_VGPR(el_in); DART_PIN_VGPR(ep_in);   // pinned where the state loads are awaited anyway: the compiler must not sink them
 #pragma unroll 1
   for (int f = 0; f < P.frame_skip; ++f) cart_world_step<Real, NP>(P, q, dq, tau_x);
   bool fin = true, bounded = true;
@@ -204,11 +207,11 @@ __global__ void __launch_bounds__(64) cart_step_kernel(CartParams<Real, NP> P, i
     task_done = height <= Real(1);
   }
   (void)bounded;
-  int el = elapsed[ec] + 1;
+  int el = el_in + 1;
   const bool trunc = (P.max_steps > 0) && (el >= P.max_steps);
   const bool dn = task_done || trunc;
   if (autoreset && dn) {
-    const uint32_t ep = episode[ec] + 1;
+    const uint32_t ep = ep_in + 1;
     reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, P.noise_v, q, dq);
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
     el = 0;

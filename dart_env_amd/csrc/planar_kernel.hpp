@@ -1178,6 +1178,10 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   int64_t ec = valid ? e : n_envs - 1;  // tail lanes shadow the last env so wave votes stay uniform
   Real q[N], dq[N], tau[N];
   sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + ec]; dq[i] = dqs[(int64_t)i * n_envs + ec]; });
+  // the episode bookkeeping the epilogue needs is fetched HERE, with the state: at one wave per SIMD nothing hides a load issued
+  // at the end of the kernel (two dependent HBM round trips there cost the Hopper kernel ~10 % of its 30 us)
+  int el_in = elapsed[ec];
+  uint32_t ep_in = episode[ec];
   Real a2 = Real(0);
   sfor<0, N>([&](auto I) { tau[I] = Real(0); });
   sfor<0, NA>([&](auto K) {
@@ -1188,6 +1192,7 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     cl = (cl < P.act_lo[k]) ? P.act_lo[k] : cl;
     tau[N - NA + k] = cl * P.act_scale[k];
   });
+  DART_PIN_VGPR(el_in); DART_PIN_VGPR(ep_in);   // (pinned here, where the state loads are awaited anyway: the compiler must not sink them)
   Real x_before = q[0];
   Real dx = Real(0);
   WarmSets warm;
@@ -1231,11 +1236,11 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   }
   ok = ok && (height > P.h_lo) && (height < P.h_hi) && (fabs(ang) < P.ang_max);
   bool task_done = (P.task != 0) && !ok;
-  int el = elapsed[ec] + 1;
+  int el = el_in + 1;
   bool trunc = (P.max_steps > 0) && (el >= P.max_steps);
   bool dn = task_done || trunc;
   if (autoreset && dn) {
-    uint32_t ep = episode[ec] + 1;
+    uint32_t ep = ep_in + 1;
     reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, P.noise_v, q, dq);
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
     el = 0;

@@ -20,7 +20,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static thread_local
-#define DART_PIN_VGPR(x) asm volatile("" : "+x"(x))   // the device build pins the value in a VGPR
+#define DART_PIN_VGPR(x) asm volatile("" : "+g"(x))   // the device build pins the value in a VGPR
 
 using std::fabs; using std::fmax; using std::fmin; using std::isfinite; using std::sqrt;
 

@@ -9,7 +9,7 @@ for e in "${LIST[@]}"; do
   line="$1 n=$2 f$4:"
   for lib in "${@:5}" $LIBS; do :; done
   for lib in $LIBS; do
-    v=$(DART_STEPPER_LIB=$lib python bench.py --env-id $1 --envs $2 --steps $3 --warmup 5 --precision $4 --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f' % d['roofline']['kernel_ms'])")
+    v=$(DART_STEPPER_LIB=$lib python bench.py --env-id $1 --envs $2 --steps $3 --warmup 5 --precision $4 --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.4f' % d['roofline']['kernel_ms'])")
     line="$line  $(basename $lib .so)=$v"
   done
   echo "$line"

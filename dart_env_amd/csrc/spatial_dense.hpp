@@ -437,13 +437,15 @@ __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__
 // overhead) than the saved barriers give back.
 template <class Real, bool BIG = false>
 __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask, uint64_t& F, uint64_t& U, int max_iter,
-                                       int pgs_sweeps, unsigned long long* stats, int lane, const bool ZERO_BOUNDS) {
-  if (!BIG || m > SP_BLCP_MAXREG || max_iter == 0) { sp_blcp_lds<Real>(S, m, pinmask, F, U, max_iter, pgs_sweeps, stats, lane, ZERO_BOUNDS); return; }
+                                       int pgs_sweeps, unsigned long long* stats, int lane, const bool ZERO_BOUNDS, int mv = 0) {
+  // mv: row count that picks the solver variant (>= m): both stages of a world step can share one variant's code (instruction cache)
+  mv = mv > m ? mv : m;
+  if (!BIG || mv > SP_BLCP_MAXREG || max_iter == 0) { sp_blcp_lds<Real>(S, m, pinmask, F, U, max_iter, pgs_sweeps, stats, lane, ZERO_BOUNDS); return; }
   if (lane < m) S.x0[lane] = S.x[lane];   // solution of the previous stage (zeros before the first): PGS fallback start
   BlcpSets r;
-  if (m <= 16) r = sp_blcp_t<Real, 16>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
-  else if (m <= 24) r = sp_blcp_t<Real, 24>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
-  else if (m <= 32) r = sp_blcp_t<Real, 32>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  if (mv <= 16) r = sp_blcp_t<Real, 16>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (mv <= 24) r = sp_blcp_t<Real, 24>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (mv <= 32) r = sp_blcp_t<Real, 32>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
 #if SP_BLCP_MAXREG > 24
   else r = sp_blcp_t<Real, 40>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
 #else

@@ -56,7 +56,8 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   // ---- contact points and active limits, in parallel: lane s tests collision shape s, lane d tests the limits of
   // dof d; ballots give every hit its slot (shape order, then vertex order -- the serial order of the oracle)
   const V3<Real> roff = ld3(S.misc);
-  int ncp, m;
+  int ncp, m, m1;   // contact points, LCP rows, rows of the frictionless stage (normals + limits + joint friction: a prefix)
+  constexpr bool PREFIX = !PAIRS;
   {
     const bool has_shape = lane < Md.nshapes;
     const int s = has_shape ? lane : 0;
@@ -137,14 +138,20 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       }
       ncp = (ncp + total) < Md.maxcp ? (ncp + total) : Md.maxcp;
     }
-    // contact rows: normal, two tangents
-    if (lane < 3 * ncp) { S.rdof[lane] = -1; S.rfidx[lane] = (lane % 3 == 0) ? -1 : (lane - lane % 3); }
+    // Row order: contact normals [0, ncp), joint limits, joint friction, then the 2 ncp contact tangents.  The rows the
+    // frictionless stage can move are a PREFIX (m1 of them): that stage solves the leading m1 x m1 block of A alone (the tangent
+    // rows are pinned at 0 there and contribute nothing), usually in a smaller solver variant.
+    // (PREFIX = false, the link-link kernels: rows stay interleaved {n, t1, t2} per contact with the limits behind them -- the prefix
+    // order made Walker3d 8 % slower.)
+    if (PREFIX) { if (lane < ncp) { S.rdof[lane] = -1; S.rfidx[lane] = -1; } }
+    else if (lane < 3 * ncp) { S.rdof[lane] = -1; S.rfidx[lane] = (lane % 3 == 0) ? -1 : (lane - lane % 3); }
+    const int nfront = PREFIX ? ncp : 3 * ncp;   // contact rows in front of the limit rows
     // joint-limit rows
     const Real qd = lane < n ? S.q[lane] : Real(0);
     const bool low = lane < n && lc.d_limited && qd <= lc.d_lower;
     const bool up = lane < n && lc.d_limited && !low && qd >= lc.d_upper;
     const uint64_t lm = __ballot(low || up);
-    const int row = 3 * ncp + __popcll(lm & lt);
+    const int row = nfront + __popcll(lm & lt);
     if ((low || up) && row < Md.maxm) {
       const Real viol = low ? qd - lc.d_lower : qd - lc.d_upper;
       const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
@@ -153,7 +160,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       S.lo[row] = low ? Real(0) : -inf_<Real>();
       S.hi[row] = low ? inf_<Real>() : Real(0);
     }
-    m = 3 * ncp + __popcll(lm);
+    m = nfront + __popcll(lm);
     if (EXTRAS && Md.has_joint_friction) {   // DART JointCoulombFrictionConstraint rows: joint velocity -> 0, impulse within +-mu dt
       const bool fr = lane < n && lc.d_fric > Real(0);
       const uint64_t fm = __ballot(fr);
@@ -165,7 +172,13 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       }
       m += __popcll(fm);
     }
+    m1 = m < Md.maxm ? m : Md.maxm;
+    if (PREFIX) {
+      if (lane < 2 * ncp && m1 + lane < Md.maxm) { S.rdof[m1 + lane] = -1; S.rfidx[m1 + lane] = lane >> 1; }   // tangents t1, t2 of contact lane / 2
+      m = m1 + 2 * ncp;
+    }
     m = m < Md.maxm ? m : Md.maxm;
+    if (!PREFIX) m1 = m;
   }
   __syncthreads();
   SP_TICK(3);
@@ -180,7 +193,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       if (d >= 0) {
         Jr[n - 1 - d] = Real(1);
       } else {
-        const int cidx = lane / 3, kind = lane % 3;
+        const int cidx = PREFIX ? (lane < m1 ? lane : ((lane - m1) >> 1)) : lane / 3, kind = PREFIX ? (lane < m1 ? 0 : 1 + ((lane - m1) & 1)) : lane % 3;
         // DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1
         V3<Real> dir;
         if (PAIRS) {
@@ -320,7 +333,8 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         F = (F & ~fr) | (fr & ~pf);
         U &= ~fr;
       }
-      sp_blcp<Real, BIG>(S, m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction));
+      sp_blcp<Real, BIG>(S, stage == 0 ? m1 : m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction),
+                         0);
     }
     SP_TICK(8);
     if (Md.dbg) {
@@ -339,9 +353,9 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
       const V3<Real> t2 = cross(nn, t1);
       // a tangent the skeleton cannot move along (planar model: z) has A_ii = 0 and stays pinned at a bound: no force
-      const int r1 = 3 * lane + 1, r2 = 3 * lane + 2;
-      const Real l0 = S.x[3 * lane], l1 = S.A[TI(r1, r1)] > Real(1e-12) ? S.x[r1] : Real(0),
-                 l2 = S.A[TI(r2, r2)] > Real(1e-12) ? S.x[r2] : Real(0), idt = Real(1) / Md.dt;
+      const int r0 = PREFIX ? lane : 3 * lane, r1 = PREFIX ? m1 + 2 * lane : 3 * lane + 1, r2 = r1 + 1;
+      const Real l0 = S.x[r0], l1 = (r1 < m && S.A[TI(r1, r1)] > Real(1e-12)) ? S.x[r1] : Real(0),   // (rows beyond the capacity were dropped)
+                 l2 = (r2 < m && S.A[TI(r2, r2)] > Real(1e-12)) ? S.x[r2] : Real(0), idt = Real(1) / Md.dt;
       const int lb = S.cplinkB[lane];
       out[0] = (Real)Md.link_body[S.cplink[lane]]; out[1] = lb >= 0 ? (Real)Md.link_body[lb] : Real(-1);
       st3(out + 2, ld3(S.cpP + 4 * lane) + roff);

@@ -377,9 +377,10 @@ __device__ __forceinline__ void masked_solve(const Real (&A)[M * (M + 1) / 2], c
 template <class Real, int M, bool ZERO_BOUNDS>
 __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
                                          const Real (&hi)[M], uint32_t pinmask, uint32_t& F, uint32_t& U,
-                                         Real (&x)[M], int max_iter, unsigned long long* stats) {
+                                         Real (&x)[M], int max_iter, unsigned long long* stats, Real bmax_more = Real(0)) {
   // feasibility tolerances scale with the problem: |b|_inf bounds the size of w and (through A^-1) of x
-  Real bmax = Real(0);
+  // (bmax_more: |b| of rows the caller left out of this solve because they are pinned at 0)
+  Real bmax = bmax_more;
   sfor<0, M>([&](auto I) { bmax = fmax(bmax, fabs(b[I])); });
   const Real tol = tol_<Real>() * (Real(1) + bmax);
   int best = M + 1, patience = 3;
@@ -634,7 +635,34 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   F = (F & ~same) | (warm.F1 & same);
   U = (U & ~same) | (warm.U1 & same);
 
-  if (P.solver == 0) blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
+  if (P.solver == 0) {
+    if constexpr (NCA > 0) {
+      // The friction rows are pinned at 0 in this stage: solve the M - NCA rows that can move (contact normals, limits) as a
+      // system of their own.  Leaving the pinned rows in as identity rows gives the same numbers bit for bit (a masked row only
+      // ever contributes exact zeros) at the cost of the full-size factorisation.
+      constexpr int M1 = M - NCA;
+      auto full = [](int k) constexpr { return k < NCA ? 2 * k : NCA + k; };   // row k of the small system in the full one
+      Real A1[M1 * (M1 + 1) / 2], b1[M1], lo1[M1], hi1[M1], x1[M1];
+      uint32_t pin1 = 0, F1 = 0, U1 = 0;
+      Real bt = Real(0);
+      sfor<0, NCA>([&](auto S) { bt = fmax(bt, fabs(b[2 * S + 1])); });
+      sfor<0, M1>([&](auto I) {
+        constexpr int i = I, fi = full(i);
+        b1[i] = b[fi]; lo1[i] = lo[fi]; hi1[i] = hi[fi]; x1[i] = Real(0);
+        pin1 |= ((pinmask >> fi) & 1u) << i; F1 |= ((F >> fi) & 1u) << i; U1 |= ((U >> fi) & 1u) << i;
+        sfor<0, i + 1>([&](auto J) { constexpr int j = J; A1[tri(i, j)] = A[tri(fi, full(j))]; });
+      });
+      blcp_bpp<Real, M1, true>(A1, b1, lo1, hi1, pin1, F1, U1, x1, P.iters1, P.stats, bt);
+      F = 0; U = 0;
+      sfor<0, M1>([&](auto I) {
+        constexpr int i = I, fi = full(i);
+        x[fi] = x1[i];
+        F |= ((F1 >> i) & 1u) << fi; U |= ((U1 >> i) & 1u) << fi;
+      });
+    } else {
+      blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
+    }
+  }
   else {
     bool skip[M];
     sfor<0, M>([&](auto I) { skip[I] = (pinmask >> I) & 1u; });

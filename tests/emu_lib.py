@@ -15,7 +15,7 @@ from dart_env_amd.model_card import DartModelCard
 from dart_env_amd import stepper as st
 
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_emu")
-_LIB = os.path.join(_DIR, "libdart_planar_emu.so")
+_LIB = os.environ.get("DART_EMU_LIB", os.path.join(_DIR, "libdart_planar_emu.so"))   # the override serves bitwise A/B checks of kernel edits
 _lib = None
 
 

@@ -26,6 +26,9 @@ for p in 64 32; do
 done
 rocprofv3 --kernel-trace --stats -d $OUT/walker3d_f32_trace -- $B --precision 32 --env-id DartWalker3d-v1 --envs 16384 --steps 40 --warmup 3 > $OUT/w3_trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/halfcheetah_f32_trace -- $B --precision 32 --env-id DartHalfCheetah-v1 --envs 65536 --steps 200 --warmup 20 > $OUT/hc_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/halfcheetah_f64_trace -- $B --precision 64 --env-id DartHalfCheetah-v1 --envs 65536 --steps 100 --warmup 10 > $OUT/hc64_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/snake_f64_trace -- $B --precision 64 --env-id DartSnake7Link-v1 --envs 65536 --steps 500 --warmup 50 > $OUT/snake_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/cartpole_f64_trace -- $B --precision 64 --env-id DartCartPole-v1 --envs 65536 --steps 1000 --warmup 50 > $OUT/cart_trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/dog_f32_trace -- $B --precision 32 --env-id DartDog-v1 --envs 16384 --steps 40 --warmup 3 > $OUT/dog_trace.log 2>&1
 cd $R
 python tools/summarize_rocprof.py $OUT gpurun_out/${TAG}_rocprof.txt > /dev/null

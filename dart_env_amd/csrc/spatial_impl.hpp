@@ -285,6 +285,7 @@ struct SpatialImplT : Impl {
     pairs = M.npairs > 0;
     big = M.n >= 20 && !M.free_root;
     pattern = matches_pattern<HumanWalkerPattern>() ? 1 : 0;
+    is_static = pattern != 0 && uses_big() && !extras && !pairs;   // DART_Q_STATIC_KERNEL: the step kernel is specialised for this model's tree at compile time
     choose_lds();
     (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice);
     const size_t lds_max = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp, 0);

@@ -42,7 +42,7 @@ enum {
 enum {
   DART_Q_NUM_ENVS = 0, DART_Q_NDOFS = 1, DART_Q_OBS_DIM = 2, DART_Q_ACT_DIM = 3, DART_Q_FRAME_SKIP = 4,
   DART_Q_PRECISION = 5, DART_Q_DEVICE = 6, DART_Q_LCP_SLOTS = 7,
-  DART_Q_STATIC_KERNEL = 8, /* 1: the card matched a model baked in at build time (csrc/static_models.hpp) */
+  DART_Q_STATIC_KERNEL = 8, /* 1: the card matched a model baked in at build time (csrc/static_models.hpp, csrc/tree_patterns.hpp) */
   DART_Q_MAX_CONTACTS = 9,  /* contact points the kernel keeps per env and world step (0: no reporting in this kernel) */
   DART_Q_LDS_BYTES = 10     /* LDS bytes per workgroup of the step kernel (tree kernel: the per-env block; planar kernels: the fallback solver's) */
 };

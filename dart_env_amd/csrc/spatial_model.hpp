@@ -133,7 +133,7 @@ struct SpLds {
   Real* cpN;     // [maxcp][3]: contact normal, pointing into the first link (ground: +y)
   int* cplink;   // [maxcp] first link
   int* cplinkB;  // [maxcp] second link of a link-link contact, -1 for the ground
-  Real* sinv;    // [n]: 1 / L_jj of the mass-matrix Cholesky factor
+  Real* sinv;    // [sp_npad(n)]: 1 / L_jj of the mass-matrix Cholesky factor
   Real* root;    // [24] free root joint: R (9), p (3), body twist w v (6); 6 spare
   Real* cf;      // [n]: J^T lambda / dt of the previous world step (pydart2 constraint_forces(), SPD task only)
   Real* misc;    // [16]: roff(3), scalars
@@ -165,7 +165,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   S.cpP = p; p += maxcp * 4;
   S.cpN = p; p += maxcp * 3;
   S.misc = p; p += 16;
-  S.sinv = p; p += n;
+  S.sinv = p; p += sp_npad(n);   // the factorisation writes the padding columns' entries too
   S.cf = p; p += n;
   S.root = p; p += 24;
   S.rdof = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
@@ -181,7 +181,7 @@ __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes,
   const bool alias = sp_lw_aliases_links(nl, maxm);
   const size_t lw = alias ? 0 : (size_t)sp_tri(maxm) + maxm;
   const size_t a = (reg_lcp && alias) ? 0 : (size_t)sp_tri(maxm);
-  size_t reals = (size_t)nl * SP_LINKF + 6 * n + (size_t)HR(sp_npad(n)) + 3 + (size_t)(maxm + 1) * n + a + lw + 5 * maxm +
+  size_t reals = (size_t)nl * SP_LINKF + 5 * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)(maxm + 1) * n + a + lw + 5 * maxm +
                  maxcp * 7 + 16 + 24;
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }

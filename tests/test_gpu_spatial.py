@@ -827,3 +827,30 @@ def test_sliding_box_known_answer_on_gpu():
             if 1 <= k < 50:
                 assert np.allclose(fc[:, :, 0].sum(axis=1), -3.5 * 9.81, rtol=2e-4 if prec == 64 else 5e-3)
         g.close()
+
+
+def test_tree_pattern_kernel_is_selected_only_on_an_exact_match():
+    """csrc/tree_patterns.hpp: the HumanWalker card's factor pattern is baked in; the library runs the symbolic factorisation of
+    the card it is given and takes the pattern kernel only when it is that tree (DART_Q_STATIC_KERNEL reports which)."""
+    from dart_env_amd import stepper as st
+    for env_id, kwargs, want in (("DartHumanWalker-v1", {}, 1), ("DartHumanWalker-v1", {"generic_kernel": True}, 0),
+                                 ("DartWalker3d-v1", {}, 0), ("DartDog-v1", {}, 0)):
+        s = st.HipStepper(card_for(env_id, **kwargs), 64, precision=32)
+        assert s.query(st.Q_STATIC_KERNEL) == want, (env_id, kwargs)
+        s.close()
+    # same tree, other numbers (heavier thighs): still the pattern kernel, and still the oracle's trajectory
+    card = card_for("DartHumanWalker-v1")
+    for b in range(card.nbodies):
+        card.mass[b] *= 1.25
+    s = st.HipStepper(card, 32, precision=64)
+    assert s.query(st.Q_STATIC_KERNEL) == 1
+    ora = OracleBatch(card, 32)
+    rng = np.random.RandomState(2)
+    qn = rng.uniform(-.005, .005, (32, card.ndofs)); vn = rng.uniform(-.005, .005, (32, card.ndofs))
+    s.reset(None, qn, vn, want_obs=False); ora.reset(None, qn, vn)
+    for t in range(15):
+        a = rng.uniform(-1, 1, (32, card.act_dim)).astype(np.float32)
+        s.step(a); ora.step(a)
+    qg, dqg = s.get_state(); qo, dqo = ora.state()
+    assert np.abs(qg - qo).max() < 1e-8 and np.abs(dqg - dqo).max() < 1e-6
+    s.close()

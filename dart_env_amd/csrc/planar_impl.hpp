@@ -10,6 +10,7 @@
 #include "planar_kernel.hpp"
 #include "static_models.hpp"
 #include "cart_kernel.hpp"
+#include "arm_kernel.hpp"
 
 namespace dartk {
 
@@ -394,6 +395,127 @@ std::unique_ptr<Impl> make_cart(const DartModelCard& c, std::string& why) {
   return p;
 }
 
+// ------------------------------------------------------------------ fixed-base arm in the horizontal plane (arm_kernel.hpp)
+template <class Real, int NP>
+struct ArmImplT : Impl {
+  ArmParams<Real, NP> P;
+  Real* d_tstate = nullptr;
+  hipError_t prepare(int64_t n) override {
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_tstate, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
+    if ((e = hipMemset(d_tstate, 0, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
+    P.tstate = d_tstate;
+    return hipSuccess;
+  }
+  void release() override { if (d_tstate) (void)hipFree(d_tstate); d_tstate = nullptr; P.tstate = nullptr; }
+  hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
+                  float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
+    dim3 grid((unsigned)((n + block_threads - 1) / block_threads)), block(block_threads);
+    hipLaunchKernelGGL((arm_step_kernel<Real, NP>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew, done, trunc,
+                       autoreset, seed, off);
+    return hipGetLastError();
+  }
+  hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
+                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off, int obs_masked_only) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((arm_reset_kernel<Real, NP>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, mask, qn, vn, obs, seed, off,
+                       obs_masked_only);
+    return hipGetLastError();
+  }
+  hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((state_io_kernel<Real, NP>), grid, block, 0, s, n, (Real*)q, (Real*)dq, qh, dqh, to_device);
+    return hipGetLastError();
+  }
+  int set_task_state(hipStream_t s, const uint8_t* d_mask, const double* d_values, int64_t n) override {
+    hipLaunchKernelGGL((arm_task_state_kernel<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_mask, d_values, d_tstate);
+    return hipGetLastError() == hipSuccess ? DART_OK : DART_E_HIP;
+  }
+  void persistent(std::vector<std::pair<void*, size_t>>& v, int64_t n) override {
+    if (d_tstate) v.push_back({d_tstate, sizeof(Real) * 4 * (size_t)n});      // the reach targets
+  }
+  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : 24; }   // no contacts: one exact (pivoting) stage
+  void set_stats(unsigned long long*) override {}
+  int slots() const override { return 2 * NP; }
+};
+
+// NP links on revolute +-y joints in a chain from the world, moving in the x-z plane; welded bodies (the finger tip) fold into
+// their link.  Task: the 2-D reacher (reacher2d.py).
+template <class Real, int NP>
+std::string fill_arm(const DartModelCard& c, ArmParams<Real, NP>& P) {
+  if (c.task != DART_TASK_REACHER2D) return "task";
+  if (c.ndofs != NP || c.nbodies < NP) return "body/dof count";
+  if (c.act_dim != NP || c.act_dof0 != 0) return "action layout";
+  if (c.obs_dim != arm_obs_dim<NP>()) return "obs_dim";
+  if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be normal to the plane of motion";
+  for (int s = 0; s < c.nshapes; s++) if (c.shape_collidable[s]) return "collidable shapes";
+  int link_of_body[DART_MAX_BODIES], body_of_link[NP], nl = 0;
+  double wx[DART_MAX_BODIES], wy[DART_MAX_BODIES];   // origin of a (welded) body's frame in its link frame, plane coordinates (x, z)
+  for (int b = 0; b < c.nbodies; b++) { link_of_body[b] = -1; wx[b] = 0; wy[b] = 0; }
+  for (int b = 0; b < c.nbodies; b++) {
+    const int pb = c.parent[b];
+    if (!is_identity3(c.T_pj[b]) || !is_identity3(c.T_cj[b])) return "rotated joint frames";
+    if (c.jtype[b] == DART_JT_WELD) {
+      if (pb < 0 || link_of_body[pb] < 0) return "weld without a link to hold it";
+      if (c.T_pj[b][7] != 0 || c.T_cj[b][7] != 0) return "weld off plane";
+      link_of_body[b] = link_of_body[pb];
+      wx[b] = wx[pb] + c.T_pj[b][3] - c.T_cj[b][3]; wy[b] = wy[pb] + c.T_pj[b][11] - c.T_cj[b][11];
+      continue;
+    }
+    if (nl >= NP) return "body/dof count";
+    if (c.jtype[b] != DART_JT_REVOLUTE || std::fabs(std::fabs(c.axes[c.dof_offset[b]][1]) - 1) > 1e-12) return "link joint must be revolute about +-y";
+    if (nl == 0 ? pb != -1 : (pb < 0 || link_of_body[pb] != nl - 1 || c.jtype[pb] == DART_JT_WELD)) return "not a chain from the world";
+    if (c.T_cj[b][3] != 0 || c.T_cj[b][7] != 0 || c.T_cj[b][11] != 0 || (nl > 0 && c.T_pj[b][7] != 0)) return "joint offsets";
+    if (c.dof_offset[b] != nl) return "dof order";
+    body_of_link[nl] = b; link_of_body[b] = nl++;
+  }
+  if (nl != NP) return "body/dof count";
+  double lm[NP], lcx[NP], lcy[NP], lizz[NP];
+  for (int k = 0; k < NP; k++) {
+    const int b = body_of_link[k];
+    if (c.com[b][1] != 0) return "com off plane";
+    lm[k] = c.mass[b]; lcx[k] = c.com[b][0]; lcy[k] = c.com[b][2]; lizz[k] = c.inertia[b][4];
+  }
+  for (int b = 0; b < c.nbodies; b++) {   // fold the welded bodies in: composite mass, COM, inertia about the new COM
+    if (c.jtype[b] != DART_JT_WELD || c.mass[b] == 0) continue;
+    if (c.com[b][1] != 0) return "com off plane";
+    const int k = link_of_body[b];
+    const double mb = c.mass[b], bx = wx[b] + c.com[b][0], by = wy[b] + c.com[b][2];
+    const double m = lm[k] + mb, nx = (lm[k] * lcx[k] + mb * bx) / m, ny = (lm[k] * lcy[k] + mb * by) / m;
+    lizz[k] = lizz[k] + lm[k] * ((lcx[k] - nx) * (lcx[k] - nx) + (lcy[k] - ny) * (lcy[k] - ny)) + c.inertia[b][4] +
+              mb * ((bx - nx) * (bx - nx) + (by - ny) * (by - ny));
+    lm[k] = m; lcx[k] = nx; lcy[k] = ny;
+  }
+  const int tb = c.aux_body[0];   // reacher2d.py:31: bodynodes[-1].com()
+  if (tb < 0 || tb >= c.nbodies || link_of_body[tb] != NP - 1) return "tip body must ride on the last link";
+  if (c.aux_real[1] != 0) return "tip offset off plane";
+  P.tipx = (Real)(wx[tb] + c.aux_real[0]); P.tipy = (Real)(wy[tb] + c.aux_real[2]);
+  P.height = (Real)(c.T_pj[body_of_link[0]][7]);
+  for (int k = 0; k < NP; k++) {
+    const int b = body_of_link[k], d = c.dof_offset[b];
+    P.sigma[k] = (Real)(c.axes[d][1] > 0 ? -1.0 : 1.0);   // a turn about +y is clockwise in (x, z)
+    P.mass[k] = (Real)lm[k]; P.cx[k] = (Real)lcx[k]; P.cy[k] = (Real)lcy[k]; P.izz[k] = (Real)lizz[k];
+    P.jx[k] = (Real)c.T_pj[b][3]; P.jy[k] = (Real)c.T_pj[b][11];
+    P.lo[k] = (Real)(c.limited[d] ? c.lower[d] : -INFINITY); P.hi[k] = (Real)(c.limited[d] ? c.upper[d] : INFINITY);
+    P.damp[k] = (Real)c.damping[d]; P.stiff[k] = (Real)c.stiffness[d]; P.rest[k] = (Real)c.rest[d];
+    P.q0[k] = (Real)c.init_pos[d]; P.dq0[k] = (Real)c.init_vel[d];
+    P.fric_dt[k] = (Real)(c.joint_friction[d] * c.dt);
+    P.act_scale[k] = (Real)c.act_scale[k]; P.act_lo[k] = (Real)c.act_low[k]; P.act_hi[k] = (Real)c.act_high[k];
+  }
+  P.dt = (Real)c.dt; P.limit_erp_dt = (Real)(c.limit_erp / c.dt); P.max_erv = (Real)c.max_erv; P.cfm1 = (Real)(1.0 + c.cfm);
+  P.noise = (Real)c.reset_noise; P.noise_v = (Real)c.reset_noise_vel;
+  P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task; P.iters = 24; P.tstate = nullptr;
+  return "";
+}
+
+template <class Real, int NP>
+std::unique_ptr<Impl> make_arm(const DartModelCard& c, std::string& why) {
+  auto p = std::make_unique<ArmImplT<Real, NP>>();
+  std::string w = fill_arm<Real, NP>(c, p->P);
+  if (!w.empty()) { why += w; return nullptr; }
+  return p;
+}
+
 template <class Real>
 std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool allow_static) {
   why += "hopper-chain, feet only: ";
@@ -412,6 +534,8 @@ std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool
   if (auto p = make_cart<Real, 1>(c, why)) return p;
   why += "; cart + 2 links: ";
   if (auto p = make_cart<Real, 2>(c, why)) return p;
+  why += "; two-link arm in the x-z plane: ";
+  if (auto p = make_arm<Real, 2>(c, why)) return p;
   return nullptr;
 }
 

@@ -33,6 +33,7 @@ def lib():
         L.emu_set_solver.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.emu_enable_stats.argtypes = [vp, C.c_int]
         L.emu_force_slow.argtypes = [vp, C.c_int]
+        L.emu_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), dp]
         L.emu_set_ext_force.argtypes = [vp, C.c_int, dp]
         L.emu_contact_report.argtypes = [vp, C.c_int]
         L.emu_max_contacts.argtypes = [vp]
@@ -100,6 +101,16 @@ class EmuStepper:
         cf = np.zeros((self.n, self.nd))
         assert self.L.emu_get_constraint_forces(self.h, _p(cf, C.c_double)) == 0
         return cf
+
+    def set_task_state(self, mask, values):
+        """(N, <=4) per-env task state (reach target) for the masked envs; call before reset() -- as HipStepper.set_task_state"""
+        v = np.zeros((self.n, 4), dtype=np.float64)
+        vals = np.asarray(values, dtype=np.float64).reshape(self.n, -1)
+        v[:, :vals.shape[1]] = vals
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        rc = self.L.emu_set_task_state(self.h, _p(m, C.c_uint8) if m is not None else None, _p(v, C.c_double))
+        if rc != 0:
+            raise RuntimeError("set_task_state rc=%d" % rc)
 
     def force_slow(self, on=True):
         """every env with a contact goes through the single-lane fallback solver (validates it against the oracle)"""

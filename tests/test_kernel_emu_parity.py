@@ -180,3 +180,31 @@ def test_snake_on_the_register_kernel():
             qn = rng.uniform(-.005, .005, (n, nd)); vn = rng.uniform(-.005, .005, (n, nd))
             g.reset(do.astype(np.uint8), qn, vn, want_obs=False); o.reset(do, qn, vn)
     assert dones > 10
+
+
+def test_reacher2d_on_the_arm_lane_kernel():
+    """csrc/arm_kernel.hpp: two links on +y hinges in the horizontal plane, fixed base, welded finger tip folded into the last link,
+    one joint-limit and one Coulomb-friction row per dof in the LCP, per-env reach targets as task state, TimeLimit resets"""
+    from tests.batch_oracle import OracleBatch
+    card = card_for("DartReacher-v1"); n, nd = 64, card.ndofs
+    rng = np.random.RandomState(4)
+    g = EmuStepper(card, n, precision=64); o = OracleBatch(card, n)
+    tg = np.zeros((n, 3)); tg[:, 0] = rng.uniform(-.2, .2, n); tg[:, 1] = 0.01; tg[:, 2] = rng.uniform(-.2, .2, n)
+    g.set_task_state(None, tg)
+    for i, w in enumerate(o.worlds):
+        w.set_task_state(tg[i])
+    qn = rng.uniform(-.01, .01, (n, nd)); vn = np.zeros((n, nd)); vn[n // 2:] = rng.uniform(-.005, .005, (n // 2, nd))
+    og = g.reset(None, qn, vn); o.reset(None, qn, vn)
+    assert np.allclose(og, o.obs(), atol=1e-6)
+    for t in range(49):
+        a = rng.uniform(-1.3, 1.3, (n, 2)).astype(np.float32)
+        a[: n // 2] = 0.0002 * np.sign(a[: n // 2])           # 0.04 Nm < 0.05 Nm of Coulomb friction: that half stays put
+        ob, r, d, tr = g.step(a); oo, ro, do, to = o.step(a)
+        qg, dqg = g.get_state(); qo, dqo = o.state()
+        assert np.abs(qg - qo).max() < 1e-12 and np.abs(dqg - dqo).max() < 1e-11, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        assert np.allclose(ob, oo, atol=1e-5) and np.allclose(r, ro, atol=5e-6) and not d.any() and not do.any()
+    q, dq = g.get_state()
+    assert np.abs(dq[: n // 2]).max() < 1e-9 and np.abs(q[: n // 2] - qn[: n // 2]).max() < 1e-9      # stuck by friction
+    assert np.abs(dq[n // 2:]).max() > 0.1
+    ob, r, d, tr = g.step(np.zeros((n, 2), dtype=np.float32)); oo, ro, do, to = o.step(np.zeros((n, 2), dtype=np.float32))
+    assert d.all() and tr.all() and do.all()                  # step 50: the TimeLimit ends every episode

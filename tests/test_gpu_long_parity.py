@@ -31,6 +31,22 @@ def test_fp64_untrimmed_rms_below_1e_4_over_1000_steps(env_id, ne):
     assert stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])
 
 
+@pytest.mark.parametrize("env_id,steps", [("DartHalfCheetah-v1", 100), ("DartSnake7Link-v1", 1000), ("DartCartPole-v1", 1000),
+                                          ("DartDoubleInvertedPendulumEnv-v1", 1000), ("DartReacher-v1", 1000)])
+def test_lane_kernels_added_in_round_2_meet_the_same_bound(env_id, steps):
+    """The same untrimmed protocol for the tasks that moved from the tree kernel to lane-per-env kernels in round 2.  The half
+    cheetah is compared over 100 env-steps: its episodes only end with the 1 000-step TimeLimit, and a cheetah thrashing under
+    random torques is chaotic -- two fp64 evaluation orders of the same equations drift apart by ~10^4 per 90 env-steps (measured:
+    RMS q 3e-17 after 1 step, 2e-16 after 10, 3e-12 after 100, O(0.1) after 1 000; two copies of the ORACLE started 1e-15 apart do
+    the same: 1e-11 after 100 env-steps, 7e-7 after 200, 0.09 after 400); the configs of the north star reset long before that."""
+    stats, ref, _ = parity_check(env_id, 64, 4096, steps, 0)
+    print(env_id, {k: (v["q"], v["dq"]) for k, v in stats["by_step"].items()}, "episodes", stats["episodes"],
+          "oracle %.1fs on %d threads, gpu %.1fs" % (ref["seconds"], ref["threads"], stats["stepper_seconds"]))
+    assert stats["envs"] >= 4096 and stats["env_steps"] >= steps and stats["done_flag_mismatches"] == 0
+    assert all(v["envs_non_finite"] == 0 for v in stats["by_step"].values())
+    assert stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])
+
+
 @pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1"])
 def test_fp32_fast_mode_divergence_is_a_few_flipped_events(env_id):
     """What fp32 delivers under the same protocol: almost every env within 1e-4 of the oracle at every checkpoint; the

@@ -96,7 +96,7 @@ def test_sled_translation_and_batch_invariance_fp32_bitwise():
         assert np.array_equal(dq, outs[0][1]) and np.array_equal(q[1:], outs[0][0][1:]) and abs((q[0] - off) - outs[0][0][0]) < 1e-5
 
 
-@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartHumanWalker-v1", "DartWalker3dSPD-v1"])
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartHumanWalker-v1", "DartWalker3dSPD-v1", "DartReacher-v1"])
 def test_snapshot_restore_resumes_bitwise(env_id):
     """dart_snapshot / dart_restore: after a restore the next steps -- including on-device auto-resets from the MT19937
     bank, TimeLimit truncations, episode statistics and the SPD controller's carried constraint forces -- are bitwise those

@@ -224,10 +224,11 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     b.mark(0)                                  # HIP events on the kernels' stream around EXACTLY args.steps launches (enqueue only)
     b.run(args.steps, args.warmup)
     b.mark(1)
-    b.sync()
+    if env_factory is not None:
+        b.sync()                               # (the stand-in shard of the CPU plumbing test has no device to synchronise)
     if dist is not None:
         dist.barrier()
-    device_sync()
+    device_sync()                              # torch.cuda.synchronize(): waits for every stream of the device, the stepper's included
     elapsed = time.perf_counter() - t0
     ms_kernel = b.elapsed_ms() / args.steps    # the event wait and read-out sit outside the wall-clock region
     offsets = [env_offset]

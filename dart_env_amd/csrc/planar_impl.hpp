@@ -11,6 +11,8 @@
 #include "static_models.hpp"
 #include "cart_kernel.hpp"
 #include "arm_kernel.hpp"
+#include "chain3d_kernel.hpp"
+#include "spatial_build.hpp"
 
 namespace dartk {
 
@@ -516,6 +518,90 @@ std::unique_ptr<Impl> make_arm(const DartModelCard& c, std::string& why) {
   return p;
 }
 
+// ------------------------------------------------------------------ fixed-base 3-D chain of revolute links (chain3d_kernel.hpp)
+template <class Real, int NL, bool FRIC>
+struct Chain3dImplT : Impl {
+  Chain3Params<Real, NL> P;
+  Real* d_tstate = nullptr;
+  hipError_t prepare(int64_t n) override {
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_tstate, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
+    if ((e = hipMemset(d_tstate, 0, sizeof(Real) * 4 * (size_t)n)) != hipSuccess) return e;
+    P.tstate = d_tstate;
+    return hipSuccess;
+  }
+  void release() override { if (d_tstate) (void)hipFree(d_tstate); d_tstate = nullptr; P.tstate = nullptr; }
+  hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
+                  float* rew, uint8_t* done, uint8_t* trunc, int autoreset, uint64_t seed, uint64_t off) override {
+    dim3 grid((unsigned)((n + block_threads - 1) / block_threads)), block(block_threads);
+    hipLaunchKernelGGL((chain3d_step_kernel<Real, NL, FRIC>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, act, obs, rew, done, trunc,
+                       autoreset, seed, off);
+    return hipGetLastError();
+  }
+  hipError_t reset(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const uint8_t* mask,
+                   const double* qn, const double* vn, float* obs, uint64_t seed, uint64_t off, int obs_masked_only) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((chain3d_reset_kernel<Real, NL>), grid, block, 0, s, P, n, (Real*)q, (Real*)dq, el, ep, mask, qn, vn, obs, seed, off,
+                       obs_masked_only);
+    return hipGetLastError();
+  }
+  hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) override {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL((state_io_kernel<Real, NL>), grid, block, 0, s, n, (Real*)q, (Real*)dq, qh, dqh, to_device);
+    return hipGetLastError();
+  }
+  int set_task_state(hipStream_t s, const uint8_t* d_mask, const double* d_values, int64_t n) override {
+    hipLaunchKernelGGL((arm_task_state_kernel<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_mask, d_values, d_tstate);
+    return hipGetLastError() == hipSuccess ? DART_OK : DART_E_HIP;
+  }
+  void persistent(std::vector<std::pair<void*, size_t>>& v, int64_t n) override {
+    if (d_tstate) v.push_back({d_tstate, sizeof(Real) * 4 * (size_t)n});      // the reach targets
+  }
+  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : 24; }   // no contacts: one exact (pivoting) stage
+  void set_stats(unsigned long long*) override {}
+  int slots() const override { return FRIC ? 2 * NL : NL; }
+};
+
+// The card through the tree kernel's model builder (multi-dof joints expanded into 1-dof links), then the checks that make it this
+// kernel's case: NL revolute links in one chain from the world, one dof each in chain order, nothing that collides.  Task: the
+// 3-D reacher (reacher.py).
+template <class Real, int NL, bool FRIC>
+std::unique_ptr<Impl> make_chain3d(const DartModelCard& c, std::string& why) {
+  if (c.task != DART_TASK_REACHER3D) { why += "task"; return nullptr; }
+  if (c.ndofs != NL || c.act_dim != NL || c.act_dof0 != 0 || c.obs_dim != chain3d_obs_dim<NL>()) { why += "dof / action / observation layout"; return nullptr; }
+  auto Mp = std::make_unique<SpatialModel<Real>>();
+  SpatialModel<Real>& M = *Mp;
+  const std::string w = fill_spatial<Real>(c, M);
+  if (!w.empty()) { why += w; return nullptr; }
+  if (M.nl != NL || M.n != NL) { why += "expanded link count"; return nullptr; }
+  if (M.nshapes != 0 || M.npairs != 0 || M.free_root) { why += "contacts or a free root"; return nullptr; }
+  if ((M.has_joint_friction != 0) != FRIC) { why += "joint friction"; return nullptr; }
+  for (int i = 0; i < NL; i++)
+    if (M.parent[i] != i - 1 || M.jtype[i] != 2 || M.dof[i] != i) { why += "not a chain of revolute links in dof order"; return nullptr; }
+  if (M.aux_link[0] != NL - 1) { why += "tip body must be the last link"; return nullptr; }
+  auto p = std::make_unique<Chain3dImplT<Real, NL, FRIC>>();
+  Chain3Params<Real, NL>& P = p->P;
+  for (int i = 0; i < NL; i++) {
+    const Real* g = M.lconst[i];
+    for (int k = 0; k < 9; k++) { P.Rpre[i][k] = g[LC_RPRE + k]; P.Rpost[i][k] = g[LC_RPOST + k]; P.inertia[i][k] = g[LC_INERTIA + k]; }
+    for (int k = 0; k < 3; k++) {
+      P.ppre[i][k] = g[LC_PPRE + k]; P.ppost[i][k] = g[LC_PPOST + k]; P.axis[i][k] = g[LC_AXIS + k]; P.axr[i][k] = g[LC_AXR + k];
+      P.cpost[i][k] = g[LC_CPOST + k]; P.com[i][k] = g[LC_COM + k];
+    }
+    P.mass[i] = M.mass[i];
+    P.lo[i] = M.limited[i] ? M.lower[i] : (Real)-INFINITY; P.hi[i] = M.limited[i] ? M.upper[i] : (Real)INFINITY;
+    P.damp[i] = M.damp[i]; P.stiff[i] = M.stiff[i]; P.rest[i] = M.rest[i]; P.q0[i] = M.q0[i]; P.dq0[i] = M.dq0[i];
+    P.fric_dt[i] = M.jfric_dt[i];
+    P.act_scale[i] = M.act_scale[i]; P.act_lo[i] = M.act_lo[i]; P.act_hi[i] = M.act_hi[i];
+  }
+  for (int k = 0; k < 3; k++) { P.g[k] = M.g[k]; P.tip[k] = M.aux_real[k]; }
+  P.dt = M.dt; P.limit_erp_dt = M.limit_erp_dt; P.max_erv = M.max_erv; P.cfm1 = M.cfm1;
+  P.ctrl_w = M.aux_real[3]; P.done_dist = M.aux_real[4];
+  P.noise = M.noise; P.noise_v = M.noise_v;
+  P.frame_skip = M.frame_skip; P.max_steps = M.max_steps; P.task = M.task; P.iters = 24; P.tstate = nullptr;
+  return p;
+}
+
 template <class Real>
 std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool allow_static) {
   why += "hopper-chain, feet only: ";
@@ -536,6 +622,8 @@ std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool
   if (auto p = make_cart<Real, 2>(c, why)) return p;
   why += "; two-link arm in the x-z plane: ";
   if (auto p = make_arm<Real, 2>(c, why)) return p;
+  why += "; five-link revolute chain in 3-D: ";
+  if (auto p = make_chain3d<Real, 5, false>(c, why)) return p;
   return nullptr;
 }
 

@@ -31,6 +31,8 @@ typedef void* hipStream_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 // "device" memory is host memory here
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }

@@ -9,7 +9,7 @@ from dart_env_amd.model_card import card_for
 
 pytestmark = pytest.mark.gpu
 
-ENVS = ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1", "DartSnake7Link-v1", "DartCartPole-v1", "DartReacher-v1",
+ENVS = ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1", "DartSnake7Link-v1", "DartCartPole-v1", "DartReacher-v1", "DartReacher3d-v1",
         "DartDoubleInvertedPendulumEnv-v1"]
 
 

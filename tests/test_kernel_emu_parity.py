@@ -208,3 +208,42 @@ def test_reacher2d_on_the_arm_lane_kernel():
     assert np.abs(dq[n // 2:]).max() > 0.1
     ob, r, d, tr = g.step(np.zeros((n, 2), dtype=np.float32)); oo, ro, do, to = o.step(np.zeros((n, 2), dtype=np.float32))
     assert d.all() and tr.all() and do.all()                  # step 50: the TimeLimit ends every episode
+
+
+def test_reacher3d_on_the_chain_lane_kernel():
+    """csrc/chain3d_kernel.hpp: reacher.skel's universal - revolute - universal joints as five revolute links in 3-D, one env per
+    lane: free motion, joint limits through the LCP, reward / done from the tip-target distance BEFORE the step (reacher.py:23-33)"""
+    from tests.batch_oracle import OracleBatch
+    card = card_for("DartReacher3d-v1"); n, nd = 64, card.ndofs
+    rng = np.random.RandomState(5)
+    g = EmuStepper(card, n, precision=64); o = OracleBatch(card, n)
+    tg = rng.uniform(-.3, .3, (n, 3))
+    g.set_task_state(None, tg)
+    for i, w in enumerate(o.worlds):
+        w.set_task_state(tg[i])
+    qn = rng.uniform(-.01, .01, (n, nd)); vn = rng.uniform(-.01, .01, (n, nd))
+    og = g.reset(None, qn, vn); o.reset(None, qn, vn)
+    assert np.allclose(og, o.obs(), atol=1e-6)
+    tip = og[:, -3:].astype(np.float64) + tg                     # obs ends with tip - target
+    tg[:16] = tip[:16] + 0.01                                    # these envs start within 0.1 of their target: done at once
+    g.set_task_state(None, tg)
+    for i, w in enumerate(o.worlds):
+        w.set_task_state(tg[i])
+    q, dq = g.get_state()
+    q[32:] = rng.choice([-3.13, 3.13], (32, nd)); dq[32:] = np.sign(q[32:]) * 4.0      # these run into their joint limits
+    g.set_state(q, dq)
+    for i in range(n):
+        o.worlds[i].set_state(q[i], dq[i])
+    dones = beyond = 0
+    for t in range(60):
+        a = rng.uniform(-1.3, 1.3, (n, 5)).astype(np.float32)
+        ob, r, d, tr = g.step(a); oo, ro, do, to = o.step(a)
+        qg, dqg = g.get_state(); qo, dqo = o.state()
+        assert np.array_equal(d.astype(bool), do.astype(bool)), t
+        assert np.abs(qg - qo).max() < 1e-12 and np.abs(dqg - dqo).max() < 1e-11, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        assert np.allclose(ob, oo, atol=1e-5) and np.allclose(r, ro, atol=1e-5)
+        dones += int(do.sum()); beyond += int((np.abs(qo) >= 3.14).sum())
+        if do.any():
+            qn = rng.uniform(-.01, .01, (n, nd)); vn = rng.uniform(-.01, .01, (n, nd))
+            g.reset(do.astype(np.uint8), qn, vn, want_obs=False); o.reset(do, qn, vn)
+    assert dones >= 16 and beyond > 100

@@ -626,6 +626,28 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     sig |= act[i] ? (1u << i) : 0u;
     up |= (act[i] && upper) ? (1u << i) : 0u;
   });
+#ifdef DART_LCP_STAGE1_SWEEP
+  {
+    // (experiment, off by default; tests/diag/diag_lcp_active_sets.py) one projected Gauss-Seidel sweep over the rows that can move,
+    // started from each violated row's own impulse b_i / A_ii: rows the others push across their bound start free, rows another
+    // row already takes care of start on their bound
+    Real xe[M];
+    sfor<0, M>([&](auto I) { constexpr int i = I; xe[i] = ((F >> i) & 1u) ? b[i] * rcp_<Real>(A[tri(i, i)]) : Real(0); });
+    sfor<0, M>([&](auto I) {
+      constexpr int i = I;
+      const bool pinned = (pinmask >> i) & 1u, upper = !(lo[i] == Real(0));
+      Real r = b[i];
+      sfor<0, M>([&](auto J) { constexpr int j = J; if constexpr (j != i) r -= A[tri(i, j)] * xe[j]; });
+      Real xn = r * rcp_<Real>(A[tri(i, i)]);
+      xn = upper ? fmin(xn, Real(0)) : fmax(xn, Real(0));
+      xn = (pinned || !act[i]) ? Real(0) : xn;
+      xe[i] = xn;
+      const bool fr = upper ? (xn < Real(0)) : (xn > Real(0));
+      F = fr ? (F | (1u << i)) : (F & ~(1u << i));
+      U = (upper && !fr && !pinned) ? (U | (1u << i)) : (U & ~(1u << i));
+    });
+  }
+#endif
   sfor<0, NCA>([&](auto S) { has_contact = has_contact || act[2 * S]; });
   // rows that were active on the same side in the previous substep (contact slots: and hold the same capsule) inherit
   // that substep's final set

@@ -715,8 +715,13 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       // complement A_tt - A_tn^2 / A_nn.  (tests/diag/diag_lcp_active_sets.py: with the plain A_tt 92 % of the wrong stage-2 guesses
       // were friction rows guessed sticking that ended up sliding; with the complement a Hopper lane needs one stage-2 solve in 98 %
       // instead of 84 % of the substeps, which takes a wave -- the maximum over its lanes -- from 3 solves to 2 or 1: 34.1 -> 31.2 us.)
-      const bool nfree = (F >> sn) & 1u;
-      const Real att = nfree ? A[tri(stt, stt)] - A[tri(stt, sn)] * A[tri(stt, sn)] * rcp_<Real>(A[tri(sn, sn)]) : A[tri(stt, stt)];
+      // (Topologies whose big tier is an isolated call -- the half cheetah -- keep the plain A_tt: their kernels were validated on
+      // the GPU, repeatability included, before this change and the round's GPU budget ended with the Hopper / Walker2d measurement.)
+      Real att = A[tri(stt, stt)];
+      if constexpr (!T::ISOLATED_TIER1) {
+        const bool nfree = (F >> sn) & 1u;
+        att = nfree ? att - A[tri(stt, sn)] * A[tri(stt, sn)] * rcp_<Real>(A[tri(sn, sn)]) : att;
+      }
       const Real xe = -wt * rcp_<Real>(att);
       const bool up = xe > hb, dn = xe < -hb;
       F = (pinned || up || dn) ? (F & ~(1u << stt)) : (F | (1u << stt));

@@ -25,6 +25,8 @@ struct ArmParams {
   Real sigma[NP], mass[NP], cx[NP], cy[NP], izz[NP], jx[NP], jy[NP];   // link k; joint position in the parent frame (link 0: in the world)
   Real lo[NP], hi[NP];              // +-inf: no limit on that dof
   Real damp[NP], stiff[NP], rest[NP], q0[NP], dq0[NP];
+  Real sqe[NP];     // sqrt(dt damp + dt^2 stiff) per dof (planar_kernel.hpp: implicit_accel)
+  int impulse_M;    // card.impulse_inertia (A3): 1 = impulses act on M (DART 6), 0 = on M + dt D + dt^2 K
   Real fric_dt[NP];                 // Coulomb joint friction * dt (0 = none)
   Real tipx, tipy;                  // the finger tip (COM of the last body, reacher2d.py:31) in the last link's frame
   Real act_scale[NP], act_lo[NP], act_hi[NP];
@@ -80,16 +82,21 @@ __device__ __forceinline__ void arm_world_step(const ArmParams<Real, NP>& P, Rea
       H[tri(k, j)] = P.sigma[k] * P.sigma[j] * (Ip[k] + dcx[k] * (px[k] - px[j]) + dcy[k] * (py[k] - py[j]));
     });
     rhs[k] = tau[k] - P.sigma[k] * Nz[k] - P.damp[k] * dq[k] - P.stiff[k] * (q[k] + P.dt * dq[k] - P.rest[k]);
-    H[tri(k, k)] += P.dt * P.damp[k] + P.dt * P.dt * P.stiff[k];
+    if (!P.impulse_M) H[tri(k, k)] += P.dt * P.damp[k] + P.dt * P.dt * P.stiff[k];
   });
-  spd_inverse<Real, N>(H);
+  spd_inverse<Real, N>(H);   // inverse of the impulse inertia: M (DART 6) or M + E (card.impulse_inertia = 0)
   Real vs[N];
-  sfor<0, N>([&](auto I) {
-    constexpr int i = I;
-    Real a = Real(0);
-    sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(i, j)] * rhs[j]; });
-    vs[i] = dq[i] + P.dt * a;
-  });
+  {
+    Real acc[N];
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      Real a = Real(0);
+      sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(i, j)] * rhs[j]; });
+      acc[i] = a;
+    });
+    if (P.impulse_M) implicit_accel<Real, N, false, AllDofs<N>>(P, H, acc);   // qdd = (M + E)^-1 rhs from M^-1
+    sfor<0, N>([&](auto I) { constexpr int i = I; vs[i] = dq[i] + P.dt * acc[i]; });
+  }
   // LCP rows: joint limits at q_t (rows 0..N-1), Coulomb joint friction (rows N..2N-1); both act on a single dof
   constexpr int M = 2 * N;
   Real A[M * (M + 1) / 2], b[M], lo[M], hi[M], x[M];

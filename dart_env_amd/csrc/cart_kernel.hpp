@@ -24,6 +24,8 @@ struct CartParams {
   Real sigma[NP], mass[NP], cx[NP], cy[NP], izz[NP], jx[NP], jy[NP];   // pendulum link k = 1..NP at index k - 1; joint position in the parent frame
   Real lo[N], hi[N];                                                 // +-inf: no limit on that dof
   Real damp[N], stiff[N], rest[N], q0[N], dq0[N];
+  Real sqe[N];      // sqrt(dt damp + dt^2 stiff) per dof (planar_kernel.hpp: implicit_accel)
+  int impulse_M;    // card.impulse_inertia (A3): 1 = impulses act on M (DART 6), 0 = on M + dt D + dt^2 K
   Real tipx, tipy;                  // inverted_double_pendulum.py:27-32: the 'weight' body's origin in the last link's frame
   Real act_scale, act_lo, act_hi;   // cart_pole.py:16: tau[0] = a[0] * scale (act_lo / act_hi = -/+inf: no clamp)
   Real aux[8], angle_max, s_max, noise, noise_v;
@@ -81,16 +83,21 @@ __device__ __forceinline__ void cart_world_step(const CartParams<Real, NP>& P, R
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
     rhs[i] -= P.damp[i] * dq[i] + P.stiff[i] * (q[i] + P.dt * dq[i] - P.rest[i]);
-    H[tri(i, i)] += P.dt * P.damp[i] + P.dt * P.dt * P.stiff[i];
+    if (!P.impulse_M) H[tri(i, i)] += P.dt * P.damp[i] + P.dt * P.dt * P.stiff[i];
   });
-  spd_inverse<Real, N>(H);
+  spd_inverse<Real, N>(H);   // inverse of the impulse inertia: M (DART 6) or M + E (card.impulse_inertia = 0)
   Real vs[N];
-  sfor<0, N>([&](auto I) {
-    constexpr int i = I;
-    Real a = Real(0);
-    sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(i, j)] * rhs[j]; });
-    vs[i] = dq[i] + P.dt * a;
-  });
+  {
+    Real acc[N];
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      Real a = Real(0);
+      sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(i, j)] * rhs[j]; });
+      acc[i] = a;
+    });
+    if (P.impulse_M) implicit_accel<Real, N, false, AllDofs<N>>(P, H, acc);   // qdd = (M + E)^-1 rhs from M^-1
+    sfor<0, N>([&](auto I) { constexpr int i = I; vs[i] = dq[i] + P.dt * acc[i]; });
+  }
   // joint limits at q_t (inclusive, DART's JointLimitConstraint): one LCP row per dof
   Real A[N * (N + 1) / 2], b[N], lo[N], hi[N], x[N];
   bool act[N], any = false;

@@ -25,6 +25,8 @@ struct Chain3Params {
   // frame and in the child link frame, joint origin in the child link frame, COM and inertia about the COM in the link frame
   Real Rpre[NL][9], ppre[NL][3], Rpost[NL][9], ppost[NL][3], axis[NL][3], axr[NL][3], cpost[NL][3], com[NL][3], inertia[NL][9], mass[NL];
   Real lo[NL], hi[NL], damp[NL], stiff[NL], rest[NL], q0[NL], dq0[NL], fric_dt[NL];
+  Real sqe[NL];     // sqrt(dt damp + dt^2 stiff) per dof (planar_kernel.hpp: implicit_accel)
+  int impulse_M;    // card.impulse_inertia (A3): 1 = impulses act on M (DART 6), 0 = on M + dt D + dt^2 K
   Real act_scale[NL], act_lo[NL], act_hi[NL];
   Real tip[3];            // the finger tip in the last link's frame (reacher.py:21)
   Real ctrl_w, done_dist; // reacher.py:25-33: reward = -dist - ctrl_w sum tau^2, done when the distance was below done_dist
@@ -144,16 +146,21 @@ __device__ __forceinline__ void chain3d_world_step(const Chain3Params<Real, NL>&
       H[tri(k, j)] = dot(a[j], Kv + cross(pj[k] - pj[j], Lm));
     });
     rhs[k] = tau[k] - dot(a[k], Nm[k]) - P.damp[k] * dq[k] - P.stiff[k] * (q[k] + P.dt * dq[k] - P.rest[k]);
-    H[tri(k, k)] += P.dt * P.damp[k] + P.dt * P.dt * P.stiff[k];
+    if (!P.impulse_M) H[tri(k, k)] += P.dt * P.damp[k] + P.dt * P.dt * P.stiff[k];
   });
-  spd_inverse<Real, N>(H);
+  spd_inverse<Real, N>(H);   // inverse of the impulse inertia: M (DART 6) or M + E (card.impulse_inertia = 0)
   Real vs[N];
-  sfor<0, N>([&](auto I) {
-    constexpr int i = I;
-    Real acc = Real(0);
-    sfor<0, N>([&](auto J) { constexpr int j = J; acc += H[tri(i, j)] * rhs[j]; });
-    vs[i] = dq[i] + P.dt * acc;
-  });
+  {
+    Real acc[N];
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      Real t = Real(0);
+      sfor<0, N>([&](auto J) { constexpr int j = J; t += H[tri(i, j)] * rhs[j]; });
+      acc[i] = t;
+    });
+    if (P.impulse_M) implicit_accel<Real, N, false, AllDofs<N>>(P, H, acc);   // qdd = (M + E)^-1 rhs from M^-1
+    sfor<0, N>([&](auto I) { constexpr int i = I; vs[i] = dq[i] + P.dt * acc[i]; });
+  }
   // LCP rows: joint limits at q_t (rows 0..N-1) and, with FRIC, Coulomb joint friction (rows N..2N-1); each acts on one dof
   constexpr int M = FRIC ? 2 * N : N;
   Real A[M * (M + 1) / 2], b[M], lo[M], hi[M], x[M];

@@ -217,8 +217,28 @@ int dart_query(const DartStepper* h, int what, int64_t* out) {
   return DART_OK;
 }
 
+// reset_model() of these tasks draws more than the two noise vectors (swing-up sign, reach targets): the in-kernel Philox
+// auto-reset re-noises q / dq only, so it would run them with degenerate episodes -- refused; the MT19937 bank draws all of it
+static bool philox_autoreset_unsupported(const DartStepper* h) {
+  const int t = h->card.task;
+  return h->autoreset && h->noise_mode == 0 &&
+         (t == DART_TASK_CARTPOLE_SWINGUP || t == DART_TASK_REACHER2D || t == DART_TASK_REACHER3D);
+}
+#define CHK_AUTORESET(h)                                                                                                     \
+  do {                                                                                                                       \
+    if (philox_autoreset_unsupported(h)) {                                                                                   \
+      (h)->err = "on-device auto-reset of this task needs the MT19937 bank (dart_seed_mt19937): its reset_model also draws "  \
+                 "the swing-up sign / the reach target, which the Philox reset does not";                                    \
+      return DART_E_UNSUPPORTED;                                                                                             \
+    }                                                                                                                        \
+  } while (0)
+
 int dart_configure(DartStepper* h, int key, double value) {
   if (!h) return DART_E_INVALID;
+  if (h->pending) { h->err = "dart_configure while a step is pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
+  // some keys allocate device buffers or re-upload the model block: nothing of this handle may still be running
+  CHK(h, hipStreamSynchronize(h->stream));
   switch (key) {
     case DART_CFG_SOLVER: h->solver = (int)value; break;
     case DART_CFG_ITERS_STAGE1: h->it1 = (int)value; break;
@@ -257,7 +277,7 @@ int dart_configure(DartStepper* h, int key, double value) {
     default: h->err = "unknown configure key"; return DART_E_INVALID;
   }
   if (h->solver < 0 || h->solver > 1 || h->it1 < 0 || h->it2 < 0) { h->err = "bad solver setting"; return DART_E_INVALID; }
-  h->impl->set_solver(h->solver, h->it1, h->it2);
+  if (key == DART_CFG_SOLVER || key == DART_CFG_ITERS_STAGE1 || key == DART_CFG_ITERS_STAGE2) h->impl->set_solver(h->solver, h->it1, h->it2);
   return DART_OK;
 }
 
@@ -418,6 +438,7 @@ int dart_get_state(DartStepper* h, double* q, double* dq) { return state_copy(h,
 int dart_step_async(DartStepper* h, const float* actions) {
   if (!h || !actions) return DART_E_INVALID;
   if (h->pending) { h->err = "step_async called while a step is pending"; return DART_E_PENDING; }
+  CHK_AUTORESET(h);
   CHK(h, hipSetDevice(h->device));
   size_t N = (size_t)h->n;
   memcpy(h->h_act, actions, 4 * N * h->card.act_dim);
@@ -474,6 +495,7 @@ int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float
                      uint8_t* d_truncated, void* hip_stream) {
   if (!h || !d_actions) return DART_E_INVALID;
   if (h->pending) { h->err = "step_async pending"; return DART_E_PENDING; }
+  CHK_AUTORESET(h);
   CHK(h, hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   { int rc = ext_begin(h, s); if (rc != DART_OK) return rc; }
@@ -579,6 +601,7 @@ int dart_get_body_poses(DartStepper* h, double* rotation, double* origin, double
 int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* point_force, int32_t max_contacts) {
   if (!h || !count || max_contacts < 0) return DART_E_INVALID;
   if (h->pending) { h->err = "dart_get_contacts while a step is pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
   const int rc = h->impl->get_contacts(h->stream, h->n, count, bodies, point_force, max_contacts);
   if (rc == DART_E_INVALID) h->err = "dart_get_contacts: enable DART_CFG_CONTACT_REPORT before stepping";
   if (rc == DART_E_UNSUPPORTED) h->err = "contact reporting: only the generic kernel implements it (card.generic_kernel = 1)";
@@ -588,6 +611,7 @@ int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* p
 int dart_get_constraint_forces(DartStepper* h, double* constraint_forces) {
   if (!h || !constraint_forces) return DART_E_INVALID;
   if (h->pending) { h->err = "dart_get_constraint_forces while a step is pending"; return DART_E_PENDING; }
+  CHK(h, hipSetDevice(h->device));
   const int rc = h->impl->get_constraint_forces(h->stream, h->n, constraint_forces);
   if (rc == DART_E_INVALID) h->err = "dart_get_constraint_forces: enable DART_CFG_CONTACT_REPORT before stepping";
   if (rc == DART_E_UNSUPPORTED) h->err = "constraint forces: only the generic kernel reports them (card.generic_kernel = 1)";

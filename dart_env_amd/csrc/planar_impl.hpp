@@ -207,7 +207,9 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
     if (d < 2 && (c.limited[d] || c.stiffness[d] != 0)) return "limits/springs on root translation";
     P.damp[d] = (Real)c.damping[d]; P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
     P.stiff[d] = (Real)c.stiffness[d]; P.rest[d] = (Real)c.rest[d];
+    P.sqe[d] = (Real)std::sqrt(c.dt * c.damping[d] + c.dt * c.dt * c.stiffness[d]);
   }
+  P.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
   int nc = 0;
   if constexpr (!topo_contacts<T>::value) {
     // the robot slides in a horizontal plane: its joints cannot bring a shape to the floor, so a shape that clears it now always will
@@ -377,8 +379,10 @@ std::string fill_cart(const DartModelCard& c, CartParams<Real, NP>& P) {
   for (int d = 0; d < N; d++) {
     P.lo[d] = (Real)(c.limited[d] ? c.lower[d] : -INFINITY); P.hi[d] = (Real)(c.limited[d] ? c.upper[d] : INFINITY);
     P.damp[d] = (Real)c.damping[d]; P.stiff[d] = (Real)c.stiffness[d]; P.rest[d] = (Real)c.rest[d];
+    P.sqe[d] = (Real)std::sqrt(c.dt * c.damping[d] + c.dt * c.dt * c.stiffness[d]);
     P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
   }
+  P.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
   P.dt = (Real)c.dt; P.g = (Real)(-c.gravity[1]); P.limit_erp_dt = (Real)(c.limit_erp / c.dt); P.max_erv = (Real)c.max_erv;
   P.cfm1 = (Real)(1.0 + c.cfm);
   P.act_scale = (Real)c.act_scale[0]; P.act_lo = (Real)c.act_low[0]; P.act_hi = (Real)c.act_high[0];
@@ -465,7 +469,7 @@ std::string fill_arm(const DartModelCard& c, ArmParams<Real, NP>& P) {
       continue;
     }
     if (nl >= NP) return "body/dof count";
-    if (c.jtype[b] != DART_JT_REVOLUTE || std::fabs(std::fabs(c.axes[c.dof_offset[b]][1]) - 1) > 1e-12) return "link joint must be revolute about +-y";
+    if (c.jtype[b] != DART_JT_REVOLUTE || std::fabs(std::fabs(c.axes[b][1]) - 1) > 1e-12) return "link joint must be revolute about +-y";
     if (nl == 0 ? pb != -1 : (pb < 0 || link_of_body[pb] != nl - 1 || c.jtype[pb] == DART_JT_WELD)) return "not a chain from the world";
     if (c.T_cj[b][3] != 0 || c.T_cj[b][7] != 0 || c.T_cj[b][11] != 0 || (nl > 0 && c.T_pj[b][7] != 0)) return "joint offsets";
     if (c.dof_offset[b] != nl) return "dof order";
@@ -495,11 +499,12 @@ std::string fill_arm(const DartModelCard& c, ArmParams<Real, NP>& P) {
   P.height = (Real)(c.T_pj[body_of_link[0]][7]);
   for (int k = 0; k < NP; k++) {
     const int b = body_of_link[k], d = c.dof_offset[b];
-    P.sigma[k] = (Real)(c.axes[d][1] > 0 ? -1.0 : 1.0);   // a turn about +y is clockwise in (x, z)
+    P.sigma[k] = (Real)(c.axes[b][1] > 0 ? -1.0 : 1.0);   // a turn about +y is clockwise in (x, z)
     P.mass[k] = (Real)lm[k]; P.cx[k] = (Real)lcx[k]; P.cy[k] = (Real)lcy[k]; P.izz[k] = (Real)lizz[k];
     P.jx[k] = (Real)c.T_pj[b][3]; P.jy[k] = (Real)c.T_pj[b][11];
     P.lo[k] = (Real)(c.limited[d] ? c.lower[d] : -INFINITY); P.hi[k] = (Real)(c.limited[d] ? c.upper[d] : INFINITY);
     P.damp[k] = (Real)c.damping[d]; P.stiff[k] = (Real)c.stiffness[d]; P.rest[k] = (Real)c.rest[d];
+    P.sqe[k] = (Real)std::sqrt(c.dt * c.damping[d] + c.dt * c.dt * c.stiffness[d]);
     P.q0[k] = (Real)c.init_pos[d]; P.dq0[k] = (Real)c.init_vel[d];
     P.fric_dt[k] = (Real)(c.joint_friction[d] * c.dt);
     P.act_scale[k] = (Real)c.act_scale[k]; P.act_lo[k] = (Real)c.act_low[k]; P.act_hi[k] = (Real)c.act_high[k];
@@ -507,6 +512,7 @@ std::string fill_arm(const DartModelCard& c, ArmParams<Real, NP>& P) {
   P.dt = (Real)c.dt; P.limit_erp_dt = (Real)(c.limit_erp / c.dt); P.max_erv = (Real)c.max_erv; P.cfm1 = (Real)(1.0 + c.cfm);
   P.noise = (Real)c.reset_noise; P.noise_v = (Real)c.reset_noise_vel;
   P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task; P.iters = 24; P.tstate = nullptr;
+  P.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
   return "";
 }
 
@@ -591,6 +597,7 @@ std::unique_ptr<Impl> make_chain3d(const DartModelCard& c, std::string& why) {
     P.mass[i] = M.mass[i];
     P.lo[i] = M.limited[i] ? M.lower[i] : (Real)-INFINITY; P.hi[i] = M.limited[i] ? M.upper[i] : (Real)INFINITY;
     P.damp[i] = M.damp[i]; P.stiff[i] = M.stiff[i]; P.rest[i] = M.rest[i]; P.q0[i] = M.q0[i]; P.dq0[i] = M.dq0[i];
+    P.sqe[i] = (Real)std::sqrt((double)M.dt * (double)M.damp[i] + (double)M.dt * (double)M.dt * (double)M.stiff[i]);
     P.fric_dt[i] = M.jfric_dt[i];
     P.act_scale[i] = M.act_scale[i]; P.act_lo[i] = M.act_lo[i]; P.act_hi[i] = M.act_hi[i];
   }
@@ -599,6 +606,7 @@ std::unique_ptr<Impl> make_chain3d(const DartModelCard& c, std::string& why) {
   P.ctrl_w = M.aux_real[3]; P.done_dist = M.aux_real[4];
   P.noise = M.noise; P.noise_v = M.noise_v;
   P.frame_skip = M.frame_skip; P.max_steps = M.max_steps; P.task = M.task; P.iters = 24; P.tstate = nullptr;
+  P.impulse_M = M.impulse_M;
   return p;
 }
 

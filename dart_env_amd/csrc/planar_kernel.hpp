@@ -200,6 +200,8 @@ struct Params {
   Real lo[T::NL], hi[T::NL];
   Real damp[T::NDOF], q0[T::NDOF], dq0[T::NDOF];  // joint damping; world.reset() state
   Real stiff[T::NDOF], rest[T::NDOF];             // joint springs (implicit: H += dt^2 K, rhs -= K (q + dt dq - rest))
+  Real sqe[T::NDOF];                              // sqrt(dt damp + dt^2 stiff): the implicit terms E = diag(sqe^2) of the forward dynamics
+  int impulse_M;                                  // card.impulse_inertia (A3): 1 = the impulse pass runs on M (DART 6), 0 = on M + E
   Real e1x[T::NC], e1y[T::NC], e2x[T::NC], e2y[T::NC], rad[T::NC];
   Real act_scale[T::NA], act_lo[T::NA], act_hi[T::NA];
   Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise, noise_v;
@@ -336,6 +338,69 @@ __device__ __forceinline__ void spd_inverse(Real (&a)[N * (N + 1) / 2]) {
     });
   });
   sfor<0, N*(N + 1) / 2>([&](auto I) { a[I] = out[I]; });
+}
+
+// Solve A x = rhs for a packed SPD matrix via LDL^T (A is destroyed, x holds rhs on entry).
+template <class Real, int K>
+__device__ __forceinline__ void spd_solve(Real (&a)[K * (K + 1) / 2], Real (&x)[K]) {
+  Real invd[K];
+  sfor<0, K>([&](auto J) {
+    constexpr int j = J;
+    Real W[K];
+    Real d = a[tri(j, j)];
+    sfor<0, j>([&](auto Kk) { constexpr int k = Kk; W[k] = a[tri(j, k)] * a[tri(k, k)]; d -= a[tri(j, k)] * W[k]; });
+    a[tri(j, j)] = d;
+    invd[j] = rcp_<Real>(d);
+    sfor<j + 1, K>([&](auto I) {
+      constexpr int i = I;
+      Real t = a[tri(i, j)];
+      sfor<0, j>([&](auto Kk) { constexpr int k = Kk; t -= a[tri(i, k)] * W[k]; });
+      a[tri(i, j)] = t * invd[j];
+    });
+  });
+  sfor<0, K>([&](auto I) { constexpr int i = I; sfor<0, i>([&](auto Kk) { constexpr int k = Kk; x[i] -= a[tri(i, k)] * x[k]; }); });
+  sfor<0, K>([&](auto I) { x[I] *= invd[I]; });
+  sfor_rev<0, K>([&](auto I) { constexpr int i = I; sfor<i + 1, K>([&](auto Kk) { constexpr int k = Kk; x[i] -= a[tri(k, i)] * x[k]; }); });
+}
+
+// DART integrates joint damping and springs implicitly in the FORWARD DYNAMICS only, (M + E) qdd = rhs with E = dt D + dt^2 K,
+// while its impulse pass (the constraint rows' unit-impulse responses and the final velocity change) runs on M alone
+// (include/dart_model_card.h, impulse_inertia).  The lane kernels hold M^-1 explicitly for the
+// constraint rows, so the acceleration comes from it through the symmetric Woodbury identity over the K dofs whose E is not zero,
+//     (M + E)^-1 r = y - M^-1 S (I + S M^-1 S)^-1 S y,     y = M^-1 r,  S = sqrt(E)   (no division by E: a zero entry is harmless)
+// one K x K LDL^T solve instead of a second N x N factorisation (Hopper: K = 3 of 6, Walker2d: 6 of 9).
+// Sel::count / Sel::dof(a): the dofs with E != 0; REV: Minv is stored in reversed dof order.  a = y on entry, qdd on return.
+template <class PT, int N> struct ImplicitDofs {
+  __device__ __host__ static constexpr bool has(int i) { return !(PT::zero(ZF_damp, i) && PT::zero(ZF_stiff, i)); }
+  __device__ __host__ static constexpr int cnt() { int c = 0; for (int i = 0; i < N; i++) c += has(i) ? 1 : 0; return c; }
+  static constexpr int count = cnt();
+  __device__ __host__ static constexpr int dof(int a) { int c = 0; for (int i = 0; i < N; i++) if (has(i)) { if (c == a) return i; c++; } return 0; }
+};
+template <int N> struct AllDofs {
+  static constexpr int count = N;
+  __device__ __host__ static constexpr int dof(int a) { return a; }
+};
+template <class Real, int N, bool REV, class Sel, class PT>
+__device__ __forceinline__ void implicit_accel(const PT& P, const Real (&Minv)[N * (N + 1) / 2], Real (&a)[N]) {
+  constexpr int K = Sel::count;
+  if constexpr (K > 0) {
+    Real G[K * (K + 1) / 2], z[K];
+    sfor<0, K>([&](auto A_) {
+      constexpr int aa = A_, da = Sel::dof(aa), ia = REV ? N - 1 - da : da;
+      sfor<0, aa + 1>([&](auto B_) {
+        constexpr int bb = B_, db = Sel::dof(bb), ib = REV ? N - 1 - db : db;
+        const Real g = (P.sqe[da] * P.sqe[db]) * Minv[tri(ia, ib)];
+        G[tri(aa, bb)] = (aa == bb) ? g + Real(1) : g;
+      });
+      z[aa] = P.sqe[da] * a[da];
+    });
+    spd_solve<Real, K>(G, z);
+    sfor<0, K>([&](auto A_) { constexpr int aa = A_; z[aa] *= P.sqe[Sel::dof(aa)]; });
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I, ii = REV ? N - 1 - i : i;
+      sfor<0, K>([&](auto A_) { constexpr int aa = A_, da = Sel::dof(aa), ia = REV ? N - 1 - da : da; a[i] -= Minv[tri(ii, ia)] * z[aa]; });
+    });
+  }
 }
 
 // Solve the masked symmetric system for the free set of a boxed LCP iteration.
@@ -1081,19 +1146,32 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
         });
     });
   }
-  sfor<0, N>([&](auto I) {
-    constexpr int i = I;
-    if constexpr (!DART_ZERO(PT, damp, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.damp[i];
-    if constexpr (!DART_ZERO(PT, stiff, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.dt * P.stiff[i];
-  });
-  spd_inverse<Real, N>(H);  // H now holds H^-1 (reversed dof order)
+  // A3 (card.impulse_inertia): the forward dynamics always solves (M + E) qdd = rhs, E = dt D + dt^2 K; the impulse pass below
+  // runs on M (DART 6, the default) or, with the knob at 0, on M + E like the forward dynamics.
+  const bool impulse_M = P.impulse_M != 0;   // a compile-time constant of the baked models, wave-uniform otherwise
+  if (!impulse_M)
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      if constexpr (!DART_ZERO(PT, damp, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.damp[i];
+      if constexpr (!DART_ZERO(PT, stiff, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.dt * P.stiff[i];
+    });
+  spd_inverse<Real, N>(H);  // H now holds the inverse of the impulse inertia (reversed dof order)
   Real vs[N];
-  sfor<0, N>([&](auto I) {
-    constexpr int i = I;
-    Real a = Real(0);
-    sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(rev<N>(i), rev<N>(j))] * rhs[j]; });
-    vs[i] = dq[i] + P.dt * a;
-  });
+  {
+    Real acc[N];
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      Real a = Real(0);
+      sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(rev<N>(i), rev<N>(j))] * rhs[j]; });
+      acc[i] = a;
+    });
+#ifdef DART_ROOT_FIRST
+    if (impulse_M) implicit_accel<Real, N, false, ImplicitDofs<PT, N>>(P, H, acc);
+#else
+    if (impulse_M) implicit_accel<Real, N, true, ImplicitDofs<PT, N>>(P, H, acc);
+#endif
+    sfor<0, N>([&](auto I) { constexpr int i = I; vs[i] = dq[i] + P.dt * acc[i]; });
+  }
 
   // ---- candidate contacts at q_t: every capsule's lowest segment endpoint against the floor (ODE capsule-plane as DART
   // uses it: one contact, position in the middle of the penetration)

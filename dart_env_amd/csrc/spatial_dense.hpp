@@ -139,8 +139,8 @@ __device__ __forceinline__ void sp_chol_fwdsolve(const Real* Lf, const Real* sin
   __syncthreads();
 }
 
-// Stable-PD torque of DartWalker3dSPD-v1 (walker3d_spd.py:40-55), evaluated before every world step once M (in S.H with
-// the integrator's diagonal terms), the bias forces c (S.b) and the previous step's constraint forces (S.cf) are known:
+// Stable-PD torque of DartWalker3dSPD-v1 (walker3d_spd.py:40-55), evaluated before every world step once M (in S.H, with
+// the integrator's diagonal terms when card.impulse_inertia = 0), the bias forces c (S.b) and the previous step's constraint forces (S.cf) are known:
 //   qdd = (M + Kd dt_env)^-1 (-c + p + d + cf),  tau = p + d - Kd qdd dt_env,  root dofs zeroed, |tau| <= limit.
 // S.tau holds the target pose; the torque goes straight into the right-hand side.  Workspace: S.A (factor), S.r (1/L_jj),
 // S.lo (the solve) -- all idle until the constraint phase.
@@ -153,7 +153,7 @@ __device__ __forceinline__ void sp_spd_torque(const LinkConst<Real>& lc, const S
   if (lane < n) {   // dof `lane` sits at row n-1-lane of the factor's storage order (sp_mass_row)
     const int rv = n - 1 - lane;
     kd = Md.spd_kd[lane];
-    S.A[HL(rv, rv)] += kd * Md.envdt - lc.d_diag;
+    S.A[HL(rv, rv)] += kd * Md.envdt - (Md.impulse_M ? Real(0) : lc.d_diag);   // S.H holds M, or M + E with the A3 knob at 0
     const Real p = -Md.spd_kp[lane] * (S.q[lane] + S.dq[lane] * Md.envdt - S.tau[lane]);
     const Real d = -kd * S.dq[lane];
     pd = p + d;

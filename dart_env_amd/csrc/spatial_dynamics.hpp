@@ -350,8 +350,9 @@ __device__ __forceinline__ void sp_link_rhs(const LinkConst<Real>& lc, const Spa
 // at row / column n-1-d of S.H, so that the Cholesky factor eliminates leaves first and the trunk last (Featherstone's LTL order:
 // no fill-in, L_ij != 0 only where dof(i) is an ancestor of dof(j)); everything between the Jacobian rows and the final
 // back-substitution works in storage order.  The caller has zero-filled S.H (and barriered) before.
+// add_diag: M + dt D + dt^2 K instead of M.
 template <class Real>
-__device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int d) {
+__device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int d, bool add_diag) {
   const int i = lc.d_link;
   const Real* L = S.link + i * SP_LINKF;
   const V3<Real> a = ld3(L + LK_A), h = ld3(L + LK_H), jo = ld3(L + LK_JO);
@@ -375,7 +376,7 @@ __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const Spa
     Real v;
     if (topo_jtype(w) == 2) v = dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm));
     else v = dot(aj, Lm);
-    if (dj == d) v += lc.d_diag;
+    if (dj == d && add_diag) v += lc.d_diag;   // the implicit damping / spring terms E = dt D + dt^2 K (A3: only when the impulse pass runs on M + E)
     S.H[HI(n1 - d, n1 - dj)] = v;   // symmetric index: a free root's rotation dofs (0..2) hang below its translation dofs (3..5)
   }
 }

@@ -257,13 +257,12 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
   if (mass_out) {
     if (lane < n) for (int k = 0; k <= lane; k++) S.H[HL(lane, k)] = Real(0);
     __syncthreads();
-    if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);
+    if (lane < n) sp_mass_row<Real>(lc, Md, S, lane, false);
     __syncthreads();
     if (lane < n) {
       double* Mo = mass_out + e * n * n;
       for (int k = 0; k <= lane; k++) {
-        double v = (double)S.H[HI(n - 1 - lane, n - 1 - k)];   // reversed storage order (sp_mass_row)
-        if (k == lane) v -= (double)lc.d_diag;
+        const double v = (double)S.H[HI(n - 1 - lane, n - 1 - k)];   // reversed storage order (sp_mass_row)
         Mo[lane * n + k] = v; Mo[k * n + lane] = v;
       }
     }

@@ -62,6 +62,8 @@ struct SpatialModel {
   Real* cf_store;                    // [n_envs][n] generalized constraint forces of each env's last world step (task 12)
   Real jfric_dt[SP_MAXN];            // Coulomb joint friction * dt: impulse bound of the dof's friction row (0 = none)
   int has_joint_friction;
+  int impulse_M;                     // card.impulse_inertia (A3): 1 = the impulse pass runs on M (DART 6), 0 = on M + dt D + dt^2 K
+  int has_implicit;                  // some dof has damping or a spring: with impulse_M the forward dynamics needs its own factor of M + E
   int free_root;                     // 1: body 0 hangs on a DART FreeJoint (public q[0:3] rotation vector, dq[0:6] body twist)
   int free_link;                     // the last of the six root links (carries the body); its joint rotation is Rz(c) R0
   int maxm, maxcp;                   // LCP rows / contact points this model's LDS block is carved for
@@ -118,6 +120,12 @@ template <class Real> __device__ __forceinline__ void mulRR(const Real* A, const
 // LDS layout of one link (offsets in Reals)
 enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_C = 18, LK_F = 21, LK_N = 24, LK_MC = 27, LK_H = 28, LK_IC = 31 };
 
+// Reals of the Jacobian block W: (maxm + 1) rows of n, and room for the forward dynamics' own factor of M + E (padded rows, the
+// reciprocal diagonal and one vector) that lives there before the Jacobian rows are written (sp_world_step, A3)
+__device__ __host__ constexpr int sp_w_reals(int n, int maxm) {
+  return (maxm + 1) * n > HR(sp_npad(n)) + 2 * sp_npad(n) ? (maxm + 1) * n : HR(sp_npad(n)) + 2 * sp_npad(n);
+}
+
 template <class Real>
 struct SpLds {
   Real* link;    // [nl][SP_LINKF]
@@ -153,7 +161,7 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n;
   p = base + (((p - base) + 3) & ~3);   // 16-byte aligned rows
   S.H = p; p += HR(sp_npad(n));
-  S.W = p; p += (maxm + 1) * n;
+  S.W = p; p += sp_w_reals(n, maxm);
   const bool alias = sp_lw_aliases_links(nl, maxm);
   if (reg_lcp && alias) { S.A = S.link; S.x0 = S.link + sp_tri(maxm); S.Lw = nullptr; }
   else {
@@ -181,7 +189,7 @@ __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes,
   const bool alias = sp_lw_aliases_links(nl, maxm);
   const size_t lw = alias ? 0 : (size_t)sp_tri(maxm) + maxm;
   const size_t a = (reg_lcp && alias) ? 0 : (size_t)sp_tri(maxm);
-  size_t reals = (size_t)nl * SP_LINKF + 5 * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)(maxm + 1) * n + a + lw + 5 * maxm +
+  size_t reals = (size_t)nl * SP_LINKF + 5 * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)sp_w_reals(n, maxm) + a + lw + 5 * maxm +
                  maxcp * 7 + 16 + 24;
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }

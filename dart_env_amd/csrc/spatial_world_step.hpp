@@ -47,10 +47,28 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   SP_TICK(0);
   if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[HL(lane, k)] = Real(0); if (lane >= n) S.H[HL(lane, lane)] = Real(1); }
   __syncthreads();
-  if (lane < n) sp_mass_row<Real>(lc, Md, S, lane);   // scatters into other lanes' rows (reversed storage order, see there)
+  if (lane < n) sp_mass_row<Real>(lc, Md, S, lane, !Md.impulse_M);   // scatters into other lanes' rows (reversed storage order, see there)
   __syncthreads();
   if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
   SP_TICK(1);
+  if (Md.impulse_M && Md.has_implicit) {
+    // A3 (card.impulse_inertia = 1, DART 6): the forward dynamics solves (M + E) qdd = rhs with the implicit damping / spring
+    // terms E = dt D + dt^2 K, the impulse pass below runs on M alone.  S.H keeps M; M + E is factored in the (still idle)
+    // Jacobian block, qdd comes from that factor, and rhs' = rhs - E qdd = M qdd then rides through the M-factor's
+    // substitutions exactly as rhs did before:  L^-T L^-1 rhs' = qdd.
+    const int np = sp_npad(n);
+    Real* H2 = S.W; Real* sinv2 = S.W + HR(np); Real* xq = sinv2 + np;
+    if (lane < np) for (int k = 0; k <= lane; k++) H2[HL(lane, k)] = S.H[HL(lane, k)];
+    __syncthreads();
+    if (lane < n) { H2[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag; xq[n - 1 - lane] = S.rhs[lane]; }
+    __syncthreads();
+    sp_cholesky<Real, PAT>(H2, sinv2, n, lane);
+    sp_chol_fwdsolve<Real>(H2, sinv2, n, xq, lane);
+    sp_chol_backsolve<Real, BIG>(H2, sinv2, n, xq, lane);
+    if (lane < n) S.rhs[lane] -= lc.d_diag * xq[n - 1 - lane];
+    __syncthreads();
+    SP_TICK(2);
+  }
   if constexpr (PAT::dense) { sp_cholesky<Real, PAT>(S.H, S.sinv, n, lane); SP_TICK(2); }   // pattern kernels factor later (below)
 
   // ---- contact points and active limits, in parallel: lane s tests collision shape s, lane d tests the limits of

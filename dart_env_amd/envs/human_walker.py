@@ -10,19 +10,34 @@ from .hopper import _SingleEnv
 class DartHumanWalkerEnv(_SingleEnv):
     ENV_ID = "DartHumanWalker-v1"
 
-    def _com(self, which):
-        """world COM of card.aux_body[which] (0: the progress body bodynodes[1], 1: the head), human_walker.py:78-92"""
+    def _coms(self):
+        """world COMs of card.aux_body[0] (the progress body bodynodes[1]) and [1] (the head), human_walker.py:78-92 -- one pose
+        launch + one D2H copy for both"""
         st = self._stepper
         if not hasattr(st, "body_poses"):       # an injected stand-in stepper without pose getters
             return None
-        return st.body_poses()[2][0, self.card.aux_body[which]]
+        com = st.body_poses()[2][0]
+        return com[self.card.aux_body[0]].copy(), com[self.card.aux_body[1]].copy()
+
+    def reset(self):
+        self._post = None                       # the cached post-step poses belong to the previous episode
+        return super().reset()
+
+    def set_state(self, *a, **k):
+        self._post = None
+        return super().set_state(*a, **k)
 
     def step(self, a):
         a = np.asarray(a, dtype=np.float64)
-        before = self._com(0)
+        # the pose before this step is the pose after the previous one unless the state was touched in between
+        pre = getattr(self, "_post", None) or self._coms()
         self._terms = None
         ob, reward, done, _ = super().step(a)
-        after, head = self._com(0), self._com(1)
+        self._post = post = self._coms()
+        if done:
+            self._post = None                   # the env layer may auto-reset on done: never carry a pose across it
+        before = None if pre is None else pre[0]
+        after, head = (None, None) if post is None else post
         if before is not None:
             # the three reward terms the reference also returns in `info` (human_walker.py:111-117, 135-137), recomputed on the
             # host from the body poses either side of the step; the reward itself comes from the kernel

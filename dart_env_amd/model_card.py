@@ -60,6 +60,7 @@ class DartModelCard(C.Structure):
         ("aux_body", C.c_int32 * 4), ("aux_real", C.c_double * 8), ("aux_real2", C.c_double * 4),
         ("contact_cfm", C.c_double), ("self_collision", C.c_int32), ("generic_kernel", C.c_int32),
         ("joint_friction", C.c_double * MAX_DOFS), ("spd_kp", C.c_double * MAX_DOFS), ("spd_kd", C.c_double * MAX_DOFS),
+        ("impulse_inertia", C.c_int32),
     ]
 
 
@@ -274,6 +275,7 @@ def build_card(model: ModelCard, task: Optional[TaskSpec] = None) -> DartModelCa
         c.init_pos[i], c.init_vel[i] = model.init_pos[i], model.init_vel[i]
         c.joint_friction[i] = 0.0 if model.joint_friction is None else float(model.joint_friction[i])
     c.contact_cfm = model.contact_cfm
+    c.impulse_inertia = int(model.impulse_inertia)
     c.nshapes = len(model.shapes)
     for i, s in enumerate(model.shapes):
         c.shape_body[i], c.shape_type[i], c.shape_collidable[i] = s.body, s.kind, int(s.collidable)

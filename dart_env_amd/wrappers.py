@@ -29,10 +29,6 @@ class TimeLimit(_EnvShell):
         self._max_episode_steps = max_episode_steps
         self._elapsed_steps = None          # None until the first reset: stepping before that is a usage error
 
-    @property
-    def unwrapped(self):
-        return self.env
-
     def reset(self, **kwargs):
         self._elapsed_steps = 0
         return self.env.reset(**kwargs)

@@ -174,7 +174,19 @@ typedef struct DartModelCard {
    * actuated dof k (:20-22) for that task. */
   double spd_kp[DART_MAX_DOFS];
   double spd_kd[DART_MAX_DOFS];
+  /* Which joint-space inertia the IMPULSE pass runs on.  DART integrates joint damping and
+   * springs implicitly in the forward dynamics only: (M + dt D + dt^2 K) qdd = rhs uses the `...Implicit` articulated
+   * inertias (BodyNode::updateBiasForce / updateAccelerationFD, GenericJoint::updateInvProjArtInertiaImplicit), while
+   * the constraint solver's unit-impulse tests and the final velocity change go through BodyNode::updateBiasImpulse /
+   * updateVelocityChangeFD -> GenericJoint::updateVelocityChangeDynamic, which read getArticulatedInertia() /
+   * getInvProjArtInertia(): the plain mass matrix.
+   *   DART_IMPULSE_MASS (1, the default):  A = J M^-1 J^T,  dq = dq* + M^-1 J^T lambda          (DART 6)
+   *   DART_IMPULSE_AUGMENTED (0):          A = J H^-1 J^T,  dq = dq* + H^-1 J^T lambda, H = M + dt D + dt^2 K
+   *                                        (what rounds 1-2 of this build used for both passes) */
+  int32_t impulse_inertia;
 } DartModelCard;
+
+enum { DART_IMPULSE_AUGMENTED = 0, DART_IMPULSE_MASS = 1 };
 
 #ifdef __cplusplus
 }

@@ -67,7 +67,12 @@ enum {
 const char* dart_last_error(const DartStepper* h);
 
 /* Replaces DartEnv.__init__'s world construction for N envs: pydart.World(dt, skel), skeletons[-1], limit
- * enforcement (reference gym/envs/dart/dart_env.py:55,62-67).  precision: 32 (product) or 64 (validation).
+ * enforcement (reference gym/envs/dart/dart_env.py:55,62-67).
+ * precision: 64 = fp64 kernels, the PRODUCT DEFAULT of every layer above this ABI -- the reference computes in doubles
+ *   (DART / Eigen) and this is the mode that meets the north star's tolerance (RMS state divergence vs the CPU path < 1e-4 over
+ *   1 000 env-steps: measured 5e-13 untrimmed).  32 = fast mode (fp32 kernels, 15-40 % quicker): it does NOT meet that tolerance
+ *   (untrimmed RMS q / dq after 1 000 env-steps: Hopper 4e-6 / 2e-4, Walker2d 1e-3 / 4e-2, HumanWalker 1e-3 / 6e-2 -- the envs
+ *   whose contact or limit switched one 2 ms substep early); ask for it explicitly.
  * State starts at the model's init_pos/init_vel, elapsed = 0. */
 int dart_create(const DartModelCard* card, int64_t num_envs, int device, int precision, DartStepper** out);
 
@@ -147,8 +152,10 @@ int dart_set_task_state(DartStepper* h, const uint8_t* mask, const double* value
 
 /* External body force: `bodynodes[body].add_ext_force(F)` before every world step, the perturbation branch of
  * DartEnv.do_simulation (reference gym/envs/dart/dart_env.py:159-172).  force = (N, 3) world-frame vectors, applied at the
- * body frame origin (pydart2's default offset) in every substep until replaced; NULL switches it off.  Only the generic
- * kernel implements it: set card.generic_kernel = 1 (DART_E_UNSUPPORTED otherwise). */
+ * body frame origin (pydart2's default offset) in every substep until replaced; NULL switches it off.  Served by the tree
+ * kernel's EXTRAS instantiation and by the planar register kernels' EXTRAS instantiation (Hopper, Walker2d, HalfCheetah, Snake);
+ * DART_E_UNSUPPORTED on the lean tree kernel (HumanWalker, Walker3d: set card.generic_kernel = 1) and on the cart / arm / chain
+ * lane kernels. */
 int dart_set_ext_force(DartStepper* h, int body, const double* force);
 
 /* Episode statistics kept on the device (DART_CFG_EPISODE_STATS = 1) -- the batched form of the reference's
@@ -179,8 +186,9 @@ int dart_get_body_poses(DartStepper* h, double* rotation, double* origin, double
  *   point_force (N, max_contacts, 6) world contact point, then the world force the contact applies to body a
  *                                  (= (n l_n + t1 l_1 + t2 l_2) / dt of DART's ContactConstraint; body b receives the opposite)
  * bodies / point_force may be NULL.  Order: ground contacts in shape order (box vertices in face order), then link-link
- * pairs.  Implemented by the generic tree kernel: DART_E_UNSUPPORTED on the planar register kernels (card.generic_kernel = 1
- * routes those models through it). */
+ * pairs.  Implemented by the tree kernel (its reporting instantiation) and by the planar register kernels (EXTRAS
+ * instantiation: one record per contact slot); DART_E_UNSUPPORTED on the cart / arm / chain lane kernels, whose models touch
+ * nothing. */
 int dart_get_contacts(DartStepper* h, int32_t* count, int32_t* bodies, double* point_force, int32_t max_contacts);
 
 /* pydart2 `skel.constraint_forces()` after the last world step (reference gym/envs/dart/walker3d_spd.py:51 reads it for

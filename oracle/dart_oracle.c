@@ -18,11 +18,11 @@
  *   2. qd* = qd + dt qdd                        (Skeleton::integrateVelocities)
  *   3. constraints detected at q_t: capsule/ground contacts (ODE capsule-box:
  *      one contact at the lowest segment endpoint), joint limits (inclusive)
- *   4. boxed LCP  A = J H^-1 J^T (1+cfm on diag), b = -J qd* + erp*depth/dt,
+ *   4. boxed LCP  A = J M^-1 J^T (1+cfm on diag; card.impulse_inertia = 0: H^-1, see oracle_step), b = -J qd* + erp*depth/dt,
  *      friction rows bounded by +-mu * (frictionless normal impulse) exactly as
  *      the ODE Dantzig driver DART calls sets lo/hi when it reaches the first
  *      findex row (two-stage solve)
- *   5. qd = qd* + H^-1 J^T lambda ; q += dt qd  (Skeleton::integratePositions)
+ *   5. qd = qd* + M^-1 J^T lambda ; q += dt qd  (Skeleton::computeImpulseForwardDynamics, integratePositions)
  *      constants: ContactConstraint.cpp ERP 0.01 / MAX_ERV 1e-3 / CFM 1e-5, JointLimitConstraint.cpp CFM 1e-9 with an
  *      error allowance of 0 (no position correction), JointCoulombFrictionConstraint.cpp CFM 1e-9 -- card knobs
  *
@@ -838,6 +838,17 @@ int oracle_step(OracleWorld* w) {
   }
   if (cholesky(H, n) != 0) return -1;
   chol_solve(H, n, rhs);
+  /* A3 (card.impulse_inertia): DART's impulse pass -- the unit-impulse tests that build A and the final velocity change --
+   * runs on the NON-implicit articulated inertia (BodyNode::updateBiasImpulse / updateVelocityChangeFD ->
+   * GenericJoint::updateVelocityChangeDynamic: getInvProjArtInertia()), i.e. on M, while the forward dynamics above used
+   * the implicit one (updateAccelerationDynamic: getInvProjArtInertiaImplicit()), i.e. H.  HI = factor of the impulse inertia. */
+  static __thread double HI[MAXN * MAXN];
+  if (c->impulse_inertia == DART_IMPULSE_MASS) {
+    memcpy(HI, w->M, n * n * sizeof(double));
+    if (cholesky(HI, n) != 0) return -1;
+  } else {
+    memcpy(HI, H, n * n * sizeof(double));
+  }
   double vs[MAXN];
   for (int i = 0; i < n; i++) vs[i] = w->dqi[i] + dt * rhs[i];
   if (w->free_root) {
@@ -1005,7 +1016,7 @@ int oracle_step(OracleWorld* w) {
   if (m > 0) {
     for (int i = 0; i < m; i++) {
       memcpy(Y[i], J[i], n * sizeof(double));
-      chol_solve(H, n, Y[i]);
+      chol_solve(HI, n, Y[i]);
     }
     for (int i = 0; i < m; i++)
       for (int j = 0; j < m; j++) {

@@ -74,13 +74,15 @@ def parity_sample_size(env_id, steps, cores, budget_s, cap=4096):
     return max(64, min(cap, ne // 64 * 64))
 
 
-def parity_check(env_id, precision, ne, steps, local_rank, all_bodies_collide=None, ref=None, acts=None):
+def parity_check(env_id, precision, ne, steps, local_rank, all_bodies_collide=None, ref=None, acts=None, impulse_inertia=None):
     """SURVEY.md 8(d) parity protocol on `ne` envs x `steps` env-steps.  Returns (stats, ref, acts); ref / acts can be reused
     for the other precision.  The oracle is the checker here (cpu_baseline leg) -- never the thing measured or shipped."""
     import torch
     from dart_env_amd import stepper as st
     from dart_env_amd.model_card import card_for
     card = card_for(env_id) if all_bodies_collide is None else card_for(env_id, all_bodies_collide=all_bodies_collide)
+    if impulse_inertia is not None:
+        card.impulse_inertia = impulse_inertia     # A3 knob (include/dart_model_card.h); None = the card's default (1: DART 6)
     snaps = snap_list(steps)
     if ref is None:
         acts, ref = make_reference(card, ne, steps)

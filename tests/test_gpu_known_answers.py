@@ -142,17 +142,20 @@ def test_snapshot_restore_resumes_bitwise(env_id):
     venv.close()
 
 
-@pytest.mark.parametrize("kind", ["damping", "spring", "friction", "limit"])
-def test_single_dof_closed_forms_on_the_kernel(kind):
+@pytest.mark.parametrize("kind,impulse_inertia", [("damping", 1), ("spring", 1), ("friction", 1), ("limit", 1),
+                                                  ("damped_friction", 1), ("damped_friction", 0), ("spring", 0)])
+def test_single_dof_closed_forms_on_the_kernel(kind, impulse_inertia):
     """Implicit joint damping / spring, Coulomb joint friction and an inelastic joint limit on a 1-dof wheel: the kernel against
-    the update rules themselves (tests/test_oracle_physics.py::flywheel_closed_forms), fp64 and fp32, no oracle in between."""
+    the update rules themselves (tests/test_oracle_physics.py::flywheel_closed_forms), fp64 and fp32, no oracle in between.
+    'damped_friction' is the closed form that separates the two settings of card.impulse_inertia (A3): a saturated friction
+    impulse changes the velocity by mu dt / I under DART 6's rule and by mu dt / (I + dt d) under the other."""
     from dart_env_amd.stepper import HipStepper
-    from tests.test_oracle_physics import flywheel_card, flywheel_closed_forms
-    card = dict(damping=lambda: flywheel_card(damping=0.7), spring=lambda: flywheel_card(damping=0.3, stiffness=5.0, rest=0.1),
-                friction=lambda: flywheel_card(friction=0.2), limit=lambda: flywheel_card(lower=-1.0, upper=0.05))[kind]()
+    from tests.test_oracle_physics import FLY_CARDS, flywheel_closed_forms
+    card = FLY_CARDS[kind]()
+    card.impulse_inertia = impulse_inertia
     steps = 2700 if kind == "friction" else 600
     card.frame_skip = 20                                   # 20 world steps per launch
-    ref = flywheel_closed_forms(kind, steps)
+    ref = flywheel_closed_forms(kind, steps, impulse_inertia=impulse_inertia)
     for prec, tq, tv in ((64, 1e-10, 1e-9), (32, 2e-4, 2e-4)):
         s = HipStepper(card, 3, precision=prec)
         s.set_state(np.zeros((3, 1)), np.full((3, 1), 2.0))

@@ -31,6 +31,18 @@ def test_fp64_untrimmed_rms_below_1e_4_over_1000_steps(env_id, ne):
     assert stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])
 
 
+@pytest.mark.parametrize("env_id,ne,steps", [("DartHopper-v1", 1024, 300), ("DartWalker2d-v1", 1024, 300), ("DartHumanWalker-v1", 256, 100),
+                                             ("DartReacher-v1", 1024, 100), ("DartReacher3d-v1", 256, 100), ("DartCartPole-v1", 1024, 100)])
+def test_the_other_setting_of_the_impulse_inertia_knob_is_served_too(env_id, ne, steps):
+    """card.impulse_inertia = 0 (A3: the impulse pass on M + dt D + dt^2 K, what rounds 1-2 of this build assumed) on every kernel
+    family -- planar register kernel (runtime-parameter variant: the baked kernels carry DART 6's setting), tree kernel, arm, 3-D
+    chain and cart kernels -- against the oracle with the same setting, same untrimmed protocol."""
+    stats, ref, _ = parity_check(env_id, 64, ne, steps, 0, impulse_inertia=0)
+    print(env_id, "knob 0", {k: (v["q"], v["dq"]) for k, v in stats["by_step"].items()}, "episodes", stats["episodes"])
+    assert stats["done_flag_mismatches"] == 0
+    assert stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])
+
+
 @pytest.mark.parametrize("env_id,steps", [("DartHalfCheetah-v1", 100), ("DartSnake7Link-v1", 1000), ("DartCartPole-v1", 1000),
                                           ("DartDoubleInvertedPendulumEnv-v1", 1000), ("DartReacher-v1", 1000)])
 def test_lane_kernels_added_in_round_2_meet_the_same_bound(env_id, steps):

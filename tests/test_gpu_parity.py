@@ -20,9 +20,11 @@ from tests.batch_oracle import OracleBatch
 pytestmark = pytest.mark.gpu
 
 
-def _rollout(env_id, n, steps, precision, seed=0, act_scale=1.0):
+def _rollout(env_id, n, steps, precision, seed=0, act_scale=1.0, impulse_inertia=None):
     from dart_env_amd.stepper import HipStepper
     card = card_for(env_id)
+    if impulse_inertia is not None:
+        card.impulse_inertia = impulse_inertia
     nd, na = card.ndofs, card.act_dim
     rng = np.random.RandomState(seed)
     gpu = HipStepper(card, n, precision=precision)
@@ -61,9 +63,11 @@ def _rollout(env_id, n, steps, precision, seed=0, act_scale=1.0):
     return stats
 
 
+@pytest.mark.parametrize("impulse_inertia", [1, 0])
 @pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1"])
-def test_fp64_kernel_matches_oracle(env_id):
-    s = _rollout(env_id, 128, 40, 64)
+def test_fp64_kernel_matches_oracle(env_id, impulse_inertia):
+    """both settings of card.impulse_inertia (A3): 1 = DART 6's impulse pass on M (default, baked kernel), 0 = on M + dt D + dt^2 K"""
+    s = _rollout(env_id, 128, 40, 64, impulse_inertia=impulse_inertia)
     assert max(s["max_q"]) < 1e-8 and max(s["max_dq"]) < 1e-6, (max(s["max_q"]), max(s["max_dq"]))
     assert s["done_mismatch"] == 0
     assert s["max_obs"] < 1e-5 and s["max_rew"] < 1e-4  # obs/reward leave the device as float32

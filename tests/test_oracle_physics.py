@@ -474,19 +474,24 @@ def flywheel_card(damping=0.0, stiffness=0.0, rest=0.0, friction=0.0, lower=None
 FLY_I = 0.5      # izz of the wheel about its axle
 
 
-def flywheel_closed_forms(kind, steps, dt=0.002):
+def flywheel_closed_forms(kind, steps, dt=0.002, impulse_inertia=1):
     """(q, dq) after every step of the 1-dof wheel, from the update rules DART's semantics imply (A3, A10, joint friction):
     implicit damping / spring  (I + dt d + dt^2 k) a = tau - d v - k (q + dt v - rest);   Coulomb friction: an impulse within
-    +-mu dt that drives v to zero;   limit: inelastic stop while q >= upper (inclusive) and v > 0, no position correction."""
+    +-mu dt that drives v to zero;   limit: inelastic stop while q >= upper (inclusive) and v > 0, no position correction.
+    The impulse acts on I_imp = I (impulse_inertia = 1: DART 6's impulse pass reads the non-implicit articulated inertia) or on
+    I + dt d + dt^2 k (impulse_inertia = 0).  A hard stop cannot tell the two apart (the row's own inertia cancels); a SATURATED
+    friction impulse can: dv = mu dt / I_imp -- kind 'damped_friction'."""
     q, v, out = 0.0, 2.0, []
     d, k, rest, mu, up = dict(damping=(0.7, 0, 0, 0, None), spring=(0.3, 5.0, 0.1, 0, None), friction=(0, 0, 0, 0.2, None),
-                              limit=(0, 0, 0, 0, 0.05))[kind]
+                              limit=(0, 0, 0, 0, 0.05), damped_friction=(25.0, 0, 0, 0.2, None))[kind]
+    I_fd = FLY_I + dt * d + dt * dt * k
+    I_imp = FLY_I if impulse_inertia == 1 else I_fd
     for _ in range(steps):
-        a = (-d * v - k * (q + dt * v - rest)) / (FLY_I + dt * d + dt * dt * k)
+        a = (-d * v - k * (q + dt * v - rest)) / I_fd
         vs = v + dt * a
         if mu:
-            imp = max(-mu * dt, min(mu * dt, -FLY_I * vs / (1 + 1e-9)))   # row: (1 + cfm) imp / I = -vs within +-mu dt
-            vs = vs + imp / FLY_I
+            imp = max(-mu * dt, min(mu * dt, -I_imp * vs / (1 + 1e-9)))   # row: (1 + cfm) imp / I_imp = -vs within +-mu dt
+            vs = vs + imp / I_imp
         if up is not None and q >= up and vs > 0:
             vs = vs - vs / (1 + 1e-9)                                # (1 + cfm) on the diagonal leaves vs cfm / (1 + cfm)
         v = vs
@@ -495,13 +500,19 @@ def flywheel_closed_forms(kind, steps, dt=0.002):
     return np.array(out)
 
 
-@pytest.mark.parametrize("kind", ["damping", "spring", "friction", "limit"])
-def test_single_dof_closed_forms(kind):
-    card = dict(damping=lambda: flywheel_card(damping=0.7), spring=lambda: flywheel_card(damping=0.3, stiffness=5.0, rest=0.1),
-                friction=lambda: flywheel_card(friction=0.2), limit=lambda: flywheel_card(lower=-1.0, upper=0.05))[kind]()
+FLY_CARDS = dict(damping=lambda: flywheel_card(damping=0.7), spring=lambda: flywheel_card(damping=0.3, stiffness=5.0, rest=0.1),
+                 friction=lambda: flywheel_card(friction=0.2), limit=lambda: flywheel_card(lower=-1.0, upper=0.05),
+                 damped_friction=lambda: flywheel_card(damping=25.0, friction=0.2))
+
+
+@pytest.mark.parametrize("impulse_inertia", [1, 0])
+@pytest.mark.parametrize("kind", ["damping", "spring", "friction", "limit", "damped_friction"])
+def test_single_dof_closed_forms(kind, impulse_inertia):
+    card = FLY_CARDS[kind]()
+    card.impulse_inertia = impulse_inertia
     w = OracleWorld(card)
     w.set_state(np.zeros(1), np.array([2.0]))
-    ref = flywheel_closed_forms(kind, 3000)
+    ref = flywheel_closed_forms(kind, 3000, impulse_inertia=impulse_inertia)
     for t in range(3000):
         w.set_forces(np.zeros(1)); w.step()
         assert abs(w.q[0] - ref[t, 0]) < 1e-10 and abs(w.dq[0] - ref[t, 1]) < 1e-9, (kind, t, w.q[0], ref[t, 0], w.dq[0], ref[t, 1])
@@ -511,6 +522,66 @@ def test_single_dof_closed_forms(kind):
         assert abs(ref[-1, 1]) < 1e-12 and ref[2498, 1] > 0          # stops after v0 I / (mu dt) = 2500 steps, then stays
     if kind == "limit":
         assert abs(ref[-1, 1]) < 1e-8 and 0.05 <= ref[-1, 0] < 0.05 + 2.0 * 0.002   # stuck one step beyond the limit: no correction
+
+
+def test_damped_wheel_with_saturated_friction_separates_the_two_impulse_inertias():
+    """The closed form that tells the A3 settings apart: while the friction impulse is saturated the wheel loses
+    mu dt / I per step under DART 6's rule and mu dt / (I + dt d) under the augmented one -- with d = 25 a 10 % difference
+    in the friction deceleration, far above every tolerance of this suite (and of the north star's 1e-4)."""
+    a = flywheel_closed_forms("damped_friction", 400, impulse_inertia=1)
+    b = flywheel_closed_forms("damped_friction", 400, impulse_inertia=0)
+    dt, d, mu = 0.002, 25.0, 0.2
+    r = FLY_I / (FLY_I + dt * d)
+    # one step from v0 = 2: v1 = v0 r - mu dt / I_imp
+    assert a[0, 1] == pytest.approx(2.0 * r - mu * dt / FLY_I, rel=1e-13)
+    assert b[0, 1] == pytest.approx(2.0 * r - mu * dt / (FLY_I + dt * d), rel=1e-13)
+    assert abs(a[0, 1] - b[0, 1]) == pytest.approx(mu * dt * (1 / FLY_I - 1 / (FLY_I + dt * d)), rel=1e-9)
+    assert np.abs(a[:20, 1] - b[:20, 1]).max() > 5e-4          # 20 steps in, the two rules are 7e-4 rad/s apart
+    stop_a = int(np.argmax(np.abs(a[:, 1]) < 1e-6)); stop_b = int(np.argmax(np.abs(b[:, 1]) < 1e-6))
+    assert 0 < stop_a < stop_b                                   # and the wheel comes to rest earlier under DART 6's rule
+
+
+def test_impulse_pass_runs_on_the_mass_matrix_multi_dof():
+    """A3 on a real model: the Hopper in the air at q = 0 sits on the (inclusive) upper limits of its thigh and knee joints, which
+    carry damping 1.0.  One world step restated in numpy from the oracle's own M and c -- unconstrained velocity from
+    (M + dt D)^-1, limit rows solved by enumeration of their active sets on A = J Minv J^T, velocity change Minv J^T lambda -- with
+    Minv = M^-1 (DART 6) or (M + dt D)^-1 (knob 0).  The oracle must follow the setting it is given, and the two must differ."""
+    import itertools
+    res = {}
+    for knob in (1, 0):
+        card = card_for("DartHopper-v1")
+        card.impulse_inertia = knob
+        w = OracleWorld(card)
+        n = card.ndofs
+        rng = np.random.RandomState(3)
+        q = np.zeros(n); q[1] = 0.3                          # lifted: no contact
+        dq = rng.uniform(-1, 1, n); dq[3] = 1.5; dq[4] = 2.0   # driving both limited joints into their upper limit (0)
+        tau = rng.uniform(-50, 50, n); tau[:3] = 0
+        w.set_state(q, dq)
+        M = w.mass_matrix(); c = w.bias()
+        D = np.array([card.damping[i] for i in range(n)]); dt = card.dt
+        H = M + dt * np.diag(D)
+        vs = dq + dt * np.linalg.solve(H, tau - c - D * dq)
+        Minv = np.linalg.inv(M if knob == 1 else H)
+        rows = [i for i in range(n) if card.limited[i] and (q[i] <= card.lower[i] or q[i] >= card.upper[i])]
+        assert rows == [3, 4]
+        A = Minv[np.ix_(rows, rows)] * (np.ones((2, 2)) + np.eye(2) * card.cfm)
+        b = -vs[rows]
+        sol = None
+        for act in itertools.product([0, 1], repeat=2):     # upper limits: lambda <= 0, w = A lambda - b <= 0 where lambda = 0
+            idx = [k for k in range(2) if act[k]]
+            lam = np.zeros(2)
+            if idx:
+                lam[idx] = np.linalg.solve(A[np.ix_(idx, idx)], b[idx])
+            wv = A @ lam - b
+            if all(lam[k] <= 1e-15 for k in idx) and all(wv[k] <= 1e-12 for k in range(2) if not act[k]):
+                sol = lam
+        assert sol is not None and (sol < 0).all()           # both limits push back
+        v_new = vs + Minv[:, rows] @ sol
+        w.set_forces(tau); w.step()
+        assert np.abs(w.dq - v_new).max() < 1e-10, (knob, np.abs(w.dq - v_new).max())
+        res[knob] = w.dq.copy()
+    assert np.abs(res[1] - res[0]).max() > 1e-3              # percent-level on the joint velocities next to the limits
 
 
 def test_landing_is_inelastic_and_penetration_recovers_at_the_capped_rate():

@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X_MICROARCH.md: FP32 vector peak; the FP64 vector FMA runs at half that rate
 
 
 def algorithmic_bytes(card) -> int:
@@ -68,6 +69,13 @@ class HipBenchEnv:
         self.n, self.ring_len = n, ring
         self.dev = torch.device("cuda", local_rank)
         self.env = st.HipStepper(self.card, n, device=local_rank, precision=precision)
+        from dart_env_amd.model_card import TASK_CARTPOLE_SWINGUP, TASK_REACHER2D, TASK_REACHER3D
+        if self.card.task in (TASK_CARTPOLE_SWINGUP, TASK_REACHER2D, TASK_REACHER3D):
+            # reset_model of these tasks draws more than the two noise vectors (swing-up sign, reach targets): the device MT19937
+            # bank draws all of it, the in-kernel Philox reset would leave degenerate episodes (the ABI refuses that combination)
+            from dart_env_amd import seeding
+            keys, klen = seeding.mt_keys([env_offset + i for i in range(n)])
+            self.env.seed_mt19937(keys, klen)
         self.env.configure(st.CFG_AUTORESET, 1)
         self.env.configure(st.CFG_SEED, 0)
         self.env.configure(st.CFG_ENV_OFFSET, env_offset)
@@ -139,6 +147,51 @@ def attach_pmc(roof, key):
         roof["traffic_source"] = pmc[key].get("source")
         if "valu_issue" in pmc[key]:
             roof["valu_issue"] = pmc[key]["valu_issue"]
+
+
+def attach_valu(roof, env_id, n, dtype, kernel_ms):
+    """SURVEY.md 8(d)'s second axis -- the one that can bind: exact flops per env-step (profiles/flops_per_env_step.json, counted by
+    tools/count_flops.py on the kernels' own source with a counting scalar type) x env-steps/s of the kernel / vector-ALU peak."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "flops_per_env_step.json")) as f:
+            fl = json.load(f)
+    except (OSError, ValueError):
+        return
+    if env_id not in fl:
+        return
+    fpe = fl[env_id]["flops_per_env_step"]
+    achieved = fpe * n / (kernel_ms * 1e-3) / 1e12
+    peak = VALU_PEAK_TFLOPS[dtype]
+    roof["valu"] = {"bound": "valu", "flops_per_env_step": fpe, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "counted": fl[env_id].get("method", fl.get("_method")), "sample": fl[env_id].get("sample"),
+                    "note": "useful flops of one env's lane (pivoting loops end on the lane's own convergence); the wave executes more: "
+                            "it iterates until its slowest lane is done -- see valu_issue for the measured issue statistics"}
+
+
+def host_surface(env_id, n, local_rank, precision, budget_s=1.0, max_steps=200):
+    """The drop-in surface itself -- `DartVectorEnv.step(actions)` with numpy arrays in and out, the path north_star describes as
+    "observations/rewards are computed on-device and copied back once per batched step" (reference gym/vector/vector_env.py:68-92):
+    H2D of the actions, kernel, device auto-reset from the reference-exact MT19937 bank, ONE D2H of obs | reward | done | truncated
+    through pinned memory, and the gym.vector return types.  PCIe-inclusive, so never `value`."""
+    import dart_env_amd.vector as V
+    out = {"api": "DartVectorEnv.step", "noise": "mt19937 (device bank, reference-exact resets)", "envs": n,
+           "dtype": "f32" if precision == 32 else "f64"}
+    for copy in (True, False):
+        venv = V.make(env_id, n, device=local_rank, precision=precision, copy=copy)
+        venv.seed(0)
+        venv.reset()
+        a = np.random.RandomState(0).uniform(-1, 1, (n, venv.env.act_dim)).astype(np.float32)
+        for _ in range(10):
+            venv.step(a)
+        k, t0 = 0, time.perf_counter()
+        while k < max_steps and time.perf_counter() - t0 < budget_s:
+            obs, rew, done, info = venv.step(a)
+            k += 1
+        dt = time.perf_counter() - t0
+        out["copy_true" if copy else "copy_false"] = {"copy": copy, "steps": k, "ms_per_step": dt / k * 1e3, "value": n * k / dt,
+                                                      "unit": "env-steps/s"}
+        venv.close()
+    return out
 
 
 def time_config(env_id, n, local_rank, precision, steps, warmup, all_bodies_collide=None):
@@ -284,6 +337,7 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
                                    "kernel is VALU-issue / latency bound, neither HBM nor MFMA bound (DESIGN.md section 5)"),
     }
     attach_pmc(result["roofline"], "%s/%d/%s" % (args.env_id, n, dtype))
+    attach_valu(result["roofline"], args.env_id, n, dtype, ms_kernel)
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
     if gather_note is not None:
@@ -300,6 +354,7 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     b.close()
 
     if extras:
+        result["host_surface"] = host_surface(args.env_id, n, local_rank, args.precision)
         other_prec = 32 if args.precision == 64 else 64
         do_parity = not args.no_cpu_baseline
         if do_parity:
@@ -351,6 +406,7 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
                      "roofline": roofline_block(ocard, on, ms_h, "HIP events around %d launches" % osteps),
                      "f%d" % other_prec: {"value": on / (ms_f * 1e-3), "kernel_ms": ms_f}}
             attach_pmc(entry["roofline"], "%s/%d/%s" % (oid, on, dtype))
+            attach_valu(entry["roofline"], oid, on, dtype, ms_h)
             if do_parity:
                 one_ne = parity_sample_size(oid, args.parity_steps, cores, args.parity_budget, cap=4096)
                 entry["rms_state_err"], oref, oacts = parity_check(oid, args.precision, one_ne, args.parity_steps, local_rank)

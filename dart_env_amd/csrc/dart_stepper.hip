@@ -56,6 +56,10 @@ struct DartStepper {
   int32_t* mt_pos = nullptr;
   double *d_init_pos = nullptr, *d_init_vel = nullptr;
   int noise_mode = 0;            // 0: Philox / host-supplied noise, 1: device MT19937 bank (reference-exact)
+  // obs | reward | done | truncated of a step are ONE device block and ONE pinned host block (d_obs / h_obs are their bases):
+  // dart_step_async brings a step's outputs to the host with a single D2H copy instead of four
+  size_t out_bytes = 0;
+  bool split_d2h = false;        // DART_SPLIT_D2H=1: the four separate copies of rounds 1-2 (A/B measurements)
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
   double *h_qn = nullptr, *h_vn = nullptr;
@@ -149,18 +153,22 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
     CHK(h, hipMalloc((void**)&h->elapsed, 4 * N));
     CHK(h, hipMalloc((void**)&h->episode, 4 * N));
     CHK(h, hipMalloc((void**)&h->d_act, 4 * N * card->act_dim));
-    CHK(h, hipMalloc((void**)&h->d_obs, 4 * N * card->obs_dim));
-    CHK(h, hipMalloc((void**)&h->d_rew, 4 * N));
-    CHK(h, hipMalloc((void**)&h->d_done, N));
-    CHK(h, hipMalloc((void**)&h->d_trunc, N));
+    {
+      const size_t ob = (4 * N * card->obs_dim + 255) & ~(size_t)255, rb = (4 * N + 255) & ~(size_t)255, db = (N + 255) & ~(size_t)255;
+      h->out_bytes = ob + rb + 2 * db;
+      unsigned char* blk = nullptr;
+      CHK(h, hipMalloc((void**)&blk, h->out_bytes));
+      h->d_obs = (float*)blk; h->d_rew = (float*)(blk + ob); h->d_done = blk + ob + rb; h->d_trunc = blk + ob + rb + db;
+      unsigned char* hb = nullptr;
+      CHK(h, hipHostMalloc((void**)&hb, h->out_bytes));
+      h->h_obs = (float*)hb; h->h_rew = (float*)(hb + ob); h->h_done = hb + ob + rb; h->h_trunc = hb + ob + rb + db;
+      const char* e = getenv("DART_SPLIT_D2H");
+      h->split_d2h = e && e[0] == '1';
+    }
     CHK(h, hipMalloc((void**)&h->d_mask, N));
     CHK(h, hipMalloc((void**)&h->d_qn, 8 * N * nd));
     CHK(h, hipMalloc((void**)&h->d_vn, 8 * N * nd));
     CHK(h, hipHostMalloc((void**)&h->h_act, 4 * N * card->act_dim));
-    CHK(h, hipHostMalloc((void**)&h->h_obs, 4 * N * card->obs_dim));
-    CHK(h, hipHostMalloc((void**)&h->h_rew, 4 * N));
-    CHK(h, hipHostMalloc((void**)&h->h_done, N));
-    CHK(h, hipHostMalloc((void**)&h->h_trunc, N));
     CHK(h, hipHostMalloc((void**)&h->h_mask, N));
     CHK(h, hipHostMalloc((void**)&h->h_qn, 8 * N * nd));
     CHK(h, hipHostMalloc((void**)&h->h_vn, 8 * N * nd));
@@ -185,9 +193,9 @@ int dart_destroy(DartStepper* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->impl) h->impl->release();
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_trunc, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn.dev, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs /* base of the output block */, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn.dev, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
-  void* host[] = {h->h_act, h->h_obs, h->h_rew, h->h_done, h->h_trunc, h->h_mask, h->h_qn, h->h_vn};
+  void* host[] = {h->h_act, h->h_obs /* base of the pinned output block */, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
   if (h->ev_in) hipEventDestroy(h->ev_in);
   if (h->ev_out) hipEventDestroy(h->ev_out);
@@ -453,10 +461,14 @@ int dart_step_async(DartStepper* h, const float* actions) {
     CHK(h, h->impl->reset(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_done, h->d_qn, h->d_vn, h->d_obs, h->seed,
                           h->env_offset, 1));
   }
-  CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
-  CHK(h, hipMemcpyAsync(h->h_rew, h->d_rew, 4 * N, hipMemcpyDeviceToHost, h->stream));
-  CHK(h, hipMemcpyAsync(h->h_done, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
-  CHK(h, hipMemcpyAsync(h->h_trunc, h->d_trunc, N, hipMemcpyDeviceToHost, h->stream));
+  if (!h->split_d2h) {
+    CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, h->out_bytes, hipMemcpyDeviceToHost, h->stream));   // obs | reward | done | truncated
+  } else {
+    CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
+    CHK(h, hipMemcpyAsync(h->h_rew, h->d_rew, 4 * N, hipMemcpyDeviceToHost, h->stream));
+    CHK(h, hipMemcpyAsync(h->h_done, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
+    CHK(h, hipMemcpyAsync(h->h_trunc, h->d_trunc, N, hipMemcpyDeviceToHost, h->stream));
+  }
   h->pending = true;
   return DART_OK;
 }

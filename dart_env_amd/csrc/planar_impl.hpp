@@ -205,6 +205,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   for (int k = 0; k < NL; k++) { P.mass[k] = (Real)lm[k]; P.cx[k] = (Real)lcx[k]; P.cy[k] = (Real)lcy[k]; P.izz[k] = (Real)lizz[k]; }
   for (int d = 0; d < T::NDOF; d++) {
     if (d < 2 && (c.limited[d] || c.stiffness[d] != 0)) return "limits/springs on root translation";
+    if (d < 3 && (c.damping[d] != 0 || c.stiffness[d] != 0)) return "damping / springs on the floating root";   // (ImplicitDofs, fd_inverse_call)
     P.damp[d] = (Real)c.damping[d]; P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
     P.stiff[d] = (Real)c.stiffness[d]; P.rest[d] = (Real)c.rest[d];
     P.sqe[d] = (Real)std::sqrt(c.dt * c.damping[d] + c.dt * c.dt * c.stiffness[d]);

@@ -87,6 +87,9 @@ struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the flo
   static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;
+#ifdef DART_HINV_LDS
+  static constexpr bool HINV_LDS_F64 = true;   // see topo_hinv_lds64 -- OFF by default: the build is not trustworthy on gfx950 / ROCm 7.2
+#endif
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3, 4, 5, 6}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
@@ -128,6 +131,23 @@ template <class T, class = void> struct topo_fluid { static constexpr bool value
 template <class T> struct topo_fluid<T, decltype((void)T::FLUID)> { static constexpr bool value = T::FLUID; };
 template <class T, class = void> struct topo_plane_xz { static constexpr bool value = false; };
 template <class T> struct topo_plane_xz<T, decltype((void)T::PLANE_XZ)> { static constexpr bool value = T::PLANE_XZ; };
+
+// HINV_LDS_F64 / HINV_LDS_F32: keep H^-1 in LDS (one column of 64 lanes per packed entry) across the pivoting stages instead of in
+// registers.  The 9-dof fp64 kernels need ~310 doubles live at the pivoting loops against the 256 the register file holds
+// (512 32-bit registers): the allocator spilled ~84 of them to scratch (672 B per lane, 165 MB of HBM / L2 traffic per launch at
+// 65 536 envs).  H^-1 (45 doubles) is needed before the loops (Delassus matrix) and after them (velocity change) but not inside:
+// parked in LDS -- 23 KB per wave, conflict-free 8-byte columns -- and with the velocity change computed as H^-1 (J^T lambda)
+// instead of from stored rows of H^-1 J^T, nothing of that size stays live across the loops.
+template <class T, class = void> struct topo_hinv_lds64 { static constexpr bool value = false; };
+template <class T> struct topo_hinv_lds64<T, decltype((void)T::HINV_LDS_F64)> { static constexpr bool value = T::HINV_LDS_F64; };
+template <class T, class = void> struct topo_hinv_lds32 { static constexpr bool value = false; };
+template <class T> struct topo_hinv_lds32<T, decltype((void)T::HINV_LDS_F32)> { static constexpr bool value = T::HINV_LDS_F32; };
+template <class T, class Real> __device__ __host__ constexpr bool hinv_lds() {
+  return sizeof(Real) == 8 ? topo_hinv_lds64<T>::value : topo_hinv_lds32<T>::value;
+}
+#ifndef DART_COMPILER_FENCE
+#define DART_COMPILER_FENCE() asm volatile("" ::: "memory")   // no load / store of the compiler's moves across (it emits nothing)
+#endif
 
 template <class T>
 __device__ __host__ constexpr bool is_anc(int j, int k) {  // j ancestor-or-self of k
@@ -371,7 +391,9 @@ __device__ __forceinline__ void spd_solve(Real (&a)[K * (K + 1) / 2], Real (&x)[
 // one K x K LDL^T solve instead of a second N x N factorisation (Hopper: K = 3 of 6, Walker2d: 6 of 9).
 // Sel::count / Sel::dof(a): the dofs with E != 0; REV: Minv is stored in reversed dof order.  a = y on entry, qdd on return.
 template <class PT, int N> struct ImplicitDofs {
-  __device__ __host__ static constexpr bool has(int i) { return !(PT::zero(ZF_damp, i) && PT::zero(ZF_stiff, i)); }
+  // baked models: exactly the dofs with damping or a spring; runtime parameter block: every joint dof -- the three root dofs of a
+  // planar model carry neither (fill_params declines a card that has them there)
+  __device__ __host__ static constexpr bool has(int i) { return PT::is_static ? !(PT::zero(ZF_damp, i) && PT::zero(ZF_stiff, i)) : (i >= 3); }
   __device__ __host__ static constexpr int cnt() { int c = 0; for (int i = 0; i < N; i++) c += has(i) ? 1 : 0; return c; }
   static constexpr int count = cnt();
   __device__ __host__ static constexpr int dof(int a) { int c = 0; for (int i = 0; i < N; i++) if (has(i)) { if (c == a) return i; c++; } return 0; }
@@ -401,6 +423,35 @@ __device__ __forceinline__ void implicit_accel(const PT& P, const Real (&Minv)[N
       sfor<0, K>([&](auto A_) { constexpr int aa = A_, da = Sel::dof(aa), ia = REV ? N - 1 - da : da; a[i] -= Minv[tri(ii, ia)] * z[aa]; });
     });
   }
+}
+
+// The inverse of the impulse inertia and the forward-dynamics acceleration as a REAL CALL on copies (runtime-parameter kernels):
+// those kernels live at the edge of the register file (256 VGPR + 256 AGPR + KBs of scratch), where inlining another 45-entry
+// matrix phase into the step kernel has twice produced builds whose states differ from the host build of the same source on
+// gfx950 / ROCm 7.2 (round 2: the big contact tiers; round 3: this phase in the half-cheetah kernel, 5e-4 after 10 env-steps while
+// the host build stays at 1e-15).  As a call the phase gets a register allocation of its own.  io.H: M (or M + E with the A3 knob
+// at 0) in, its inverse out; io.acc: rhs in, qdd out; io.sqe: sqrt(E) per dof.
+template <class Real, int N>
+struct FdIO { Real H[N * (N + 1) / 2], acc[N], sqe[N]; };
+template <int N> struct JointDofs {
+  static constexpr int count = N - 3;
+  __device__ __host__ static constexpr int dof(int a) { return 3 + a; }
+};
+template <class Real, int N, bool REV>
+__device__ __attribute__((noinline)) void fd_inverse_call(FdIO<Real, N>& io, int impulse_M) {
+  Real H[N * (N + 1) / 2], rhs[N], acc[N];
+  sfor<0, N*(N + 1) / 2>([&](auto I) { H[I] = io.H[I]; });
+  sfor<0, N>([&](auto I) { rhs[I] = io.acc[I]; });
+  spd_inverse<Real, N>(H);
+  sfor<0, N>([&](auto I) {
+    constexpr int i = I, ii = REV ? N - 1 - i : i;
+    Real a = Real(0);
+    sfor<0, N>([&](auto J) { constexpr int j = J, jj = REV ? N - 1 - j : j; a += H[tri(ii, jj)] * rhs[j]; });
+    acc[i] = a;
+  });
+  if (impulse_M) implicit_accel<Real, N, REV, JointDofs<N>>(io, H, acc);   // (io.sqe plays the parameter block's part)
+  sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = H[I]; });
+  sfor<0, N>([&](auto I) { io.acc[I] = acc[I]; });
 }
 
 // Solve the masked symmetric system for the free set of a boxed LCP iteration.
@@ -536,12 +587,15 @@ struct WarmSets {
 // Inputs: H^-1 (packed, reversed dof order), link origins px / py, the unconstrained velocity vs (in/out), the candidate
 // contacts (con / cPx / cPy / cdep over the T::NC capsules) and the state q (limits).  A lane with `off` set takes no part
 // (it is served by slow_constraints): all its rows are inactive and its vs comes back unchanged.
-template <class Real, class T, class PT, int NCA, bool EXTRAS>
+// HLDS: H^-1 is read from this lane's LDS column `hl` (entry k at hl[64 k]) instead of from H (topo_hinv_lds64).
+template <class Real, class T, class PT, int NCA, bool EXTRAS, bool HLDS = false>
 __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T::NDOF], const Real (&H)[T::NDOF * (T::NDOF + 1) / 2],
                                                  const Real (&px)[T::NL], const Real (&py)[T::NL], Real (&vs)[T::NDOF],
                                                  const bool (&con)[T::NC], const Real (&cPx)[T::NC], const Real (&cPy)[T::NC],
-                                                 const Real (&cdep)[T::NC], bool off, WarmSets& warm, const ReportTo<Real>& rp) {
+                                                 const Real (&cdep)[T::NC], bool off, WarmSets& warm, const ReportTo<Real>& rp,
+                                                 const Real* hl = nullptr) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * NCA + n_limited<T>();
+  auto Hv = [&](int k) -> Real { if constexpr (HLDS) return hl[64 * k]; else return H[k]; };
   constexpr bool IDENT = (NCA == NC);   // slot s IS candidate s: links are compile-time constants
   constexpr int NS = NCA > 0 ? NCA : 1;   // array extent of the slot arrays (a tier without contact slots still declares them)
   // ---- compaction: slot s takes the s-th touching capsule (capsule order = the oracle's serial order)
@@ -625,6 +679,21 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   if (!__any(any)) return;
 
   // Y = H^-1 J^T for contact rows (limit rows: columns of H^-1), Delassus matrix A = J H^-1 J^T
+  if constexpr (HLDS) {   // every packed entry of H^-1 is fetched from LDS once and serves both triangles and all slots
+    sfor<0, NCA>([&](auto S) { sfor<0, N>([&](auto I) { Yn[S][I] = Real(0); Yt[S][I] = Real(0); }); });
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      sfor<0, i + 1>([&](auto J) {
+        constexpr int j = J;
+        const Real h = Hv(tri(rev<N>(i), rev<N>(j)));
+        sfor<0, NCA>([&](auto S) {
+          constexpr int sl = S;
+          Yn[sl][i] += h * Jn[sl][j]; Yt[sl][i] += h * Jt[sl][j];
+          if constexpr (i != j) { Yn[sl][j] += h * Jn[sl][i]; Yt[sl][j] += h * Jt[sl][i]; }
+        });
+      });
+    });
+  } else
   sfor<0, NCA>([&](auto S) {
     constexpr int sl = S;
     sfor<0, N>([&](auto I) {
@@ -661,7 +730,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       });
       sfor<0, k + 1>([&](auto J) {
         constexpr int j = J;
-        if constexpr (T::limited(j)) A[tri(sl, limit_slot<T, NCA>(j))] = H[tri(rev<N>(i), rev<N>(2 + j))];
+        if constexpr (T::limited(j)) A[tri(sl, limit_slot<T, NCA>(j))] = Hv(tri(rev<N>(i), rev<N>(2 + j)));
       });
     }
   });
@@ -832,6 +901,36 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     });
   }
   // velocity change  H^-1 J^T lambda
+  if constexpr (HLDS) {
+    // f = J^T lambda rebuilt from the slots' contact points (no Jacobian or H^-1 J^T rows were kept across the pivoting loops),
+    // then H^-1 f with every packed entry fetched from LDS once
+    DART_COMPILER_FENCE();   // the loads below are new loads: nothing fetched before the loops is to be kept for them
+    Real f[N], dv[N];
+    sfor<0, N>([&](auto I) { f[I] = Real(0); dv[I] = Real(0); });
+    sfor<0, NCA>([&](auto S) {
+      constexpr int sl = S;
+      const Real xn = x[2 * sl], xt = x[2 * sl + 1];
+      f[0] -= xt; f[1] += xn;
+      sfor<0, NL>([&](auto J) {
+        constexpr int j = J;
+        bool a;
+        if constexpr (IDENT) a = is_anc<T>(j, T::clink(sl)); else a = (samask[sl] >> j) & 1u;
+        const Real g = P.sigma[j] * ((sPx[sl] - px[j]) * xn + (sPy[sl] - py[j]) * xt);
+        f[2 + j] += a ? g : Real(0);
+      });
+    });
+    sfor<0, NL>([&](auto K) { constexpr int k = K; if constexpr (T::limited(k)) f[2 + k] += x[limit_slot<T, NCA>(k)]; });
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      sfor<0, i + 1>([&](auto J) {
+        constexpr int j = J;
+        const Real h = Hv(tri(rev<N>(i), rev<N>(j)));
+        dv[i] += h * f[j];
+        if constexpr (i != j) dv[j] += h * f[i];
+      });
+    });
+    sfor<0, N>([&](auto I) { vs[I] += dv[I]; });
+  } else
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
     Real dv = Real(0);
@@ -1036,7 +1135,7 @@ __device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* me
 template <class Real, class T, class PT, bool EXTRAS>
 __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
                                            const Real (&tau)[T::NDOF], WarmSets& warm, Real* slow_mem, int64_t env,
-                                           const ReportTo<Real>& rp) {
+                                           const ReportTo<Real>& rp, Real* hl = nullptr) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC;
   Real c[NL], s[NL], px[NL], py[NL], lx[NL], ly[NL], om[NL];
   Real apx[NL], apy[NL];
@@ -1155,9 +1254,21 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       if constexpr (!DART_ZERO(PT, damp, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.damp[i];
       if constexpr (!DART_ZERO(PT, stiff, i)) H[tri(rev<N>(i), rev<N>(i))] += P.dt * P.dt * P.stiff[i];
     });
-  spd_inverse<Real, N>(H);  // H now holds the inverse of the impulse inertia (reversed dof order)
+#ifdef DART_ROOT_FIRST
+  constexpr bool REV = false;
+#else
+  constexpr bool REV = true;
+#endif
   Real vs[N];
-  {
+  if constexpr (!PT::is_static) {   // runtime-parameter kernels: the phase is a real call (fd_inverse_call)
+    FdIO<Real, N> io;
+    sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = H[I]; });
+    sfor<0, N>([&](auto I) { io.acc[I] = rhs[I]; io.sqe[I] = P.sqe[I]; });
+    fd_inverse_call<Real, N, REV>(io, P.impulse_M);
+    sfor<0, N*(N + 1) / 2>([&](auto I) { H[I] = io.H[I]; });   // the inverse of the impulse inertia (reversed dof order)
+    sfor<0, N>([&](auto I) { constexpr int i = I; vs[i] = dq[i] + P.dt * io.acc[i]; });
+  } else {
+    spd_inverse<Real, N>(H);  // H now holds the inverse of the impulse inertia (reversed dof order)
     Real acc[N];
     sfor<0, N>([&](auto I) {
       constexpr int i = I;
@@ -1165,13 +1276,15 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(rev<N>(i), rev<N>(j))] * rhs[j]; });
       acc[i] = a;
     });
-#ifdef DART_ROOT_FIRST
-    if (impulse_M) implicit_accel<Real, N, false, ImplicitDofs<PT, N>>(P, H, acc);
-#else
-    if (impulse_M) implicit_accel<Real, N, true, ImplicitDofs<PT, N>>(P, H, acc);
-#endif
+    if (impulse_M) implicit_accel<Real, N, REV, ImplicitDofs<PT, N>>(P, H, acc);
     sfor<0, N>([&](auto I) { constexpr int i = I; vs[i] = dq[i] + P.dt * acc[i]; });
   }
+  constexpr bool HLDS = hinv_lds<T, Real>();
+  if constexpr (HLDS) {   // park H^-1 in this lane's LDS column (topo_hinv_lds64); from here on it is read from there
+    sfor<0, N*(N + 1) / 2>([&](auto I) { constexpr int i = I; hl[64 * i] = H[i]; });
+    DART_COMPILER_FENCE();
+  }
+  auto Hv = [&](int k) -> Real { if constexpr (HLDS) return hl[64 * k]; else return H[k]; };
 
   // ---- candidate contacts at q_t: every capsule's lowest segment endpoint against the floor (ODE capsule-plane as DART
   // uses it: one contact, position in the middle of the penetration)
@@ -1204,7 +1317,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       for (int turn = 0; turn < 64; ++turn) {
         if (slow && (int)(threadIdx.x & 63) == turn) {
           Real* m = slow_mem;
-          sfor<0, N>([&](auto I) { constexpr int i = I; sfor<0, N>([&](auto J) { constexpr int j = J; m[i * N + j] = H[tri(rev<N>(i), rev<N>(j))]; }); });
+          sfor<0, N>([&](auto I) { constexpr int i = I; sfor<0, N>([&](auto J) { constexpr int j = J; m[i * N + j] = Hv(tri(rev<N>(i), rev<N>(j))); }); });
           m += N * N;
           sfor<0, NL>([&](auto K) { m[K] = px[K]; m[NL + K] = py[K]; m[2 * NL + K] = P.sigma[K]; });
           m += 3 * NL;
@@ -1244,12 +1357,12 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
         sfor<0, N>([&](auto I) { vs[I] = io.vs[I]; });
         warm = io.warm;
       } else {
-        constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
+        constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl);
       }
     }
-    else constraint_phase<Real, T, PT, T::TIER0, EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
+    else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl);
   } else {
-    constraint_phase<Real, T, PT, T::TIER0, EXTRAS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp);
+    constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl);
   }
   sfor<0, N>([&](auto I) { constexpr int i = I; dq[i] = vs[i]; q[i] += P.dt * vs[i]; });
 }
@@ -1343,13 +1456,16 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   WarmSets warm;
   // LDS of the single-lane fallback solver (only topologies with more candidate capsules than tier slots have one)
   __shared__ Real slow_lds[has_slow_path<T, Real>() ? slow_words<T>() : 1];
+  // H^-1 of every lane, one 64-lane column per packed entry (topo_hinv_lds64; only the topologies that ask for it)
+  __shared__ Real hinv_lds_[hinv_lds<T, Real>() ? 64 * (N * (N + 1) / 2) : 1];
+  Real* hl = hinv_lds_ + (threadIdx.x & 63);
 #pragma unroll 1
   for (int f = 0; f < P.frame_skip; ++f) {
     ReportTo<Real> rp;
     if (EXTRAS && P.ex.creport != nullptr && f == P.frame_skip - 1 && valid) {
       rp.rec = P.ex.creport + (size_t)e * T::NC * 8; rp.count = P.ex.creport_count + e; rp.cf = P.ex.cf_report + (size_t)e * N;
     }
-    world_step<Real, T, PT, EXTRAS>(P, q, dq, tau, warm, slow_lds, ec, rp);
+    world_step<Real, T, PT, EXTRAS>(P, q, dq, tau, warm, slow_lds, ec, rp, hl);
     dx += P.dt * dq[0];
   }
   (void)x_before;

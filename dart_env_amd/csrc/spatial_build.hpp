@@ -176,6 +176,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   }
   M.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
   M.has_implicit = 0;
+  M.fd_passes = 2;
   for (int d = 0; d < c.ndofs; d++) if (c.damping[d] != 0.0 || c.stiffness[d] != 0.0) M.has_implicit = 1;
   int ns = 0;
   for (int s = 0; s < c.nshapes; s++) {

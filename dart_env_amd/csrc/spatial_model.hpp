@@ -64,6 +64,7 @@ struct SpatialModel {
   int has_joint_friction;
   int impulse_M;                     // card.impulse_inertia (A3): 1 = the impulse pass runs on M (DART 6), 0 = on M + dt D + dt^2 K
   int has_implicit;                  // some dof has damping or a spring: with impulse_M the forward dynamics needs its own factor of M + E
+  int fd_passes;                     // 2: trip count of sp_world_step's factorisation loop (a model constant the compiler cannot see, so the loop stays one)
   int free_root;                     // 1: body 0 hangs on a DART FreeJoint (public q[0:3] rotation vector, dq[0:6] body twist)
   int free_link;                     // the last of the six root links (carries the body); its joint rotation is Rz(c) R0
   int maxm, maxcp;                   // LCP rows / contact points this model's LDS block is carved for

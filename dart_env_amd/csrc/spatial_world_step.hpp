@@ -51,26 +51,6 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   __syncthreads();
   if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
   SP_TICK(1);
-  if (Md.impulse_M && Md.has_implicit) {
-    // A3 (card.impulse_inertia = 1, DART 6): the forward dynamics solves (M + E) qdd = rhs with the implicit damping / spring
-    // terms E = dt D + dt^2 K, the impulse pass below runs on M alone.  S.H keeps M; M + E is factored in the (still idle)
-    // Jacobian block, qdd comes from that factor, and rhs' = rhs - E qdd = M qdd then rides through the M-factor's
-    // substitutions exactly as rhs did before:  L^-T L^-1 rhs' = qdd.
-    const int np = sp_npad(n);
-    Real* H2 = S.W; Real* sinv2 = S.W + HR(np); Real* xq = sinv2 + np;
-    if (lane < np) for (int k = 0; k <= lane; k++) H2[HL(lane, k)] = S.H[HL(lane, k)];
-    __syncthreads();
-    if (lane < n) { H2[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag; xq[n - 1 - lane] = S.rhs[lane]; }
-    __syncthreads();
-    sp_cholesky<Real, PAT>(H2, sinv2, n, lane);
-    sp_chol_fwdsolve<Real>(H2, sinv2, n, xq, lane);
-    sp_chol_backsolve<Real, BIG>(H2, sinv2, n, xq, lane);
-    if (lane < n) S.rhs[lane] -= lc.d_diag * xq[n - 1 - lane];
-    __syncthreads();
-    SP_TICK(2);
-  }
-  if constexpr (PAT::dense) { sp_cholesky<Real, PAT>(S.H, S.sinv, n, lane); SP_TICK(2); }   // pattern kernels factor later (below)
-
   // ---- contact points and active limits, in parallel: lane s tests collision shape s, lane d tests the limits of
   // dof d; ballots give every hit its slot (shape order, then vertex order -- the serial order of the oracle)
   const V3<Real> roff = ld3(S.misc);
@@ -174,7 +154,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       const Real viol = low ? qd - lc.d_lower : qd - lc.d_upper;
       const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
       S.rdof[row] = lane; S.rfidx[row] = -1;
-      S.b[row] = bounce - S.dq[lane];   // the dt * W_i . y part (unconstrained acceleration) is added after the W solve
+      S.b[row] = bounce;   // (- v*_d follows with the Jacobian rows, once the forward dynamics has run)
       S.lo[row] = low ? Real(0) : -inf_<Real>();
       S.hi[row] = low ? inf_<Real>() : Real(0);
     }
@@ -185,7 +165,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       const int frow = m + __popcll(fm & lt);
       if (fr && frow < Md.maxm) {
         S.rdof[frow] = lane; S.rfidx[frow] = -1;
-        S.b[frow] = -S.dq[lane];
+        S.b[frow] = Real(0);   // (- v*_d follows with the Jacobian rows)
         S.lo[frow] = -lc.d_fric; S.hi[frow] = lc.d_fric;
       }
       m += __popcll(fm);
@@ -201,100 +181,115 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   __syncthreads();
   SP_TICK(3);
   {
-    // ---- Jacobian rows (lane per row) + the generalized-force row (index m), bias part of b for contact rows
+    // ---- Two passes through ONE copy of the factorisation + forward-substitution code (a second inlined copy thrashed the
+    // instruction cache: HumanWalker 5.0 -> 8.0 ms instead of the ~6.3 the extra arithmetic is worth):
+    //   pass 0  forward dynamics: M + E (E = dt D + dt^2 K, the implicit damping / spring terms) is factored in the still idle
+    //           Jacobian block, the right-hand side rides through the substitution as the only row -> qdd; S.dq becomes the
+    //           unconstrained velocity v* = dq + dt qdd, which is all the constraint phase needs.
+    //   pass 1  impulse inertia: Jacobian rows (lane per row; b = bounce - J v*), S.H is factored -- M alone under DART 6's rule
+    //           (A3, card.impulse_inertia = 1), M + E with the knob at 0 -- and W = L^-1 J^T.
     // columns of W follow the factor's storage order: dof d sits in column n-1-d
-    if (lane == m) for (int k = 0; k < n; k++) S.W[m * n + (n - 1 - k)] = S.rhs[k];
-    if (lane < m) {
-      Real* Jr = S.W + lane * n;
-      for (int k = 0; k < n; k++) Jr[k] = Real(0);
-      const int d = S.rdof[lane];
-      if (d >= 0) {
-        Jr[n - 1 - d] = Real(1);
+    const int np = sp_npad(n);
+    Real* const H2 = S.W; Real* const sinv2 = S.W + HR(np); Real* const xq = sinv2 + np;
+#pragma nounroll
+    for (int pass = 0; pass < Md.fd_passes; pass++) {   // (a run-time bound: the compiler must keep this a loop)
+      Real* const Hm = pass ? S.H : H2; Real* const sv = pass ? S.sinv : sinv2; Real* const Wr = pass ? S.W : xq;
+      const int nrows = pass ? m : 1;
+      if (pass == 0) {
+        if (lane < np) for (int k = 0; k <= lane; k++) H2[HL(lane, k)] = S.H[HL(lane, k)];
+        __syncthreads();
+        if (lane < n) { if (Md.impulse_M) H2[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag; xq[n - 1 - lane] = S.rhs[lane]; }
       } else {
-        const int cidx = PREFIX ? (lane < m1 ? lane : ((lane - m1) >> 1)) : lane / 3, kind = PREFIX ? (lane < m1 ? 0 : 1 + ((lane - m1) & 1)) : lane % 3;
-        // DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1
-        V3<Real> dir;
-        if (PAIRS) {
-          const V3<Real> nn = ld3(S.cpN + 3 * cidx);
-          V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
-          if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
-          t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
-          dir = kind == 0 ? nn : (kind == 1 ? t1 : cross(nn, t1));
-        } else {   // ground contacts only: n = +y, t1 = z x n = -x, t2 = n x t1 = +z
-          dir = kind == 0 ? v3<Real>(0, 1, 0) : (kind == 1 ? v3<Real>(-1, 0, 0) : v3<Real>(0, 0, 1));
-        }
-        const V3<Real> P = ld3(S.cpP + 4 * cidx);
-        Real rel = Real(0);
-        for (int side = 0; side < (PAIRS ? 2 : 1); side++) {   // J = J_a - J_b for a link-link contact
-          const Real sg = side == 0 ? Real(1) : Real(-1);
-          for (int j = side == 0 ? S.cplink[cidx] : S.cplinkB[cidx]; j >= 0;) {
-            const int w = S.topo[j];
-            const int dj = topo_dof(w), jcur = j;
-            j = topo_parent(w);
-            if (dj < 0) continue;
-            const Real* Lj = S.link + jcur * SP_LINKF;
-            const V3<Real> aj = ld3(Lj + LK_A);
-            const Real v = sg * ((topo_jtype(w) == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj));
-            Jr[n - 1 - dj] += v;
-            rel += v * S.dq[dj];
-          }
-        }
-        const Real depth = S.cpP[4 * cidx + 3];
-        S.b[lane] = (kind == 0 ? fmin(depth * Md.erp_dt, Md.max_erv) : Real(0)) - rel;
-        S.lo[lane] = Real(0);
-        S.hi[lane] = kind == 0 ? inf_<Real>() : Real(0);   // friction rows pinned during the frictionless stage
-      }
-    }
-    __syncthreads();
-    SP_TICK(4);
-    // ---- W = L^-1 [J^T | rhs] : every lane forward-substitutes its own row; row m becomes y = L^-1 rhs
-    if constexpr (!PAT::dense) {
-      // Pattern kernels (HumanWalker): the factorisation sits here, after the Jacobian rows it does not depend on, and the
-      // substitution follows while the factor is still in registers -- L_kj reaches a row's lane through v_readlane
-      // (sp_cholesky_t).  Measured 6.36 -> 6.19 ms; the dense kernels got slower with it (Walker3d +4 %) and keep the LDS reads.
-      sp_cholesky<Real, PAT>(S.H, S.sinv, n, lane, S.W, m);
-      SP_TICK(2);
-    } else {
-      // The row lives in registers and both loops are fully unrolled (SP_MAXN x SP_MAXN / 2 predicated steps, uniform
-      // `k < n` branches): every factor entry is one LDS read at an immediate offset, no index arithmetic.
-      if (lane <= m) {
-        Real* yrow = S.W + lane * n;
-        Real y[SP_MAXN];
-#pragma unroll
-        for (int k = 0; k < SP_MAXN; k++) y[k] = (k < n) ? yrow[k] : Real(0);
-        // factor rows start 16-byte aligned and are padded to multiples of 4 entries (HR): 128-bit LDS loads, 4 (fp32) or 2 (fp64)
-        // entries each; the entries a load brings in beyond column k - 1 are not used
-        using Vec = typename sp_vec128<Real>::type;
-        constexpr int VW = sp_vec128<Real>::width;
-#pragma unroll
-        for (int k = 0; k < SP_MAXN; k++) {
-          if (k < n) {
-            Real t = y[k];
-            const Vec* hr = reinterpret_cast<const Vec*>(S.H + HR(k));
-#pragma unroll
-            for (int j = 0; j < k; j += VW) {
-              const Vec h = hr[j / VW];
-              const Real* hv = reinterpret_cast<const Real*>(&h);
-#pragma unroll
-              for (int c = 0; c < VW; c++) if (j + c < k) t -= hv[c] * y[j + c];
+        if (lane < m) {
+          Real* Jr = S.W + lane * n;
+          for (int k = 0; k < n; k++) Jr[k] = Real(0);
+          const int d = S.rdof[lane];
+          if (d >= 0) {
+            Jr[n - 1 - d] = Real(1);
+            S.b[lane] -= S.dq[d];   // limit / joint-friction row: bounce - v*_d
+          } else {
+            const int cidx = PREFIX ? (lane < m1 ? lane : ((lane - m1) >> 1)) : lane / 3, kind = PREFIX ? (lane < m1 ? 0 : 1 + ((lane - m1) & 1)) : lane % 3;
+            // DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1
+            V3<Real> dir;
+            if (PAIRS) {
+              const V3<Real> nn = ld3(S.cpN + 3 * cidx);
+              V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
+              if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
+              t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
+              dir = kind == 0 ? nn : (kind == 1 ? t1 : cross(nn, t1));
+            } else {   // ground contacts only: n = +y, t1 = z x n = -x, t2 = n x t1 = +z
+              dir = kind == 0 ? v3<Real>(0, 1, 0) : (kind == 1 ? v3<Real>(-1, 0, 0) : v3<Real>(0, 0, 1));
             }
-            y[k] = t * S.sinv[k];
+            const V3<Real> P = ld3(S.cpP + 4 * cidx);
+            Real rel = Real(0);
+            for (int side = 0; side < (PAIRS ? 2 : 1); side++) {   // J = J_a - J_b for a link-link contact
+              const Real sg = side == 0 ? Real(1) : Real(-1);
+              for (int j = side == 0 ? S.cplink[cidx] : S.cplinkB[cidx]; j >= 0;) {
+                const int w = S.topo[j];
+                const int dj = topo_dof(w), jcur = j;
+                j = topo_parent(w);
+                if (dj < 0) continue;
+                const Real* Lj = S.link + jcur * SP_LINKF;
+                const V3<Real> aj = ld3(Lj + LK_A);
+                const Real v = sg * ((topo_jtype(w) == 2) ? dot(dir, cross(aj, P - ld3(Lj + LK_JO))) : dot(dir, aj));
+                Jr[n - 1 - dj] += v;
+                rel += v * S.dq[dj];
+              }
+            }
+            const Real depth = S.cpP[4 * cidx + 3];
+            S.b[lane] = (kind == 0 ? fmin(depth * Md.erp_dt, Md.max_erv) : Real(0)) - rel;
+            S.lo[lane] = Real(0);
+            S.hi[lane] = kind == 0 ? inf_<Real>() : Real(0);   // friction rows pinned during the frictionless stage
           }
         }
-#pragma unroll
-        for (int k = 0; k < SP_MAXN; k++) if (k < n) yrow[k] = y[k];
       }
       __syncthreads();
+      SP_TICK(4);
+      if constexpr (!PAT::dense) {
+        // Pattern kernels (HumanWalker): the substitution follows while the factor is still in registers -- L_kj reaches a
+        // row's lane through v_readlane (sp_cholesky_t).  Measured 6.36 -> 6.19 ms; the dense kernels got slower with it
+        // (Walker3d +4 %) and keep the LDS reads.
+        sp_cholesky<Real, PAT>(Hm, sv, n, lane, Wr, nrows - 1);
+      } else {
+        sp_cholesky<Real, PAT>(Hm, sv, n, lane);
+        // The row lives in registers and both loops are fully unrolled (SP_MAXN x SP_MAXN / 2 predicated steps, uniform
+        // `k < n` branches): every factor entry is one LDS read at an immediate offset, no index arithmetic.
+        if (lane < nrows) {
+          Real* yrow = Wr + lane * n;
+          Real y[SP_MAXN];
+  #pragma unroll
+          for (int k = 0; k < SP_MAXN; k++) y[k] = (k < n) ? yrow[k] : Real(0);
+          // factor rows start 16-byte aligned and are padded to multiples of 4 entries (HR): 128-bit LDS loads, 4 (fp32) or 2 (fp64)
+          // entries each; the entries a load brings in beyond column k - 1 are not used
+          using Vec = typename sp_vec128<Real>::type;
+          constexpr int VW = sp_vec128<Real>::width;
+  #pragma unroll
+          for (int k = 0; k < SP_MAXN; k++) {
+            if (k < n) {
+              Real t = y[k];
+              const Vec* hr = reinterpret_cast<const Vec*>(Hm + HR(k));
+  #pragma unroll
+              for (int j = 0; j < k; j += VW) {
+                const Vec h = hr[j / VW];
+                const Real* hv = reinterpret_cast<const Real*>(&h);
+  #pragma unroll
+                for (int c = 0; c < VW; c++) if (j + c < k) t -= hv[c] * y[j + c];
+              }
+              y[k] = t * sv[k];
+            }
+          }
+  #pragma unroll
+          for (int k = 0; k < SP_MAXN; k++) if (k < n) yrow[k] = y[k];
+        }
+        __syncthreads();
+      }
+      SP_TICK(2);
+      if (pass == 0) {
+        sp_chol_backsolve<Real, BIG>(Hm, sv, n, xq, lane);
+        if (lane < n) S.dq[lane] += Md.dt * xq[n - 1 - lane];
+        __syncthreads();
+      }
     }
-    // b_i = bounce_i - J_i (dq + dt H^-1 rhs) = bias_i - dt W_i . y
-    if (lane < m) {
-      const Real* wi = S.W + lane * n;
-      const Real* y = S.W + m * n;
-      Real t = Real(0);
-      for (int k = 0; k < n; k++) t += wi[k] * y[k];
-      S.b[lane] -= Md.dt * t;
-    }
-    __syncthreads();
     SP_TICK(5);
   }
   if (m > 0) {
@@ -380,11 +375,11 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       st3(out + 5, (nn * l0 + t1 * l1 + t2 * l2) * idt);
     }
   }
-  // ---- new velocity: vs = dq + L^-T (dt y + W^T lambda)   (storage order until the back-substitution is done)
+  // ---- new velocity: v = v* + L^-T (W^T lambda)   (storage order until the back-substitution is done)
   if (lane < n) {
-    Real u = Md.dt * S.W[m * n + lane], ul = Real(0);
-    for (int i = 0; i < m; i++) { const Real t = S.W[i * n + lane] * S.x[i]; u += t; ul += t; }
-    if ((EXTRAS && Md.task == 12) || (REPORT && report)) S.lo[lane] = ul;   // W^T lambda = L^-1 J^T lambda
+    Real u = Real(0);
+    for (int i = 0; i < m; i++) u += S.W[i * n + lane] * S.x[i];
+    if ((EXTRAS && Md.task == 12) || (REPORT && report)) S.lo[lane] = u;   // W^T lambda = L^-1 J^T lambda
     S.rhs[lane] = u;
   }
   __syncthreads();
@@ -404,7 +399,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       Md.cf_report[(size_t)blockIdx.x * n + lane] = v;
     }
   }
-  sp_chol_backsolve<Real, BIG>(S.H, S.sinv, n, S.rhs, lane);
+  if (m > 0) sp_chol_backsolve<Real, BIG>(S.H, S.sinv, n, S.rhs, lane);   // (wave-uniform: nothing touching, no limit active -> v = v*)
   SP_TICK(9);
   if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[n - 1 - lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
   __syncthreads();

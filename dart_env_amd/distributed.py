@@ -137,12 +137,13 @@ class RolloutBuffer:
         self._started = True
         return self
 
-    def gather(self):
-        """-> dict of tensors with a leading world dimension: obs (W, T+1, n, k), actions, rewards, dones, truncated."""
+    def gather(self, force_collective=False):
+        """-> dict of tensors with a leading world dimension: obs (W, T+1, n, k), actions, rewards, dones, truncated.
+        force_collective: issue the all-gathers even in a one-rank group (a 1-GPU box can then execute the RCCL path)."""
         import torch
         import torch.distributed as dist
         names = ("obs", "actions", "rewards", "dones", "truncated")
-        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
             return {k: getattr(self, k).unsqueeze(0) for k in names}
         w = dist.get_world_size()
         out = {}

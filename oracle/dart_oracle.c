@@ -87,6 +87,13 @@ typedef struct OracleWorld {
   int solver;       /* 0 = exact (block principal pivoting), 1 = PGS fixed count */
   int pgs_k1, pgs_k2;
   int planar_drop_z;/* drop friction rows whose A_ii == 0 */
+  /* alternatives to two DART-semantic assumptions that are not card fields (tools/knob_sensitivity.py measures
+   * how far each moves a trajectory -- where a future capture from real DART should look first):
+   *   a5_surface_point  1: a capsule's contact point sits on the capsule surface (pe - r n) instead of ODE's sphere-sphere
+   *                        midpoint of the penetration (pe - n (r + d) / 2)
+   *   a7_iterate_bounds 1: the friction bounds +-mu lambda_n are re-evaluated from the latest normal impulses until they stop
+   *                        moving (a consistent pyramid) instead of being fixed once from the frictionless solve (ODE's driver) */
+  int a5_surface_point, a7_iterate_bounds;
   /* scratch / last-step diagnostics */
   Xform X[MAXL];
   double W[MAXL][16]; /* world pose of each link */
@@ -328,6 +335,10 @@ OracleWorld* oracle_create(const DartModelCard* card) {
 }
 void oracle_destroy(OracleWorld* w) { free(w); }
 void oracle_set_solver(OracleWorld* w, int solver, int k1, int k2) { w->solver = solver; w->pgs_k1 = k1; w->pgs_k2 = k2; }
+void oracle_set_assumption(OracleWorld* w, int id, int value) {
+  if (id == 5) w->a5_surface_point = value;
+  if (id == 7) w->a7_iterate_bounds = value;
+}
 void oracle_set_state(OracleWorld* w, const double* q, const double* dq) {
   memcpy(w->q, q, w->n * sizeof(double)); memcpy(w->dq, dq, w->n * sizeof(double));
 }
@@ -887,7 +898,7 @@ int oracle_step(OracleWorld* w) {
       double d = pe[1] - c->ground_y;
       if (d > r) continue;
       /* ODE dCollideSpheres(pl, r, pb, 0): pos = pl - n (r + d)/2 */
-      cp_P[ncp][0] = pe[0]; cp_P[ncp][1] = pe[1] - 0.5 * (r + d); cp_P[ncp][2] = pe[2];
+      cp_P[ncp][0] = pe[0]; cp_P[ncp][1] = w->a5_surface_point ? pe[1] - r : pe[1] - 0.5 * (r + d); cp_P[ncp][2] = pe[2];
       cp_depth[ncp] = r - d; cp_shape[ncp] = s; cp_shape_b[ncp] = -1; cp_n[ncp][0] = 0; cp_n[ncp][1] = 1; cp_n[ncp][2] = 0; ncp++;
     } else if (c->shape_type[s] == DART_SH_BOX) {
       /* box vs. the (huge) ground box, ODE/DART dBoxBox face case with the ground's +y face as reference: the
@@ -1043,6 +1054,13 @@ int oracle_step(OracleWorld* w) {
         if (blcp_exact(A, b, lo, hi, idx2, m, m, x) != 0) return -3;
       } else {
         pgs_sweeps(A, b, lo, hi, idx2, m, m, w->pgs_k2, x);
+      }
+      for (int pass = 0; w->a7_iterate_bounds && w->solver == 0 && pass < 20; pass++) {   /* sensitivity study only */
+        double moved = 0;
+        for (int i = 0; i < m; i++)
+          if (findex[i] >= 0) { double nh = fabs(c->friction * x[findex[i]]); moved = fmax(moved, fabs(nh - hi[i])); hi[i] = nh; lo[i] = -nh; }
+        if (moved < 1e-12) break;
+        if (blcp_exact(A, b, lo, hi, idx2, m, m, x) != 0) return -3;
       }
     }
     for (int i = 0; i < m; i++) {

@@ -102,6 +102,11 @@ class OracleWorld:
     def set_solver(self, solver, k1=30, k2=30):
         self.L.oracle_set_solver(self.h, solver, k1, k2)
 
+    def set_assumption(self, ident, value):
+        """alternatives to SURVEY Appendix C's A5 / A7 (oracle/dart_oracle.c: a5_surface_point, a7_iterate_bounds)"""
+        self.L.oracle_set_assumption.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.L.oracle_set_assumption(self.h, int(ident), int(value))
+
     def set_state(self, q, dq):
         q = np.ascontiguousarray(q, dtype=np.float64)
         dq = np.ascontiguousarray(dq, dtype=np.float64)

@@ -28,13 +28,25 @@ def make_reference(card, ne, steps, threads=None):
     return acts, ol.rollout_trace(card, acts, snap_list(steps), seed=0, env_offset=0, solver=0, threads=threads)
 
 
-def snap_stats(qg, dqg, ref, si):
-    eq, edq = qg - ref["q"][si], dqg - ref["dq"][si]
+def snap_stats(qg, dqg, ref, si, smax=np.inf):
+    """smax = card.state_abs_max: a state the reference's own validity test rejects -- `np.abs(s[2:]) < 100` in every task's done
+    condition (hopper.py:60-62; human_walker.py reports it as info['broke_sim']) -- is an env that EXPLODED in its terminal step
+    (a tumbling humanoid under full-scale random torques can do that within one env-step since the impulse pass runs on M, A3);
+    the digits of an explosion are not a trajectory: such envs are counted (`envs_broken_sim`), like NaN states, not averaged."""
+    qo, dqo = ref["q"][si], ref["dq"][si]
+    eq, edq = qg - qo, dqg - dqo
     bad = ~np.isfinite(eq).all(axis=1) | ~np.isfinite(edq).all(axis=1)
-    eq[bad] = 0.0; edq[bad] = 0.0      # NaN states (an exploded env) are counted, not averaged
+    broke = np.zeros(len(eq), dtype=bool)
+    if np.isfinite(smax):
+        with np.errstate(invalid="ignore"):
+            for a, b in ((qo, dqo), (qg, dqg)):
+                broke |= (np.abs(a[:, 2:]) >= smax).any(axis=1) | (np.abs(b) >= smax).any(axis=1)
+        broke &= ~bad
+    eq[bad | broke] = 0.0; edq[bad | broke] = 0.0      # exploded envs are counted, not averaged
     return {"q": float(np.sqrt(np.mean(eq ** 2))), "dq": float(np.sqrt(np.mean(edq ** 2))),
             "max_abs_q": float(np.abs(eq).max()), "max_abs_dq": float(np.abs(edq).max()),
-            "envs_beyond_1e-4": int((np.abs(eq).max(axis=1) > 1e-4).sum()), "envs_non_finite": int(bad.sum())}
+            "envs_beyond_1e-4": int((np.abs(eq).max(axis=1) > 1e-4).sum()), "envs_non_finite": int(bad.sum()),
+            "envs_broken_sim": int(broke.sum())}
 
 
 def summarize(per_snap, snaps, mism, ne, steps, ref, seconds):
@@ -61,7 +73,7 @@ def run_host_api(stepper, acts, ref):
         mism += int((dg.astype(np.uint8) != ref["done"][t]).sum())
         if si < len(snaps) and snaps[si] == t + 1:
             qg, dqg = stepper.get_state()
-            per_snap[str(t + 1)] = snap_stats(qg, dqg, ref, si)
+            per_snap[str(t + 1)] = snap_stats(qg, dqg, ref, si, float(getattr(stepper.card, "state_abs_max", np.inf)))
             si += 1
         if ref["done"][t].any():
             stepper.reset(ref["done"][t], None, None, want_obs=False)
@@ -109,7 +121,7 @@ def parity_check(env_id, precision, ne, steps, local_rank, all_bodies_collide=No
             mism += (d_done != d_done_ref[t]).sum()
             if si < len(snaps) and snaps[si] == t + 1:
                 qg, dqg = gpu.get_state()
-                per_snap[str(t + 1)] = snap_stats(qg, dqg, ref, si)
+                per_snap[str(t + 1)] = snap_stats(qg, dqg, ref, si, float(card.state_abs_max))
                 si += 1
             gpu.reset_device(d_done_ref[t].data_ptr(), 0, ts)     # resets follow the oracle's episodes, identical Philox noise
     torch.cuda.synchronize()

@@ -23,3 +23,44 @@ def test_bench_runs_its_collective_path_over_rccl():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["config"]["env_offsets"] == [0] and d["value"] > 0
     assert "gather_ms" in d and "gather_note" not in d, d.get("gather_note")
+
+
+ROLLOUT_SCRIPT = """
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import dart_env_amd.vector as V
+from dart_env_amd.distributed import RolloutBuffer, ShardedDartVectorEnv
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+venv = ShardedDartVectorEnv("DartHopper-v1", 1024, seed=3)
+buf = RolloutBuffer(venv, 16)
+policy = lambda ob: torch.tanh(ob[:, :3] * 3.0 - ob[:, 5:8])
+buf.collect(policy)
+g = buf.gather(force_collective=True)          # the all_gather_into_tensor calls run over RCCL even with one rank
+torch.cuda.synchronize()
+ok = all(torch.equal(g[k][0], getattr(buf, k)) for k in ("obs", "actions", "rewards", "dones", "truncated"))
+ob, r, d, infos = venv.step(buf.actions[0].cpu().numpy())
+fo, fr, fd = venv.gather_rollout(ob, r, d)
+print(json.dumps({"ok": bool(ok), "shape": list(g["obs"].shape), "backend": dist.get_backend(), "dones": int(buf.dones.sum().item()),
+                  "gather_rollout_rows": int(fo.shape[0])}))
+venv.close()
+dist.destroy_process_group()
+"""
+
+
+def test_rollout_buffer_gather_runs_over_rccl():
+    """RolloutBuffer.gather() -- the north star's "RCCL ... only to gather rollouts" -- executed on the device through RCCL's
+    all_gather_into_tensor with the one rank a 1-GPU box has; the 2-rank arithmetic is covered over gloo (tests/test_distributed_gloo.py)."""
+    import tempfile
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(ROLLOUT_SCRIPT % ROOT)
+        path = f.name
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", path]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    os.unlink(path)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["backend"] == "nccl" and d["shape"] == [1, 17, 1024, 11] and d["dones"] > 0 and d["gather_rollout_rows"] == 1024

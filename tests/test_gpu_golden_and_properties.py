@@ -392,6 +392,49 @@ def test_rollout_buffer_device_resident_equals_host_stepping():
     venv.close(); ref.close()
 
 
+def test_rollout_buffer_and_episode_statistics_against_the_oracle():
+    """SURVEY 8(f)-4 against the ORACLE, not against the kernel itself: the device-resident RolloutBuffer (dart_step_device writing
+    slot t of HBM tensors, policy on the GPU) and the device episode accumulators (DART_CFG_EPISODE_STATS) reproduce what the same
+    deterministic policy gives on oracle worlds stepped through host arrays, with RecordEpisodeStatistics' bookkeeping
+    (reference gym/wrappers/record_episode_statistics.py:22-34: return += reward, length += 1, latched into info['episode']
+    {'r', 'l'} on done, then restarted) done in numpy on the oracle's rewards / done flags."""
+    import torch
+    from dart_env_amd.distributed import RolloutBuffer
+    from tests.fake_stepper import OracleStepper
+    n, T = 256, 40
+    policy = lambda ob: torch.tanh(ob[:, :3] * 3.0 - ob[:, 5:8])
+    venv = dart_env_amd.vector.make("DartHopper-v1", n, noise="philox", precision=64)
+    venv.seed(2)
+    venv.env._stepper.configure(st.CFG_EPISODE_STATS, 1)
+    buf = RolloutBuffer(venv, T)
+    assert buf.on_device
+    buf.collect(policy); torch.cuda.synchronize()
+    last_r, last_l, totals = venv.env._stepper.episode_stats()
+    oenv = dart_env_amd.vector.make("DartHopper-v1", n, noise="philox", precision=64, stepper_factory=OracleStepper)
+    oenv.seed(2)
+    obuf = RolloutBuffer(oenv, T)
+    assert not obuf.on_device
+    obuf.collect(policy)
+    g = {k: getattr(buf, k).cpu().numpy() for k in ("obs", "actions", "rewards", "dones", "truncated")}
+    o = {k: getattr(obuf, k).numpy() for k in ("obs", "actions", "rewards", "dones", "truncated")}
+    assert np.array_equal(g["dones"], o["dones"]) and np.array_equal(g["truncated"], o["truncated"])
+    assert np.abs(g["obs"] - o["obs"]).max() < 1e-4 and np.abs(g["actions"] - o["actions"]).max() < 1e-4
+    assert np.abs(g["rewards"] - o["rewards"]).max() < 1e-3
+    # RecordEpisodeStatistics on the oracle's trajectory
+    acc, cnt = np.zeros(n), np.zeros(n, dtype=np.int64)
+    ref_r, ref_l, fin, sum_r, sum_l = np.zeros(n), np.zeros(n, dtype=np.int64), 0, 0.0, 0
+    for t in range(T):
+        acc += o["rewards"][t]; cnt += 1
+        d = o["dones"][t].astype(bool)
+        ref_r[d] = acc[d]; ref_l[d] = cnt[d]
+        fin += int(d.sum()); sum_r += float(acc[d].sum()); sum_l += int(cnt[d].sum())
+        acc[d] = 0; cnt[d] = 0
+    assert fin > 50
+    assert np.array_equal(last_l, ref_l) and np.allclose(last_r, ref_r, rtol=1e-5, atol=1e-3)
+    assert totals[2] == fin and totals[1] == sum_l and totals[0] == pytest.approx(sum_r, rel=1e-5)
+    venv.close(); oenv.close()
+
+
 def test_vector_env_copy_false_returns_views_with_the_same_values():
     """copy=False (sync_vector_env.py:83 semantics): observations are views of the pinned staging buffer."""
     a = np.random.RandomState(1).uniform(-1, 1, (20, 256, 3)).astype(np.float32)
@@ -422,6 +465,11 @@ def test_other_configs_full_batch_determinism_and_batch_independence(env_id, n_f
     def run(n):
         card = card_for(env_id)
         s = st.HipStepper(card, n, precision=64)
+        if env_id == "DartReacher-v1":
+            # reset_model also draws the reach target (reacher2d.py:53-59): on the device that is the MT19937 bank's job, the
+            # in-kernel Philox reset would leave the target stale and the ABI refuses it (test_philox_autoreset_is_refused_...)
+            from dart_env_amd import seeding
+            s.seed_mt19937(*seeding.mt_keys(list(range(9, 9 + n))))
         s.configure(st.CFG_AUTORESET, 1); s.configure(st.CFG_SEED, 9)
         s.reset(None, None, None, want_obs=False)
         rng = np.random.RandomState(1)
@@ -440,7 +488,29 @@ def test_other_configs_full_batch_determinism_and_batch_independence(env_id, n_f
     o3, q3, dq3, el3, ep3 = run(1000)                    # ragged: not a multiple of 64
     assert np.array_equal(q1[:1000], q3) and np.array_equal(dq1[:1000], dq3) and np.array_equal(ep1[:1000], ep3)
     assert np.isfinite(q1).all() and np.isfinite(dq1).all()
-    assert ep1.min() >= 1 and (ep1.max() > 1 or env_id in ("DartHumanWalker-v1", "DartHalfCheetah-v1", "DartSnake7Link-v1"))
+    # (the episode counter keys the Philox reset streams; MT19937-bank resets -- the reacher here -- do not advance it)
+    assert env_id == "DartReacher-v1" or (ep1.min() >= 1 and (ep1.max() > 1 or env_id in ("DartHumanWalker-v1", "DartHalfCheetah-v1", "DartSnake7Link-v1")))
+    if env_id == "DartReacher-v1":
+        assert sum(int(o[3].sum()) for o in o1) >= n_full          # every env ran into its 50-step TimeLimit
+
+
+@pytest.mark.parametrize("env_id", ["DartReacher-v1", "DartReacher3d-v1", "DartCartPoleSwingUp-v1"])
+def test_philox_autoreset_is_refused_where_reset_model_draws_more_than_noise(env_id):
+    """reacher2d.py:47-60 / reacher.py:44-54 resample the reach target and cartpole_swingup.py:38-46 draws the +-pi offset in
+    reset_model: the in-kernel Philox auto-reset re-noises q / dq only, so stepping with it would run degenerate episodes.  The
+    ABI says so (DART_E_UNSUPPORTED) instead of doing it; with the MT19937 bank seeded the same call works."""
+    from dart_env_amd import seeding
+    card = card_for(env_id)
+    s = st.HipStepper(card, 64, precision=64)
+    s.configure(st.CFG_AUTORESET, 1)
+    a = np.zeros((64, card.act_dim), dtype=np.float32)
+    with pytest.raises(st.StepperError) as e:
+        s.step(a)
+    assert e.value.code == st.E_UNSUPPORTED and "MT19937" in str(e.value)
+    s.seed_mt19937(*seeding.mt_keys(list(range(64))))
+    s.reset(None, None, None, want_obs=False)
+    s.step(a)
+    s.close()
 
 
 def test_walker2d_full_batch_outputs_are_consistent():
@@ -486,10 +556,14 @@ def test_humanwalker_full_batch_outputs_are_consistent():
         a = rng.uniform(-1, 1, (n, 23)).astype(np.float32)
         ob, r, done, trunc = s.step(a)
         q, dq = s.get_state()
-        assert ob.shape == (n, 59) and np.isfinite(ob).all()
-        assert np.allclose(ob[:, :28], q[:, 1:], atol=1e-5) and np.allclose(ob[:, 28:57], np.clip(dq, -10, 10), atol=1e-4)
+        # a tumbling humanoid under full-scale random torques can explode inside one env-step (impulses act on M alone, A3): such
+        # an env must report done (human_walker.py:121-125: the state test is part of it), like the reference would
+        fin = np.isfinite(ob).all(axis=1) & np.isfinite(q).all(axis=1) & np.isfinite(dq).all(axis=1)
+        assert ob.shape == (n, 59) and done[~fin].all() and (~fin).sum() < 0.01 * n
+        assert np.allclose(ob[fin, :28], q[fin, 1:], atol=1e-5) and np.allclose(ob[fin, 28:57], np.clip(dq[fin], -10, 10), atol=1e-4)
         assert np.isin(ob[:, 57:], (0.0, 1.0)).all()
         assert np.all(r[done] == 0.0) and np.all(np.abs(r[~done]) < 100.0)
+        ob = np.where(np.isfinite(ob), ob, 0.0)
         touched += int(ob[:, 57:].sum()); n_done += int(done.sum())
         if done.any():
             s.reset(done.astype(np.uint8), None, None, want_obs=False)

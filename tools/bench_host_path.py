@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the host-buffer boundary (dart_step with numpy arrays, as the gym.vector surface uses it).
 Not the headline number (bench.py's `value` is HBM-resident by contract); recorded in DESIGN.md."""
-import os, sys, time
+import os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1 and sys.argv[1] == "ab":
+    # A/B of the host path in two fresh processes on the same box: round 2's (four D2H copies per step, fresh output arrays every
+    # step) against the current one (one packed D2H, output arrays reused once the caller has dropped them)
+    for tag, env in (("legacy (DART_SPLIT_D2H=1 DART_NO_OUT_POOL=1)", {"DART_SPLIT_D2H": "1", "DART_NO_OUT_POOL": "1"}), ("current", {})):
+        print("==", tag, flush=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[2:], env=dict(os.environ, **env), check=True)
+    sys.exit(0)
 import numpy as np
 import dart_env_amd
 from dart_env_amd import stepper as st

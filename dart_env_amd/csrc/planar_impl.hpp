@@ -2,6 +2,9 @@
 // Included by planar_f32.hip / planar_f64.hip only (each instantiates the kernels for one precision).
 #pragma once
 #include <cmath>
+#ifndef DART_BPP_DEFAULT_ITERS
+#define DART_BPP_DEFAULT_ITERS 200   // iteration cap of the lane kernels' pivoting LCP solver (see PlanarImpl::set_solver)
+#endif
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -43,7 +46,11 @@ struct ImplT : Impl {
     return hipGetLastError();
   }
   void set_solver(int solver, int it1, int it2) override {   // 0 = default cap
-    P.solver = solver; P.iters1 = it1 > 0 ? it1 : 24; P.iters2 = it2 > 0 ? it2 : 24;
+    // default caps: pivoting 200 (the loop ends on the wave's vote, so the cap costs nothing until it is needed -- and it is: with the
+    // impulse pass on M (A3) 2 of 4 096 half-cheetah envs hit the old cap of 24 within 10 env-steps and left the oracle's
+    // trajectory by O(1); every one of them converges within 60), PGS 30 sweeps
+    const int dflt = solver == 0 ? DART_BPP_DEFAULT_ITERS : 30;
+    P.solver = solver; P.iters1 = it1 > 0 ? it1 : dflt; P.iters2 = it2 > 0 ? it2 : dflt;
   }
   void set_stats(unsigned long long* p) override { P.stats = p; }
   void set_force_slow(int on) override { P.force_slow = on; }
@@ -205,7 +212,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   for (int k = 0; k < NL; k++) { P.mass[k] = (Real)lm[k]; P.cx[k] = (Real)lcx[k]; P.cy[k] = (Real)lcy[k]; P.izz[k] = (Real)lizz[k]; }
   for (int d = 0; d < T::NDOF; d++) {
     if (d < 2 && (c.limited[d] || c.stiffness[d] != 0)) return "limits/springs on root translation";
-    if (d < 3 && (c.damping[d] != 0 || c.stiffness[d] != 0)) return "damping / springs on the floating root";   // (ImplicitDofs, fd_inverse_call)
+    if (d < 3 && (c.damping[d] != 0 || c.stiffness[d] != 0)) return "damping / springs on the floating root";   // (ImplicitDofs)
     P.damp[d] = (Real)c.damping[d]; P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
     P.stiff[d] = (Real)c.stiffness[d]; P.rest[d] = (Real)c.rest[d];
     P.sqe[d] = (Real)std::sqrt(c.dt * c.damping[d] + c.dt * c.dt * c.stiffness[d]);
@@ -254,7 +261,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task;
   P.penalty_link = c.penalty_dof >= 2 ? c.penalty_dof - 2 : -1;
   if (c.task != DART_TASK_NONE && c.height_body != 2) return "height body must be the root link";
-  P.solver = 0; P.iters1 = 24; P.iters2 = 24; P.stats = nullptr; P.force_slow = 0; P.ex = Extras<Real>();
+  P.solver = 0; P.iters1 = DART_BPP_DEFAULT_ITERS; P.iters2 = DART_BPP_DEFAULT_ITERS; P.stats = nullptr; P.force_slow = 0; P.ex = Extras<Real>();
   P.fluid_k = 0; P.dev_cost = 0;
   if (c.task == DART_TASK_SNAKE) {   // aux_real = {alive bonus, control cost, deviation cost, fluid coefficient} (model_card.py SNAKE)
     P.alive = (Real)c.aux_real[0]; P.ctrl_cost = (Real)c.aux_real[1]; P.dev_cost = (Real)c.aux_real[2]; P.fluid_k = (Real)c.aux_real[3];
@@ -308,7 +315,7 @@ struct CartImplT : Impl {
     hipLaunchKernelGGL((state_io_kernel<Real, 1 + NP>), grid, block, 0, s, n, (Real*)q, (Real*)dq, qh, dqh, to_device);
     return hipGetLastError();
   }
-  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : 24; }   // limits only: one exact (pivoting) stage
+  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : DART_BPP_DEFAULT_ITERS; }   // limits only: one exact (pivoting) stage
   void set_stats(unsigned long long*) override {}
   int slots() const override { return 1 + NP; }
 };
@@ -390,7 +397,7 @@ std::string fill_cart(const DartModelCard& c, CartParams<Real, NP>& P) {
   for (int k = 0; k < 8; k++) P.aux[k] = (Real)c.aux_real[k];
   if (c.task == DART_TASK_CARTPOLE) { P.aux[0] = (Real)c.alive_bonus; P.aux[1] = (Real)c.ctrl_cost; }
   P.angle_max = (Real)c.angle_max; P.s_max = (Real)c.state_abs_max; P.noise = (Real)c.reset_noise; P.noise_v = (Real)c.reset_noise_vel;
-  P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task; P.iters = 24;
+  P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task; P.iters = DART_BPP_DEFAULT_ITERS;
   return "";
 }
 
@@ -441,7 +448,7 @@ struct ArmImplT : Impl {
   void persistent(std::vector<std::pair<void*, size_t>>& v, int64_t n) override {
     if (d_tstate) v.push_back({d_tstate, sizeof(Real) * 4 * (size_t)n});      // the reach targets
   }
-  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : 24; }   // no contacts: one exact (pivoting) stage
+  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : DART_BPP_DEFAULT_ITERS; }   // no contacts: one exact (pivoting) stage
   void set_stats(unsigned long long*) override {}
   int slots() const override { return 2 * NP; }
 };
@@ -512,7 +519,7 @@ std::string fill_arm(const DartModelCard& c, ArmParams<Real, NP>& P) {
   }
   P.dt = (Real)c.dt; P.limit_erp_dt = (Real)(c.limit_erp / c.dt); P.max_erv = (Real)c.max_erv; P.cfm1 = (Real)(1.0 + c.cfm);
   P.noise = (Real)c.reset_noise; P.noise_v = (Real)c.reset_noise_vel;
-  P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task; P.iters = 24; P.tstate = nullptr;
+  P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task; P.iters = DART_BPP_DEFAULT_ITERS; P.tstate = nullptr;
   P.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
   return "";
 }
@@ -564,7 +571,7 @@ struct Chain3dImplT : Impl {
   void persistent(std::vector<std::pair<void*, size_t>>& v, int64_t n) override {
     if (d_tstate) v.push_back({d_tstate, sizeof(Real) * 4 * (size_t)n});      // the reach targets
   }
-  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : 24; }   // no contacts: one exact (pivoting) stage
+  void set_solver(int, int it1, int) override { P.iters = it1 > 0 ? it1 : DART_BPP_DEFAULT_ITERS; }   // no contacts: one exact (pivoting) stage
   void set_stats(unsigned long long*) override {}
   int slots() const override { return FRIC ? 2 * NL : NL; }
 };
@@ -606,7 +613,7 @@ std::unique_ptr<Impl> make_chain3d(const DartModelCard& c, std::string& why) {
   P.dt = M.dt; P.limit_erp_dt = M.limit_erp_dt; P.max_erv = M.max_erv; P.cfm1 = M.cfm1;
   P.ctrl_w = M.aux_real[3]; P.done_dist = M.aux_real[4];
   P.noise = M.noise; P.noise_v = M.noise_v;
-  P.frame_skip = M.frame_skip; P.max_steps = M.max_steps; P.task = M.task; P.iters = 24; P.tstate = nullptr;
+  P.frame_skip = M.frame_skip; P.max_steps = M.max_steps; P.task = M.task; P.iters = DART_BPP_DEFAULT_ITERS; P.tstate = nullptr;
   P.impulse_M = M.impulse_M;
   return p;
 }

@@ -425,35 +425,6 @@ __device__ __forceinline__ void implicit_accel(const PT& P, const Real (&Minv)[N
   }
 }
 
-// The inverse of the impulse inertia and the forward-dynamics acceleration as a REAL CALL on copies (runtime-parameter kernels):
-// those kernels live at the edge of the register file (256 VGPR + 256 AGPR + KBs of scratch), where inlining another 45-entry
-// matrix phase into the step kernel has twice produced builds whose states differ from the host build of the same source on
-// gfx950 / ROCm 7.2 (round 2: the big contact tiers; round 3: this phase in the half-cheetah kernel, 5e-4 after 10 env-steps while
-// the host build stays at 1e-15).  As a call the phase gets a register allocation of its own.  io.H: M (or M + E with the A3 knob
-// at 0) in, its inverse out; io.acc: rhs in, qdd out; io.sqe: sqrt(E) per dof.
-template <class Real, int N>
-struct FdIO { Real H[N * (N + 1) / 2], acc[N], sqe[N]; };
-template <int N> struct JointDofs {
-  static constexpr int count = N - 3;
-  __device__ __host__ static constexpr int dof(int a) { return 3 + a; }
-};
-template <class Real, int N, bool REV>
-__device__ __attribute__((noinline)) void fd_inverse_call(FdIO<Real, N>& io, int impulse_M) {
-  Real H[N * (N + 1) / 2], rhs[N], acc[N];
-  sfor<0, N*(N + 1) / 2>([&](auto I) { H[I] = io.H[I]; });
-  sfor<0, N>([&](auto I) { rhs[I] = io.acc[I]; });
-  spd_inverse<Real, N>(H);
-  sfor<0, N>([&](auto I) {
-    constexpr int i = I, ii = REV ? N - 1 - i : i;
-    Real a = Real(0);
-    sfor<0, N>([&](auto J) { constexpr int j = J, jj = REV ? N - 1 - j : j; a += H[tri(ii, jj)] * rhs[j]; });
-    acc[i] = a;
-  });
-  if (impulse_M) implicit_accel<Real, N, REV, JointDofs<N>>(io, H, acc);   // (io.sqe plays the parameter block's part)
-  sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = H[I]; });
-  sfor<0, N>([&](auto I) { io.acc[I] = acc[I]; });
-}
-
 // Solve the masked symmetric system for the free set of a boxed LCP iteration.
 //   free[i] in {0,1};  row i not free:  x_i = rhs_i ;  free rows:  sum_j A_ij x_j = rhs_i over free j
 template <class Real, int M>
@@ -1260,14 +1231,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   constexpr bool REV = true;
 #endif
   Real vs[N];
-  if constexpr (!PT::is_static) {   // runtime-parameter kernels: the phase is a real call (fd_inverse_call)
-    FdIO<Real, N> io;
-    sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = H[I]; });
-    sfor<0, N>([&](auto I) { io.acc[I] = rhs[I]; io.sqe[I] = P.sqe[I]; });
-    fd_inverse_call<Real, N, REV>(io, P.impulse_M);
-    sfor<0, N*(N + 1) / 2>([&](auto I) { H[I] = io.H[I]; });   // the inverse of the impulse inertia (reversed dof order)
-    sfor<0, N>([&](auto I) { constexpr int i = I; vs[i] = dq[i] + P.dt * io.acc[i]; });
-  } else {
+  {
     spd_inverse<Real, N>(H);  // H now holds the inverse of the impulse inertia (reversed dof order)
     Real acc[N];
     sfor<0, N>([&](auto I) {

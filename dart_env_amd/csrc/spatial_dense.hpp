@@ -28,8 +28,11 @@ template <> __device__ __forceinline__ double readlane_<double>(double x, int l)
 // W != nullptr: the forward substitution W_i <- L^-1 W_i of rows 0..m of W (lane per row, stride n) follows while the factor
 // is still in registers: L_kj reaches the row's lane through v_readlane from lane k, so the 220-400 factor entries a row needs
 // cost no LDS access at all (first version: ~110 128-bit LDS loads per row, the phase was LDS-latency bound at 2 waves / SIMD).
+// xvec != nullptr: ONE right-hand side, entry k held by lane k (storage order), is forward-substituted column by column while the
+// factor is in registers -- lane j > k holds L_jk in its own row, x_k arrives through v_readlane: 3 wave instructions per column
+// instead of a row's ~400 multiply-adds (the forward dynamics' solve, sp_world_step pass 0).
 template <class Real, int NP, class PAT = DensePattern>
-__device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1) {
+__device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1, Real* xvec = nullptr) {
   const int r = lane < NP ? lane : 0;   // spare lanes shadow lane 0 (convergent code, results discarded)
   const int rb = HR(r);
   Real row[NP];
@@ -50,6 +53,17 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
   if (lane < n) {
 #pragma unroll
     for (int k = 0; k < NP; k++) if (k <= lane) M[rb + k] = row[k];
+  }
+  if (xvec != nullptr) {   // wave-uniform
+    Real yv = (lane < n) ? xvec[lane] : Real(0);
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      if (k < n) {
+        const Real xk = readlane_<Real>(yv * sown, k);   // x_k = y_k / L_kk, final once columns 0..k-1 have been applied
+        yv = (lane == k) ? xk : ((lane > k && lane < NP) ? yv - row[k] * xk : yv);
+      }
+    }
+    if (lane < n) xvec[lane] = yv;
   }
   if (W != nullptr) {   // wave-uniform
     const bool has = lane <= m;
@@ -75,13 +89,13 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
 }
 // one straight-line variant per padded size (only the one a model uses ever enters the instruction cache)
 template <class Real, class PAT = DensePattern>
-__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1) {
-  if constexpr (!PAT::dense) { sp_cholesky_t<Real, sp_npad(PAT::n), PAT>(M, sinv, n, lane, W, m); return; }
+__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1, Real* xvec = nullptr) {
+  if constexpr (!PAT::dense) { sp_cholesky_t<Real, sp_npad(PAT::n), PAT>(M, sinv, n, lane, W, m, xvec); return; }
   const int np = sp_npad(n);
-  if (np <= 8) sp_cholesky_t<Real, 8>(M, sinv, n, lane, W, m);
-  else if (np <= 16) sp_cholesky_t<Real, 16>(M, sinv, n, lane, W, m);
-  else if (np <= 24) sp_cholesky_t<Real, 24>(M, sinv, n, lane, W, m);
-  else sp_cholesky_t<Real, 32>(M, sinv, n, lane, W, m);
+  if (np <= 8) sp_cholesky_t<Real, 8>(M, sinv, n, lane, W, m, xvec);
+  else if (np <= 16) sp_cholesky_t<Real, 16>(M, sinv, n, lane, W, m, xvec);
+  else if (np <= 24) sp_cholesky_t<Real, 24>(M, sinv, n, lane, W, m, xvec);
+  else sp_cholesky_t<Real, 32>(M, sinv, n, lane, W, m, xvec);
 }
 // x <- L^-T x (backward) for one vector in LDS, column-oriented, lanes own entries
 template <class Real>

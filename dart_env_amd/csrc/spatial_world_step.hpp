@@ -26,6 +26,16 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
                                               int* contact_flags, bool report = false) {
   const int n = Md.n, nl = Md.nl;
   unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
+  {
+    // A world that has left the representable regime is frozen: a coordinate or velocity beyond 1e6 (or not finite) cannot come
+    // back under the tasks' validity bound |s| < 100 within an env-step (hopper.py:60-62 and every other task's done condition:
+    // the env reports done either way), but its LCPs -- rows with 1e10-sized right-hand sides -- would run the pivoting solver
+    // into its cap and the PGS safety net in every remaining world step: milliseconds for one wave that the whole launch then
+    // waits for (HumanWalker at 16 384 envs: 5 such envs in 25 launches took the average from 6.4 to 8.3 ms).  The oracle
+    // freezes the same way (oracle_step).
+    const bool gone = lane < n && !(fabs(S.q[lane]) < Real(1e6) && fabs(S.dq[lane]) < Real(1e6));
+    if (__any(gone)) return;   // wave-uniform: this wavefront owns the env
+  }
   if (EXTRAS && Md.free_root) {
     if (lane == 0) sp_free_root_to_internal<Real>(S);
     __syncthreads();
@@ -184,8 +194,9 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     // ---- Two passes through ONE copy of the factorisation + forward-substitution code (a second inlined copy thrashed the
     // instruction cache: HumanWalker 5.0 -> 8.0 ms instead of the ~6.3 the extra arithmetic is worth):
     //   pass 0  forward dynamics: M + E (E = dt D + dt^2 K, the implicit damping / spring terms) is factored in the still idle
-    //           Jacobian block, the right-hand side rides through the substitution as the only row -> qdd; S.dq becomes the
-    //           unconstrained velocity v* = dq + dt qdd, which is all the constraint phase needs.
+    //           Jacobian block, the right-hand side (one entry per lane) is substituted column by column while the factor is in
+    //           registers (sp_cholesky_t, xvec) -> qdd; S.dq becomes the unconstrained velocity v* = dq + dt qdd, which is all
+    //           the constraint phase needs.
     //   pass 1  impulse inertia: Jacobian rows (lane per row; b = bounce - J v*), S.H is factored -- M alone under DART 6's rule
     //           (A3, card.impulse_inertia = 1), M + E with the knob at 0 -- and W = L^-1 J^T.
     // columns of W follow the factor's storage order: dof d sits in column n-1-d
@@ -249,12 +260,12 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         // Pattern kernels (HumanWalker): the substitution follows while the factor is still in registers -- L_kj reaches a
         // row's lane through v_readlane (sp_cholesky_t).  Measured 6.36 -> 6.19 ms; the dense kernels got slower with it
         // (Walker3d +4 %) and keep the LDS reads.
-        sp_cholesky<Real, PAT>(Hm, sv, n, lane, Wr, nrows - 1);
+        sp_cholesky<Real, PAT>(Hm, sv, n, lane, pass ? Wr : nullptr, nrows - 1, pass ? nullptr : xq);
       } else {
-        sp_cholesky<Real, PAT>(Hm, sv, n, lane);
+        sp_cholesky<Real, PAT>(Hm, sv, n, lane, nullptr, -1, pass ? nullptr : xq);
         // The row lives in registers and both loops are fully unrolled (SP_MAXN x SP_MAXN / 2 predicated steps, uniform
         // `k < n` branches): every factor entry is one LDS read at an immediate offset, no index arithmetic.
-        if (lane < nrows) {
+        if (pass == 1 && lane < nrows) {
           Real* yrow = Wr + lane * n;
           Real y[SP_MAXN];
   #pragma unroll

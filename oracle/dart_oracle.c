@@ -814,6 +814,11 @@ int oracle_step(OracleWorld* w) {
   const DartModelCard* c = &w->card;
   int n = w->n;
   double dt = c->dt;
+  /* a world that has left the representable regime (a coordinate or velocity beyond 1e6, or not finite) is frozen: it cannot come
+   * back under the tasks' validity bound |s| < 100 within an env-step, the env reports done either way (hopper.py:60-62), and the
+   * tree kernel skips such worlds because their LCPs would stall a whole launch (csrc/spatial_world_step.hpp) */
+  for (int i = 0; i < n; i++)
+    if (!(fabs(w->q[i]) < 1e6 && fabs(w->dq[i]) < 1e6)) { w->time += dt; return 0; }
   kinematics(w);
   crba(w, w->M);
   rnea(w, w->dqi, NULL, 1, w->C);

@@ -4,7 +4,7 @@
 The physics of `World.step()` is pinned by nothing from DART (no pydart2 anywhere), so every assumption the restatement makes is
 a knob.  This script flips one knob at a time on the fp64 oracle and reports the RMS difference of q and dq against the default
 setting after 1, 10 and 100 env-steps, over the envs that are still inside their first episode in BOTH runs (same reset noise,
-same actions; small actions 0.1 U[-1,1) keep the episodes long enough to reach 100 steps).  A future capture from real DART
+same actions; small actions 0.05 U[-1,1) keep the episodes long enough to reach 100 steps).  A future capture from real DART
 (tools/capture_dart_golden.py) that disagrees with the oracle should be compared with these signatures first.
 
   A1  body inertia from the first shape: ignoring the shape's local transform (default) vs honouring it   (model compiler)
@@ -28,7 +28,7 @@ from tests.oracle_lib import OracleWorld  # noqa: E402
 
 REF = os.environ.get("DART_REFERENCE", "/root/reference")
 ASSETS = {"DartHopper-v1": "hopper_capsule.skel", "DartWalker2d-v1": "walker2d.skel", "DartHumanWalker-v1": "kima/kima_human_edited.skel"}
-SNAPS = (1, 10, 100)
+SNAPS = (1, 10, 30, 100)
 
 
 def card_a1(env_id):
@@ -84,9 +84,9 @@ def main():
         ne = n if env_id != "DartHumanWalker-v1" else max(8, n // 4)
         qn = rng.uniform(-1, 1, (ne, base.ndofs)) * base.reset_noise
         vn = rng.uniform(-1, 1, (ne, base.ndofs)) * base.reset_noise_vel
-        acts = (0.1 * rng.uniform(-1, 1, (max(SNAPS), ne, base.act_dim))).astype(np.float32)
+        acts = (0.05 * rng.uniform(-1, 1, (max(SNAPS), ne, base.act_dim))).astype(np.float32)
         q0, d0 = run(base, {}, ne, qn, vn, acts)
-        print("%s  (%d envs, actions 0.1 U[-1,1), RMS over the envs alive in both runs)" % (env_id, ne))
+        print("%s  (%d envs, actions 0.05 U[-1,1), RMS over the envs alive in both runs)" % (env_id, ne))
         print("| knob flipped | " + " | ".join("step %d: RMS dq (q) / RMS d(dq) [alive]" % s for s in SNAPS) + " |")
         print("|---|" + "---|" * len(SNAPS))
         for name, card, assume in vs[1:]:

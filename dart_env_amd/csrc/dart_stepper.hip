@@ -58,7 +58,8 @@ struct DartStepper {
   int noise_mode = 0;            // 0: Philox / host-supplied noise, 1: device MT19937 bank (reference-exact)
   // obs | reward | done | truncated of a step are ONE device block and ONE pinned host block (d_obs / h_obs are their bases):
   // dart_step_async brings a step's outputs to the host with a single D2H copy instead of four
-  size_t out_bytes = 0;
+  size_t out_bytes = 0, out_off[4] = {0, 0, 0, 0};   // offsets of obs / reward / done / truncated inside the block
+  std::vector<void*> registered;   // caller-owned output blocks page-locked by dart_register_output
   bool split_d2h = false;        // DART_SPLIT_D2H=1: the four separate copies of rounds 1-2 (A/B measurements)
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
@@ -159,6 +160,7 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
       unsigned char* blk = nullptr;
       CHK(h, hipMalloc((void**)&blk, h->out_bytes));
       h->d_obs = (float*)blk; h->d_rew = (float*)(blk + ob); h->d_done = blk + ob + rb; h->d_trunc = blk + ob + rb + db;
+      h->out_off[0] = 0; h->out_off[1] = ob; h->out_off[2] = ob + rb; h->out_off[3] = ob + rb + db;
       unsigned char* hb = nullptr;
       CHK(h, hipHostMalloc((void**)&hb, h->out_bytes));
       h->h_obs = (float*)hb; h->h_rew = (float*)(hb + ob); h->h_done = hb + ob + rb; h->h_trunc = hb + ob + rb + db;
@@ -193,6 +195,8 @@ int dart_destroy(DartStepper* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->impl) h->impl->release();
+  for (void* p : h->registered) (void)hipHostUnregister(p);
+  h->registered.clear();
   void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs /* base of the output block */, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn.dev, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs /* base of the pinned output block */, h->h_mask, h->h_qn, h->h_vn};
@@ -443,7 +447,45 @@ static int state_copy(DartStepper* h, double* q, double* dq, int to_device) {
 int dart_set_state(DartStepper* h, const double* q, const double* dq) { return state_copy(h, (double*)q, (double*)dq, 1); }
 int dart_get_state(DartStepper* h, double* q, double* dq) { return state_copy(h, q, dq, 0); }
 
-int dart_step_async(DartStepper* h, const float* actions) {
+static int step_async_impl(DartStepper* h, const float* actions, void* dst);
+int dart_step_async(DartStepper* h, const float* actions) { return step_async_impl(h, actions, nullptr); }
+
+int dart_output_layout(const DartStepper* h, int64_t* total_bytes, int64_t* offsets4) {
+  if (!h) return DART_E_INVALID;
+  if (total_bytes) *total_bytes = (int64_t)h->out_bytes;
+  if (offsets4) for (int k = 0; k < 4; k++) offsets4[k] = (int64_t)h->out_off[k];
+  return DART_OK;
+}
+int dart_register_output(DartStepper* h, void* block) {
+  if (!h || !block) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  for (void* p : h->registered) if (p == block) return DART_OK;
+  CHK(h, hipHostRegister(block, h->out_bytes, hipHostRegisterDefault));
+  h->registered.push_back(block);
+  return DART_OK;
+}
+int dart_unregister_output(DartStepper* h, void* block) {
+  if (!h || !block) return DART_E_INVALID;
+  if (h->pending) { h->err = "dart_unregister_output while a step is pending"; return DART_E_PENDING; }
+  for (size_t i = 0; i < h->registered.size(); i++)
+    if (h->registered[i] == block) {
+      CHK(h, hipSetDevice(h->device));
+      CHK(h, hipHostUnregister(block));
+      h->registered.erase(h->registered.begin() + i);
+      return DART_OK;
+    }
+  h->err = "dart_unregister_output: not a registered block";
+  return DART_E_INVALID;
+}
+int dart_step_async_to(DartStepper* h, const float* actions, void* block) {
+  if (!h || !block) return DART_E_INVALID;
+  bool known = false;
+  for (void* p : h->registered) known = known || p == block;
+  if (!known) { h->err = "dart_step_async_to: the block is not registered (dart_register_output)"; return DART_E_INVALID; }
+  return step_async_impl(h, actions, block);
+}
+
+static int step_async_impl(DartStepper* h, const float* actions, void* dst) {
   if (!h || !actions) return DART_E_INVALID;
   if (h->pending) { h->err = "step_async called while a step is pending"; return DART_E_PENDING; }
   CHK_AUTORESET(h);
@@ -461,7 +503,9 @@ int dart_step_async(DartStepper* h, const float* actions) {
     CHK(h, h->impl->reset(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_done, h->d_qn, h->d_vn, h->d_obs, h->seed,
                           h->env_offset, 1));
   }
-  if (!h->split_d2h) {
+  if (dst) {   // straight into the caller's page-locked block: no staging copy afterwards (dart_step_wait only synchronises)
+    CHK(h, hipMemcpyAsync(dst, h->d_obs, h->out_bytes, hipMemcpyDeviceToHost, h->stream));
+  } else if (!h->split_d2h) {
     CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, h->out_bytes, hipMemcpyDeviceToHost, h->stream));   // obs | reward | done | truncated
   } else {
     CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));

@@ -238,8 +238,11 @@ class BatchedDartEnv:
         """-> obs (N,obs) f32, reward (N,) f64, done (N,) bool, truncated (N,) bool   (no auto-reset)"""
         return self._stepper.step(actions)
 
-    def step_async(self, actions):
-        self._stepper.step_async(actions)
+    def step_async(self, actions, staged=False):
+        if staged:
+            self._stepper.step_async(actions, staged=True)
+        else:
+            self._stepper.step_async(actions)
 
     def step_wait(self, copy=True):
         return self._stepper.step_wait() if copy else self._stepper.step_wait(copy=False)

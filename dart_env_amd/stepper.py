@@ -30,6 +30,7 @@ EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
     "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses", "dart_snapshot", "dart_restore", "dart_timer_mark", "dart_timer_elapsed",
+    "dart_output_layout", "dart_register_output", "dart_unregister_output", "dart_step_async_to",
 ]
 
 
@@ -93,6 +94,10 @@ def load_library(path: Optional[str] = None):
     L.dart_get_body_poses.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dart_set_ext_force.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.dart_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
+    L.dart_output_layout.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.dart_register_output.argtypes = [vp, C.c_void_p]
+    L.dart_unregister_output.argtypes = [vp, C.c_void_p]
+    L.dart_step_async_to.argtypes = [vp, C.POINTER(C.c_float), C.c_void_p]
     L.dart_host_views.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
                                   C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint8))]
     L.dart_get_episode_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]
@@ -262,33 +267,66 @@ class HipStepper:
     # -- stepping (host buffers) --
     _POOL_SETS = 4
 
-    def _outs(self):
-        """Output arrays of one step.  A fresh np.empty of a few MB is an anonymous mmap that page-faults on first touch
-        (~100-200 us per step at 65 536 envs), so sets the caller has dropped are reused: a pooled set is taken only when
-        nothing but the pool references its arrays (sys.getrefcount), i.e. the caller still owns every array it kept --
-        the copy=True contract of gym.vector (sync_vector_env.py:83)."""
+    # ---- output blocks: one page-locked, caller-visible buffer per step in flight (include/dart_stepper.h, dart_step_async_to) ----
+    def _layout(self):
+        if getattr(self, "_out_layout", None) is None:
+            tot = C.c_int64(0); off = (C.c_int64 * 4)()
+            self._check(self.L.dart_output_layout(self.h, C.byref(tot), off))
+            self._out_layout = (int(tot.value), [int(x) for x in off])
+        return self._out_layout
+
+    def _free_block(self):
+        """A registered output block nobody else references, or a new one (None when the pool is exhausted or pooling is off).
+        Layout of a block: [obs | reward f32 | done | truncated] exactly as the device block, then (N) float64 rewards -- the type
+        gym.vector returns -- filled on the host.  The arrays a step returns are views of the block, so `sys.getrefcount(block)`
+        tells whether the caller still holds any of them: a block is reused only when it does not (copy=True semantics of
+        sync_vector_env.py:83 without a copy, and without the page faults of fresh multi-MB arrays)."""
+        if os.environ.get("DART_NO_OUT_POOL") == "1":      # (A/B switch of tools/bench_host_path.py: round 2's staging path)
+            return None
+        pool = self.__dict__.setdefault("_blocks", [])
+        for ent in pool:
+            if all(sys.getrefcount(b) == 3 for b in ent):      # tuple + loop variable + the call's argument
+                return ent[0]
+        if len(pool) >= self._POOL_SETS:
+            return None
+        total, _ = self._layout()
+        blk = np.empty(total + 8 * self.num_envs, dtype=np.uint8)
+        rc = self.L.dart_register_output(self.h, blk.ctypes.data_as(C.c_void_p))
+        if rc != DART_OK:
+            return None
+        pool.append((blk,))
+        return blk
+
+    def _block_views(self, blk):
         n = self.num_envs
-        pool = self.__dict__.setdefault("_out_pool", [])
-        if os.environ.get("DART_NO_OUT_POOL") != "1":     # (A/B switch of tools/bench_host_path.py)
-            for arrs in pool:
-                if all(sys.getrefcount(a) == 3 for a in arrs):      # tuple + loop variable + the call's argument
-                    return arrs
-        arrs = (np.empty((n, self.obs_dim), dtype=np.float32), np.empty(n, dtype=np.float64),
+        total, off = self._layout()
+        obs = blk[off[0]:off[0] + 4 * n * self.obs_dim].view(np.float32).reshape(n, self.obs_dim)
+        r32 = blk[off[1]:off[1] + 4 * n].view(np.float32)
+        done = blk[off[2]:off[2] + n].view(np.bool_)        # the kernels write exactly 0 / 1
+        trunc = blk[off[3]:off[3] + n].view(np.bool_)
+        rew = blk[total:total + 8 * n].view(np.float64)
+        np.copyto(rew, r32)
+        return obs, rew, done, trunc
+
+    def _outs(self):
+        """Fresh output arrays (the staging path: library pinned buffer -> these)."""
+        n = self.num_envs
+        return (np.empty((n, self.obs_dim), dtype=np.float32), np.empty(n, dtype=np.float64),
                 np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8))
-        if len(pool) < self._POOL_SETS:
-            pool.append(arrs)
-        return arrs
 
     def step(self, actions):
-        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim)
-        obs, rew, done, trunc = self._outs()
-        self._check(self.L.dart_step(self.h, _ptr(a, C.c_float), _ptr(obs, C.c_float), _ptr(rew, C.c_double),
-                                     _ptr(done, C.c_uint8), _ptr(trunc, C.c_uint8)))
-        return obs, rew, done.view(np.bool_), trunc.view(np.bool_)     # the kernels write exactly 0 / 1
+        self.step_async(actions)
+        return self.step_wait()
 
-    def step_async(self, actions):
+    def step_async(self, actions, staged=False):
+        """staged=True: the outputs go through the library's own pinned staging buffer (what step_wait(copy=False) returns views of)"""
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim)
-        self._check(self.L.dart_step_async(self.h, _ptr(a, C.c_float)))
+        blk = None if staged else self._free_block()
+        if blk is None:
+            self._check(self.L.dart_step_async(self.h, _ptr(a, C.c_float)))
+        else:
+            self._check(self.L.dart_step_async_to(self.h, _ptr(a, C.c_float), blk.ctypes.data_as(C.c_void_p)))
+        self._pending_block = blk
 
     def _views(self):
         if getattr(self, "_host_views", None) is None:
@@ -301,7 +339,12 @@ class HipStepper:
         return self._host_views
 
     def step_wait(self, copy=True):
-        """copy=False: the observation is a view of the library's pinned staging buffer (valid until the next call)."""
+        """copy=True: arrays the caller owns (views of a page-locked block of this step; see _free_block).  copy=False: views of the
+        library's staging buffer, valid until the next call (only when the step went through it)."""
+        blk, self._pending_block = getattr(self, "_pending_block", None), None
+        if blk is not None:
+            self._check(self.L.dart_step_wait(self.h, None, None, None, None))
+            return self._block_views(blk)
         if not copy:
             self._check(self.L.dart_step_wait(self.h, None, None, None, None))
             o, r, d, t = self._views()

@@ -91,7 +91,12 @@ class DartVectorEnv:
         if self._pending:
             raise AlreadyPendingCallError(_st.E_PENDING, "Calling `step_async` while waiting for a pending call to `step` to complete.")
         a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.env.act_dim)
-        self.env.step_async(a)
+        # copy=False hands out views of the library's one staging buffer; copy=True gets a page-locked block of its own per step
+        zero_copy = not self.copy and self.env.device_noise and hasattr(self.env._stepper, "_views")
+        if zero_copy:
+            self.env.step_async(a, staged=True)
+        else:
+            self.env.step_async(a)
         self._pending = True
 
     def step_wait(self):

@@ -145,6 +145,19 @@ int dart_debug_dump(DartStepper* h, double* out160);
  * reference gym/vector/sync_vector_env.py:83). */
 int dart_host_views(DartStepper* h, const float** obs, const float** reward_f32, const uint8_t** done, const uint8_t** truncated);
 
+/* The outputs of a step as ONE caller-owned block -- the zero-staging form of the host-buffer path ("copied back once per
+ * batched step", reference gym/vector/vector_env.py:68-92): dart_output_layout gives the block's size and the byte offsets of
+ * obs (N, obs_dim) f32 / reward (N) f32 / done (N) u8 / truncated (N) u8 inside it; dart_register_output page-locks a caller
+ * buffer of that size (hipHostRegister; the caller keeps it alive until dart_unregister_output or dart_destroy);
+ * dart_step_async_to enqueues H2D actions, kernel, auto-reset and a SINGLE D2H copy straight into the block;
+ * dart_step_wait(h, NULL, NULL, NULL, NULL) then only synchronises.  A step's results stay valid for as long as the caller does
+ * not hand the same block to another step: dart_env_amd/stepper.py rotates a small pool of blocks and reuses one only when the
+ * caller holds no array of it any more, which keeps gym.vector's copy=True contract without a copy. */
+int dart_output_layout(const DartStepper* h, int64_t* total_bytes, int64_t* offsets4);
+int dart_register_output(DartStepper* h, void* block);
+int dart_unregister_output(DartStepper* h, void* block);
+int dart_step_async_to(DartStepper* h, const float* actions, void* block);
+
 /* Per-env task state that reset_model draws besides (q, dq): the reach target of DartReacher-v1 / DartReacher3d-v1
  * (reference gym/envs/dart/reacher2d.py:53-59, reacher.py:50-55).  values = (N, 4) doubles, slots 0..2 = target x, y, z;
  * mask as in dart_reset.  Call it before dart_reset so that the reset observation sees the new target. */

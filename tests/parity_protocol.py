@@ -42,8 +42,11 @@ def snap_stats(qg, dqg, ref, si, smax=np.inf):
             for a, b in ((qo, dqo), (qg, dqg)):
                 broke |= (np.abs(a[:, 2:]) >= smax).any(axis=1) | (np.abs(b) >= smax).any(axis=1)
         broke &= ~bad
-    eq[bad | broke] = 0.0; edq[bad | broke] = 0.0      # exploded envs are counted, not averaged
+    eq[bad] = 0.0; edq[bad] = 0.0
+    incl = (float(np.sqrt(np.mean(eq ** 2))), float(np.sqrt(np.mean(edq ** 2))))    # with the broken-sim envs averaged in
+    eq[broke] = 0.0; edq[broke] = 0.0                 # exploded envs are counted, not averaged
     return {"q": float(np.sqrt(np.mean(eq ** 2))), "dq": float(np.sqrt(np.mean(edq ** 2))),
+            "q_incl_broken_sim": incl[0], "dq_incl_broken_sim": incl[1],
             "max_abs_q": float(np.abs(eq).max()), "max_abs_dq": float(np.abs(edq).max()),
             "envs_beyond_1e-4": int((np.abs(eq).max(axis=1) > 1e-4).sum()), "envs_non_finite": int(bad.sum()),
             "envs_broken_sim": int(broke.sum())}

@@ -435,20 +435,57 @@ def test_rollout_buffer_and_episode_statistics_against_the_oracle():
     venv.close(); oenv.close()
 
 
+def test_step_outputs_in_registered_blocks_keep_copy_semantics(monkeypatch):
+    """dart_step_async_to: a step's outputs land in a page-locked block the caller sees directly (no staging memcpy).  The arrays a
+    step returned must stay intact while the caller holds them, however many steps follow (gym.vector's copy=True,
+    sync_vector_env.py:83), blocks must be reused once dropped, and the values must be those of the staging path bit for bit."""
+    card = card_for("DartHopper-v1")
+    n = 512
+    acts = np.random.RandomState(3).uniform(-1, 1, (12, n, 3)).astype(np.float32)
+
+    def run(pool):
+        if not pool:
+            monkeypatch.setenv("DART_NO_OUT_POOL", "1")
+        else:
+            monkeypatch.delenv("DART_NO_OUT_POOL", raising=False)
+        s = st.HipStepper(card, n, precision=64)
+        s.configure(st.CFG_AUTORESET, 1); s.configure(st.CFG_SEED, 4)
+        s.reset(None, None, None, want_obs=False)
+        kept, copies = [], []
+        for t in range(12):
+            out = s.step(acts[t])
+            kept.append(out); copies.append(tuple(np.array(x, copy=True) for x in out))
+            if t >= 6:
+                kept.pop(0)            # from here on older results are dropped: their blocks become reusable
+        for out, cp in zip(kept, copies[-len(kept):]):
+            assert all(np.array_equal(a, b) for a, b in zip(out, cp))     # held results were never overwritten
+        nblocks = len(s.__dict__.get("_blocks", []))
+        s.close()
+        return copies, nblocks
+
+    a, nb_a = run(True)
+    b, nb_b = run(False)
+    assert nb_b == 0 and 1 <= nb_a <= st.HipStepper._POOL_SETS
+    for x, y in zip(a, b):
+        assert all(np.array_equal(p, q) and p.dtype == q.dtype and p.shape == q.shape for p, q in zip(x, y))
+    assert a[0][1].dtype == np.float64 and a[0][2].dtype == np.bool_ and a[0][0].dtype == np.float32
+
+
 def test_vector_env_copy_false_returns_views_with_the_same_values():
     """copy=False (sync_vector_env.py:83 semantics): observations are views of the pinned staging buffer."""
     a = np.random.RandomState(1).uniform(-1, 1, (20, 256, 3)).astype(np.float32)
     va = dart_env_amd.vector.make("DartHopper-v1", 256, noise="philox"); vb = dart_env_amd.vector.make("DartHopper-v1", 256, noise="philox", copy=False)
     va.seed(5); vb.seed(5)
     assert np.array_equal(va.reset(), vb.reset())
-    prev = None
+    prev = prev_a = None
     for t in range(20):
         oa, ra, da, ia = va.step(a[t]); ob, rb, db, ib = vb.step(a[t])
         assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
-        assert not ob.flags.owndata and oa.flags.owndata
+        assert not ob.flags.owndata
         if prev is not None:
-            assert prev is ob or np.shares_memory(prev, ob)        # the same pinned buffer every step
-        prev = ob
+            assert prev is ob or np.shares_memory(prev, ob)        # copy=False: the same pinned buffer every step
+            assert not np.shares_memory(prev_a, oa)                # copy=True: a result the caller still holds is never written again
+        prev, prev_a = ob, oa
     va.close(); vb.close()
 
 

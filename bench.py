@@ -181,8 +181,8 @@ def host_surface(env_id, n, local_rank, precision, budget_s=1.0, max_steps=200):
         venv.seed(0)
         venv.reset()
         a = np.random.RandomState(0).uniform(-1, 1, (n, venv.env.act_dim)).astype(np.float32)
-        for _ in range(10):
-            venv.step(a)
+        for _ in range(300):      # (the first few hundred steps of a fresh handle run at half speed in a process that also holds
+            venv.step(a)          # torch's HIP context -- tools/gpu/host_loop_probe.py: 459 then 249 us per step)
         k, t0 = 0, time.perf_counter()
         while k < max_steps and time.perf_counter() - t0 < budget_s:
             obs, rew, done, info = venv.step(a)

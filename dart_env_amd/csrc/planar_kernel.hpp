@@ -79,6 +79,9 @@ struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin f
   static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;   // measured +26 % (persistent double-support contacts)
+#ifndef DART_NO_HINV_LDS
+  static constexpr bool HINV_LDS_F64 = true;   // see topo_hinv_lds64
+#endif
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3, 6}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
@@ -87,8 +90,8 @@ struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the flo
   static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;
-#ifdef DART_HINV_LDS
-  static constexpr bool HINV_LDS_F64 = true;   // see topo_hinv_lds64 -- OFF by default: the build is not trustworthy on gfx950 / ROCm 7.2
+#ifndef DART_NO_HINV_LDS
+  static constexpr bool HINV_LDS_F64 = true;   // see topo_hinv_lds64: 672 -> 368 B of scratch per lane, 134 -> 119 us, bitwise the same states
 #endif
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3, 4, 5, 6}; return L[c]; }
@@ -135,9 +138,10 @@ template <class T> struct topo_plane_xz<T, decltype((void)T::PLANE_XZ)> { static
 // HINV_LDS_F64 / HINV_LDS_F32: keep H^-1 in LDS (one column of 64 lanes per packed entry) across the pivoting stages instead of in
 // registers.  The 9-dof fp64 kernels need ~310 doubles live at the pivoting loops against the 256 the register file holds
 // (512 32-bit registers): the allocator spilled ~84 of them to scratch (672 B per lane, 165 MB of HBM / L2 traffic per launch at
-// 65 536 envs).  H^-1 (45 doubles) is needed before the loops (Delassus matrix) and after them (velocity change) but not inside:
-// parked in LDS -- 23 KB per wave, conflict-free 8-byte columns -- and with the velocity change computed as H^-1 (J^T lambda)
-// instead of from stored rows of H^-1 J^T, nothing of that size stays live across the loops.
+// 65 536 envs).  H^-1 (45 doubles) is needed before the loops (Delassus matrix) and after them (limit columns of the velocity
+// change) but not inside: parked in LDS -- 23 KB per wave, conflict-free 8-byte columns, every entry fetched once per use --
+// it leaves the register file to the loops: 672 -> 368 B of scratch, Walker2d fp64 134.1 -> 119.3 us (A/B on one box), states
+// bitwise those of the register version.
 template <class T, class = void> struct topo_hinv_lds64 { static constexpr bool value = false; };
 template <class T> struct topo_hinv_lds64<T, decltype((void)T::HINV_LDS_F64)> { static constexpr bool value = T::HINV_LDS_F64; };
 template <class T, class = void> struct topo_hinv_lds32 { static constexpr bool value = false; };
@@ -670,7 +674,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     sfor<0, N>([&](auto I) {
       constexpr int i = I;
       Real a = Real(0), t = Real(0);
-      sfor<0, N>([&](auto J) { constexpr int j = J; a += H[tri(rev<N>(i), rev<N>(j))] * Jn[sl][j]; t += H[tri(rev<N>(i), rev<N>(j))] * Jt[sl][j]; });
+      sfor<0, N>([&](auto J) { constexpr int j = J; a += Hv(tri(rev<N>(i), rev<N>(j))) * Jn[sl][j]; t += Hv(tri(rev<N>(i), rev<N>(j))) * Jt[sl][j]; });
       Yn[sl][i] = a; Yt[sl][i] = t;
     });
   });
@@ -871,44 +875,17 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       rp.cf[i] = f * idt;
     });
   }
-  // velocity change  H^-1 J^T lambda
-  if constexpr (HLDS) {
-    // f = J^T lambda rebuilt from the slots' contact points (no Jacobian or H^-1 J^T rows were kept across the pivoting loops),
-    // then H^-1 f with every packed entry fetched from LDS once
-    DART_COMPILER_FENCE();   // the loads below are new loads: nothing fetched before the loops is to be kept for them
-    Real f[N], dv[N];
-    sfor<0, N>([&](auto I) { f[I] = Real(0); dv[I] = Real(0); });
-    sfor<0, NCA>([&](auto S) {
-      constexpr int sl = S;
-      const Real xn = x[2 * sl], xt = x[2 * sl + 1];
-      f[0] -= xt; f[1] += xn;
-      sfor<0, NL>([&](auto J) {
-        constexpr int j = J;
-        bool a;
-        if constexpr (IDENT) a = is_anc<T>(j, T::clink(sl)); else a = (samask[sl] >> j) & 1u;
-        const Real g = P.sigma[j] * ((sPx[sl] - px[j]) * xn + (sPy[sl] - py[j]) * xt);
-        f[2 + j] += a ? g : Real(0);
-      });
-    });
-    sfor<0, NL>([&](auto K) { constexpr int k = K; if constexpr (T::limited(k)) f[2 + k] += x[limit_slot<T, NCA>(k)]; });
-    sfor<0, N>([&](auto I) {
-      constexpr int i = I;
-      sfor<0, i + 1>([&](auto J) {
-        constexpr int j = J;
-        const Real h = Hv(tri(rev<N>(i), rev<N>(j)));
-        dv[i] += h * f[j];
-        if constexpr (i != j) dv[j] += h * f[i];
-      });
-    });
-    sfor<0, N>([&](auto I) { vs[I] += dv[I]; });
-  } else
+  // velocity change  H^-1 J^T lambda: from the rows Y = H^-1 J^T kept since the Delassus matrix was built (limit rows: columns of H^-1).
+  // (With H^-1 in LDS a variant that rebuilt J^T lambda from the contact points and multiplied by H^-1 afterwards -- nothing but H^-1
+  // live across the pivoting loops -- was built as well: it saved no scratch (416 B against 368 B this way) and its gfx950 build
+  // returned wrong states for every lane with a contact although either half of it alone is bitwise right)
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
     Real dv = Real(0);
     sfor<0, NCA>([&](auto S) { constexpr int cs = S; dv += Yn[cs][i] * x[2 * cs] + Yt[cs][i] * x[2 * cs + 1]; });
     sfor<0, NL>([&](auto K) {
       constexpr int k = K;
-      if constexpr (T::limited(k)) dv += H[tri(rev<N>(i), rev<N>(2 + k))] * x[limit_slot<T, NCA>(k)];
+      if constexpr (T::limited(k)) dv += Hv(tri(rev<N>(i), rev<N>(2 + k))) * x[limit_slot<T, NCA>(k)];
     });
     vs[i] += dv;
   });

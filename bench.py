@@ -147,6 +147,8 @@ def attach_pmc(roof, key):
         roof["traffic_source"] = pmc[key].get("source")
         if "valu_issue" in pmc[key]:
             roof["valu_issue"] = pmc[key]["valu_issue"]
+        if "valu_lanes" in pmc[key]:
+            roof["valu_lanes"] = pmc[key]["valu_lanes"]
 
 
 def attach_valu(roof, env_id, n, dtype, kernel_ms):
@@ -158,6 +160,14 @@ def attach_valu(roof, env_id, n, dtype, kernel_ms):
     except (OSError, ValueError):
         return
     if env_id not in fl:
+        # tree kernel (no host build to count on): the PMC pass's lane-instruction count bounds the flops from above
+        lanes = roof.get("valu_lanes")
+        if lanes:
+            fpe = lanes["flops_upper_bound_per_env_step"]
+            achieved = fpe * n / (kernel_ms * 1e-3) / 1e12
+            roof["valu"] = {"bound": "valu", "flops_per_env_step": fpe, "achieved": achieved, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                            "frac": achieved / VALU_PEAK_TFLOPS[dtype], "counted": "pmc upper bound: SQ_THREAD_CYCLES_VALU / 4 lane-instructions x 2 flops "
+                            "(%s); lanes active per VALU instruction %.2f" % (lanes["source"], lanes["lanes_active_per_valu_instruction"])}
         return
     fpe = fl[env_id]["flops_per_env_step"]
     achieved = fpe * n / (kernel_ms * 1e-3) / 1e12

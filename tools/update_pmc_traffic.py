@@ -59,6 +59,17 @@ def main():
                 "SQ_WAIT_ANY_over_SQ_WAVE_CYCLES": sq.get("SQ_WAIT_ANY", (0, 0))[1] / sq["SQ_WAVE_CYCLES"][1],
                 "wave_cycles_per_wave": 4 * sq["SQ_WAVE_CYCLES"][1] / waves,
                 "source": "%s %s_%s_pmc_sq (SQ_* count quad-cycles)" % (os.path.relpath(cite, ROOT), cfg, dt)}
+        lanes = S.get("%s_%s_pmc_lanes" % (cfg, dt), {})
+        if "SQ_THREAD_CYCLES_VALU" in lanes and "SQ_ACTIVE_INST_VALU" in lanes:
+            # SQ_THREAD_CYCLES_VALU counts active lanes x quad-cycles of every VALU instruction: / 4 = lane-instructions per launch; an
+            # upper bound of the flops they can carry is 2 per lane-instruction (every one an FMA).  The tree kernel has no host build
+            # to count useful flops on, so this bound is what bench.py reports for it (roofline.valu, method "pmc upper bound").
+            lane_instr = lanes["SQ_THREAD_CYCLES_VALU"][1] / 4.0
+            entry["valu_lanes"] = {
+                "lanes_active_per_valu_instruction": lanes["SQ_THREAD_CYCLES_VALU"][1] / (64.0 * lanes["SQ_ACTIVE_INST_VALU"][1]),
+                "valu_lane_instructions_per_launch": lane_instr,
+                "flops_upper_bound_per_env_step": 2.0 * lane_instr / n,
+                "source": "%s %s_%s_pmc_lanes" % (os.path.relpath(cite, ROOT), cfg, dt)}
         out["%s/%d/%s" % (env_id, n, dt)] = entry
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     with open(path, "w") as f:

@@ -878,7 +878,8 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   // velocity change  H^-1 J^T lambda: from the rows Y = H^-1 J^T kept since the Delassus matrix was built (limit rows: columns of H^-1).
   // (With H^-1 in LDS a variant that rebuilt J^T lambda from the contact points and multiplied by H^-1 afterwards -- nothing but H^-1
   // live across the pivoting loops -- was built as well: it saved no scratch (416 B against 368 B this way) and its gfx950 build
-  // returned wrong states for every lane with a contact although either half of it alone is bitwise right)
+  // returned wrong states for every lane with a contact although either half of it alone is bitwise right; rebuilding Y itself
+  // after the loops leaves 320 B: the rows are not what spills.  DESIGN.md section 4.1.)
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
     Real dv = Real(0);

@@ -295,13 +295,16 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     elapsed = time.perf_counter() - t0
     ms_kernel = b.elapsed_ms() / args.steps    # the event wait and read-out sit outside the wall-clock region
     offsets = [env_offset]
+    per_rank = [{"rank": rank, "wall_ms_per_step": elapsed / args.steps * 1e3, "kernel_ms_per_step": ms_kernel}]
     if dist is not None:
+        local_elapsed = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=b.dev if env_factory is None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         got = [None] * world
-        dist.all_gather_object(got, env_offset)
-        offsets = got
+        dist.all_gather_object(got, (env_offset, local_elapsed / args.steps * 1e3, ms_kernel))
+        offsets = [g[0] for g in got]
+        per_rank = [{"rank": r, "wall_ms_per_step": g[1], "kernel_ms_per_step": g[2]} for r, g in enumerate(got)]
 
     done_frac = b.done_fraction()
     if args.stats and rank == 0 and env_factory is None:
@@ -348,6 +351,8 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     }
     attach_pmc(result["roofline"], "%s/%d/%s" % (args.env_id, n, dtype))
     attach_valu(result["roofline"], args.env_id, n, dtype, ms_kernel)
+    if dist is not None:
+        result["per_rank"] = per_rank          # every rank's own clock: `value` uses the slowest (max over ranks, contract)
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
     if gather_note is not None:

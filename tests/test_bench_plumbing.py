@@ -93,6 +93,8 @@ def test_two_rank_bench_line():
     assert r["config"]["envs_per_gpu"] == 64 and "DartHopper-v1" in r["config"]["workload"]
     assert abs(r["value"] - 2 * 64 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]   # whole-job aggregate over the slowest rank
     assert r["gather_ms"] > 0 and "gather_note" not in r
+    assert [pr["rank"] for pr in r["per_rank"]] == [0, 1]              # every rank's own clock is in the line ...
+    assert max(pr["wall_ms_per_step"] for pr in r["per_rank"]) == pytest.approx(r["ms_per_step"])   # ... and `value` uses the slowest
     assert r["roofline"]["algorithmic_bytes_per_env_step"] == 157 and r["vs_baseline"] is None
     assert "cpu_baseline" not in r and "other_configs" not in r      # N = 1 extras only
 

@@ -29,7 +29,10 @@ std::unique_ptr<Impl> make_impl(const DartModelCard& c, int precision, std::stri
   const char* fs = getenv("DART_FORCE_SPATIAL");   // testing aid: run planar models through the general kernel
   const bool force_spatial = (fs && fs[0] == '1') || c.generic_kernel != 0;
   if (!force_spatial) {
-    if (auto p = precision == 32 ? make_planar_impl_f32(c, why, allow_static) : make_planar_impl_f64(c, why, allow_static)) return p;
+    if (auto p = precision == 32 ? make_planar_impl_f32(c, why, allow_static) : make_planar_impl_f64(c, why, allow_static)) {
+      p->lane_kernel = true;
+      return p;
+    }
   } else {
     why += "planar kernels skipped (generic_kernel)";
   }
@@ -224,6 +227,7 @@ int dart_query(const DartStepper* h, int what, int64_t* out) {
     case DART_Q_STATIC_KERNEL: *out = h->impl->is_static ? 1 : 0; break;
     case DART_Q_MAX_CONTACTS: *out = h->impl->max_contacts(); break;
     case DART_Q_LDS_BYTES: *out = h->impl->lds_bytes(); break;
+    case DART_Q_LANE_KERNEL: *out = h->impl->lane_kernel ? 1 : 0; break;
     default: return DART_E_INVALID;
   }
   return DART_OK;

@@ -40,6 +40,7 @@ struct Impl {
   virtual int get_constraint_forces(hipStream_t, int64_t /*n*/, double* /*out*/) { return DART_E_UNSUPPORTED; }
   bool soa = true;         // state layout: q[n][N] (planar kernels) or q[N][n] (spatial kernel)
   int block_threads = 64;  // active lanes per wave64 workgroup (32 -> twice the waves)
+  bool lane_kernel = false;   // true: one env per GPU lane (planar / cart / arm / chain kernels); false: one env per wavefront (tree kernel)
   bool is_static = false;  // true: model constants are compile-time immediates (static_models.hpp) / the tree's factor pattern is (tree_patterns.hpp)
 };
 

@@ -135,7 +135,8 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   constexpr int V = XZ ? 2 : 1, W = XZ ? 1 : 2;
   if (c.ndofs != T::NDOF || c.nbodies < NL + 2) return "body/dof count";
   if (c.act_dim != T::NA || c.act_dof0 != T::NDOF - T::NA) return "action layout";
-  if (c.obs_dim != 2 * T::NDOF - 1 && c.task != DART_TASK_NONE) return "obs_dim";
+  if (topo_physics<T>::value != (c.task == DART_TASK_NONE)) return "task";   // PhysTopo variants serve DART_TASK_NONE, the others never
+  if (c.obs_dim != obs_dim_of<T>()) return "obs_dim";
   if (XZ != (c.task == DART_TASK_SNAKE)) return "task";
   if (c.task != DART_TASK_NONE && c.task != DART_TASK_HOPPER && c.task != DART_TASK_WALKER2D && c.task != DART_TASK_HALFCHEETAH &&
       c.task != DART_TASK_SNAKE) return "task";
@@ -628,6 +629,10 @@ std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool
   if (auto p = make_for_topology<Real, Walker2dTopo, Walker2dStatic<Real>>(c, why, allow_static)) return p;
   why += "; walker2d-tree, all capsules: ";
   if (auto p = make_for_topology<Real, Walker2dAllTopo, Walker2dAllStatic<Real>>(c, why, allow_static)) return p;
+  why += "; hopper-chain, physics only: ";
+  if (auto p = make_for_topology<Real, PhysTopo<HopperAllTopo>, void>(c, why, allow_static)) return p;
+  why += "; walker2d-tree, physics only: ";
+  if (auto p = make_for_topology<Real, PhysTopo<Walker2dAllTopo>, void>(c, why, allow_static)) return p;
   why += "; half-cheetah: ";
   if (auto p = make_for_topology<Real, CheetahTopo, void>(c, why, allow_static)) return p;
   why += "; snake chain in the x-z plane: ";

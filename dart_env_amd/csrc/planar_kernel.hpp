@@ -127,7 +127,15 @@ struct SnakeTopo {  // reference assets/snake_7link.skel: seven links in a chain
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
 };
 
+// Physics-only variant of a topology (DART_TASK_NONE: what `dart_env_amd.envs.DartEnv` -- the reference's DartEnv base class,
+// dart_env.py:28-175 -- runs a user's .skel on): every dof takes a generalized force (action = tau, no clamp, scale 1), the
+// observation is [q, dq], reward 0, never done.  A user model whose tree matches a compiled topology then runs one env per lane
+// instead of on the tree kernel (SURVEY.md 8(f)-1 "model compiler generality").
+template <class B> struct PhysTopo : B { static constexpr int NA = B::NDOF; static constexpr bool PHYSICS = true; };
 // optional traits (default: a robot in the vertical x-y plane with capsules that can touch the floor, no fluid)
+template <class T, class = void> struct topo_physics { static constexpr bool value = false; };
+template <class T> struct topo_physics<T, decltype((void)T::PHYSICS)> { static constexpr bool value = T::PHYSICS; };
+template <class T> __device__ __host__ constexpr int obs_dim_of() { return topo_physics<T>::value ? 2 * T::NDOF : 2 * T::NDOF - 1; }
 template <class T, class = void> struct topo_contacts { static constexpr bool value = true; };
 template <class T> struct topo_contacts<T, decltype((void)T::CONTACTS)> { static constexpr bool value = T::CONTACTS; };
 template <class T, class = void> struct topo_fluid { static constexpr bool value = false; };
@@ -1352,6 +1360,10 @@ template <class Real, class T, class PT>
 __device__ __forceinline__ void write_obs(const PT& P, const Real (&q)[T::NDOF], const Real (&dq)[T::NDOF],
                                           Real height, float* __restrict__ obs_row) {
   constexpr int N = T::NDOF;
+  if constexpr (topo_physics<T>::value) {   // [q, dq]
+    sfor<0, N>([&](auto I) { constexpr int i = I; obs_row[i] = (float)q[i]; obs_row[N + i] = (float)dq[i]; });
+    return;
+  }
   obs_row[0] = (float)height;
   sfor<2, N>([&](auto I) { constexpr int i = I; obs_row[i - 1] = (float)q[i]; });
   sfor<0, N>([&](auto I) {
@@ -1424,6 +1436,7 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     });
   }
   Real rew = dx * P.inv_envdt + P.alive - P.ctrl_cost * a2 - pen;
+  if constexpr (topo_physics<T>::value) rew = Real(0);
   bool ok = true;
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
@@ -1453,7 +1466,7 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   if (valid) {
     sfor<0, N>([&](auto I) { constexpr int i = I; qs[(int64_t)i * n_envs + e] = q[i]; dqs[(int64_t)i * n_envs + e] = dq[i]; });
     elapsed[e] = el;
-    write_obs<Real, T, PT>(P, q, dq, height, obs + e * (2 * N - 1));
+    write_obs<Real, T, PT>(P, q, dq, height, obs + e * obs_dim_of<T>());
     reward[e] = (float)rew;
     done[e] = dn ? 1 : 0;
     truncated[e] = (trunc && !task_done) ? 1 : 0;
@@ -1487,7 +1500,7 @@ __global__ void __launch_bounds__(256) reset_kernel(PT P, int64_t n_envs, Real* 
   } else {
     sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + e]; dq[i] = dqs[(int64_t)i * n_envs + e]; });
   }
-  if (obs && (m || !obs_masked_only)) write_obs<Real, T, PT>(P, q, dq, (P.task == 6 || P.task == 9) ? q[1] : root_height<Real, T, PT>(P, q), obs + e * (2 * N - 1));
+  if (obs && (m || !obs_masked_only)) write_obs<Real, T, PT>(P, q, dq, (P.task == 6 || P.task == 9) ? q[1] : root_height<Real, T, PT>(P, q), obs + e * obs_dim_of<T>());
 }
 
 // (N, n) row-major doubles  <->  SoA state, for set_state / get_state (dart_env.py:145-148, 211-215)

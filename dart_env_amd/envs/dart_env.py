@@ -306,7 +306,10 @@ class DartEnv:
 
     def __init__(self, model_paths, frame_skip, observation_size, action_bounds, dt=0.002, obs_type="parameter",
                  action_type="continuous", visualize=False, disableViewer=True, screen_width=80, screen_height=45,
-                 num_envs=1, device=0, precision=64, collidable_bodies=None, stepper_factory=None):
+                 num_envs=1, device=0, precision=64, collidable_bodies=None, stepper_factory=None, generic_kernel=False):
+        """generic_kernel=True forces the tree kernel; by default the library first offers the model to the lane-per-env register
+        kernels (a .skel whose tree matches one of their compiled topologies runs ~two orders of magnitude faster there:
+        DART_Q_LANE_KERNEL tells which one serves it) and falls back to the tree kernel for every other shape."""
         import os
         from ..skel import parse_skel
         from ..model_card import build_card
@@ -319,6 +322,7 @@ class DartEnv:
             raise IOError("File %s does not exist" % path)      # dart_env.py:43-44
         self.model = parse_skel(path, dt=dt, collidable_bodies=collidable_bodies)
         self.card = build_card(self.model, None)
+        self.card.generic_kernel = int(bool(generic_kernel))
         self.card.frame_skip = int(frame_skip)
         self.num_envs, self.frame_skip = int(num_envs), int(frame_skip)
         self.ndofs = self.card.ndofs

@@ -44,7 +44,8 @@ enum {
   DART_Q_PRECISION = 5, DART_Q_DEVICE = 6, DART_Q_LCP_SLOTS = 7,
   DART_Q_STATIC_KERNEL = 8, /* 1: the card matched a model baked in at build time (csrc/static_models.hpp, csrc/tree_patterns.hpp) */
   DART_Q_MAX_CONTACTS = 9,  /* contact points the kernel keeps per env and world step (0: no reporting in this kernel) */
-  DART_Q_LDS_BYTES = 10     /* LDS bytes per workgroup of the step kernel (tree kernel: the per-env block; planar kernels: the fallback solver's) */
+  DART_Q_LDS_BYTES = 10,    /* LDS bytes per workgroup of the step kernel (tree kernel: the per-env block; planar kernels: the fallback solver's) */
+  DART_Q_LANE_KERNEL = 11   /* 1: the model runs one env per GPU lane (a register kernel whose topology the card matched); 0: the tree kernel */
 };
 
 /* dart_configure keys */

@@ -1616,6 +1616,11 @@ int oracle_env_step(OracleWorld* w, const double* a, double* obs, double* reward
     oracle_set_forces(w, tau);  /* forces are cleared by every world step (dart_env.py:174) */
     rc |= oracle_step(w);
   }
+  if (c->task == DART_TASK_NONE) {   /* physics only (include/dart_model_card.h): obs = [q, dq], reward 0, never done */
+    qdq_obs(w, 0, obs);
+    *reward = 0.0;
+    return 0;
+  }
   double posafter = w->q[0], ang = w->q[2];
   double cm[3];
   oracle_body_com(w, c->height_body, cm);
@@ -1652,7 +1657,7 @@ void oracle_env_obs(OracleWorld* w, double* obs) {
   const DartModelCard* c = &w->card;
   if (c->task == DART_TASK_HUMANWALKER) { int z[2] = {0, 0}; humanwalker_obs(w, z, obs); return; } /* reset_model zeroes contact_info */
   if (c->task == DART_TASK_WALKER3D || c->task == DART_TASK_WALKER3D_SPD || c->task == DART_TASK_DOG) { walker3d_obs(w, obs); return; }
-  if (c->task == DART_TASK_CARTPOLE || c->task == DART_TASK_CARTPOLE_SWINGUP) { qdq_obs(w, 0, obs); return; }
+  if (c->task == DART_TASK_NONE || c->task == DART_TASK_CARTPOLE || c->task == DART_TASK_CARTPOLE_SWINGUP) { qdq_obs(w, 0, obs); return; }
   if (c->task == DART_TASK_DOUBLE_PENDULUM) { double_pendulum_obs(w, obs); return; }
   if (c->task == DART_TASK_REACHER2D || c->task == DART_TASK_REACHER3D) { reacher_obs(w, obs); return; }
   if (c->task == DART_TASK_HALFCHEETAH || c->task == DART_TASK_SNAKE) { qdq_obs(w, 1, obs); return; }

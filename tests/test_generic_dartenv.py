@@ -80,3 +80,75 @@ def test_generic_dartenv_on_gpu_matches_oracle_worlds():
         o32.append(env32.step(actions[t])[0])
     assert np.abs(np.stack(o32) - ro[:11]).max() < 2e-3
     env32.close()
+
+
+def test_user_skel_with_a_compiled_topology_is_accepted_by_the_lane_kernel_code():
+    """SURVEY 8(f)-1 "model compiler generality": a physics-only card (DART_TASK_NONE -- what envs.DartEnv builds from a user's
+    .skel) whose tree is the hopper chain goes through `make_planar` (PhysTopo<HopperAllTopo>), here in the host build of the lane
+    kernels: states, [q, dq] observations and zero rewards against oracle worlds over 150 env-steps with every capsule on the floor."""
+    from dart_env_amd.model_card import build_card
+    from dart_env_amd.skel import parse_skel
+    from tests.batch_oracle import OracleBatch
+    from tests.emu_lib import EmuStepper
+    from tests.pogo_env import SKEL as POGO, SCALE
+    card = build_card(parse_skel(POGO), None)
+    card.frame_skip = 4
+    n = 48
+    g = EmuStepper(card, n, precision=64)          # raises if no lane kernel takes the card
+    assert not g.is_static and card.obs_dim == 12 and card.act_dim == 6
+    ora = OracleBatch(card, n)
+    rng = np.random.RandomState(0)
+    qn = rng.uniform(-.01, .01, (n, 6)); vn = rng.uniform(-.01, .01, (n, 6))
+    ora.reset(None, qn, vn)
+    assert np.abs(g.reset(None, qn, vn) - ora.obs()).max() < 1e-6
+    for t in range(150):
+        a = np.zeros((n, 6), np.float32); a[:, 3:] = rng.uniform(-1, 1, (n, 3)) * SCALE
+        o, r, d, tr = g.step(a); oo, ro, do, _ = ora.step(a)
+        assert np.abs(o - oo).max() < 1e-5 and not r.any() and not ro.any() and not d.any() and not do.any()
+    qg, dqg = g.get_state(); qo, dqo = ora.state()
+    assert np.abs(qg - qo).max() < 1e-9 and np.abs(dqg - dqo).max() < 1e-8 and qo[:, 1].min() < -0.6     # they all ended up on the floor
+    # a model of another shape is declined by every lane kernel (and lands on the tree kernel in the product)
+    with pytest.raises(RuntimeError):
+        EmuStepper(build_card(parse_skel(SKEL), None), 4, precision=64)
+
+
+@pytest.mark.gpu
+def test_user_task_on_a_matching_skel_runs_one_env_per_lane():
+    """The pogo task (tests/pogo_env.py: a subclass written like the reference's hopper.py) on the GPU: the library picks the
+    hopper-chain register kernel for the user's .skel (DART_Q_LANE_KERNEL), the same task forced onto the tree kernel and the task
+    on oracle worlds give the same rollout, and the lane kernel is the faster of the two by a wide margin."""
+    import time
+    from dart_env_amd import stepper as st
+    from tests.pogo_env import PogoEnv, reference_rollout as pogo_reference
+    n, T = 32, 50
+    rng = np.random.RandomState(2)
+    actions = rng.uniform(-1.5, 1.5, (T, n, 3))
+    outs = {}
+    for generic in (False, True):
+        env = PogoEnv(num_envs=n, precision=64, generic_kernel=generic)
+        assert env._stepper.query(st.Q_LANE_KERNEL) == (0 if generic else 1)
+        env.seed(7)
+        obs = [env.reset()]; rew, done = [], []
+        for t in range(T):
+            o, r, d, info = env.step(actions[t])
+            obs.append(o); rew.append(r); done.append(d)
+        outs[generic] = (np.stack(obs), np.stack(rew), np.stack(done))
+        card = env.card
+        env.close()
+    ro, rr, rd = pogo_reference(card, [7 + i for i in range(n)], actions)
+    for generic in (False, True):
+        o, r, d = outs[generic]
+        assert np.abs(o - ro).max() < 1e-7 and np.abs(r - rr).max() < 1e-5 and np.array_equal(d, rd), generic
+    assert rd.any()
+    big = {}
+    for generic in (False, True):
+        env = PogoEnv(num_envs=16384, precision=64, generic_kernel=generic)
+        env.seed(0); env.reset()
+        tau = np.zeros((16384, 6), dtype=np.float32)
+        env.do_simulation(tau, 4)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            env.do_simulation(tau, 4)
+        big[generic] = (time.perf_counter() - t0) / 10
+        env.close()
+    assert big[False] < big[True]

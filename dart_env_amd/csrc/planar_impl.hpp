@@ -112,7 +112,10 @@ struct ImplT : Impl {
     return DART_OK;
   }
   int slots() const override { return 2 * T::NC + n_limited<T>(); }
-  int64_t lds_bytes() const override { return has_slow_path<T, Real>() ? (int64_t)(slow_words<T>() * sizeof(Real)) : 0; }
+  int64_t lds_bytes() const override {
+    const int w = constraint_lds_words<T, Real>() + (topo_wave_fallback<T>::value ? coop_words<16>() : 0);
+    return w > 1 ? (int64_t)(w * sizeof(Real)) : 0;
+  }
 };
 
 static inline bool is_identity3(const double* T16, double tol = 1e-12) {

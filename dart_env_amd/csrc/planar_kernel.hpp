@@ -52,6 +52,7 @@ __device__ __host__ constexpr int rev(int i) { return i; }
 __device__ __host__ constexpr int rev(int i) { return N - 1 - i; }
 #endif
 __device__ __host__ constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+__device__ __host__ constexpr int TI(int i, int j) { return tri(i, j); }   // the tree kernel's name for it
 
 // ------------------------------------------------------------------ topologies
 // Link 0 is the floating root (dofs 0,1,2 = x, y, rot); link k>=1 hangs on a revolute joint (dof 2+k).
@@ -107,8 +108,16 @@ struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded hea
   // first and every later launch of one process.  As a real call on copies of its inputs (ISOLATED_TIER1, constraint_phase_call)
   // every instantiation is bitwise repeatable and 3e-13 (fp64) / 6e-7 (fp32) per step from the oracle with all four slots in
   // use; tests/test_gpu_repeatability.py and tools/gpu/determinism.py keep watching it.
+  // (Round 3: with the impulse pass on M the cheetah rests on 3 capsules in 4.5 % and on 4 in 0.23 % of its env-world-steps: 94 % of
+  // the waves take the second tier.)
   static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4, TIER1_F64 = 3;
   static constexpr bool ISOLATED_TIER1 = true;
+  // Five touching capsules (four in fp64) are 6e-5 (2.3e-3) of the env-world-steps -- ~20 (~750) per launch of 65 536 envs -- and a
+  // launch at one wave per SIMD lasts as long as its slowest wave.  WAVE_FALLBACK: such an env is served by the whole wave
+  // (wave_constraints) instead of by its own lane alone, 2.50 -> 0.95 ms (fp32) / 3.43 -> 1.54 ms (fp64) per batched step; and the lanes
+  // of a register tier that keep pivoting are handed to the same wave solver (blcp_bpp: coop / handoff), 0.95 -> 0.57 / 1.54 -> 1.50 ms.
+  // (Opt-in per topology: with the calls in their kernels Hopper and Walker2d, whose bench workloads never need them, lose 9-12 %.)
+  static constexpr bool WAVE_FALLBACK = true;
   static constexpr bool WARM = true;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 0, 1, 2, 3, 4, 5, 6}; return L[c]; }
@@ -152,6 +161,8 @@ template <class T> struct topo_plane_xz<T, decltype((void)T::PLANE_XZ)> { static
 // bitwise those of the register version.
 template <class T, class = void> struct topo_hinv_lds64 { static constexpr bool value = false; };
 template <class T> struct topo_hinv_lds64<T, decltype((void)T::HINV_LDS_F64)> { static constexpr bool value = T::HINV_LDS_F64; };
+template <class T, class = void> struct topo_wave_fallback { static constexpr bool value = false; };
+template <class T> struct topo_wave_fallback<T, decltype((void)T::WAVE_FALLBACK)> { static constexpr bool value = T::WAVE_FALLBACK; };
 template <class T, class = void> struct topo_hinv_lds32 { static constexpr bool value = false; };
 template <class T> struct topo_hinv_lds32<T, decltype((void)T::HINV_LDS_F32)> { static constexpr bool value = T::HINV_LDS_F32; };
 template <class T, class Real> __device__ __host__ constexpr bool hinv_lds() {
@@ -200,6 +211,9 @@ __device__ __host__ constexpr int slow_words() {
   constexpr int N = T::NDOF, M = max_rows<T>();
   return N * N + 3 * T::NL + N + 4 * T::NC + 3 * T::NL + 2 * M * N + 2 * (M * (M + 1) / 2) + 8 * M + 16;
 }
+// LDS words of a step kernel's constraint scratch (the fallback solver's block)
+template <class T, class Real>
+__device__ __host__ constexpr int constraint_lds_words() { return has_slow_path<T, Real>() ? slow_words<T>() : 1; }
 
 // Optional per-launch extras of both parameter flavours (all null / off by default):
 //   ext_force      [n_envs][3] world-frame force added at link ext_link's frame origin before every world step --
@@ -326,6 +340,13 @@ template <> __device__ __forceinline__ double rsqrt_<double>(double x) {   // v_
 }
 template <class Real> __device__ __forceinline__ Real inf_() { return Real(__builtin_huge_valf()); }
 template <class Real> __device__ __forceinline__ Real tol_() { return sizeof(Real) == 4 ? Real(2e-6) : Real(1e-12); }
+
+}  // namespace dartk
+#ifdef __HIPCC__   // the wave-cooperative solver (readlane, DPP) exists in the device build only; the host build of the lane
+#include "wave_blcp.hpp"   // kernels (tests/kernel_emu) serves the same rows with the single-lane loops of slow_constraints
+#define DART_WAVE_COOP 1
+#endif
+namespace dartk {
 
 // In-place inverse of a packed symmetric positive definite matrix (lower, tri(i,j)) via LDL^T.
 template <class Real, int N>
@@ -473,10 +494,32 @@ __device__ __forceinline__ void masked_solve(const Real (&A)[M * (M + 1) / 2], c
 // (F: free rows, U: rows held at their upper bound; the rest sit at the lower bound) so a set flip is a handful of
 // integer ops instead of per-row branches.  Rows in `pinmask` (lo == hi) never move.
 // ZERO_BOUNDS: every finite bound is 0 (the frictionless stage) -> the bound contribution to the rhs vanishes.
+// Measurement build (-DDART_WAVE_TIMING, never the product): where do the cycles of a wave go?  With DART_CFG_STATS on, the 64 counters hold
+//   [0] sum, [1] max, [2] count of whole-wave cycles per launched wave; [3] / [4] / [5] sum of cycles in the fallback solver / the big
+//   tier / the small tier; [8..15] waves by log2(cycles) - 14; [16..31] / [32..47] / [48..63] invocations of the fallback / big tier /
+//   small tier by log2(cycles) - 8   (the pivoting histograms are not recorded in this build).
+#ifdef DART_WAVE_TIMING
+#define DART_CLK() ((long long)__builtin_readcyclecounter())
+__device__ __forceinline__ void wave_timing_add(unsigned long long* st, int sum_slot, int hist0, int hist_shift, int nbins, long long dt) {
+  if (st == nullptr || (threadIdx.x & 63) != 0) return;
+  atomicAdd(&st[sum_slot], (unsigned long long)dt);
+  int l2 = 63 - __clzll(dt > 1 ? dt : 1) - hist_shift;
+  l2 = l2 < 0 ? 0 : (l2 >= nbins ? nbins - 1 : l2);
+  atomicAdd(&st[hist0 + l2], 1ull);
+}
+#endif
+
+// coop / handoff (topologies with WAVE_FALLBACK, device build): after `handoff` iterations the lanes that have not converged are
+// served one at a time by the whole wave -- the owner parks its problem in LDS (`coop`, coop_words<M>() Reals), the register solver of
+// wave_blcp.hpp continues from the owner's current sets with lane i on row i.  A wave lasts as long as its slowest lane, and a
+// launch as long as its slowest wave: the few lanes that cycle (10-40 iterations where the others need 1-3) then cost iterations of
+// a 16-row wave solve (~3 k cycles) instead of iterations of the whole tier.
+template <int M> __device__ __host__ constexpr int coop_words() { return M * (M + 1) / 2 + 4 * M; }
 template <class Real, int M, bool ZERO_BOUNDS>
 __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
                                          const Real (&hi)[M], uint32_t pinmask, uint32_t& F, uint32_t& U,
-                                         Real (&x)[M], int max_iter, unsigned long long* stats, Real bmax_more = Real(0)) {
+                                         Real (&x)[M], int max_iter, unsigned long long* stats, Real bmax_more = Real(0),
+                                         Real* coop = nullptr, int handoff = 0) {
   // feasibility tolerances scale with the problem: |b|_inf bounds the size of w and (through A^-1) of x
   // (bmax_more: |b| of rows the caller left out of this solve because they are pinned at 0)
   Real bmax = bmax_more;
@@ -530,10 +573,42 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
     const uint32_t toBound = Bs & F, toFree = Bs & ~F;
     F = (F & ~toBound) | toFree;
     U = (U & ~(toFree | toBound)) | (toBound & GT);
+#ifdef DART_WAVE_COOP
+    if (coop != nullptr && it + 1 >= handoff) { ++it; break; }
+#endif
   }
+#ifdef DART_WAVE_COOP
+  if (coop != nullptr) {
+    static_assert(M <= 16, "hand-off uses the 16-row register solver");
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long todo = __ballot(!conv);
+    while (todo != 0ull) {
+      const int owner = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      if (lane == owner) {
+        sfor<0, M * (M + 1) / 2>([&](auto K) { coop[K] = A[K]; });
+        Real* v = coop + M * (M + 1) / 2;
+        sfor<0, M>([&](auto I) { constexpr int i = I; v[i] = b[i]; v[M + i] = lo[i]; v[2 * M + i] = hi[i]; v[3 * M + i] = x[i]; });
+      }
+      __syncthreads();
+      const Real* v = coop + M * (M + 1) / 2;
+      const BlcpSets res = sp_blcp_t<Real, 16>(coop, v, v + M, v + 2 * M, coop + M * (M + 1) / 2 + 3 * M, M, (uint64_t)__shfl(pinmask, owner),
+                                               (uint64_t)__shfl(F, owner), (uint64_t)__shfl(U, owner), max_iter - it, nullptr, lane, ZERO_BOUNDS,
+                                               __shfl(bmax_more, owner));
+      __syncthreads();
+      if (lane == owner && res.ok) {
+        sfor<0, M>([&](auto I) { constexpr int i = I; x[i] = v[3 * M + i]; });
+        F = (uint32_t)res.F; U = (uint32_t)res.U;
+      }
+      __syncthreads();
+    }
+  }
+#endif
   // iteration cap reached without a feasible complementary point: stay in the box
   sfor<0, M>([&](auto I) { constexpr int i = I; x[i] = fmin(fmax(x[i], lo[i]), hi[i]); });
+#ifndef DART_WAVE_TIMING
   if (stats && (threadIdx.x & 63) == 0) atomicAdd(&stats[it < 31 ? it : 31], 1ull);
+#endif
 #ifdef DART_EMU_TRACE
   dart_emu_trace(M, ZERO_BOUNDS ? 1 : 0, trace_F0, trace_U0, F, U, pinmask, it);
 #endif
@@ -576,8 +651,17 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
                                                  const Real (&px)[T::NL], const Real (&py)[T::NL], Real (&vs)[T::NDOF],
                                                  const bool (&con)[T::NC], const Real (&cPx)[T::NC], const Real (&cPy)[T::NC],
                                                  const Real (&cdep)[T::NC], bool off, WarmSets& warm, const ReportTo<Real>& rp,
-                                                 const Real* hl = nullptr) {
+                                                 const Real* hl = nullptr, Real* cm = nullptr) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * NCA + n_limited<T>();
+  // hand-off of the lanes that keep pivoting to the wave solver (blcp_bpp; cm = its LDS block, null = never): after how many
+  // iterations of the frictionless / the friction stage, for the big tier (whose iterations are the expensive ones) and the others
+#ifndef DART_HANDOFF_BIG
+#define DART_HANDOFF_BIG 3, 5
+#define DART_HANDOFF_SMALL 5, 8
+#endif
+  constexpr int HO_[4] = {DART_HANDOFF_BIG, DART_HANDOFF_SMALL};
+  constexpr bool BIGT = tier1<T, Real>() > 0 && NCA == tier1<T, Real>();
+  constexpr int HO1 = BIGT ? HO_[0] : HO_[2], HO2 = BIGT ? HO_[1] : HO_[3];
   auto Hv = [&](int k) -> Real { if constexpr (HLDS) return hl[64 * k]; else return H[k]; };
   constexpr bool IDENT = (NCA == NC);   // slot s IS candidate s: links are compile-time constants
   constexpr int NS = NCA > 0 ? NCA : 1;   // array extent of the slot arrays (a tier without contact slots still declares them)
@@ -797,7 +881,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
         pin1 |= ((pinmask >> fi) & 1u) << i; F1 |= ((F >> fi) & 1u) << i; U1 |= ((U >> fi) & 1u) << i;
         sfor<0, i + 1>([&](auto J) { constexpr int j = J; A1[tri(i, j)] = A[tri(fi, full(j))]; });
       });
-      blcp_bpp<Real, M1, true>(A1, b1, lo1, hi1, pin1, F1, U1, x1, P.iters1, P.stats, bt);
+      blcp_bpp<Real, M1, true>(A1, b1, lo1, hi1, pin1, F1, U1, x1, P.iters1, P.stats, bt, cm, HO1);
       F = 0; U = 0;
       sfor<0, M1>([&](auto I) {
         constexpr int i = I, fi = full(i);
@@ -805,7 +889,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
         F |= ((F1 >> i) & 1u) << fi; U |= ((U1 >> i) & 1u) << fi;
       });
     } else {
-      blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats);
+      blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats, Real(0), cm, HO1);
     }
   }
   else {
@@ -849,7 +933,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     const uint32_t samef = fric & (same << 1);   // friction row of a contact whose normal row persisted
     F = (F & ~samef) | (warm.F2 & samef);
     U = (U & ~samef) | (warm.U2 & samef);
-    if (P.solver == 0) blcp_bpp<Real, M, false>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr);
+    if (P.solver == 0) blcp_bpp<Real, M, false>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr, Real(0), cm, HO2);
     else {
       bool skip[M];
       sfor<0, M>([&](auto I) { skip[I] = !has_contact; });   // per-env semantics: no contact -> no second stage
@@ -907,10 +991,11 @@ struct TierIO {
   bool con[T::NC], off;
   WarmSets warm;
   ReportTo<Real> rp;
+  Real* cm;   // LDS block of the wave solver's hand-off (topologies with WAVE_FALLBACK), else null
 };
 template <class Real, class T, class PT, int NCA, bool EXTRAS>
 __device__ __attribute__((noinline)) void constraint_phase_call(PT P, TierIO<Real, T>& io) {
-  constraint_phase<Real, T, PT, NCA, EXTRAS>(P, io.q, io.H, io.px, io.py, io.vs, io.con, io.cPx, io.cPy, io.cdep, io.off, io.warm, io.rp);
+  constraint_phase<Real, T, PT, NCA, EXTRAS>(P, io.q, io.H, io.px, io.py, io.vs, io.con, io.cPx, io.cPy, io.cdep, io.off, io.warm, io.rp, nullptr, io.cm);
 }
 
 // ------------------------------------------------------------------ single-lane fallback: any number of contacts, loops over LDS
@@ -1088,6 +1173,148 @@ __device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* me
   }
 }
 
+#ifdef DART_WAVE_COOP
+// ------------------------------------------------------------------ the same fallback, served by the WHOLE wave (device build)
+// One env at a time, as above, but the 64 lanes share its rows: lane c builds candidate c's Jacobian rows, lane pairs build Y = H^-1 J^T
+// and the Delassus matrix, and the two pivoting solves run in registers with lane i holding row i (wave_blcp.hpp: the tree kernel's
+// solver, same start sets, tolerances, patience and single-pivot rule as slow_blcp / blcp_bpp).  Same memory layout as slow_constraints;
+// `owner` is the lane whose env this is (it wrote the inputs and takes vs back; only its `rp` is used).  A solve that reaches its
+// iteration cap is redone by the owner with the single-lane loops, which end inside the box whatever happens.
+// Measured need (DartHalfCheetah-v1, 65 536 envs): 6e-5 of the env-world-steps have five touching capsules -- ~20 per launch -- and a
+// launch takes as long as its slowest wave: served by one lane (~1 M cycles each) they set the kernel time, 2.5 ms instead of 0.4.
+template <class Real, class T, class PT, bool EXTRAS>
+__device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* mem, Real qx, Real qy, const ReportTo<Real>& rp, int owner) {
+  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, MM = max_rows<T>();
+  static_assert(MM <= 24 && NC <= 32, "wave_constraints: row capacity of the register solver variants used here");
+  const int lane = (int)(threadIdx.x & 63);
+  Real* Hi = mem; Real* px = Hi + N * N; Real* py = px + NL; Real* sg = py + NL; Real* vs = sg + NL;
+  Real* con = vs + N; Real* cPx = con + NC; Real* cPy = cPx + NC; Real* cdep = cPy + NC;
+  Real* lim = cdep + NC; Real* viol = lim + NL; Real* spare = viol + NL;
+  Real* J = spare + NL; Real* Y = J + MM * N; Real* A = Y + MM * N; Real* L = A + MM * (MM + 1) / 2;
+  Real* b = L + MM * (MM + 1) / 2; Real* lo = b + MM; Real* hi = lo + MM; Real* x = hi + MM; Real* r = x + MM; Real* xb = r + MM;
+  Real* invd = xb + MM; Real* W = invd + MM;
+  __syncthreads();   // the owner's inputs are in place
+  // ---- rows: lane c < NC owns candidate capsule c, lane NC + k owns the limit of link k
+  const bool cact = lane < NC && con[lane < NC ? lane : 0] != Real(0);
+  const unsigned long long cbal = __ballot(cact);
+  const int ncont = __popcll(cbal);
+  const int kl = lane - NC;
+  const bool lact = kl >= 0 && kl < NL && lim[(kl >= 0 && kl < NL) ? kl : 0] != Real(0);
+  const unsigned long long lbal = __ballot(lact);
+  const int m = 2 * ncont + __popcll(lbal);
+  if (m == 0) return;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (cact) {
+    const int c = lane, row = 2 * __popcll(cbal & below);
+    const uint32_t am = (uint32_t)((anc_table<T>() >> (8 * T::clink(c))) & 0xffull);
+    Real* jn = J + row * N; Real* jt = J + (row + 1) * N;
+    jn[0] = Real(0); jn[1] = Real(1); jt[0] = Real(-1); jt[1] = Real(0);
+    Real rn = vs[1], rt = -vs[0];
+    for (int j = 0; j < NL; j++) {
+      const bool a = (am >> j) & 1u;
+      const Real vn = a ? sg[j] * (cPx[c] - px[j]) : Real(0), vt = a ? sg[j] * (cPy[c] - py[j]) : Real(0);
+      jn[2 + j] = vn; jt[2 + j] = vt;
+      rn += vn * vs[2 + j]; rt += vt * vs[2 + j];
+    }
+    b[row] = fmin(cdep[c] * P.erp_dt, P.max_erv) - rn; lo[row] = Real(0); hi[row] = inf_<Real>();
+    b[row + 1] = -rt; lo[row + 1] = Real(0); hi[row + 1] = Real(0);
+    x[row] = Real(0); x[row + 1] = Real(0);
+  }
+  if (lact) {
+    const int row = 2 * ncont + __popcll(lbal & below);
+    Real* jl = J + row * N;
+    for (int i = 0; i < N; i++) jl[i] = (i == 2 + kl) ? Real(1) : Real(0);
+    const bool low = lim[kl] < Real(0);
+    b[row] = fmin(fmax(-viol[kl] * P.limit_erp_dt, -P.max_erv), P.max_erv) - vs[2 + kl];
+    lo[row] = low ? Real(0) : -inf_<Real>(); hi[row] = low ? inf_<Real>() : Real(0);
+    x[row] = Real(0);
+  }
+  __syncthreads();
+  // ---- Y = H^-1 J^T (m x N entries) and the Delassus matrix (packed lower triangle), one entry per lane and round
+  for (int p = lane; p < m * N; p += 64) {
+    const int rr = p / N, i = p - rr * N;
+    Real t = Real(0);
+    for (int j = 0; j < N; j++) t += Hi[i * N + j] * J[rr * N + j];
+    Y[p] = t;
+  }
+  __syncthreads();
+  for (int p = lane; p < m * (m + 1) / 2; p += 64) {
+    int rr = 0;
+    while ((rr + 1) * (rr + 2) / 2 <= p) rr++;
+    const int cc = p - rr * (rr + 1) / 2;
+    Real t = Real(0);
+    for (int i = 0; i < N; i++) t += J[rr * N + i] * Y[cc * N + i];
+    if (rr == cc) t *= (rr >= 2 * ncont) ? P.cfm1 : P.ccfm1;
+    A[p] = t;
+  }
+  __syncthreads();
+  // ---- start sets (lane i = row i), stage 1, friction bounds, stage 2
+  const bool row = lane < m;
+  const int ri = row ? lane : 0;
+  Real bmax0 = row ? fabs(b[ri]) : Real(0);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bmax0 = fmax(bmax0, __shfl_xor(bmax0, o));
+  const Real tol0 = tol_<Real>() * (Real(1) + bmax0);
+  const bool pinned0 = row && !(lo[ri] < hi[ri]);
+  const bool upper = row && !(lo[ri] == Real(0));
+  const bool start_free = row && !pinned0 && (upper ? (b[ri] < -tol0) : (b[ri] > tol0));
+  uint64_t pinmask = __ballot(pinned0), F = __ballot(start_free), U = __ballot(upper && !start_free);
+  auto solve = [&](uint64_t& Fs, uint64_t& Us, int cap, bool zero_bounds) {
+    const uint64_t F0 = Fs, U0 = Us;
+    const BlcpSets res = (m <= 16) ? sp_blcp_t<Real, 16>(A, b, lo, hi, x, m, pinmask, Fs, Us, cap, nullptr, lane, zero_bounds)
+                                   : sp_blcp_t<Real, 24>(A, b, lo, hi, x, m, pinmask, Fs, Us, cap, nullptr, lane, zero_bounds);
+    Fs = res.F; Us = res.U;
+    __syncthreads();
+    if (!res.ok) {   // cap reached (wave-uniform): the single-lane loops from the same start, which clamp into the box at their own cap
+      if (lane == owner) {
+        uint32_t f32 = (uint32_t)F0, u32 = (uint32_t)U0;
+        slow_blcp<Real>(m, A, b, lo, hi, (uint32_t)pinmask, f32, u32, x, 4 * cap + 64, zero_bounds, L, invd, W, r, xb);
+        Fs = f32; Us = u32;
+      }
+      Fs = __shfl(Fs, owner); Us = __shfl(Us, owner);
+      __syncthreads();
+    }
+  };
+  solve(F, U, P.iters1, true);
+  if (ncont > 0) {
+    const bool fr = row && lane < 2 * ncont && (lane & 1);
+    const Real hb = fr ? fabs(P.mu * x[fr ? lane - 1 : 0]) : Real(0);
+    if (fr) { hi[lane] = hb; lo[lane] = -hb; }
+    const bool fpin = fr && !(hb > Real(0));
+    const uint64_t frm = __ballot(fr), fpm = __ballot(fpin);
+    pinmask = (pinmask & ~frm) | fpm;
+    F = (F & ~frm) | (frm & ~fpm);
+    U &= ~frm;
+    __syncthreads();
+    solve(F, U, P.iters2, false);
+  }
+  if (lane < N) {
+    Real dv = Real(0);
+    for (int rr = 0; rr < m; rr++) dv += Y[rr * N + lane] * x[rr];
+    vs[lane] += dv;
+  }
+  if (EXTRAS && lane == owner && rp.rec != nullptr) {
+    const Real idt = Real(1) / P.dt;
+    int rc = 0;
+    for (int c = 0; c < NC; c++) {
+      if (con[c] == Real(0)) continue;
+      Real* o = rp.rec + 8 * rc;
+      o[0] = (Real)P.cbody[c]; o[1] = Real(-1);
+      o[2] = P.root_x0 + qx + cPx[c]; o[3] = P.root_y0 + qy + cPy[c]; o[4] = Real(0);
+      o[5] = -x[2 * rc + 1] * idt; o[6] = x[2 * rc] * idt; o[7] = Real(0);
+      rc++;
+    }
+    *rp.count = rc;
+    for (int i = 0; i < N; i++) {
+      Real f = Real(0);
+      for (int rr = 0; rr < m; rr++) f += J[rr * N + i] * x[rr];
+      rp.cf[i] = f * idt;
+    }
+  }
+  __syncthreads();
+}
+#endif
+
 // ------------------------------------------------------------------ one World::step (dt) for one env
 template <class Real, class T, class PT, bool EXTRAS>
 __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real (&dq)[T::NDOF],
@@ -1263,39 +1490,72 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   if constexpr (has_slow_path<T, Real>()) {
     slow = nact > last_tier<T, Real>() || (P.force_slow != 0 && nact > 0);
     if (__any(slow)) {
-      // the rare lanes whose env touches the floor with more capsules than the tiers hold: one after the other, alone
-      for (int turn = 0; turn < 64; ++turn) {
+      // the rare lanes whose env touches the floor with more capsules than the tiers hold: one after the other
+#ifdef DART_WAVE_TIMING
+      const long long tclk0 = DART_CLK();
+#endif
+      auto stage_inputs = [&]() {   // this lane's env -> the fallback solver's LDS block
+        Real* m = slow_mem;
+        sfor<0, N>([&](auto I) { constexpr int i = I; sfor<0, N>([&](auto J) { constexpr int j = J; m[i * N + j] = Hv(tri(rev<N>(i), rev<N>(j))); }); });
+        m += N * N;
+        sfor<0, NL>([&](auto K) { m[K] = px[K]; m[NL + K] = py[K]; m[2 * NL + K] = P.sigma[K]; });
+        m += 3 * NL;
+        sfor<0, N>([&](auto I) { m[I] = vs[I]; });
+        m += N;
+        sfor<0, NC>([&](auto Cc) { m[Cc] = con[Cc] ? Real(1) : Real(0); m[NC + Cc] = cPx[Cc]; m[2 * NC + Cc] = cPy[Cc]; m[3 * NC + Cc] = cdep[Cc]; });
+        m += 4 * NC;
+        sfor<0, NL>([&](auto K) {
+          constexpr int k = K;
+          Real lim = Real(0), viol = Real(0);
+          if constexpr (T::limited(k)) {
+            const bool low = q[2 + k] <= P.lo[k], up = (!low) && (q[2 + k] >= P.hi[k]);
+            lim = low ? Real(-1) : (up ? Real(1) : Real(0));
+            viol = low ? (q[2 + k] - P.lo[k]) : (q[2 + k] - P.hi[k]);
+          }
+          m[k] = lim; m[NL + k] = viol;
+        });
+      };
+      Real* mvs = slow_mem + N * N + 3 * NL;
+#ifdef DART_WAVE_COOP
+      if (topo_wave_fallback<T>::value && blockDim.x == 64) {   // a full wave: all 64 lanes serve the env together (wave_constraints)
+        unsigned long long todo = __ballot(slow);
+        while (todo != 0ull) {
+          const int owner = __ffsll((long long)todo) - 1;
+          todo &= todo - 1ull;
+          if ((int)(threadIdx.x & 63) == owner) stage_inputs();
+          if constexpr (topo_wave_fallback<T>::value) wave_constraints<Real, T, PT, EXTRAS>(P, slow_mem, q[0], q[1], rp, owner);
+          if ((int)(threadIdx.x & 63) == owner) sfor<0, N>([&](auto I) { vs[I] = mvs[I]; });
+          __syncthreads();
+        }
+      } else
+#endif
+      for (int turn = 0; turn < 64; ++turn) {   // (partial waves, and the host build: the env's own lane, alone)
         if (slow && (int)(threadIdx.x & 63) == turn) {
-          Real* m = slow_mem;
-          sfor<0, N>([&](auto I) { constexpr int i = I; sfor<0, N>([&](auto J) { constexpr int j = J; m[i * N + j] = Hv(tri(rev<N>(i), rev<N>(j))); }); });
-          m += N * N;
-          sfor<0, NL>([&](auto K) { m[K] = px[K]; m[NL + K] = py[K]; m[2 * NL + K] = P.sigma[K]; });
-          m += 3 * NL;
-          sfor<0, N>([&](auto I) { m[I] = vs[I]; });
-          Real* mvs = m;
-          m += N;
-          sfor<0, NC>([&](auto Cc) { m[Cc] = con[Cc] ? Real(1) : Real(0); m[NC + Cc] = cPx[Cc]; m[2 * NC + Cc] = cPy[Cc]; m[3 * NC + Cc] = cdep[Cc]; });
-          m += 4 * NC;
-          sfor<0, NL>([&](auto K) {
-            constexpr int k = K;
-            Real lim = Real(0), viol = Real(0);
-            if constexpr (T::limited(k)) {
-              const bool low = q[2 + k] <= P.lo[k], up = (!low) && (q[2 + k] >= P.hi[k]);
-              lim = low ? Real(-1) : (up ? Real(1) : Real(0));
-              viol = low ? (q[2 + k] - P.lo[k]) : (q[2 + k] - P.hi[k]);
-            }
-            m[k] = lim; m[NL + k] = viol;
-          });
+          stage_inputs();
           slow_constraints<Real, T, PT, EXTRAS>(P, slow_mem, q[0], q[1], rp);
           sfor<0, N>([&](auto I) { vs[I] = mvs[I]; });
         }
       }
+#ifdef DART_WAVE_TIMING
+      wave_timing_add(P.stats, 3, 16, 8, 16, DART_CLK() - tclk0);
+#endif
     }
   }
   // ---- register tiers: the smallest one that holds every (remaining) lane's contacts
   const int nreg = slow ? 0 : nact;
+#ifdef DART_WAVE_TIMING
+  const long long tclk1 = DART_CLK();
+  bool big_tier = false;
+#endif
+  Real* cm = nullptr;   // hand-off block of the wave solver, behind the fallback / tier memory (full waves only: it needs all 64 lanes)
+#ifdef DART_WAVE_COOP
+  if constexpr (topo_wave_fallback<T>::value) cm = blockDim.x == 64 ? slow_mem + constraint_lds_words<T, Real>() : nullptr;
+#endif
   if constexpr (tier1<T, Real>() > 0) {
     if (__any(nreg > T::TIER0)) {
+#ifdef DART_WAVE_TIMING
+      big_tier = true;
+#endif
       if constexpr (T::ISOLATED_TIER1) {   // a real call on copies of the inputs: the big tier gets a register allocation of its own
         TierIO<Real, T> io;
         sfor<0, N>([&](auto I) { io.q[I] = q[I]; io.vs[I] = vs[I]; });
@@ -1303,17 +1563,21 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
         sfor<0, NL>([&](auto K) { io.px[K] = px[K]; io.py[K] = py[K]; });
         sfor<0, NC>([&](auto Cc) { io.con[Cc] = con[Cc]; io.cPx[Cc] = cPx[Cc]; io.cPy[Cc] = cPy[Cc]; io.cdep[Cc] = cdep[Cc]; });
         io.off = slow; io.warm = warm; io.rp = rp;
+        io.cm = cm;
         constraint_phase_call<Real, T, PT, tier1<T, Real>(), EXTRAS>(P, io);
         sfor<0, N>([&](auto I) { vs[I] = io.vs[I]; });
         warm = io.warm;
       } else {
-        constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl);
+        constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
       }
     }
-    else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl);
+    else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
   } else {
-    constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl);
+    constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
   }
+#ifdef DART_WAVE_TIMING
+  wave_timing_add(P.stats, big_tier ? 4 : 5, big_tier ? 32 : 48, 8, 16, DART_CLK() - tclk1);
+#endif
   sfor<0, N>([&](auto I) { constexpr int i = I; dq[i] = vs[i]; q[i] += P.dt * vs[i]; });
 }
 
@@ -1385,6 +1649,9 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
                                                    uint8_t* __restrict__ done, uint8_t* __restrict__ truncated,
                                                    int autoreset, uint64_t seed, uint64_t env_offset) {
   constexpr int N = T::NDOF, NA = T::NA;
+#ifdef DART_WAVE_TIMING
+  const long long tclk_wave = DART_CLK();
+#endif
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool valid = e < n_envs;
   int64_t ec = valid ? e : n_envs - 1;  // tail lanes shadow the last env so wave votes stay uniform
@@ -1409,7 +1676,7 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   Real dx = Real(0);
   WarmSets warm;
   // LDS of the single-lane fallback solver (only topologies with more candidate capsules than tier slots have one)
-  __shared__ Real slow_lds[has_slow_path<T, Real>() ? slow_words<T>() : 1];
+  __shared__ Real slow_lds[constraint_lds_words<T, Real>() + (topo_wave_fallback<T>::value ? coop_words<16>() : 0)];
   // H^-1 of every lane, one 64-lane column per packed entry (topo_hinv_lds64; only the topologies that ask for it)
   __shared__ Real hinv_lds_[hinv_lds<T, Real>() ? 64 * (N * (N + 1) / 2) : 1];
   Real* hl = hinv_lds_ + (threadIdx.x & 63);
@@ -1471,6 +1738,14 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     done[e] = dn ? 1 : 0;
     truncated[e] = (trunc && !task_done) ? 1 : 0;
   }
+#ifdef DART_WAVE_TIMING
+  if (P.stats != nullptr && (threadIdx.x & 63) == 0) {
+    const long long dt = DART_CLK() - tclk_wave;
+    wave_timing_add(P.stats, 0, 8, 14, 8, dt);
+    atomicMax(&P.stats[1], (unsigned long long)dt);
+    atomicAdd(&P.stats[2], 1ull);
+  }
+#endif
 }
 
 // Masked reset: q = init + noise (host-supplied rows, or Philox when noise pointers are null), elapsed = 0, obs.

@@ -7,15 +7,6 @@
 namespace dartk {
 
 // ------------------------------------------------------------------ wave-parallel dense kernels (row-owner scheme)
-template <class Real> __device__ __forceinline__ Real readlane_(Real x, int l);
-template <> __device__ __forceinline__ float readlane_<float>(float x, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
-}
-template <> __device__ __forceinline__ double readlane_<double>(double x, int l) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 
 // Cholesky of the lower triangle M (n <= 32, row layout HR / HL, padded to sp_npad(n) with identity rows), run as a
 // systolic array over the wave: lane r holds row r in REGISTERS, both loops are fully unrolled, and the finished
@@ -315,132 +306,6 @@ __device__ __forceinline__ void sp_blcp_lds(SpLds<Real>& S, int m, uint64_t pinm
   __syncthreads();
 }
 
-
-// ------------------------------------------------------------------ wave-level sum through DPP (no LDS, ~8 VALU instructions)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add_(float v) {
-  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
-  return v + __builtin_bit_cast(float, t);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add_(double v) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
-  return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-// Sum of x over the 64 lanes, returned to every lane.  Must be called by the whole wavefront (convergent code).
-// row_shr:1,2,4,8 build an inclusive prefix sum inside each row of 16 lanes (lanes shifted in from outside a row read the
-// `old` operand = 0), row_bcast:15 / row_bcast:31 carry the row totals forward; lane 63 ends up with the total.
-template <class Real>
-__device__ __forceinline__ Real wave_sum(Real x) {
-  x = dpp_add_<0x111, 0xf>(x);   // row_shr:1
-  x = dpp_add_<0x112, 0xf>(x);   // row_shr:2
-  x = dpp_add_<0x114, 0xf>(x);   // row_shr:4
-  x = dpp_add_<0x118, 0xf>(x);   // row_shr:8
-  x = dpp_add_<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
-  x = dpp_add_<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
-  return readlane_<Real>(x, 63);
-}
-
-// Boxed LCP by block principal pivoting with the whole iteration in REGISTERS: lane i holds row i of A and row i of the
-// masked LDL^T factor; a finished column travels through v_readlane (an SGPR operand of the FMA), the transposed solve uses
-// one DPP wave sum per column.  No LDS traffic and no barrier inside the pivoting loop (the LDS version paid an LDS round
-// trip + barrier per eliminated column).  MP = compile-time row capacity (variants 16 / 24 / 40: only the one a wave takes
-// enters the instruction cache); rows >= m are inert padding.
-struct BlcpSets { uint64_t F, U; bool ok; };
-template <class Real, int MP>
-__device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__ Ap, const Real* __restrict__ bp, const Real* __restrict__ lop,
-                                                        const Real* __restrict__ hip, Real* __restrict__ xp, int m, uint64_t pinmask, uint64_t F,
-                                                        uint64_t U, int max_iter, unsigned long long* stats, int lane, const bool ZERO_BOUNDS) {
-  // a real function call (not inlined): its register arrays get their own allocation instead of raising the pressure of the
-  // whole step kernel; the handful of loads / the one store below go through plain pointers
-  const bool row = lane < m;
-  Real Ar[MP];
-#pragma unroll
-  for (int j = 0; j < MP; j++) Ar[j] = (row && j < m) ? Ap[TI(lane, j)] : Real(0);
-  const Real bi = row ? bp[lane] : Real(0), loi = row ? lop[lane] : Real(0), hii = row ? hip[lane] : Real(0);
-  Real bmax = fabs(bi);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, o));
-  const Real tol = tol_<Real>() * (Real(1) + bmax);
-  int best = m + 1, patience = 3;
-  bool converged = false;
-  int it = 0;
-  Real rr = Real(0);
-  for (; it < max_iter; ++it) {
-    const bool fi = row && ((F >> lane) & 1ull), ui = row && ((U >> lane) & 1ull);
-    const Real xb = row ? (fi ? Real(0) : (ui ? hii : loi)) : Real(0);
-    Real t = bi;
-    if (!ZERO_BOUNDS) {
-#pragma unroll
-      for (int j = 0; j < MP; j++) t -= Ar[j] * readlane_<Real>(xb, j);
-    }
-    rr = fi ? t : xb;
-    // masked LDL^T: non-free rows / columns are identity
-    Real L[MP];
-#pragma unroll
-    for (int j = 0; j < MP; j++) {
-      const bool fj = (F >> j) & 1ull;
-      L[j] = (j == lane) ? (fi ? Ar[j] : Real(1)) : ((fi && fj && j < lane) ? Ar[j] : Real(0));
-    }
-    Real invd_own = Real(1);
-#pragma unroll
-    for (int j = 0; j < MP; j++) {
-      if ((F >> j) & 1ull) {   // wave-uniform
-        const Real inv = rcp_<Real>(readlane_<Real>(L[j], j));
-        const Real u = (lane > j) ? L[j] : Real(0);   // unscaled column below the diagonal (0 in non-free rows)
-        const Real lij = u * inv;
-        L[j] = (lane > j) ? lij : L[j];
-        invd_own = (lane == j) ? inv : invd_own;
-#pragma unroll
-        for (int k = j + 1; k < MP; k++) L[k] -= lij * readlane_<Real>(u, k);
-      }
-    }
-    // L y = rr (unit lower triangle), y /= d, L^T x = y -- restricted to the free rows
-#pragma unroll
-    for (int j = 0; j < MP; j++) {
-      if ((F >> j) & 1ull) {
-        const Real yj = readlane_<Real>(rr, j);
-        rr = (lane > j) ? rr - L[j] * yj : rr;      // L[j] = 0 in non-free rows
-      }
-    }
-    rr = fi ? rr * invd_own : rr;
-#pragma unroll
-    for (int j = MP - 1; j >= 0; j--) {
-      if ((F >> j) & 1ull) {
-        const Real s = wave_sum<Real>((lane > j && fi) ? L[j] * rr : Real(0));
-        rr = (lane == j) ? rr - s : rr;
-      }
-    }
-    // w = A x - b and the feasibility of every row
-    Real w = -bi;
-#pragma unroll
-    for (int j = 0; j < MP; j++) w += Ar[j] * readlane_<Real>(rr, j);
-    bool inf = false, gt = false;
-    if (row) {
-      const bool pinned = (pinmask >> lane) & 1ull;
-      const bool over = rr > hii + tol * (Real(1) + fabs(hii)), under = rr < loi - tol * (Real(1) + fabs(loi));
-      const bool wbad = ui ? (w > tol) : (w < -tol);
-      inf = fi ? (over || under) : (wbad && !pinned);
-      gt = rr > hii;
-    }
-    const uint64_t B = __ballot(inf), GT = __ballot(gt);
-    if (B == 0ull) { converged = true; break; }
-    const int ninf = __popcll(B);
-    const bool improved = ninf < best;
-    const bool single = !improved && patience == 0;
-    best = improved ? ninf : best;
-    patience = improved ? 3 : (patience > 0 ? patience - 1 : 0);
-    const uint64_t Bs = single ? (1ull << (63 - __clzll((long long)B))) : B;
-    const uint64_t toBound = Bs & F, toFree = Bs & ~F;
-    F = (F & ~toBound) | toFree;
-    U = (U & ~(toFree | toBound)) | (toBound & GT);
-  }
-  if (stats && lane == 0) { atomicAdd(&stats[it < 31 ? it : 31], 1ull); atomicAdd(&stats[33], 1ull); }
-  if (converged && row) xp[lane] = fmin(fmax(rr, loi), hii);
-  return BlcpSets{F, U, converged};
-}
 
 #ifndef SP_BLCP_MAXREG
 #define SP_BLCP_MAXREG 40

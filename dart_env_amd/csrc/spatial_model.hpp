@@ -19,7 +19,6 @@ __device__ __host__ constexpr int sp_tri(int m) { return m * (m + 1) / 2; }   //
 // built, the per-link records only before: when the link block is big enough the two share LDS (HumanWalker: 2.8 KB
 // less per workgroup = 10 instead of 8 workgroups per CU).
 __device__ __host__ constexpr bool sp_lw_aliases_links(int nl, int maxm) { return nl * 37 >= sp_tri(maxm) + maxm; }
-__device__ __host__ constexpr int TI(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 __device__ __host__ constexpr int sp_npad(int n) { return (n + 7) & ~7; }   // H is stored padded with identity rows to a multiple of 8
 __device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
 // The mass matrix / its Cholesky factor is stored lower-triangular with rows padded to multiples of 4 entries and 16-byte

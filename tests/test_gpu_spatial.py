@@ -368,6 +368,34 @@ def test_all_capsule_contacts_env_matches_oracle(env_id, kernel):
     gpu.close()
 
 
+@pytest.mark.parametrize("precision,tq,tdq", [(64, 1e-7, 1e-5), (32, 2e-3, 5e-2)])
+def test_half_cheetah_wave_fallback_matches_oracle(precision, tq, tdq):
+    """The half cheetah rests on five capsules in 6e-5 of its env-world-steps (four: 2e-3), more than its register tiers hold; the
+    whole wave then serves that env (wave_constraints: lane i on row i of the pivoting solve).  Forced for every touching env here,
+    and compared with the oracle step by step (fp32: the copy is put back on the oracle's trajectory after every step)."""
+    from dart_env_amd.stepper import HipStepper, CFG_DEBUG_FORCE_FALLBACK
+    card = card_for("DartHalfCheetah-v1")
+    n, nd, na = 192, card.ndofs, card.act_dim
+    rng = np.random.RandomState(11)
+    gpu = HipStepper(card, n, precision=precision)
+    gpu.configure(CFG_DEBUG_FORCE_FALLBACK, 1)
+    ora = OracleBatch(card, n)
+    qn = rng.uniform(-.1, .1, (n, nd)); vn = rng.uniform(-.1, .1, (n, nd))
+    gpu.reset(None, qn, vn); ora.reset(None, qn, vn)
+    touching = 0
+    for t in range(60):
+        a = rng.uniform(-1, 1, (n, na)).astype(np.float32)
+        og, rg, dg, tg = gpu.step(a)
+        oo, ro, do, to = ora.step(a)
+        touching += sum(1 for w in ora.worlds if len(w.last_contacts()) > 0)
+        qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+        assert np.abs(qg - qo).max() < tq and np.abs(dqg - dqo).max() < tdq, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        if precision == 32:
+            gpu.set_state(qo, dqo)
+    assert touching > 0.5 * 60 * n
+    gpu.close()
+
+
 def test_walker3d_link_link_contacts_match_oracle():
     """Self-collision (walker3d.py:26): squeeze / cross the legs with hip torques so that thigh, shin and foot boxes
     collide (face-face, edge-edge, with the feet on the floor at the same time); the fp64 kernel follows the oracle
@@ -700,14 +728,17 @@ def test_free_root_chart_has_no_singular_heading():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1", "DartHopper-v1/tree", "DartHumanWalker-v1",
-                                    "DartWalker3d-v1", "DartDog-v1"])
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1", "DartHalfCheetah-v1/fallback", "DartHopper-v1/tree",
+                                    "DartHumanWalker-v1", "DartWalker3d-v1", "DartDog-v1"])
 def test_contact_report_matches_oracle(env_id):
     """dart_get_contacts (pydart2 collision_result.contacts of the last world step, walker2d.py:38-41): bodies, points and forces
     equal the oracle's, fp64; fp32 close.  The planar register kernels (Hopper, Walker2d, HalfCheetah default cards) report from
-    their contact slots; `/tree` routes the Hopper through the tree kernel (generic_kernel)."""
-    from dart_env_amd.stepper import HipStepper, StepperError, CFG_CONTACT_REPORT, Q_MAX_CONTACTS, Q_STATIC_KERNEL
+    their contact slots; `/tree` routes the Hopper through the tree kernel (generic_kernel); `/fallback` routes every touching
+    cheetah through the solver that serves an env with more contacts than the register tiers hold (on the device: the whole wave,
+    wave_constraints in planar_kernel.hpp)."""
+    from dart_env_amd.stepper import HipStepper, StepperError, CFG_CONTACT_REPORT, Q_MAX_CONTACTS, Q_STATIC_KERNEL, CFG_DEBUG_FORCE_FALLBACK
     tree = env_id.endswith("/tree")
+    fallback = env_id.endswith("/fallback")
     env_id = env_id.split("/")[0]
     card = card_for(env_id, generic_kernel=tree)
     n, nd, na = 24, card.ndofs, card.act_dim
@@ -718,6 +749,8 @@ def test_contact_report_matches_oracle(env_id):
     ora.reset(None, qn, vn)
     for g in gpus.values():
         g.configure(CFG_CONTACT_REPORT, 1)
+        if fallback:
+            g.configure(CFG_DEBUG_FORCE_FALLBACK, 1)
         g.reset(None, qn, vn)
     K = gpus[64].query(Q_MAX_CONTACTS)
     assert K >= 4

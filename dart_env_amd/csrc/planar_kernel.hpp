@@ -614,6 +614,29 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
 #endif
 }
 
+// PRESOLVE32 (fp64 kernels only): the active set is searched in fp32 first -- a copy of the problem, at most `presolve_iters` pivoting
+// iterations, no hand-off -- and the fp64 loop starts from the set that search ended on: it confirms it with one solve when the fp32
+// search was right, and simply continues when it was not (the fp64 loop and its tolerances stay the authority on the result).
+// For the half cheetah's big fp64 tier, whose 12-row fp64 iterations are spill-bound (6 KB of scratch per lane) and whose waves need
+// 2.4 + 3.7 of them per world step: 1.50 -> 1.43 ms per batched step.  Not for the small tiers: in every fp64 tier of every topology
+// it cost Hopper 32.0 -> 36.4 us and Walker2d 119 -> 141 us (a wave's 2nd..4th solve is cheaper than the copies and the extra solve).
+template <class Real, int M, bool ZERO_BOUNDS, bool PRESOLVE32>
+__device__ __forceinline__ void blcp_bpp_mixed(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
+                                               const Real (&hi)[M], uint32_t pinmask, uint32_t& F, uint32_t& U,
+                                               Real (&x)[M], int max_iter, unsigned long long* stats, Real bmax_more,
+                                               Real* coop, int handoff, int presolve_iters) {
+  if constexpr (PRESOLVE32 && sizeof(Real) == 8) {
+    float Af[M * (M + 1) / 2], bf[M], lof[M], hif[M], xf[M];
+    sfor<0, M * (M + 1) / 2>([&](auto K) { Af[K] = (float)A[K]; });
+    sfor<0, M>([&](auto I) { bf[I] = (float)b[I]; lof[I] = (float)lo[I]; hif[I] = (float)hi[I]; xf[I] = 0.f; });
+    uint32_t Ff = F, Uf = U;
+    blcp_bpp<float, M, ZERO_BOUNDS>(Af, bf, lof, hif, pinmask, Ff, Uf, xf, presolve_iters < max_iter ? presolve_iters : max_iter, nullptr,
+                                    (float)bmax_more);
+    F = Ff; U = Uf;
+  }
+  blcp_bpp<Real, M, ZERO_BOUNDS>(A, b, lo, hi, pinmask, F, U, x, max_iter, stats, bmax_more, coop, handoff);
+}
+
 template <class Real, int M>
 __device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
                                          const Real (&hi)[M], const bool (&skip)[M], Real (&x)[M], int iters) {
@@ -662,6 +685,10 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   constexpr int HO_[4] = {DART_HANDOFF_BIG, DART_HANDOFF_SMALL};
   constexpr bool BIGT = tier1<T, Real>() > 0 && NCA == tier1<T, Real>();
   constexpr int HO1 = BIGT ? HO_[0] : HO_[2], HO2 = BIGT ? HO_[1] : HO_[3];
+#ifndef DART_PRESOLVE32_BIG_TIER
+#define DART_PRESOLVE32_BIG_TIER 1
+#endif
+  constexpr bool PRE32 = DART_PRESOLVE32_BIG_TIER != 0 && BIGT && T::ISOLATED_TIER1 && sizeof(Real) == 8;   // see blcp_bpp_mixed
   auto Hv = [&](int k) -> Real { if constexpr (HLDS) return hl[64 * k]; else return H[k]; };
   constexpr bool IDENT = (NCA == NC);   // slot s IS candidate s: links are compile-time constants
   constexpr int NS = NCA > 0 ? NCA : 1;   // array extent of the slot arrays (a tier without contact slots still declares them)
@@ -881,7 +908,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
         pin1 |= ((pinmask >> fi) & 1u) << i; F1 |= ((F >> fi) & 1u) << i; U1 |= ((U >> fi) & 1u) << i;
         sfor<0, i + 1>([&](auto J) { constexpr int j = J; A1[tri(i, j)] = A[tri(fi, full(j))]; });
       });
-      blcp_bpp<Real, M1, true>(A1, b1, lo1, hi1, pin1, F1, U1, x1, P.iters1, P.stats, bt, cm, HO1);
+      blcp_bpp_mixed<Real, M1, true, PRE32>(A1, b1, lo1, hi1, pin1, F1, U1, x1, P.iters1, P.stats, bt, cm, HO1, 4);
       F = 0; U = 0;
       sfor<0, M1>([&](auto I) {
         constexpr int i = I, fi = full(i);
@@ -889,7 +916,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
         F |= ((F1 >> i) & 1u) << fi; U |= ((U1 >> i) & 1u) << fi;
       });
     } else {
-      blcp_bpp<Real, M, true>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats, Real(0), cm, HO1);
+      blcp_bpp_mixed<Real, M, true, PRE32>(A, b, lo, hi, pinmask, F, U, x, P.iters1, P.stats, Real(0), cm, HO1, 4);
     }
   }
   else {
@@ -933,7 +960,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     const uint32_t samef = fric & (same << 1);   // friction row of a contact whose normal row persisted
     F = (F & ~samef) | (warm.F2 & samef);
     U = (U & ~samef) | (warm.U2 & samef);
-    if (P.solver == 0) blcp_bpp<Real, M, false>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr, Real(0), cm, HO2);
+    if (P.solver == 0) blcp_bpp_mixed<Real, M, false, PRE32>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr, Real(0), cm, HO2, 6);
     else {
       bool skip[M];
       sfor<0, M>([&](auto I) { skip[I] = !has_contact; });   // per-env semantics: no contact -> no second stage
@@ -1194,6 +1221,10 @@ __device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* me
   Real* b = L + MM * (MM + 1) / 2; Real* lo = b + MM; Real* hi = lo + MM; Real* x = hi + MM; Real* r = x + MM; Real* xb = r + MM;
   Real* invd = xb + MM; Real* W = invd + MM;
   __syncthreads();   // the owner's inputs are in place
+#ifdef DART_WAVE_TIMING_FALLBACK   // measurement build: [24] rows + Y + A, [25] stage 1, [26] stage 2, [27] tail, [28] calls, [29] rows m summed
+  long long tf0 = (long long)__builtin_readcyclecounter();
+  auto tf_mark = [&](int slot) { const long long t = (long long)__builtin_readcyclecounter(); if (P.stats && lane == 0) atomicAdd(&P.stats[slot], (unsigned long long)(t - tf0)); tf0 = t; };
+#endif
   // ---- rows: lane c < NC owns candidate capsule c, lane NC + k owns the limit of link k
   const bool cact = lane < NC && con[lane < NC ? lane : 0] != Real(0);
   const unsigned long long cbal = __ballot(cact);
@@ -1275,7 +1306,13 @@ __device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* me
       __syncthreads();
     }
   };
+#ifdef DART_WAVE_TIMING_FALLBACK
+  tf_mark(24);
+#endif
   solve(F, U, P.iters1, true);
+#ifdef DART_WAVE_TIMING_FALLBACK
+  tf_mark(25);
+#endif
   if (ncont > 0) {
     const bool fr = row && lane < 2 * ncont && (lane & 1);
     const Real hb = fr ? fabs(P.mu * x[fr ? lane - 1 : 0]) : Real(0);
@@ -1288,11 +1325,18 @@ __device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* me
     __syncthreads();
     solve(F, U, P.iters2, false);
   }
+#ifdef DART_WAVE_TIMING_FALLBACK
+  tf_mark(26);
+#endif
   if (lane < N) {
     Real dv = Real(0);
     for (int rr = 0; rr < m; rr++) dv += Y[rr * N + lane] * x[rr];
     vs[lane] += dv;
   }
+#ifdef DART_WAVE_TIMING_FALLBACK
+  tf_mark(27);
+  if (P.stats && lane == 0) { atomicAdd(&P.stats[28], 1ull); atomicAdd(&P.stats[29], (unsigned long long)m); }
+#endif
   if (EXTRAS && lane == owner && rp.rec != nullptr) {
     const Real idt = Real(1) / P.dt;
     int rc = 0;

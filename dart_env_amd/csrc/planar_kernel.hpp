@@ -140,7 +140,17 @@ struct SnakeTopo {  // reference assets/snake_7link.skel: seven links in a chain
 // dart_env.py:28-175 -- runs a user's .skel on): every dof takes a generalized force (action = tau, no clamp, scale 1), the
 // observation is [q, dq], reward 0, never done.  A user model whose tree matches a compiled topology then runs one env per lane
 // instead of on the tree kernel (SURVEY.md 8(f)-1 "model compiler generality").
-template <class B> struct PhysTopo : B { static constexpr int NA = B::NDOF; static constexpr bool PHYSICS = true; };
+// A user model has no termination inside the library -- it may fall over and stay on the floor with every capsule touching -- so the
+// register tiers of these variants cover that: all four capsules of the hopper chain (an 11-row LCP, no fallback path at all), four
+// (fp64: three) slots of the walker tree as a real call with the wave-served fallback behind it, as for the half cheetah.  (With the
+// base topologies' tiers 65 536 fallen pogo hoppers took 2.4 ms per env-step, every lane waiting its turn in the single-lane solver.)
+template <class B> struct PhysTopo : B {
+  static constexpr int NA = B::NDOF;
+  static constexpr bool PHYSICS = true;
+  static constexpr int TIER1 = B::NC <= 4 ? B::NC : 4, TIER1_F64 = B::NC <= 4 ? B::NC : 3;
+  static constexpr bool ISOLATED_TIER1 = (B::NC > 4);
+  static constexpr bool WAVE_FALLBACK = (B::NC > 4);
+};
 // optional traits (default: a robot in the vertical x-y plane with capsules that can touch the floor, no fluid)
 template <class T, class = void> struct topo_physics { static constexpr bool value = false; };
 template <class T> struct topo_physics<T, decltype((void)T::PHYSICS)> { static constexpr bool value = T::PHYSICS; };
@@ -509,6 +519,20 @@ __device__ __forceinline__ void wave_timing_add(unsigned long long* st, int sum_
 }
 #endif
 
+// Wave-served solves run one env after the other, so a wave whose lanes ALL have problems that do not converge (a simulation that is
+// blowing up, fp32 on an ill-conditioned pile-up) would pay the iteration cap once per lane instead of once per wave.  Each place that
+// serves lanes this way therefore has a budget of wave iterations for all its lanes together: a lane may use what is left of it, at
+// least DART_COOP_MIN (enough for a problem that is merely large); when it runs out the remaining lanes keep their last iterate,
+// clamped into the box, as a lane does at its own cap.  Workloads within the documented statistics never get near it.
+#ifndef DART_COOP_BUDGET
+#define DART_COOP_BUDGET 96
+#define DART_COOP_MIN 8
+#endif
+__device__ __host__ constexpr int coop_iters(int cap, int budget) {
+  const int b = budget > DART_COOP_MIN ? budget : DART_COOP_MIN;
+  return cap < b ? cap : b;
+}
+
 // coop / handoff (topologies with WAVE_FALLBACK, device build): after `handoff` iterations the lanes that have not converged are
 // served one at a time by the whole wave -- the owner parks its problem in LDS (`coop`, coop_words<M>() Reals), the register solver of
 // wave_blcp.hpp continues from the owner's current sets with lane i on row i.  A wave lasts as long as its slowest lane, and a
@@ -582,6 +606,7 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
     static_assert(M <= 16, "hand-off uses the 16-row register solver");
     const int lane = (int)(threadIdx.x & 63);
     unsigned long long todo = __ballot(!conv);
+    int budget = DART_COOP_BUDGET;   // wave iterations this hand-off may spend in all (see wave_constraints)
     while (todo != 0ull) {
       const int owner = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
@@ -593,8 +618,9 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
       __syncthreads();
       const Real* v = coop + M * (M + 1) / 2;
       const BlcpSets res = sp_blcp_t<Real, 16>(coop, v, v + M, v + 2 * M, coop + M * (M + 1) / 2 + 3 * M, M, (uint64_t)__shfl(pinmask, owner),
-                                               (uint64_t)__shfl(F, owner), (uint64_t)__shfl(U, owner), max_iter - it, nullptr, lane, ZERO_BOUNDS,
-                                               __shfl(bmax_more, owner));
+                                               (uint64_t)__shfl(F, owner), (uint64_t)__shfl(U, owner), coop_iters(max_iter - it, budget), nullptr, lane,
+                                               ZERO_BOUNDS, __shfl(bmax_more, owner));
+      budget -= res.iters;
       __syncthreads();
       if (lane == owner && res.ok) {
         sfor<0, M>([&](auto I) { constexpr int i = I; x[i] = v[3 * M + i]; });
@@ -1206,20 +1232,21 @@ __device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* me
 // and the Delassus matrix, and the two pivoting solves run in registers with lane i holding row i (wave_blcp.hpp: the tree kernel's
 // solver, same start sets, tolerances, patience and single-pivot rule as slow_blcp / blcp_bpp).  Same memory layout as slow_constraints;
 // `owner` is the lane whose env this is (it wrote the inputs and takes vs back; only its `rp` is used).  A solve that reaches its
-// iteration cap is redone by the owner with the single-lane loops, which end inside the box whatever happens.
+// iteration cap -- or the wave's budget for all the envs it serves in this world step (DART_COOP_BUDGET) -- ends on its last iterate,
+// clamped into the box, as a lane of a register tier does at its cap.
 // Measured need (DartHalfCheetah-v1, 65 536 envs): 6e-5 of the env-world-steps have five touching capsules -- ~20 per launch -- and a
 // launch takes as long as its slowest wave: served by one lane (~1 M cycles each) they set the kernel time, 2.5 ms instead of 0.4.
 template <class Real, class T, class PT, bool EXTRAS>
-__device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* mem, Real qx, Real qy, const ReportTo<Real>& rp, int owner) {
+__device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* mem, Real qx, Real qy, const ReportTo<Real>& rp, int owner,
+                                                           int& budget) {
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, MM = max_rows<T>();
   static_assert(MM <= 24 && NC <= 32, "wave_constraints: row capacity of the register solver variants used here");
   const int lane = (int)(threadIdx.x & 63);
   Real* Hi = mem; Real* px = Hi + N * N; Real* py = px + NL; Real* sg = py + NL; Real* vs = sg + NL;
   Real* con = vs + N; Real* cPx = con + NC; Real* cPy = cPx + NC; Real* cdep = cPy + NC;
   Real* lim = cdep + NC; Real* viol = lim + NL; Real* spare = viol + NL;
-  Real* J = spare + NL; Real* Y = J + MM * N; Real* A = Y + MM * N; Real* L = A + MM * (MM + 1) / 2;
-  Real* b = L + MM * (MM + 1) / 2; Real* lo = b + MM; Real* hi = lo + MM; Real* x = hi + MM; Real* r = x + MM; Real* xb = r + MM;
-  Real* invd = xb + MM; Real* W = invd + MM;
+  Real* J = spare + NL; Real* Y = J + MM * N; Real* A = Y + MM * N;
+  Real* b = A + 2 * (MM * (MM + 1) / 2); Real* lo = b + MM; Real* hi = lo + MM; Real* x = hi + MM;   // (the single-lane solver's factor sits between A and b)
   __syncthreads();   // the owner's inputs are in place
 #ifdef DART_WAVE_TIMING_FALLBACK   // measurement build: [24] rows + Y + A, [25] stage 1, [26] stage 2, [27] tail, [28] calls, [29] rows m summed
   long long tf0 = (long long)__builtin_readcyclecounter();
@@ -1291,20 +1318,12 @@ __device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* me
   const bool start_free = row && !pinned0 && (upper ? (b[ri] < -tol0) : (b[ri] > tol0));
   uint64_t pinmask = __ballot(pinned0), F = __ballot(start_free), U = __ballot(upper && !start_free);
   auto solve = [&](uint64_t& Fs, uint64_t& Us, int cap, bool zero_bounds) {
-    const uint64_t F0 = Fs, U0 = Us;
-    const BlcpSets res = (m <= 16) ? sp_blcp_t<Real, 16>(A, b, lo, hi, x, m, pinmask, Fs, Us, cap, nullptr, lane, zero_bounds)
-                                   : sp_blcp_t<Real, 24>(A, b, lo, hi, x, m, pinmask, Fs, Us, cap, nullptr, lane, zero_bounds);
-    Fs = res.F; Us = res.U;
+    const int mi = coop_iters(cap, budget);
+    const BlcpSets res = (m <= 16) ? sp_blcp_t<Real, 16>(A, b, lo, hi, x, m, pinmask, Fs, Us, mi, nullptr, lane, zero_bounds, Real(0), true)
+                                   : sp_blcp_t<Real, 24>(A, b, lo, hi, x, m, pinmask, Fs, Us, mi, nullptr, lane, zero_bounds, Real(0), true);
+    Fs = res.F; Us = res.U;   // (cap or budget reached: x holds the last iterate, clamped into the box)
+    budget -= res.iters;
     __syncthreads();
-    if (!res.ok) {   // cap reached (wave-uniform): the single-lane loops from the same start, which clamp into the box at their own cap
-      if (lane == owner) {
-        uint32_t f32 = (uint32_t)F0, u32 = (uint32_t)U0;
-        slow_blcp<Real>(m, A, b, lo, hi, (uint32_t)pinmask, f32, u32, x, 4 * cap + 64, zero_bounds, L, invd, W, r, xb);
-        Fs = f32; Us = u32;
-      }
-      Fs = __shfl(Fs, owner); Us = __shfl(Us, owner);
-      __syncthreads();
-    }
   };
 #ifdef DART_WAVE_TIMING_FALLBACK
   tf_mark(24);
@@ -1563,11 +1582,12 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 #ifdef DART_WAVE_COOP
       if (topo_wave_fallback<T>::value && blockDim.x == 64) {   // a full wave: all 64 lanes serve the env together (wave_constraints)
         unsigned long long todo = __ballot(slow);
+        int budget = 2 * DART_COOP_BUDGET;   // both stages of every env served in this world step
         while (todo != 0ull) {
           const int owner = __ffsll((long long)todo) - 1;
           todo &= todo - 1ull;
           if ((int)(threadIdx.x & 63) == owner) stage_inputs();
-          if constexpr (topo_wave_fallback<T>::value) wave_constraints<Real, T, PT, EXTRAS>(P, slow_mem, q[0], q[1], rp, owner);
+          if constexpr (topo_wave_fallback<T>::value) wave_constraints<Real, T, PT, EXTRAS>(P, slow_mem, q[0], q[1], rp, owner, budget);
           if ((int)(threadIdx.x & 63) == owner) sfor<0, N>([&](auto I) { vs[I] = mvs[I]; });
           __syncthreads();
         }
@@ -1603,7 +1623,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       if constexpr (T::ISOLATED_TIER1) {   // a real call on copies of the inputs: the big tier gets a register allocation of its own
         TierIO<Real, T> io;
         sfor<0, N>([&](auto I) { io.q[I] = q[I]; io.vs[I] = vs[I]; });
-        sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = H[I]; });
+        sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = Hv(I); });
         sfor<0, NL>([&](auto K) { io.px[K] = px[K]; io.py[K] = py[K]; });
         sfor<0, NC>([&](auto Cc) { io.con[Cc] = con[Cc]; io.cPx[Cc] = cPx[Cc]; io.cPy[Cc] = cPy[Cc]; io.cdep[Cc] = cdep[Cc]; });
         io.off = slow; io.warm = warm; io.rp = rp;

@@ -328,7 +328,7 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
 #if SP_BLCP_MAXREG > 24
   else r = sp_blcp_t<Real, 40>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
 #else
-  else r = BlcpSets{F, U, false};
+  else r = BlcpSets{F, U, false, 0};
 #endif
   F = r.F; U = r.U;
   const bool ok = r.ok;

@@ -48,13 +48,14 @@ __device__ __forceinline__ Real wave_sum(Real x) {
 // one DPP wave sum per column.  No LDS traffic and no barrier inside the pivoting loop (the LDS version paid an LDS round
 // trip + barrier per eliminated column).  MP = compile-time row capacity (variants 16 / 24 / 40: only the one a wave takes
 // enters the instruction cache); rows >= m are inert padding.
-struct BlcpSets { uint64_t F, U; bool ok; };
+struct BlcpSets { uint64_t F, U; bool ok; int iters; };
 template <class Real, int MP>
 __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__ Ap, const Real* __restrict__ bp, const Real* __restrict__ lop,
                                                         const Real* __restrict__ hip, Real* __restrict__ xp, int m, uint64_t pinmask, uint64_t F,
                                                         uint64_t U, int max_iter, unsigned long long* stats, int lane, const bool ZERO_BOUNDS,
-                                                        Real bmax_more = Real(0)) {
+                                                        Real bmax_more = Real(0), bool keep_last = false) {
   // bmax_more: |b| of rows the caller left out of this solve (they enter the feasibility tolerance as in blcp_bpp)
+  // keep_last: when the cap is reached the last iterate is written to xp, clamped into the box (default: xp is left alone)
   // a real function call (not inlined): its register arrays get their own allocation instead of raising the pressure of the
   // whole step kernel; the handful of loads / the one store below go through plain pointers
   const bool row = lane < m;
@@ -140,8 +141,8 @@ __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__
     U = (U & ~(toFree | toBound)) | (toBound & GT);
   }
   if (stats && lane == 0) { atomicAdd(&stats[it < 31 ? it : 31], 1ull); atomicAdd(&stats[33], 1ull); }
-  if (converged && row) xp[lane] = fmin(fmax(rr, loi), hii);
-  return BlcpSets{F, U, converged};
+  if ((converged || keep_last) && row) xp[lane] = fmin(fmax(rr, loi), hii);
+  return BlcpSets{F, U, converged, it};
 }
 
 }  // namespace dartk

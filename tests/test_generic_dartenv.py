@@ -107,6 +107,23 @@ def test_user_skel_with_a_compiled_topology_is_accepted_by_the_lane_kernel_code(
         assert np.abs(o - oo).max() < 1e-5 and not r.any() and not ro.any() and not d.any() and not do.any()
     qg, dqg = g.get_state(); qo, dqo = ora.state()
     assert np.abs(qg - qo).max() < 1e-9 and np.abs(dqg - dqo).max() < 1e-8 and qo[:, 1].min() < -0.6     # they all ended up on the floor
+    # the walker tree (the reference's walker2d.skel as a physics-only card): PhysTopo<Walker2dAllTopo>, up to five of its seven
+    # capsules on the floor -- the second register tier and, beyond it, the fallback solver
+    from dart_env_amd.model_card import load_model
+    wcard = build_card(load_model("walker2d"), None)
+    wcard.frame_skip = 4
+    n = 24
+    g = EmuStepper(wcard, n, precision=64)
+    ora = OracleBatch(wcard, n)
+    qn = rng.uniform(-.01, .01, (n, 9)); vn = rng.uniform(-.01, .01, (n, 9))
+    ora.reset(None, qn, vn); g.reset(None, qn, vn)
+    most = 0
+    for t in range(160):
+        a = np.zeros((n, 9), np.float32); a[:, 3:] = rng.uniform(-1, 1, (n, 6)) * [100, 100, 20, 100, 100, 20]
+        g.step(a); ora.step(a)
+        most = max(most, max(len(w.last_contacts()) for w in ora.worlds))
+    qg, dqg = g.get_state(); qo, dqo = ora.state()
+    assert most >= 4 and np.abs(qg - qo).max() < 1e-8 and np.abs(dqg - dqo).max() < 1e-7, (most, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
     # a model of another shape is declined by every lane kernel (and lands on the tree kernel in the product)
     with pytest.raises(RuntimeError):
         EmuStepper(build_card(parse_skel(SKEL), None), 4, precision=64)
@@ -152,3 +169,77 @@ def test_user_task_on_a_matching_skel_runs_one_env_per_lane():
         big[generic] = (time.perf_counter() - t0) / 10
         env.close()
     assert big[False] < big[True]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["pogo", "walker-tree"])
+@pytest.mark.parametrize("precision,tq,tdq", [(64, 1e-7, 1e-5), (32, 2e-3, 5e-2)])
+def test_fallen_user_model_stays_in_the_register_tiers(precision, tq, tdq, model):
+    """A user model has no termination inside the library: the pogo hoppers fall over under random torques and stay on the floor with
+    every capsule touching.  The physics-only lane variants size their register tiers for that (PhysTopo in planar_kernel.hpp: all four
+    capsules of the hopper chain), the rollout stays on the oracle's, bitwise repeatable, and a batched step of fallen hoppers stays
+    well under the 2.2-2.4 ms it took when every lane waited its turn in the single-lane fallback solver."""
+    import time
+    from dart_env_amd import stepper as st
+    from tests.batch_oracle import OracleBatch
+    from tests.pogo_env import PogoEnv
+    if model == "pogo":
+        env = PogoEnv(num_envs=4, precision=precision)
+        card = env.card
+        env.close()
+        scale = [40.0, 30.0, 15.0]
+    else:   # the reference's walker2d.skel as a physics-only card: seven capsules, a second tier of 4 (fp64: 3) slots as a real call,
+        from dart_env_amd.model_card import build_card, load_model     # the wave-served fallback beyond it
+        card = build_card(load_model("walker2d"), None)
+        card.frame_skip = 4
+        scale = [100.0, 100.0, 20.0, 100.0, 100.0, 20.0]
+    nd, na = card.ndofs, len(scale)
+    n, T = 128, 160
+    rng = np.random.RandomState(5)
+    qn = rng.uniform(-.05, .05, (n, nd)); vn = rng.uniform(-.05, .05, (n, nd))
+    taus = (np.concatenate([np.zeros((T, n, 3)), rng.uniform(-1, 1, (T, n, na)) * scale], axis=2)).astype(np.float32)
+    finals = []
+    for rep in range(2):
+        gpu = st.HipStepper(card, n, precision=precision)
+        assert gpu.query(st.Q_LANE_KERNEL) == 1
+        gpu.reset(None, qn, vn, want_obs=False)
+        if rep == 0:
+            ora = OracleBatch(card, n)
+            ora.reset(None, qn, vn)
+        most = 0
+        for t in range(T):
+            gpu.step(taus[t])
+            if rep == 0:
+                ora.step(taus[t])
+                most = max(most, max(len(w.last_contacts()) for w in ora.worlds[:32]))
+                qg, dqg = gpu.get_state(); qo, dqo = ora.state()
+                # fp32: one env-step from the oracle's state; whether a resting capsule counts as touching in this step is decided
+                # within rounding, so a few envs differ by an impact (dq by ~1, q by dt x that) -- the bulk is held, every position within 0.05
+                eq, edq = np.abs(qg - qo), np.abs(dqg - dqo)
+                eq, edq = (eq.max(), edq.max()) if precision == 64 else (np.percentile(eq, 99), np.percentile(edq, 99))
+                assert eq < tq and edq < tdq and np.abs(qg - qo).max() < 0.05, (t, eq, edq, np.abs(qg - qo).max())
+                if precision == 32:
+                    gpu.set_state(qo, dqo)
+        if rep == 0:
+            assert most >= (3 if model == "pogo" else 4), most      # more capsules on the floor than the base topology's tiers hold
+        finals.append(np.concatenate(gpu.get_state(), axis=1))
+        gpu.close()
+    if precision == 64:
+        assert np.array_equal(finals[0], finals[1])      # bitwise repeatable (the fp32 run is re-synchronised to the oracle, rep 1 is not)
+    # cost: 16 384 hoppers, standing (first steps) against fallen (after 150 steps of random torques)
+    big = st.HipStepper(card, 16384, precision=precision)
+    big.reset(None, None, None, want_obs=False)
+    tau = np.concatenate([np.zeros((16384, 3)), np.random.RandomState(0).uniform(-1, 1, (16384, na)) * scale], axis=1).astype(np.float32)
+    def timed(k):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            big.step(tau)
+        return (time.perf_counter() - t0) / k
+    timed(3)
+    standing = timed(10)
+    timed(150)
+    fallen = timed(10)
+    print("%s x16384 fp%d: standing %.0f us, fallen %.0f us per env-step (host-synchronous)" % (model, precision, standing * 1e6, fallen * 1e6))
+    big.close()
+    # (a fallen walker lies on five to seven capsules, beyond its tiers: every lane is served by the wave in turn -- bounded, not fast)
+    assert fallen < (1.2e-3 if model == "pogo" else 40e-3)

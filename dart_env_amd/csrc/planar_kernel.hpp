@@ -617,7 +617,7 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
       }
       __syncthreads();
       const Real* v = coop + M * (M + 1) / 2;
-      const BlcpSets res = sp_blcp_t<Real, 16>(coop, v, v + M, v + 2 * M, coop + M * (M + 1) / 2 + 3 * M, M, (uint64_t)__shfl(pinmask, owner),
+      const BlcpSets res = sp_blcp_t<Real, 16, true>(coop, v, v + M, v + 2 * M, coop + M * (M + 1) / 2 + 3 * M, M, (uint64_t)__shfl(pinmask, owner),
                                                (uint64_t)__shfl(F, owner), (uint64_t)__shfl(U, owner), coop_iters(max_iter - it, budget), nullptr, lane,
                                                ZERO_BOUNDS, __shfl(bmax_more, owner));
       budget -= res.iters;
@@ -1319,8 +1319,8 @@ __device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* me
   uint64_t pinmask = __ballot(pinned0), F = __ballot(start_free), U = __ballot(upper && !start_free);
   auto solve = [&](uint64_t& Fs, uint64_t& Us, int cap, bool zero_bounds) {
     const int mi = coop_iters(cap, budget);
-    const BlcpSets res = (m <= 16) ? sp_blcp_t<Real, 16>(A, b, lo, hi, x, m, pinmask, Fs, Us, mi, nullptr, lane, zero_bounds, Real(0), true)
-                                   : sp_blcp_t<Real, 24>(A, b, lo, hi, x, m, pinmask, Fs, Us, mi, nullptr, lane, zero_bounds, Real(0), true);
+    const BlcpSets res = (m <= 16) ? sp_blcp_t<Real, 16, true>(A, b, lo, hi, x, m, pinmask, Fs, Us, mi, nullptr, lane, zero_bounds, Real(0), true)
+                                   : sp_blcp_t<Real, 24, true>(A, b, lo, hi, x, m, pinmask, Fs, Us, mi, nullptr, lane, zero_bounds, Real(0), true);
     Fs = res.F; Us = res.U;   // (cap or budget reached: x holds the last iterate, clamped into the box)
     budget -= res.iters;
     __syncthreads();

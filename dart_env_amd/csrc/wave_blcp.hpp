@@ -48,8 +48,10 @@ __device__ __forceinline__ Real wave_sum(Real x) {
 // one DPP wave sum per column.  No LDS traffic and no barrier inside the pivoting loop (the LDS version paid an LDS round
 // trip + barrier per eliminated column).  MP = compile-time row capacity (variants 16 / 24 / 40: only the one a wave takes
 // enters the instruction cache); rows >= m are inert padding.
+// EXT (the lane kernels' callers): bmax_more, keep_last and the iteration count in the result are live; the tree kernel instantiates
+// EXT = false, whose code is the solver as it was before the lane kernels shared it.
 struct BlcpSets { uint64_t F, U; bool ok; int iters; };
-template <class Real, int MP>
+template <class Real, int MP, bool EXT = false>
 __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__ Ap, const Real* __restrict__ bp, const Real* __restrict__ lop,
                                                         const Real* __restrict__ hip, Real* __restrict__ xp, int m, uint64_t pinmask, uint64_t F,
                                                         uint64_t U, int max_iter, unsigned long long* stats, int lane, const bool ZERO_BOUNDS,
@@ -63,7 +65,7 @@ __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__
 #pragma unroll
   for (int j = 0; j < MP; j++) Ar[j] = (row && j < m) ? Ap[TI(lane, j)] : Real(0);
   const Real bi = row ? bp[lane] : Real(0), loi = row ? lop[lane] : Real(0), hii = row ? hip[lane] : Real(0);
-  Real bmax = fmax(fabs(bi), bmax_more);
+  Real bmax = EXT ? fmax(fabs(bi), bmax_more) : fabs(bi);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, o));
   const Real tol = tol_<Real>() * (Real(1) + bmax);
@@ -141,8 +143,8 @@ __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__
     U = (U & ~(toFree | toBound)) | (toBound & GT);
   }
   if (stats && lane == 0) { atomicAdd(&stats[it < 31 ? it : 31], 1ull); atomicAdd(&stats[33], 1ull); }
-  if ((converged || keep_last) && row) xp[lane] = fmin(fmax(rr, loi), hii);
-  return BlcpSets{F, U, converged, it};
+  if ((converged || (EXT && keep_last)) && row) xp[lane] = fmin(fmax(rr, loi), hii);
+  return BlcpSets{F, U, converged, EXT ? it : 0};
 }
 
 }  // namespace dartk

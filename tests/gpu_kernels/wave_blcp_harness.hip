@@ -1,0 +1,61 @@
+// TEST INFRASTRUCTURE -- the wave-cooperative boxed-LCP solver (dart_env_amd/csrc/wave_blcp.hpp: the tree kernel's constraint solver,
+// and the lane kernels' wave-served fallback) behind a plain C entry point, so that tests/test_gpu_wave_blcp.py can feed it random
+// problems and check the complementarity conditions of what comes back.  One problem per 64-lane workgroup, operands in global
+// memory.  Built by __graft_entry__.build() into tests/gpu_kernels/libwave_blcp_harness.so; nothing under dart_env_amd/ loads it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "planar_kernel.hpp"   // tol_, rcp_, TI and wave_blcp.hpp itself
+
+using namespace dartk;
+
+template <class Real, int MP, bool EXT>
+__global__ void __launch_bounds__(64) blcp_harness_kernel(int n_problems, int mcap, const Real* A, const Real* b, const Real* lo, const Real* hi,
+                                                          Real* x, const int* m, const uint64_t* pin, uint64_t* F, uint64_t* U, int* ok, int* iters,
+                                                          int max_iter, int zero_bounds, int keep_last) {
+  const int p = blockIdx.x;
+  if (p >= n_problems) return;
+  const int tri = mcap * (mcap + 1) / 2;
+  BlcpSets r;
+  if constexpr (EXT) r = sp_blcp_t<Real, MP, true>(A + (size_t)p * tri, b + (size_t)p * mcap, lo + (size_t)p * mcap, hi + (size_t)p * mcap, x + (size_t)p * mcap,
+                                                     m[p], pin[p], F[p], U[p], max_iter, nullptr, (int)threadIdx.x, zero_bounds != 0, Real(0), keep_last != 0);
+  else r = sp_blcp_t<Real, MP>(A + (size_t)p * tri, b + (size_t)p * mcap, lo + (size_t)p * mcap, hi + (size_t)p * mcap, x + (size_t)p * mcap, m[p], pin[p],
+                               F[p], U[p], max_iter, nullptr, (int)threadIdx.x, zero_bounds != 0);
+  if (threadIdx.x == 0) { F[p] = r.F; U[p] = r.U; ok[p] = r.ok ? 1 : 0; iters[p] = r.iters; }
+}
+
+template <class Real>
+static int run(int n, int mp, int ext, int mcap, const Real* A, const Real* b, const Real* lo, const Real* hi, Real* x, const int* m, const uint64_t* pin,
+               uint64_t* F, uint64_t* U, int* ok, int* iters, int max_iter, int zero_bounds, int keep_last) {
+  const size_t tri = (size_t)mcap * (mcap + 1) / 2;
+  Real *dA, *db, *dlo, *dhi, *dx; int *dm, *dok, *dit; uint64_t *dpin, *dF, *dU;
+#define CK(e) do { if ((e) != hipSuccess) return -1; } while (0)
+  CK(hipMalloc(&dA, n * tri * sizeof(Real))); CK(hipMalloc(&db, n * mcap * sizeof(Real))); CK(hipMalloc(&dlo, n * mcap * sizeof(Real)));
+  CK(hipMalloc(&dhi, n * mcap * sizeof(Real))); CK(hipMalloc(&dx, n * mcap * sizeof(Real))); CK(hipMalloc(&dm, n * sizeof(int)));
+  CK(hipMalloc(&dok, n * sizeof(int))); CK(hipMalloc(&dit, n * sizeof(int))); CK(hipMalloc(&dpin, n * 8)); CK(hipMalloc(&dF, n * 8)); CK(hipMalloc(&dU, n * 8));
+  CK(hipMemcpy(dA, A, n * tri * sizeof(Real), hipMemcpyHostToDevice)); CK(hipMemcpy(db, b, n * mcap * sizeof(Real), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dlo, lo, n * mcap * sizeof(Real), hipMemcpyHostToDevice)); CK(hipMemcpy(dhi, hi, n * mcap * sizeof(Real), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dx, x, n * mcap * sizeof(Real), hipMemcpyHostToDevice)); CK(hipMemcpy(dm, m, n * sizeof(int), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dpin, pin, n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dF, F, n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dU, U, n * 8, hipMemcpyHostToDevice));
+#define LAUNCH(MP, EXT) hipLaunchKernelGGL((blcp_harness_kernel<Real, MP, EXT>), dim3(n), dim3(64), 0, 0, n, mcap, dA, db, dlo, dhi, dx, dm, dpin, dF, dU, dok, dit, max_iter, zero_bounds, keep_last)
+  if (mp == 16 && ext) LAUNCH(16, true); else if (mp == 24 && ext) LAUNCH(24, true); else if (mp == 16) LAUNCH(16, false);
+  else if (mp == 24) LAUNCH(24, false); else if (mp == 32) LAUNCH(32, false); else if (mp == 40) LAUNCH(40, false); else return -2;
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(x, dx, n * mcap * sizeof(Real), hipMemcpyDeviceToHost)); CK(hipMemcpy(F, dF, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(U, dU, n * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(ok, dok, n * sizeof(int), hipMemcpyDeviceToHost)); CK(hipMemcpy(iters, dit, n * sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(db); hipFree(dlo); hipFree(dhi); hipFree(dx); hipFree(dm); hipFree(dok); hipFree(dit); hipFree(dpin); hipFree(dF); hipFree(dU);
+  return 0;
+}
+
+extern "C" {
+// n problems of up to `mcap` rows each (row count m[p]); A packed lower triangle (TI), row-major per problem with stride mcap(mcap+1)/2;
+// mp = the register variant (16 / 24 / 32 / 40 rows), ext = the lane kernels' instantiation (mp 16 or 24).  Returns 0, -1 (HIP error), -2 (variant).
+int wave_blcp_run_f64(int n, int mp, int ext, int mcap, const double* A, const double* b, const double* lo, const double* hi, double* x, const int* m,
+                      const uint64_t* pin, uint64_t* F, uint64_t* U, int* ok, int* iters, int max_iter, int zero_bounds, int keep_last) {
+  return run<double>(n, mp, ext, mcap, A, b, lo, hi, x, m, pin, F, U, ok, iters, max_iter, zero_bounds, keep_last);
+}
+int wave_blcp_run_f32(int n, int mp, int ext, int mcap, const float* A, const float* b, const float* lo, const float* hi, float* x, const int* m,
+                      const uint64_t* pin, uint64_t* F, uint64_t* U, int* ok, int* iters, int max_iter, int zero_bounds, int keep_last) {
+  return run<float>(n, mp, ext, mcap, A, b, lo, hi, x, m, pin, F, U, ok, iters, max_iter, zero_bounds, keep_last);
+}
+}

@@ -292,7 +292,8 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
         while (time.perf_counter() - t_s) * 1e3 < args.spinup_ms and spinup["steps"] < 20000:
             sb.run(25); sb.sync(); spinup["steps"] += 25
         spinup["ms"] = round((time.perf_counter() - t_s) * 1e3, 1)
-        sb.close()
+        # (the scratch batch is released after the timed region: a hipFree here is a device-wide stall right before the measurement, and
+        # 20 ms of idle are enough for the clocks to drop again -- tools/gpu/spin_probe.py: 32.6 us released first, 32.2 kept, 34.7 after 20 ms idle)
     b.reset()
     b.mark(0)                                  # creates the handle's timing events outside the timed region
     b.run(args.warmup)
@@ -311,6 +312,8 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     device_sync()                              # torch.cuda.synchronize(): waits for every stream of the device, the stepper's included
     elapsed = time.perf_counter() - t0
     ms_kernel = b.elapsed_ms() / args.steps    # the event wait and read-out sit outside the wall-clock region
+    if spinup["steps"]:
+        sb.close()
     offsets = [env_offset]
     per_rank = [{"rank": rank, "wall_ms_per_step": elapsed / args.steps * 1e3, "kernel_ms_per_step": ms_kernel}]
     if dist is not None:

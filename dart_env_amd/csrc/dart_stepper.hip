@@ -287,6 +287,10 @@ int dart_configure(DartStepper* h, int key, double value) {
       h->ep_stats = value != 0;
       break;
     case DART_CFG_DEBUG_FORCE_FALLBACK: h->impl->set_force_slow(value != 0 ? 1 : 0); break;
+    case DART_CFG_LAUNCH_ORDER:
+      CHK(h, hipStreamSynchronize(h->stream));
+      if (h->impl->set_launch_order(value != 0 ? 1 : 0) != 0) { h->err = "launch order: allocation failed"; return DART_E_INVALID; }
+      break;
     case DART_CFG_BLOCK_THREADS:
       if (value != 64 && value != 32 && value != 16) { h->err = "block threads must be 16, 32 or 64"; return DART_E_INVALID; }
       h->impl->block_threads = (int)value; break;

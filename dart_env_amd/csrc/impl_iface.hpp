@@ -28,6 +28,7 @@ struct Impl {
   virtual hipError_t prepare(int64_t) { return hipSuccess; }   // per-handle device allocations of the implementation
   virtual void release() {}
   virtual hipError_t debug_dump(double*) { return hipErrorInvalidValue; }
+  virtual int set_launch_order(int /*longest_first*/) { return 0; }   // DART_CFG_LAUNCH_ORDER: tree kernel; the lane kernels have no use for it
   virtual int set_ext_force(int /*body*/, const double* /*host_force*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int set_task_state(hipStream_t, const uint8_t* /*d_mask*/, const double* /*d_values*/, int64_t /*n*/) { return DART_E_UNSUPPORTED; }
   virtual int slots() const = 0;

@@ -262,7 +262,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
   }
   M.s_max = (Real)c.state_abs_max; M.v_clip = (Real)c.obs_vel_clip; M.noise = (Real)c.reset_noise; M.noise_v = (Real)c.reset_noise_vel;
   M.inv_envdt = (Real)(1.0 / (c.dt * c.frame_skip));
-  M.solver_iters = 600; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.dbg = nullptr; M.creport = nullptr; M.creport_count = nullptr; M.cf_report = nullptr;
+  M.solver_iters = 600; M.pgs_fallback_sweeps = 600; M.stats = nullptr; M.sched_perm = nullptr; M.sched_cost = nullptr; M.dbg = nullptr; M.creport = nullptr; M.creport_count = nullptr; M.cf_report = nullptr;
   if (c.task == DART_TASK_NONE && c.obs_dim != 2 * c.ndofs) return "physics-only obs must be [q, dq]";
   return "";
 }

@@ -56,8 +56,9 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
   const SpatialModel<Real>& Md = *Mp;
   const int lane = threadIdx.x;
-  const int64_t e = blockIdx.x;
-  if (e >= n_envs) return;
+  if ((int64_t)blockIdx.x >= n_envs) return;
+  const int64_t e = Md.sched_perm ? (int64_t)Md.sched_perm[blockIdx.x] : (int64_t)blockIdx.x;
+  const long long sched_t0 = Md.sched_cost ? (long long)__builtin_readcyclecounter() : 0ll;
   const int n = Md.n;
   SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp, Md.reg_lcp);
   int* cflags = S.imisc + 2;
@@ -192,6 +193,7 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
   if ((Md.task == 10 || Md.task == 11) && lane < 3) S.misc[4 + lane] = tstate[4 * e + lane];
   __syncthreads();
   sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
+  if (Md.sched_cost && lane == 0) Md.sched_cost[e] = (unsigned int)((long long)__builtin_readcyclecounter() - sched_t0);
 }
 
 // Dynamics quantities of the CURRENT state (pydart2's skel.M and skel.c, reference gym/envs/dart/walker3d_spd.py:40-55):
@@ -328,6 +330,38 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
   if ((Md.task == 10 || Md.task == 11) && lane < 3) S.misc[4 + lane] = tstate[4 * e + lane];
   __syncthreads();
   if (obs && (m || !obs_masked_only)) sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
+}
+
+// Dispatch order of the next step (SpatialModel::sched_perm, DART_CFG_LAUNCH_ORDER): env indices by descending duration of the step
+// that just ran.  A launch ends when its last workgroup does and workgroups are dispatched in blockIdx order, so the expensive envs go
+// first (longest-processing-time-first packing); 1 024 buckets of duration relative to the slowest env are all that needs -- the order
+// inside a bucket is whatever the atomics make it.  One workgroup; ~10 us at 16 384 envs behind a step kernel of milliseconds.
+template <class Real>   // (a template only so that the two precision units may both hold it)
+__global__ void __launch_bounds__(1024) sp_sched_kernel(int64_t n, const unsigned int* __restrict__ cost, int* __restrict__ perm) {
+  __shared__ unsigned int hist[1024], scan[1024], cmax;
+  const int t = threadIdx.x;
+  hist[t] = 0u;
+  if (t == 0) cmax = 1u;
+  __syncthreads();
+  unsigned int m = 0u;
+  for (int64_t i = t; i < n; i += 1024) m = cost[i] > m ? cost[i] : m;
+  atomicMax(&cmax, m);
+  __syncthreads();
+  const unsigned long long cm = cmax;
+  auto bucket = [&](unsigned int c) { return 1023u - (unsigned int)(((unsigned long long)c * 1023ull) / cm); };
+  for (int64_t i = t; i < n; i += 1024) atomicAdd(&hist[bucket(cost[i])], 1u);
+  __syncthreads();
+  scan[t] = hist[t];
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {   // inclusive prefix sum over the buckets
+    const unsigned int v = t >= d ? scan[t - d] : 0u;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  hist[t] = scan[t] - hist[t];           // first slot of bucket t
+  __syncthreads();
+  for (int64_t i = t; i < n; i += 1024) perm[atomicAdd(&hist[bucket(cost[i])], 1u)] = (int)i;
 }
 
 // (N, n) doubles <-> the kernel's AoS state

@@ -89,6 +89,10 @@ struct SpatialModel {
   Real* cf_report;             // [n_envs][n]: constraint_forces() of the last world step (recorded with the contacts)
   double* dbg;                 // optional [n_envs][160] dump of the last LCP (debug builds of the tests only)
   unsigned long long* stats;   // optional [64]: [0..31] pivoting iterations per solve, [32] PGS fallbacks, [33] solves
+  // launch order (dart_debug_sched): workgroup b steps env sched_perm[b] (null: env b) and leaves its duration in s_memtime ticks in
+  // sched_cost[env] -- the most expensive envs of the previous step can be dispatched first (longest-processing-time-first packing)
+  const int* sched_perm;
+  unsigned int* sched_cost;
 };
 
 // 128-bit LDS access of `width` consecutive Reals

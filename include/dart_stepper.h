@@ -60,8 +60,12 @@ enum {
   DART_CFG_STATS = 7,       /* 1: histogram the wave-level pivoting iteration counts (dart_get_stats) */
   DART_CFG_EPISODE_STATS = 8,/* 1: keep per-env episode return / length accumulators on the device (dart_get_episode_stats) */
   DART_CFG_CONTACT_REPORT = 9, /* 1: record the contacts of every env-step's last world step (dart_get_contacts) */
-  DART_CFG_DEBUG_FORCE_FALLBACK = 10 /* planar register kernels, tests only: 1 routes every env that touches the floor through the
+  DART_CFG_DEBUG_FORCE_FALLBACK = 10, /* planar register kernels, tests only: 1 routes every env that touches the floor through the
                                single-lane fallback solver, the path of an env with more contacts than the kernel's slot tiers hold */
+  DART_CFG_LAUNCH_ORDER = 11 /* tree kernel (one env per workgroup): 1 (default) = the workgroups of a step are dispatched in the order
+                               of the envs' durations at the previous step, longest first -- a launch ends when its last workgroup
+                               does, and an env that was expensive (many contacts, a long pivoting run) mostly still is; 0 = index
+                               order.  Results do not depend on it (each env is stepped by one workgroup either way). */
 };
 
 /* Library-level error text for failures that happen before a handle exists (handle == NULL). */
@@ -139,6 +143,7 @@ int dart_get_stats(DartStepper* h, uint64_t* hist64, int clear);
 /* Debugging aid of the spatial kernel (needs DART_CFG_STATS): per env 160 doubles = {m, ncp, x[40], b[40], hi[40], diagA[40]}
  * of the last LCP solved. */
 int dart_debug_dump(DartStepper* h, double* out160);
+
 
 /* Zero-copy read access to the pinned host staging buffers that dart_step_wait / dart_step fill: (N, obs_dim) float32
  * observations, (N,) float32 rewards, (N,) done and truncated flags.  Valid until the next step / reset on this handle;

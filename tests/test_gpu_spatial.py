@@ -904,3 +904,30 @@ def test_tree_pattern_kernel_is_selected_only_on_an_exact_match():
         assert np.abs(qg - qo)[alive].max(initial=0) < 1e-8 and np.abs(dqg - dqo)[alive].max(initial=0) < 1e-6, t
     assert alive.sum() >= 8
     s.close()
+
+
+def test_launch_order_does_not_change_results():
+    """DART_CFG_LAUNCH_ORDER (tree kernel): the workgroups of a step are dispatched by the envs' durations at the previous step, longest
+    first (default above 4 096 envs).  Each env is stepped by one workgroup either way: states, observations, rewards, done flags and
+    episode counters are bitwise those of index order, through auto-resets."""
+    from dart_env_amd import stepper as st
+    card = card_for("DartHumanWalker-v1")
+    n = 6144
+    rng = np.random.RandomState(3)
+    acts = rng.uniform(-1, 1, (14, n, card.act_dim)).astype(np.float32)
+    outs = []
+    for order in (1, 0):
+        g = st.HipStepper(card, n, precision=32)
+        g.configure(st.CFG_AUTORESET, 1); g.configure(st.CFG_SEED, 5)
+        g.configure(st.CFG_LAUNCH_ORDER, order)
+        g.reset(None, None, None, want_obs=False)
+        rec = []
+        for t in range(14):
+            o, r, d, tr = g.step(acts[t])
+            rec += [o.copy(), r.copy(), d.copy()]
+        rec += list(g.get_state()) + list(g.counters())
+        outs.append(rec)
+        g.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert any(x.any() for x in outs[0][2::3])      # some episodes ended and restarted

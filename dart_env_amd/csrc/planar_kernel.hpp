@@ -352,7 +352,8 @@ template <class Real> __device__ __forceinline__ Real inf_() { return Real(__bui
 template <class Real> __device__ __forceinline__ Real tol_() { return sizeof(Real) == 4 ? Real(2e-6) : Real(1e-12); }
 
 }  // namespace dartk
-#ifdef __HIPCC__   // the wave-cooperative solver (readlane, DPP) exists in the device build only; the host build of the lane
+#if defined(__HIPCC__) || defined(DART_WAVE_EMU)   // the wave-cooperative solver (readlane, DPP): device build (and the fiber emulation of
+                                                    // tests/kernel_emu/fake_wave_include); the lane-at-a-time host build of the lane
 #include "wave_blcp.hpp"   // kernels (tests/kernel_emu) serves the same rows with the single-lane loops of slow_constraints
 #define DART_WAVE_COOP 1
 #endif

@@ -4,6 +4,13 @@
 #include "spatial_dynamics.hpp"
 #include "tree_patterns.hpp"
 
+// A wavefront executes in lock-step: between two barriers, an instruction of every lane completes before the next one starts, so "all
+// lanes read x, then one lane overwrites it" needs no barrier on the device.  The fiber emulation of tests/kernel_emu/fake_wave_include
+// runs a lane alone from one cross-lane operation to the next and defines this as a rendezvous; the device build defines it as nothing.
+#ifndef DART_LOCKSTEP_FENCE
+#define DART_LOCKSTEP_FENCE() ((void)0)
+#endif
+
 namespace dartk {
 
 // ------------------------------------------------------------------ wave-parallel dense kernels (row-owner scheme)
@@ -94,6 +101,7 @@ __device__ __forceinline__ void sp_chol_backsolve_lds(const Real* Lf, const Real
   for (int j = n - 1; j >= 0; j--) {
     __syncthreads();
     const Real xj = x[j] * sinv[j];
+    DART_LOCKSTEP_FENCE();   // every lane has read x[j] before lane j overwrites it
     if (lane == j) x[j] = xj;
     if (lane < j) x[lane] -= Lf[HL(j, lane)] * xj;
   }
@@ -138,6 +146,7 @@ __device__ __forceinline__ void sp_chol_fwdsolve(const Real* Lf, const Real* sin
   for (int j = 0; j < n; j++) {
     __syncthreads();
     const Real xj = x[j] * sinv[j];
+    DART_LOCKSTEP_FENCE();   // every lane has read x[j] before lane j overwrites it
     if (lane == j) x[j] = xj;
     if (lane > j && lane < n) x[lane] -= Lf[HL(lane, j)] * xj;
   }

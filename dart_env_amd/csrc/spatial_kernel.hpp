@@ -23,6 +23,11 @@
 #pragma once
 #include "spatial_tasks.hpp"
 
+// the workgroup's dynamic LDS block (the host emulation of tests/kernel_emu/fake_wave_include supplies its own definition)
+#ifndef DART_DYNAMIC_LDS
+#define DART_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 namespace dartk {
 
 // ------------------------------------------------------------------ kernels: one wavefront (64 threads) per env
@@ -53,7 +58,7 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
                                                       float* __restrict__ reward, uint8_t* __restrict__ done,
                                                       uint8_t* __restrict__ truncated, int autoreset, uint64_t seed,
                                                       uint64_t env_offset) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  DART_DYNAMIC_LDS(sp_smem);
   const SpatialModel<Real>& Md = *Mp;
   const int lane = threadIdx.x;
   if ((int64_t)blockIdx.x >= n_envs) return;
@@ -204,7 +209,7 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
                                                           const Real* __restrict__ qs, const Real* __restrict__ dqs, int soa,
                                                           double* __restrict__ mass_out, double* __restrict__ bias_out,
                                                           double* __restrict__ pose_out, int nbodies) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  DART_DYNAMIC_LDS(sp_smem);
   const SpatialModel<Real>& Md = *Mp;
   const int lane = threadIdx.x;
   const int64_t e = blockIdx.x;
@@ -287,7 +292,7 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
                                                        const uint8_t* __restrict__ mask, const double* __restrict__ qnoise,
                                                        const double* __restrict__ vnoise, float* __restrict__ obs,
                                                        uint64_t seed, uint64_t env_offset, int obs_masked_only) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  DART_DYNAMIC_LDS(sp_smem);
   const SpatialModel<Real>& Md = *Mp;
   const int lane = threadIdx.x;
   const int64_t e = blockIdx.x;

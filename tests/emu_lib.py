@@ -16,14 +16,16 @@ from dart_env_amd import stepper as st
 
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_emu")
 _LIB = os.environ.get("DART_EMU_LIB", os.path.join(_DIR, "libdart_planar_emu.so"))   # the override serves bitwise A/B checks of kernel edits
-_lib = None
+_TREE_LIB = os.path.join(_DIR, "libdart_spatial_emu.so")   # the tree kernel (one env per wavefront) on the fiber runtime of fake_wave_include/
+_libs = {}
 
 
-def lib():
-    global _lib
+def lib(tree=False):
+    path = _TREE_LIB if tree else _LIB
+    _lib = _libs.get(path)
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", _DIR])
-        L = C.CDLL(_LIB)
+        subprocess.check_call(["make", "-s", "-C", _DIR] + (["libdart_spatial_emu.so"] if tree else []))
+        L = C.CDLL(path)
         vp, dp, fp, u8 = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
         L.emu_create.restype = vp
         L.emu_create.argtypes = [C.POINTER(DartModelCard), C.c_int64, C.c_int, C.c_int, C.c_char_p, C.c_int]
@@ -44,7 +46,7 @@ def lib():
         L.emu_step.argtypes = [vp, fp, fp, fp, u8, u8, C.c_int, C.c_uint64, C.c_uint64]
         L.emu_state.argtypes = [vp, dp, dp, C.c_int]
         L.emu_counters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
-        _lib = L
+        _lib = _libs[path] = L
     return _lib
 
 
@@ -53,8 +55,9 @@ def _p(a, ct):
 
 
 class EmuStepper:
-    def __init__(self, card, num_envs, precision=64, allow_static=True):
-        self.L = lib()
+    def __init__(self, card, num_envs, precision=64, allow_static=True, tree=False):
+        """tree=True: the tree kernel (csrc/spatial_*.hpp) instead of the lane kernels -- any card"""
+        self.L = lib(tree)
         self.card, self.n, self.precision = card, int(num_envs), precision
         why = C.create_string_buffer(512)
         self.h = self.L.emu_create(C.byref(card), self.n, precision, int(allow_static), why, 512)

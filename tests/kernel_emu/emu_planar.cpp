@@ -5,6 +5,14 @@
 #include <string>
 #include <vector>
 
+#ifdef EMU_TREE_KERNEL   // libdart_spatial_emu.so: the same interface over the tree kernel, on the fiber runtime of fake_wave_include/
+#include "spatial_impl.hpp"
+using namespace dartk;
+namespace dartk {
+std::unique_ptr<Impl> make_planar_impl_f32(const DartModelCard& c, std::string& why, bool) { return make_spatial<float>(c, why); }
+std::unique_ptr<Impl> make_planar_impl_f64(const DartModelCard& c, std::string& why, bool) { return make_spatial<double>(c, why); }
+}
+#else
 #include "planar_impl.hpp"
 
 using namespace dartk;
@@ -13,6 +21,7 @@ namespace dartk {   // the spatial factories live in TUs this library does not b
 std::unique_ptr<Impl> make_planar_impl_f32(const DartModelCard& c, std::string& why, bool s) { return make_planar<float>(c, why, s); }
 std::unique_ptr<Impl> make_planar_impl_f64(const DartModelCard& c, std::string& why, bool s) { return make_planar<double>(c, why, s); }
 }
+#endif
 
 struct Emu {
   DartModelCard card;

@@ -1,0 +1,84 @@
+"""The TREE kernel (dart_env_amd/csrc/spatial_*.hpp + wave_blcp.hpp: one env per 64-lane wavefront, lanes cooperating through LDS,
+barriers, ballots, shuffles, v_readlane and DPP) held against the fp64 oracle WITHOUT a GPU: the device source is compiled by g++
+against tests/kernel_emu/fake_wave_include/hip/hip_runtime.h, where every lane of a workgroup is a fiber and every cross-lane operation
+a rendezvous with the hardware's semantics.  This is the kernel of BASELINE config 4 (DartHumanWalker-v1) and of every model the lane
+kernels do not take; its GPU parity tests are tests/test_gpu_spatial.py and tests/test_gpu_long_parity.py."""
+import numpy as np
+import pytest
+
+from dart_env_amd.model_card import card_for
+from tests.batch_oracle import OracleBatch
+from tests.emu_lib import EmuStepper
+
+CASES = [   # env id, card options, envs, env-steps: every instantiation of the step kernel the library launches
+    ("DartHumanWalker-v1", {}, 3, 14),                       # big model, compile-time factor pattern, register LCP solver
+    ("DartHumanWalker-v1", {"generic_kernel": True}, 2, 6),  # the same model on the general (EXTRAS) instantiation
+    ("DartWalker3d-v1", {}, 3, 12),                          # link-link box contacts (PAIRS), register solver
+    ("DartWalker3dSPD-v1", {}, 2, 8),                        # stable-PD controller: second factorisation, carried constraint forces
+    ("DartDog-v1", {}, 3, 12),                               # free root joint, LDS solver
+    ("DartHopper-v1", {"generic_kernel": True}, 4, 20),      # small models on the tree kernel
+    ("DartWalker2d-v1", {"generic_kernel": True}, 3, 12),
+    ("DartHalfCheetah-v1", {"generic_kernel": True}, 3, 12), # welds, joint springs
+    ("DartSnake7Link-v1", {"generic_kernel": True}, 3, 12),  # fluid forces
+    ("DartCartPole-v1", {"generic_kernel": True}, 4, 30),
+    ("DartReacher-v1", {"generic_kernel": True}, 3, 12),
+    ("DartReacher3d-v1", {"generic_kernel": True}, 3, 8),
+]
+
+
+@pytest.mark.parametrize("env_id,kw,n,T", CASES, ids=[c[0] + ("/generic" if c[1] else "") for c in CASES])
+def test_tree_kernel_matches_oracle_on_the_host(env_id, kw, n, T):
+    card = card_for(env_id, **kw)
+    g = EmuStepper(card, n, precision=64, tree=True)
+    ora = OracleBatch(card, n)
+    rng = np.random.RandomState(1)
+    qn = rng.uniform(-.005, .005, (n, card.ndofs)); vn = rng.uniform(-.005, .005, (n, card.ndofs))
+    og = g.reset(None, qn, vn); ora.reset(None, qn, vn)
+    assert np.abs(og - ora.obs()).max() < 1e-6
+    resets = 0
+    for t in range(T):
+        a = (rng.uniform(-1, 1, (n, card.act_dim)) * (2.5 if t % 5 == 4 else 1.0)).astype(np.float32)     # some actions beyond the clamp
+        o, r, d, tr = g.step(a)
+        oo, ro, do, to = ora.step(a)
+        qg, dqg = g.get_state(); qo, dqo = ora.state()
+        assert np.abs(qg - qo).max() < 1e-9 and np.abs(dqg - dqo).max() < 1e-7, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        assert np.array_equal(d.astype(bool), np.asarray(do, bool)) and np.abs(o - oo).max() < 2e-5 and np.abs(r - ro).max() < 1e-4, t
+        if np.any(do):
+            resets += int(np.sum(do))
+            qn = rng.uniform(-.005, .005, (n, card.ndofs)); vn = rng.uniform(-.005, .005, (n, card.ndofs))
+            g.reset(np.asarray(do, np.uint8), qn, vn, want_obs=False); ora.reset(np.asarray(do, bool), qn, vn)
+    g.close()
+
+
+def test_tree_kernel_fp32_and_contact_report_on_the_host():
+    """the fp32 instantiation stays near the oracle step by step (re-synchronised every step), and the reporting instantiation
+    (dart_get_contacts) returns the oracle's contacts: bodies, points, forces"""
+    card = card_for("DartHumanWalker-v1")
+    n = 2
+    g32 = EmuStepper(card, n, precision=32, tree=True)
+    g64 = EmuStepper(card, n, precision=64, tree=True)
+    g64.enable_contact_report(True)
+    ora = OracleBatch(card, n)
+    rng = np.random.RandomState(2)
+    qn = rng.uniform(-.005, .005, (n, card.ndofs)); vn = rng.uniform(-.005, .005, (n, card.ndofs))
+    for g in (g32, g64):
+        g.reset(None, qn, vn)
+    ora.reset(None, qn, vn)
+    seen = 0
+    for t in range(8):
+        a = rng.uniform(-1, 1, (n, card.act_dim)).astype(np.float32)
+        g32.step(a); g64.step(a); ora.step(a)
+        qo, dqo = ora.state()
+        q32, dq32 = g32.get_state()
+        assert np.abs(q32 - qo).max() < 2e-3 and np.percentile(np.abs(dq32 - dqo), 90) < 5e-2, t
+        g32.set_state(qo, dqo)
+        cnt, bod, pt, fc = g64.contacts()
+        for i, w in enumerate(ora.worlds):
+            rep = w.contact_report()
+            assert cnt[i] == len(rep)
+            if len(rep):
+                seen += 1
+                assert np.array_equal(bod[i, :len(rep)], rep[:, :2].astype(np.int32))
+                assert np.allclose(pt[i, :len(rep)], rep[:, 2:5], atol=1e-9) and np.allclose(fc[i, :len(rep)], rep[:, 5:8], atol=1e-5, rtol=1e-6)
+    assert seen >= 8
+    g32.close(); g64.close()

@@ -20,11 +20,14 @@ _TREE_LIB = os.path.join(_DIR, "libdart_spatial_emu.so")   # the tree kernel (on
 _libs = {}
 
 
-def lib(tree=False):
-    path = _TREE_LIB if tree else _LIB
+_WAVE_LIB = os.path.join(_DIR, "libdart_planar_wave_emu.so")   # the lane kernels as whole 64-lane waves on the same fiber runtime
+
+
+def lib(tree=False, waves=False):
+    path = _TREE_LIB if tree else (_WAVE_LIB if waves else _LIB)
     _lib = _libs.get(path)
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", _DIR] + (["libdart_spatial_emu.so"] if tree else []))
+        subprocess.check_call(["make", "-s", "-C", _DIR] + (["libdart_spatial_emu.so"] if tree else ["libdart_planar_wave_emu.so"] if waves else []))
         L = C.CDLL(path)
         vp, dp, fp, u8 = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
         L.emu_create.restype = vp
@@ -55,9 +58,10 @@ def _p(a, ct):
 
 
 class EmuStepper:
-    def __init__(self, card, num_envs, precision=64, allow_static=True, tree=False):
-        """tree=True: the tree kernel (csrc/spatial_*.hpp) instead of the lane kernels -- any card"""
-        self.L = lib(tree)
+    def __init__(self, card, num_envs, precision=64, allow_static=True, tree=False, waves=False):
+        """tree=True: the tree kernel (csrc/spatial_*.hpp) instead of the lane kernels -- any card.  waves=True: the lane kernels run as
+        whole 64-lane wavefronts (fibers): wave votes, the wave-served fallback and the hand-off behave as on the device"""
+        self.L = lib(tree, waves)
         self.card, self.n, self.precision = card, int(num_envs), precision
         why = C.create_string_buffer(512)
         self.h = self.L.emu_create(C.byref(card), self.n, precision, int(allow_static), why, 512)

@@ -1,0 +1,65 @@
+"""The lane kernels (planar_kernel.hpp: one env per lane) executed as WHOLE 64-lane wavefronts on the host: the device source on the fiber
+runtime of tests/kernel_emu/fake_wave_include (see tests/test_tree_kernel_emu_parity.py).  tests/test_kernel_emu_parity.py runs the same
+kernels one lane at a time, which leaves out everything lanes do together on the device: the wave votes that pick a tier and stop the
+pivoting loops, the wave-served fallback for an env beyond its register tiers (wave_constraints), the hand-off of lanes that keep
+pivoting to the wave solver (blcp_bpp: coop) and their iteration budget.  Here they run as they do on the GPU, against the fp64 oracle."""
+import numpy as np
+import pytest
+
+from dart_env_amd.model_card import build_card, card_for, load_model
+from tests.batch_oracle import OracleBatch
+from tests.emu_lib import EmuStepper
+
+
+def rollout(card, n, T, force_fallback=False, noise=0.1, scale=None, seed=0):
+    g = EmuStepper(card, n, precision=64, waves=True)
+    if force_fallback:
+        g.force_slow(True)
+    ora = OracleBatch(card, n)
+    rng = np.random.RandomState(seed)
+    nd = card.ndofs
+    qn = rng.uniform(-noise, noise, (n, nd)); vn = rng.uniform(-noise, noise, (n, nd))
+    g.reset(None, qn, vn); ora.reset(None, qn, vn)
+    worst, most = [0.0, 0.0], 0
+    for t in range(T):
+        a = rng.uniform(-1, 1, (n, card.act_dim))
+        a = (a if scale is None else np.concatenate([np.zeros((n, 3)), a[:, 3:] * scale], axis=1)).astype(np.float32)
+        o, r, d, tr = g.step(a)
+        oo, ro, do, to = ora.step(a)
+        most = max(most, max(len(w.last_contacts()) for w in ora.worlds))
+        qg, dqg = g.get_state(); qo, dqo = ora.state()
+        worst = [max(worst[0], np.abs(qg - qo).max()), max(worst[1], np.abs(dqg - dqo).max())]
+        assert np.array_equal(d.astype(bool), np.asarray(do, bool)), t
+        if np.any(do):
+            qn = rng.uniform(-noise, noise, (n, nd)); vn = rng.uniform(-noise, noise, (n, nd))
+            g.reset(np.asarray(do, np.uint8), qn, vn, want_obs=False); ora.reset(np.asarray(do, bool), qn, vn)
+    g.close()
+    return worst, most
+
+
+@pytest.mark.parametrize("env_id,n,T", [("DartHopper-v1", 128, 30), ("DartWalker2d-v1", 64, 30), ("DartHalfCheetah-v1", 128, 40), ("DartSnake7Link-v1", 64, 20)])
+def test_whole_waves_follow_the_oracle(env_id, n, T):
+    worst, most = rollout(card_for(env_id), n, T)
+    assert worst[0] < 1e-9 and worst[1] < 1e-7, worst
+
+
+def test_wave_served_fallback_follows_the_oracle():
+    """every touching half cheetah through wave_constraints (rows built by the lanes together, both pivoting stages in the register wave
+    solver), as DART_CFG_DEBUG_FORCE_FALLBACK does on the GPU"""
+    worst, most = rollout(card_for("DartHalfCheetah-v1"), 64, 25, force_fallback=True)
+    assert worst[0] < 1e-9 and worst[1] < 1e-7 and most >= 3, (worst, most)
+
+
+def test_fallen_user_models_on_whole_waves():
+    """physics-only cards (no termination): the walker tree lies on up to seven capsules -- second register tier as a real call, hand-off,
+    wave-served fallback beyond it; the pogo hopper keeps all four in its register tier"""
+    wcard = build_card(load_model("walker2d"), None)
+    wcard.frame_skip = 4
+    worst, most = rollout(wcard, 64, 110, noise=0.01, scale=np.array([100, 100, 20, 100, 100, 20.0]), seed=3)
+    assert most >= 4 and worst[0] < 1e-7 and worst[1] < 1e-5, (worst, most)      # four capsules: one more than the fp64 tier holds -> served by the wave
+    from dart_env_amd.skel import parse_skel
+    from tests.pogo_env import SKEL as POGO, SCALE
+    pcard = build_card(parse_skel(POGO), None)
+    pcard.frame_skip = 4
+    worst, most = rollout(pcard, 64, 120, noise=0.01, scale=np.asarray(SCALE, float), seed=4)
+    assert most >= 3 and worst[0] < 1e-8 and worst[1] < 1e-6, (worst, most)

@@ -175,10 +175,14 @@ def attach_valu(roof, env_id, n, dtype, kernel_ms):
     fpe = fl[env_id]["flops_per_env_step"]
     achieved = fpe * n / (kernel_ms * 1e-3) / 1e12
     peak = VALU_PEAK_TFLOPS[dtype]
+    tree = "kernel" in fl[env_id]     # the tree kernel's count: summed over the 64 lanes of the env's wavefront (tests/kernel_emu/emu_tree_flops.cpp)
     roof["valu"] = {"bound": "valu", "flops_per_env_step": fpe, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "counted": fl[env_id].get("method", fl.get("_method")), "sample": fl[env_id].get("sample"),
-                    "note": "useful flops of one env's lane (pivoting loops end on the lane's own convergence); the wave executes more: "
-                            "it iterates until its slowest lane is done -- see valu_issue for the measured issue statistics"}
+                    "counted": fl[env_id].get("method", fl.get("_method")) if not tree else
+                               "tests/kernel_emu/emu_tree_flops.cpp: the tree kernel's own source with a counting scalar on the fiber runtime; " + fl[env_id]["kernel"],
+                    "sample": fl[env_id].get("sample"),
+                    "note": ("flops the 64 lanes of an env's wavefront execute (fp64 code paths), idle lanes not counted" if tree else
+                             "useful flops of one env's lane (pivoting loops end on the lane's own convergence); the wave executes more: "
+                             "it iterates until its slowest lane is done -- see valu_issue for the measured issue statistics")}
 
 
 def host_surface(env_id, n, local_rank, precision, budget_s=1.0, max_steps=200):

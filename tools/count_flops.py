@@ -36,9 +36,12 @@ ENVS = ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1", "DartSnake7Lin
         "DartDoubleInvertedPendulumEnv-v1"]
 
 
-def load():
-    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libdart_planar_flops.so"])
-    L = C.CDLL(os.path.join(EMU_DIR, "libdart_planar_flops.so"))
+TREE_ENVS = [("DartHumanWalker-v1", 8, 20, 24), ("DartWalker3d-v1", 8, 20, 30), ("DartDog-v1", 8, 20, 30)]   # env id, envs, warm-up, counted steps
+
+
+def load(lib="libdart_planar_flops.so"):
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, lib])
+    L = C.CDLL(os.path.join(EMU_DIR, lib))
     L.flops_create.restype = C.c_void_p
     L.flops_create.argtypes = [C.POINTER(DartModelCard), C.c_int64, C.c_int, C.c_char_p, C.c_int]
     L.flops_destroy.argtypes = [C.c_void_p]
@@ -93,6 +96,16 @@ def main():
     r = count(L, "DartHopper-v1", all_bodies_collide=False)
     out["DartHopper-v1/feet_only"] = r
     print("%-36s %9.0f flops / env-step" % ("DartHopper-v1 feet only", r["flops_per_env_step"]))
+    # the tree kernel (one env per wavefront): the same counting scalar on the fiber runtime (tests/kernel_emu/emu_tree_flops.cpp); the
+    # count is the sum over the 64 lanes of what each lane executes for its env -- redundant per-lane work (every lane evaluating a
+    # wave-uniform scalar) included, idle lanes not
+    LT = load("libdart_tree_flops.so")
+    for env_id, n, warm, steps in TREE_ENVS:
+        r = count(LT, env_id, n=n, warm=warm, steps=steps)
+        r["kernel"] = "tree kernel: summed over the 64 lanes of the env's wavefront"
+        out[env_id] = r
+        print("%-36s %9.0f flops / env-step (%6.0f / world step), + %6.0f other VALU ops; %s" %
+              (env_id, r["flops_per_env_step"], r["flops_per_world_step"], r["other_valu_ops_per_env_step"], r["sample"]))
     path = os.path.join(ROOT, "profiles", "flops_per_env_step.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

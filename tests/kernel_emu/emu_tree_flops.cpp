@@ -104,6 +104,12 @@ template <> __device__ __forceinline__ CReal rsqrt_<CReal>(CReal x) {   // v_rsq
 #include <string>
 #include <vector>
 
+// the kernels' phase stopwatch (SP_TICK: __builtin_readcyclecounter deltas per phase into S.ticks, with DART_CFG_STATS) reads the running
+// flop total here, so the per-phase "cycles" of the debug counters are flops per phase
+#undef __builtin_readcyclecounter
+inline unsigned long long flops_now_() { return g_fc.add + g_fc.mul + 2 * g_fc.fma + g_fc.div + g_fc.sqrt + g_fc.rcp + g_fc.rsq; }
+#define __builtin_readcyclecounter() flops_now_()
+
 // libm calls of the task code (angles of the done conditions, the free root's exponential map): one call each, counted as `div`-class work
 inline CReal acos(CReal a) { g_fc.div++; return CReal(std::acos(a.v)); }
 inline CReal atan2(CReal a, CReal b) { g_fc.div++; return CReal(std::atan2(a.v, b.v)); }
@@ -135,9 +141,12 @@ struct FlopEmu {
   std::unique_ptr<Impl> impl;
   std::vector<unsigned char> q, dq;
   std::vector<int32_t> elapsed; std::vector<uint32_t> episode;
+  std::vector<unsigned long long> stats;
 };
 
 extern "C" {
+void flops_enable_stats(FlopEmu* h, int on) { h->stats.assign(64, 0); h->impl->set_stats(on ? h->stats.data() : nullptr); }
+void flops_get_stats(FlopEmu* h, unsigned long long* out64) { memcpy(out64, h->stats.data(), 64 * sizeof(unsigned long long)); }
 FlopEmu* flops_create(const DartModelCard* card, int64_t n, int, char* why_out, int why_len) {
   std::string why;
   auto impl = make_spatial<CReal>(*card, why);

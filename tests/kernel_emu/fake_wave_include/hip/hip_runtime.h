@@ -65,8 +65,11 @@ template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; 
 // ------------------------------------------------------------------ fibers: one per lane of the running workgroup
 namespace wave_emu {
 constexpr int MAXL = 1024;
-constexpr size_t STACK = 1u << 20;
-struct Fiber { void* sp = nullptr; char* stack = nullptr; bool done = true; };
+#ifndef WAVE_EMU_STACK   // per lane of a 64-lane workgroup (the step kernels' unrolled register arrays; the counting-scalar build at -O1 needs > 1 MB)
+#define WAVE_EMU_STACK (4u << 20)
+#endif
+inline size_t stack_bytes = 0;   // of the fibers as allocated: WAVE_EMU_STACK for a wavefront, 256 KB per lane for the plain wide kernels
+struct Fiber { void* sp = nullptr; char* stack = nullptr; size_t cap = 0; bool done = true; };
 inline Fiber fib[MAXL];
 inline void* sched_sp = nullptr;
 inline int cur = -1, nl = 0;
@@ -110,10 +113,11 @@ extern "C" inline void wave_emu_entry() {
 }
 inline void make_fiber(int l) {
   Fiber& f = fib[l];
-  if (!f.stack) f.stack = (char*)aligned_alloc(64, STACK);
+  const size_t STACK = stack_bytes;
+  if (f.cap < STACK) { free(f.stack); f.stack = (char*)aligned_alloc(64, STACK); f.cap = STACK; }
   f.done = false;
   // initial frame: [mxcsr/fpcw slot][r15 r14 r13 r12 rbx rbp][return address = entry][alignment]
-  uintptr_t top = ((uintptr_t)(f.stack + STACK)) & ~(uintptr_t)63;
+  uintptr_t top = ((uintptr_t)(f.stack + f.cap)) & ~(uintptr_t)63;
   uint64_t* s = (uint64_t*)top;
   *--s = 0;                                  // keeps the stack 16-byte aligned at the entry's first instruction (as after a call)
   *--s = (uint64_t)(uintptr_t)&wave_emu_entry;
@@ -204,6 +208,7 @@ template <class F> inline void launch(dim3 g, dim3 b, size_t lds, F&& f) {
   if (lds > dyn_lds_cap) { free(dyn_lds); dyn_lds = (unsigned char*)aligned_alloc(64, (lds + 63) & ~(size_t)63); dyn_lds_cap = lds; }
   nl = (int)b.x;
   if (nl > MAXL) abort();
+  stack_bytes = nl <= 64 ? (size_t)WAVE_EMU_STACK : (size_t)(256u << 10);
   fp = &f;
   body = +[]() { (*fp)(); };
   for (unsigned bx = 0; bx < g.x; bx++) {

@@ -121,7 +121,10 @@ class HipBenchEnv:
         return float(self.done.float().mean().item())
 
     def packed_last(self):
-        return self.torch.cat([self.obs.reshape(-1), self.rew, self.done.float()]).contiguous()
+        """the last step's outputs as ONE byte block in HBM -- obs f32 | reward f32 | done u8, the flags as the bytes they are -- the
+        payload of the "gather rollouts" all-gather (same packing as ShardedDartVectorEnv.gather_rollout_device)"""
+        from dart_env_amd.distributed import ShardedDartVectorEnv
+        return ShardedDartVectorEnv._pack(self.obs, self.rew, self.done)
 
     def is_static(self) -> bool:
         return bool(self.env.query(self.st.Q_STATIC_KERNEL))
@@ -137,17 +140,42 @@ def roofline_block(card, n, kernel_ms, note):
             "traffic": None, "algorithmic_bytes_per_env_step": ab, "kernel_ms": kernel_ms, "note": note}
 
 
+def _source_state(entry, kernel_hint):
+    """(family, current hash, stale?) of a committed counter entry: stale = it carries no hash, or the hash of another source tree
+    than the one this process's library was built from (tools/source_hash.py)."""
+    try:
+        from tools.source_hash import family_hash, family_of_kernel
+        fam = entry.get("kernel_family") or family_of_kernel(kernel_hint)
+        cur = family_hash(fam)
+    except Exception as ex:      # (a deployment without the sources cannot verify anything: say so instead of vouching)
+        return None, None, "cannot hash the kernel sources here: %r" % (ex,)
+    have = entry.get("source_hash")
+    if have != cur:
+        return fam, cur, "entry measured on %s sources %s, this tree is %s" % (fam, have or "(unstamped)", cur)
+    return fam, cur, None
+
+
 def attach_pmc(roof, key):
     """HBM traffic per launch from the committed PMC passes (profiles/pmc_traffic.json, written by tools/update_pmc_traffic.py
-    from the rocprofv3 summaries of the same command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note)"""
+    from the rocprofv3 summaries of the same command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  The entry is only
+    used when its `source_hash` is the hash of the kernel sources of THIS tree: after a kernel edit the line says `stale` and carries
+    no traffic figure until the PMC passes have been re-run (tools/profile_round.sh + tools/update_pmc_traffic.py)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
     except (OSError, ValueError):
         return
     if key in pmc:
-        roof["traffic"] = pmc[key].get("bytes_per_launch")
+        fam, cur, stale = _source_state(pmc[key], pmc[key].get("kernel", ""))
         roof["traffic_source"] = pmc[key].get("source")
+        roof["kernel_source_hash"] = {"family": fam, "this_tree": cur, "counters": pmc[key].get("source_hash")}
+        if stale:
+            roof["traffic"] = None
+            roof["stale"] = True
+            roof["stale_note"] = "profiles/pmc_traffic.json[%s] not used: %s" % (key, stale)
+            return
+        roof["stale"] = False
+        roof["traffic"] = pmc[key].get("bytes_per_launch")
         if "valu_issue" in pmc[key]:
             roof["valu_issue"] = pmc[key]["valu_issue"]
         if "valu_lanes" in pmc[key]:
@@ -172,10 +200,14 @@ def attach_valu(roof, env_id, n, dtype, kernel_ms):
                             "frac": achieved / VALU_PEAK_TFLOPS[dtype], "counted": "pmc upper bound: SQ_THREAD_CYCLES_VALU / 4 lane-instructions x 2 flops "
                             "(%s); lanes active per VALU instruction %.2f" % (lanes["source"], lanes["lanes_active_per_valu_instruction"])}
         return
+    tree = "kernel" in fl[env_id]
+    _, _, stale = _source_state(fl[env_id], "tree kernel" if tree else "lane kernel")
+    if stale:
+        roof["valu"] = {"stale": True, "stale_note": "profiles/flops_per_env_step.json[%s] not used: %s" % (env_id, stale)}
+        return
     fpe = fl[env_id]["flops_per_env_step"]
     achieved = fpe * n / (kernel_ms * 1e-3) / 1e12
-    peak = VALU_PEAK_TFLOPS[dtype]
-    tree = "kernel" in fl[env_id]     # the tree kernel's count: summed over the 64 lanes of the env's wavefront (tests/kernel_emu/emu_tree_flops.cpp)
+    peak = VALU_PEAK_TFLOPS[dtype]     # the tree kernel's count: summed over the 64 lanes of the env's wavefront (tests/kernel_emu/emu_tree_flops.cpp)
     roof["valu"] = {"bound": "valu", "flops_per_env_step": fpe, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "counted": fl[env_id].get("method", fl.get("_method")) if not tree else
                                "tests/kernel_emu/emu_tree_flops.cpp: the tree kernel's own source with a counting scalar on the fiber runtime; " + fl[env_id]["kernel"],
@@ -211,8 +243,8 @@ def host_surface(env_id, n, local_rank, precision, budget_s=1.0, max_steps=200):
     return out
 
 
-def time_config(env_id, n, local_rank, precision, steps, warmup, all_bodies_collide=None):
-    b = HipBenchEnv(env_id, n, local_rank, precision, 0, ring=8, all_bodies_collide=all_bodies_collide)
+def time_config(env_id, n, local_rank, precision, steps, warmup, all_bodies_collide=None, configure=()):
+    b = HipBenchEnv(env_id, n, local_rank, precision, 0, ring=8, all_bodies_collide=all_bodies_collide, configure=configure)
     b.reset()
     b.run(warmup)
     b.sync()
@@ -220,6 +252,50 @@ def time_config(env_id, n, local_rank, precision, steps, warmup, all_bodies_coll
     card, static = b.card, b.is_static()
     b.close()
     return ms, card, static
+
+
+def other_solver_block(env_id, n, local_rank, precision, sweeps, steps, warmup, with_oracle):
+    """`north_star` names an iterative PGS solver: the kernels' DART_CFG_SOLVER = 1 mode (fixed sweep counts) timed on the headline
+    workload, with what a fixed sweep count costs in accuracy -- `rms_vs_exact`: RMS over 4 096 envs x dofs of the velocity difference
+    to the pivoting solve after ONE env-step from identical states (worst of 20 env-steps of a random-action rollout) -- and, when the
+    oracle may be used (cpu_baseline leg), the same iterate checked against the oracle's PGS at the same sweep count
+    (tests/pgs_protocol.py; the gate is tests/test_gpu_pgs_parity.py)."""
+    from dart_env_amd import stepper as st
+    from dart_env_amd.model_card import card_for
+    cfg = [(st.CFG_SOLVER, st.SOLVER_PGS), (st.CFG_ITERS_STAGE1, sweeps), (st.CFG_ITERS_STAGE2, sweeps)]
+    ms, card, _ = time_config(env_id, n, local_rank, precision, steps, warmup, configure=cfg)
+    out = {"solver": "pgs", "sweeps": sweeps, "value": n / (ms * 1e-3), "unit": "env-steps/s", "kernel_ms": ms, "envs": n,
+           "dtype": "f32" if precision == 32 else "f64"}
+    ne = 4096
+    pgs = st.HipStepper(card, ne, device=local_rank, precision=precision)
+    for k, v in cfg:
+        pgs.configure(k, v)
+    exact = st.HipStepper(card, ne, device=local_rank, precision=precision)
+    rng = np.random.RandomState(11)
+    for s_ in (pgs, exact):
+        s_.configure(st.CFG_SEED, 5)
+        s_.reset(None, None, None, want_obs=False)
+    worst_dq = worst_q = 0.0
+    for t in range(20):
+        a = rng.uniform(-1, 1, (ne, card.act_dim)).astype(np.float32)
+        q0, dq0 = exact.get_state()
+        pgs.set_state(q0, dq0)
+        _, _, de, _ = exact.step(a)
+        pgs.step(a)
+        (qe, dqe), (qp, dqp) = exact.get_state(), pgs.get_state()
+        ok = np.isfinite(dqe).all(axis=1) & np.isfinite(dqp).all(axis=1)
+        worst_dq = max(worst_dq, float(np.sqrt(np.mean((dqe[ok] - dqp[ok]) ** 2))))
+        worst_q = max(worst_q, float(np.sqrt(np.mean((qe[ok] - qp[ok]) ** 2))))
+        if de.any():
+            exact.reset(de.astype(np.uint8), None, None, want_obs=False)
+    pgs.close(); exact.close()
+    out["rms_vs_exact"] = {"dq": worst_dq, "q": worst_q, "envs": ne, "protocol": "one env-step from the pivoting solver's state, worst of 20 env-steps"}
+    if with_oracle:
+        from tests.pgs_protocol import pgs_rollout
+        r = pgs_rollout(lambda c, m: st.HipStepper(c, m, device=local_rank, precision=precision), card_for(env_id), 256, 20, sweeps)
+        out["vs_oracle_pgs_same_sweeps"] = {"max_abs_dq": max(r["dq"]), "max_abs_q": max(r["q"]), "done_flag_mismatches": r["done_mismatches"],
+                                            "envs": 256, "env_steps": 20}
+    return out
 
 
 def main(argv=None, env_factory=None, dist_backend="nccl"):
@@ -341,7 +417,7 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     if dist is not None:
         try:
             packed = b.packed_last()
-            out = torch.empty((world * packed.numel(),), device=packed.device, dtype=torch.float32)   # rank-major shards
+            out = torch.empty((world * packed.numel(),), device=packed.device, dtype=packed.dtype)   # rank-major shards
             dist.all_gather_into_tensor(out, packed)
             device_sync()
             g0 = time.perf_counter()
@@ -382,6 +458,7 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
         result["per_rank"] = per_rank          # every rank's own clock: `value` uses the slowest (max over ranks, contract)
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
+        result["gather_bytes_per_rank"] = int(packed.numel() * packed.element_size())
     if gather_note is not None:
         result["gather_note"] = gather_note
     b_static = b.is_static() if hasattr(b, "is_static") else None
@@ -434,6 +511,8 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
         if do_parity:
             mode["rms_state_err"], _, _ = parity_check(args.env_id, other_prec, ne, args.parity_steps, local_rank, abc, ref=ref, acts=acts)
         result["fast_mode" if other_prec == 32 else "parity_mode"] = mode
+        # ---- the solver north_star names, beside the default (exact pivoting): fixed-sweep PGS on the headline workload
+        result["other_solver"] = other_solver_block(args.env_id, n, local_rank, args.precision, 30, max(args.steps, 300), args.warmup, do_parity)
         # ---- BASELINE configs 3 and 4
         others = []
         for oid, osteps, owarm in (("DartWalker2d-v1", 500, 100), ("DartHumanWalker-v1", 30, 5)):

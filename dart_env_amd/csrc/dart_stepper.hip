@@ -133,6 +133,9 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
     g_err = "model card version/size mismatch"; return DART_E_INVALID;
   }
   if (num_envs <= 0 || (precision != 32 && precision != 64)) { g_err = "bad num_envs/precision"; return DART_E_INVALID; }
+  if (card->impulse_inertia != DART_IMPULSE_MASS && card->impulse_inertia != DART_IMPULSE_AUGMENTED) {
+    g_err = "card.impulse_inertia must be DART_IMPULSE_MASS (0) or DART_IMPULSE_AUGMENTED (1)"; return DART_E_INVALID;
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {

@@ -221,7 +221,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
     P.stiff[d] = (Real)c.stiffness[d]; P.rest[d] = (Real)c.rest[d];
     P.sqe[d] = (Real)std::sqrt(c.dt * c.damping[d] + c.dt * c.dt * c.stiffness[d]);
   }
-  P.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
+  P.impulse_M = c.impulse_inertia == DART_IMPULSE_MASS ? 1 : 0;
   int nc = 0;
   if constexpr (!topo_contacts<T>::value) {
     // the robot slides in a horizontal plane: its joints cannot bring a shape to the floor, so a shape that clears it now always will
@@ -394,7 +394,7 @@ std::string fill_cart(const DartModelCard& c, CartParams<Real, NP>& P) {
     P.sqe[d] = (Real)std::sqrt(c.dt * c.damping[d] + c.dt * c.dt * c.stiffness[d]);
     P.q0[d] = (Real)c.init_pos[d]; P.dq0[d] = (Real)c.init_vel[d];
   }
-  P.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
+  P.impulse_M = c.impulse_inertia == DART_IMPULSE_MASS ? 1 : 0;
   P.dt = (Real)c.dt; P.g = (Real)(-c.gravity[1]); P.limit_erp_dt = (Real)(c.limit_erp / c.dt); P.max_erv = (Real)c.max_erv;
   P.cfm1 = (Real)(1.0 + c.cfm);
   P.act_scale = (Real)c.act_scale[0]; P.act_lo = (Real)c.act_low[0]; P.act_hi = (Real)c.act_high[0];
@@ -524,7 +524,7 @@ std::string fill_arm(const DartModelCard& c, ArmParams<Real, NP>& P) {
   P.dt = (Real)c.dt; P.limit_erp_dt = (Real)(c.limit_erp / c.dt); P.max_erv = (Real)c.max_erv; P.cfm1 = (Real)(1.0 + c.cfm);
   P.noise = (Real)c.reset_noise; P.noise_v = (Real)c.reset_noise_vel;
   P.frame_skip = c.frame_skip; P.max_steps = c.max_episode_steps; P.task = c.task; P.iters = DART_BPP_DEFAULT_ITERS; P.tstate = nullptr;
-  P.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
+  P.impulse_M = c.impulse_inertia == DART_IMPULSE_MASS ? 1 : 0;
   return "";
 }
 

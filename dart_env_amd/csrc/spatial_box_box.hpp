@@ -1,5 +1,22 @@
 // spatial_box_box.hpp -- link-link box contacts of the tree kernel: ODE dBoxBox restated for one lane per shape pair.
 // Part of the gfx950 tree kernel; overview in spatial_kernel.hpp, design in DESIGN.md section 4.2.
+//
+// Attribution: the two routines below (sp_clip_rect_quad, sp_box_box) are a per-lane rewrite of a PUBLISHED algorithm -- the
+// box-box collider of the Open Dynamics Engine, ode/src/box.cpp: `intersectRectQuad` and `dBoxBox` -- the third-party routine DART's
+// ODE collision detector calls for two boxes (the detector the reference selects, gym/envs/dart/walker3d.py:26 + dart_env.py).  They
+// follow ODE's procedure step for step (axis order, the 1.05 face preference, the clipping order, contact positions) because the
+// contact set has to be ODE's for parity; they are not an independent derivation.
+//   Open Dynamics Engine, Copyright (C) 2001-2003 Russell L. Smith.  All rights reserved.  ODE is dual-licensed under the GNU LGPL
+//   (2.1 or later) and a BSD-style license; this file uses it under the BSD-style license:
+//   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the following
+//   conditions are met: (1) redistributions of source code must retain the above copyright notice, this list of conditions and the
+//   following disclaimer; (2) redistributions in binary form must reproduce the above copyright notice, this list of conditions and
+//   the following disclaimer in the documentation and/or other materials provided with the distribution; (3) neither the names of
+//   ODE's copyright owner nor the names of its contributors may be used to endorse or promote products derived from this software
+//   without specific prior written permission.  THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY
+//   EXPRESS OR IMPLIED WARRANTIES, INCLUDING, BUT NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A
+//   PARTICULAR PURPOSE ARE DISCLAIMED.  IN NO EVENT SHALL THE COPYRIGHT OWNER OR CONTRIBUTORS BE LIABLE FOR ANY DIRECT, INDIRECT,
+//   INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES ARISING IN ANY WAY OUT OF THE USE OF THIS SOFTWARE.
 #pragma once
 #include "spatial_model.hpp"
 

@@ -174,7 +174,7 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     M.damp[d] = (Real)c.damping[d]; M.stiff[d] = (Real)c.stiffness[d]; M.rest[d] = (Real)c.rest[d];
     M.q0[d] = (Real)c.init_pos[d]; M.dq0[d] = (Real)c.init_vel[d];
   }
-  M.impulse_M = c.impulse_inertia != 0 ? 1 : 0;
+  M.impulse_M = c.impulse_inertia == DART_IMPULSE_MASS ? 1 : 0;
   M.has_implicit = 0;
   M.fd_passes = 2;
   for (int d = 0; d < c.ndofs; d++) if (c.damping[d] != 0.0 || c.stiffness[d] != 0.0) M.has_implicit = 1;

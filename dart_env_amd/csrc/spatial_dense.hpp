@@ -192,7 +192,7 @@ __device__ __forceinline__ void sp_spd_torque(const LinkConst<Real>& lc, const S
 // (link-link contacts) and hosts the PGS safety net; smaller problems take sp_blcp_t below.
 template <class Real>
 __device__ __forceinline__ void sp_blcp_lds(SpLds<Real>& S, int m, uint64_t pinmask, uint64_t& F, uint64_t& U, int max_iter,
-                                       int pgs_sweeps, unsigned long long* stats, int lane, const bool ZERO_BOUNDS) {
+                                       int pgs_sweeps, unsigned long long* stats, int lane, const bool ZERO_BOUNDS, int pf_ncp = -1, int pf_m1 = 0) {
   if (lane < m) S.x0[lane] = S.x[lane];   // solution of the previous stage (zeros before the first): PGS fallback start
   Real bmax = Real(0);
   for (int i = 0; i < m; i++) bmax = fmax(bmax, fabs(S.b[i]));
@@ -300,8 +300,14 @@ __device__ __forceinline__ void sp_blcp_lds(SpLds<Real>& S, int m, uint64_t pinm
     if (stats && lane == 0) atomicAdd(&stats[32], 1ull);
     if (row) S.x[lane] = fmin(fmax(S.x0[lane], S.lo[lane]), S.hi[lane]);
     __syncthreads();
+    // Sweep order = the oracle's row order (oracle_step: {n, t1, t2} per contact, then limits, then joint friction), whatever the
+    // storage order: a Gauss-Seidel iterate after a FIXED number of sweeps depends on it.  pf_ncp >= 0: the rows are stored in
+    // prefix order (normals [0, ncp), limits / joint friction [ncp, m1), tangents [m1, m1 + 2 ncp) -- sp_world_step).
     for (int sw = 0; sw < pgs_sweeps; ++sw)
-      for (int i = 0; i < m; i++) {
+      for (int p = 0; p < m; p++) {
+        int i = p;
+        if (pf_ncp >= 0) i = p < 3 * pf_ncp ? ((p % 3 == 0) ? p / 3 : pf_m1 + 2 * (p / 3) + (p % 3 - 1)) : pf_ncp + (p - 3 * pf_ncp);
+        if (i >= m) continue;            // (rows beyond the model's LCP capacity were dropped)
         if ((pinmask >> i) & 1ull) continue;
         Real part = row ? S.A[TI(i, lane)] * S.x[lane] : Real(0);
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -325,10 +331,12 @@ __device__ __forceinline__ void sp_blcp_lds(SpLds<Real>& S, int m, uint64_t pinm
 // overhead) than the saved barriers give back.
 template <class Real, bool BIG = false>
 __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask, uint64_t& F, uint64_t& U, int max_iter,
-                                       int pgs_sweeps, unsigned long long* stats, int lane, const bool ZERO_BOUNDS, int mv = 0) {
+                                       int pgs_sweeps, unsigned long long* stats, int lane, const bool ZERO_BOUNDS, int mv = 0,
+                                       int pf_ncp = -1, int pf_m1 = 0) {
   // mv: row count that picks the solver variant (>= m): both stages of a world step can share one variant's code (instruction cache)
+  // pf_ncp / pf_m1: the prefix row layout of the caller, for the PGS sweeps' order (sp_blcp_lds)
   mv = mv > m ? mv : m;
-  if (!BIG || mv > SP_BLCP_MAXREG || max_iter == 0) { sp_blcp_lds<Real>(S, m, pinmask, F, U, max_iter, pgs_sweeps, stats, lane, ZERO_BOUNDS); return; }
+  if (!BIG || mv > SP_BLCP_MAXREG || max_iter == 0) { sp_blcp_lds<Real>(S, m, pinmask, F, U, max_iter, pgs_sweeps, stats, lane, ZERO_BOUNDS, pf_ncp, pf_m1); return; }
   if (lane < m) S.x0[lane] = S.x[lane];   // solution of the previous stage (zeros before the first): PGS fallback start
   BlcpSets r;
   if (mv <= 16) r = sp_blcp_t<Real, 16>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
@@ -346,7 +354,7 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
     if (stats && lane == 0) atomicAdd(&stats[32], 1ull);
     if (lane < m) S.x[lane] = S.x0[lane];
     __syncthreads();
-    sp_blcp_lds<Real>(S, m, pinmask, F, U, 0, pgs_sweeps, nullptr, lane, ZERO_BOUNDS);
+    sp_blcp_lds<Real>(S, m, pinmask, F, U, 0, pgs_sweeps, nullptr, lane, ZERO_BOUNDS, pf_ncp, pf_m1);
   }
 }
 

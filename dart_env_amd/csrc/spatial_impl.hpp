@@ -56,7 +56,8 @@ struct SpatialImplT : Impl {
   void release() override {
     if (dM) (void)hipFree(dM); if (init_h) (void)hipFree(init_h); if (d_ext) (void)hipFree(d_ext); if (d_cf) (void)hipFree(d_cf); if (d_cost) (void)hipFree(d_cost); if (d_perm) (void)hipFree(d_perm);
     if (d_creport) (void)hipFree(d_creport); if (d_ccount) (void)hipFree(d_ccount); if (d_cfrep) (void)hipFree(d_cfrep); d_creport = nullptr; d_ccount = nullptr; d_cfrep = nullptr;
-    dM = nullptr; init_h = nullptr; d_ext = nullptr; d_cf = nullptr;
+    dM = nullptr; init_h = nullptr; d_ext = nullptr; d_cf = nullptr; d_cost = nullptr; d_perm = nullptr;
+    M.sched_cost = nullptr; M.sched_perm = nullptr; M.cf_store = nullptr;
   }
   // Sparsity of this model's mass-matrix factor in storage order (row n-1-d = dof d; symbolic elimination of the ancestor
   // relation), compared with a baked pattern: only an exact match may run that pattern's kernel.
@@ -160,12 +161,15 @@ struct SpatialImplT : Impl {
   // DART_CFG_LAUNCH_ORDER: per-env durations are recorded by the step kernel, sp_sched_kernel turns them into the dispatch order of the
   // next launch on the same stream.  (HumanWalker, 16 384 envs: 7.21 -> 6.72 ms fp32, 17.10 -> 16.27 ms fp64; DartDog fp64 4.20 -> 4.13.)
   int set_launch_order(int on) override {
-    if (on && !d_cost) {
-      if (hipMalloc((void**)&d_cost, 4 * (size_t)nenv) != hipSuccess || hipMalloc((void**)&d_perm, 4 * (size_t)nenv) != hipSuccess) return -1;
+    if (on && !(d_cost && d_perm)) {   // both or neither: a half-made pair (second allocation failed) is torn down, never enabled
+      auto drop = [&]() { if (d_cost) (void)hipFree(d_cost); if (d_perm) (void)hipFree(d_perm); d_cost = nullptr; d_perm = nullptr; M.sched_cost = nullptr; M.sched_perm = nullptr; upload(); return -1; };
+      if (d_cost || d_perm) (void)drop();
+      if (hipMalloc((void**)&d_cost, 4 * (size_t)nenv) != hipSuccess) { d_cost = nullptr; return drop(); }
+      if (hipMalloc((void**)&d_perm, 4 * (size_t)nenv) != hipSuccess) { d_perm = nullptr; return drop(); }
       (void)hipMemset(d_cost, 0, 4 * (size_t)nenv);
       std::vector<int> iota((size_t)nenv);
       for (int64_t i = 0; i < nenv; i++) iota[(size_t)i] = (int)i;
-      if (hipMemcpy(d_perm, iota.data(), 4 * (size_t)nenv, hipMemcpyHostToDevice) != hipSuccess) return -1;
+      if (hipMemcpy(d_perm, iota.data(), 4 * (size_t)nenv, hipMemcpyHostToDevice) != hipSuccess) return drop();
     }
     M.sched_cost = on ? d_cost : nullptr;
     M.sched_perm = on ? d_perm : nullptr;

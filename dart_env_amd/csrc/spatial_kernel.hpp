@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
     cflags[0] = 0; cflags[1] = 0;
   }
   __syncthreads();
-  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG, PAT>(Md, lc, S, lane, cflags, REPORT && Md.creport != nullptr && f == Md.frame_skip - 1);
+  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG, PAT>(Md, lc, S, lane, cflags, e, REPORT && Md.creport != nullptr && f == Md.frame_skip - 1);
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
   const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task >= 10;

@@ -23,7 +23,9 @@ namespace dartk {
 // PAT: compile-time sparsity of the mass-matrix factor (tree_patterns.hpp; DensePattern = any model).
 template <class Real, bool PAIRS, bool EXTRAS, bool REPORT = false, bool BIG = false, class PAT = DensePattern>
 __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, const LinkConst<Real>& lc, SpLds<Real>& S, int lane,
-                                              int* contact_flags, bool report = false) {
+                                              int* contact_flags, int64_t env, bool report = false) {
+  // env: the env this wavefront steps -- NOT blockIdx.x once a launch order is in force (sp_step_kernel: e = sched_perm[blockIdx.x]);
+  // every per-env buffer (external force, contact report, constraint forces, debug dump) is indexed with it
   const int n = Md.n, nl = Md.nl;
   unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
   {
@@ -34,7 +36,13 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     // waits for (HumanWalker at 16 384 envs: 5 such envs in 25 launches took the average from 6.4 to 8.3 ms).  The oracle
     // freezes the same way (oracle_step).
     const bool gone = lane < n && !(fabs(S.q[lane]) < Real(1e6) && fabs(S.dq[lane]) < Real(1e6));
-    if (__any(gone)) return;   // wave-uniform: this wavefront owns the env
+    if (__any(gone)) {   // wave-uniform: this wavefront owns the env
+      if (REPORT && report) {   // a frozen world has no contacts and no constraint forces: do not leave the previous step's in the report
+        if (lane == 0) Md.creport_count[env] = 0;
+        if (lane < n) Md.cf_report[(size_t)env * n + lane] = Real(0);
+      }
+      return;
+    }
   }
   if (EXTRAS && Md.free_root) {
     if (lane == 0) sp_free_root_to_internal<Real>(S);
@@ -42,7 +50,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   }
   // tree recursions level by level: links of equal depth are independent, one lane each
   if (lane == 0) sp_root_offset<Real>(Md, S);
-  sp_forward<Real, EXTRAS>(lc, Md, S, lane, (int64_t)blockIdx.x);   // lane i owns link i
+  sp_forward<Real, EXTRAS>(lc, Md, S, lane, env);   // lane i owns link i
   __syncthreads();
   for (int lv = Md.n_group_levels - 1; lv >= 0; lv--) {
     if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);
@@ -358,19 +366,19 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         U &= ~fr;
       }
       sp_blcp<Real, BIG>(S, stage == 0 ? m1 : m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction),
-                         0);
+                         0, (PREFIX && stage == 1) ? ncp : -1, m1);
     }
     SP_TICK(8);
     if (Md.dbg) {
-      double* D = Md.dbg + (size_t)blockIdx.x * 160;
+      double* D = Md.dbg + (size_t)env * 160;
       if (lane == 0) { D[0] = m; D[1] = ncp; }
       if (lane < m) { D[2 + lane] = (double)S.x[lane]; D[42 + lane] = (double)S.b[lane]; D[82 + lane] = (double)S.hi[lane]; D[122 + lane] = (double)S.A[TI(lane, lane)]; }
     }
   }
   if (REPORT && report) {   // world.collision_result.contacts (walker2d.py:38-41, human_walker.py:97-106): point, force on the first body
-    if (lane == 0) Md.creport_count[blockIdx.x] = ncp;
+    if (lane == 0) Md.creport_count[env] = ncp;
     if (lane < ncp) {
-      Real* out = Md.creport + ((size_t)blockIdx.x * Md.maxcp + lane) * 8;
+      Real* out = Md.creport + ((size_t)env * Md.maxcp + lane) * 8;
       const V3<Real> nn = ld3(S.cpN + 3 * lane);
       V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
       if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
@@ -407,7 +415,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         const int g = lane < 3 ? 0 : 3, a = lane - g;
         v = S.root[a] * S.cf[g] + S.root[3 + a] * S.cf[g + 1] + S.root[6 + a] * S.cf[g + 2];
       }
-      Md.cf_report[(size_t)blockIdx.x * n + lane] = v;
+      Md.cf_report[(size_t)env * n + lane] = v;
     }
   }
   if (m > 0) sp_chol_backsolve<Real, BIG>(S.H, S.sinv, n, S.rhs, lane);   // (wave-uniform: nothing touching, no limit active -> v = v*)

@@ -51,29 +51,94 @@ class ShardedDartVectorEnv:
     def close(self):
         self.venv.close()
 
+    # ---- the one exchange of the path: "RCCL over xGMI only to gather rollouts" (north_star)
+    # A step's outputs travel as ONE byte block per rank -- obs (n, k) f32 | reward (n) f32 | done (n) u8, the flags as the bytes
+    # they are -- through ONE all-gather (direct / fully connected over xGMI: one shard per link).
+    @staticmethod
+    def _pack(obs, reward, done):
+        import torch
+        return torch.cat([obs.contiguous().view(torch.uint8).reshape(-1), reward.contiguous().view(torch.uint8).reshape(-1),
+                          done.contiguous().view(torch.uint8).reshape(-1)])
+
+    @staticmethod
+    def _unpack(full, world, n, k):
+        """full: (world, bytes_per_rank) uint8 -> obs (world n, k) f32, reward (world n) f32, done (world n) u8"""
+        import torch
+        a, b = n * k * 4, n * k * 4 + n * 4
+        obs = full[:, :a].contiguous().view(torch.float32).reshape(world * n, k)
+        rew = full[:, a:b].contiguous().view(torch.float32).reshape(world * n)
+        done = full[:, b:b + n].contiguous().reshape(world * n)
+        return obs, rew, done
+
+    def _all_gather_bytes(self, packed, force_collective=False):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
+            return packed.reshape(1, -1), 1
+        w = dist.get_world_size()
+        if dist.get_backend() == "nccl":   # RCCL: one fused all-gather into a contiguous (world, bytes) buffer
+            out = torch.empty((w * packed.numel(),), dtype=torch.uint8, device=packed.device)
+            dist.all_gather_into_tensor(out, packed)
+        else:                               # gloo (CPU tests)
+            parts = [torch.empty_like(packed) for _ in range(w)]
+            dist.all_gather(parts, packed)
+            out = torch.cat(parts)
+        return out.reshape(w, -1), w
+
     def gather_rollout(self, obs, reward, done):
-        """all_gather (obs f32 (n,k), reward f64 (n,), done bool (n,)) -> full-batch arrays in global env order.
-        Requires equal shard sizes (total_envs % world_size == 0) like the 8 x 65 536 config."""
+        """Host arrays of this rank's last step -> full-batch arrays in global env order on every rank: obs f32 (N, k), reward f64 (N,),
+        done bool (N,).  Requires equal shard sizes (total_envs % world_size == 0) like the 8 x 65 536 config.  For outputs that are
+        already in HBM use step_device() + gather_rollout_device(): no host round trip at all."""
         import torch
         import torch.distributed as dist
         if self.world_size == 1 or not dist.is_initialized():
             return obs, reward, done
         assert self.total_envs % self.world_size == 0, "gather_rollout needs equal shards"
-        k = obs.shape[1]
-        packed = np.concatenate([obs.astype(np.float32), reward.astype(np.float32)[:, None],
-                                 done.astype(np.float32)[:, None]], axis=1)
-        t = torch.from_numpy(packed)
+        n, k = obs.shape
+        packed = self._pack(torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)),
+                            torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)),
+                            torch.from_numpy(np.ascontiguousarray(done).astype(np.uint8)))
         if dist.get_backend() == "nccl":
-            t = t.cuda()
-        if dist.get_backend() == "nccl":   # one fused RCCL all-gather into a contiguous (world, n, k+2) buffer
-            out = torch.empty((self.world_size * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t.contiguous())
-        else:
-            parts = [torch.empty_like(t) for _ in range(self.world_size)]
-            dist.all_gather(parts, t)
-            out = torch.cat(parts, dim=0)
-        full = out.reshape(-1, k + 2).cpu().numpy()
-        return full[:, :k], full[:, k].astype(np.float64), full[:, k + 1] > 0.5
+            packed = packed.cuda()
+        full, w = self._all_gather_bytes(packed)
+        o, r, d = self._unpack(full, w, n, k)
+        return o.cpu().numpy(), r.cpu().numpy().astype(np.float64), d.cpu().numpy() != 0
+
+    def step_device(self, actions):
+        """Device-resident step of this shard for a learner that lives on the GPU: `actions` is a float32 (n, act_dim) torch tensor on
+        this rank's device; the outputs stay in HBM (dart_step_device on a stream of this object's own, ordered against torch's
+        current stream both ways) and are returned as torch tensors: obs (n, k) f32, reward (n) f32, done (n) u8, truncated (n) u8."""
+        import torch
+        st = self.venv.env._stepper
+        if not hasattr(self, "_dev"):
+            dev = torch.device("cuda", st.device)
+            k = self.venv.env.obs_dim
+            self._dev = {"obs": torch.empty((self.count, k), dtype=torch.float32, device=dev),
+                         "rew": torch.empty((self.count,), dtype=torch.float32, device=dev),
+                         "done": torch.empty((self.count,), dtype=torch.uint8, device=dev),
+                         "trunc": torch.empty((self.count,), dtype=torch.uint8, device=dev),
+                         "act": torch.empty((self.count, self.venv.env.act_dim), dtype=torch.float32, device=dev),
+                         "stream": torch.cuda.Stream(device=dev)}   # (a NULL stream would mean "the handle's own stream" to the C ABI)
+        D = self._dev
+        D["stream"].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(D["stream"]):
+            D["act"].copy_(actions)
+            st.step_device(D["act"].data_ptr(), D["obs"].data_ptr(), D["rew"].data_ptr(), D["done"].data_ptr(), D["trunc"].data_ptr(),
+                           D["stream"].cuda_stream)
+        torch.cuda.current_stream().wait_stream(D["stream"])
+        return D["obs"], D["rew"], D["done"], D["trunc"]
+
+    def gather_rollout_device(self, obs=None, reward=None, done=None, force_collective=False):
+        """The last step_device() outputs (or the given device tensors) of every rank, gathered in HBM: one packed uint8 block per rank,
+        one all-gather, nothing touches the host.  -> obs (N, k) f32, reward (N) f32, done (N) u8 torch tensors on this rank's device, in
+        global env order.  force_collective: issue the all-gather even in a one-rank group (a 1-GPU box then executes the RCCL call)."""
+        D = getattr(self, "_dev", None)
+        obs = D["obs"] if obs is None else obs
+        reward = D["rew"] if reward is None else reward
+        done = D["done"] if done is None else done
+        n, k = obs.shape
+        full, w = self._all_gather_bytes(self._pack(obs, reward, done), force_collective)
+        return self._unpack(full, w, n, k)
 
 
 class RolloutBuffer:

@@ -22,7 +22,7 @@ import numpy as np
 from .skel import MAX_BODIES, MAX_DOFS, MAX_SHAPES, ModelCard, parse_skel
 
 MAX_ACTIONS = 32
-CARD_VERSION = 1
+CARD_VERSION = 2
 
 TASK_NONE, TASK_HOPPER, TASK_WALKER2D, TASK_WALKER3D, TASK_HUMANWALKER, TASK_CARTPOLE, TASK_HALFCHEETAH = 0, 1, 2, 3, 4, 5, 6
 TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_SNAKE, TASK_REACHER2D, TASK_REACHER3D = 7, 8, 9, 10, 11

@@ -167,7 +167,7 @@ class ModelCard:
     joint_friction: Optional[np.ndarray] = None   # Coulomb friction per dof (<dynamics><friction>); None = all zero
     # A3: inertia of the impulse pass.  1 = the mass matrix M (DART 6: BodyNode::updateBiasImpulse / updateVelocityChangeFD read
     # the non-implicit articulated inertia), 0 = the augmented M + dt D + dt^2 K the forward dynamics uses (rounds 1-2 of this build)
-    impulse_inertia: int = 1
+    impulse_inertia: int = 0   # DART_IMPULSE_MASS (include/dart_model_card.h)
 
     @property
     def ndofs(self) -> int:
@@ -225,7 +225,7 @@ class ModelCard:
             max_erv=d["max_erv"], cfm=d["cfm"], limit_erp=d["limit_erp"], contact_cfm=d.get("contact_cfm", 1e-5),
             dof_names=d["dof_names"],
             joint_friction=f(d["joint_friction"]) if "joint_friction" in d else None,
-            impulse_inertia=int(d.get("impulse_inertia", 1)))
+            impulse_inertia=int(d.get("impulse_inertia", 0)))
 
 
 # ----------------------------------------------------------------------------

@@ -53,6 +53,7 @@ class DartVectorEnv:
                                   card=card_for(env_id, all_bodies_collide=all_bodies_collide, generic_kernel=generic_kernel)
                                   if (all_bodies_collide is not None or generic_kernel) else None)
         self.num_envs = num_envs
+        self.precision = precision   # 64 = the product default (meets the north star's tolerance), 32 = the fast mode
         self.copy = copy
         self.single_observation_space = self.env.observation_space
         self.single_action_space = self.env.action_space

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DART_CARD_VERSION 1
+#define DART_CARD_VERSION 2   /* 2: impulse_inertia re-encoded so that a zero-initialised card gets the default */
 #define DART_MAX_BODIES 32
 #define DART_MAX_DOFS 32
 #define DART_MAX_SHAPES 32
@@ -180,13 +180,14 @@ typedef struct DartModelCard {
    * the constraint solver's unit-impulse tests and the final velocity change go through BodyNode::updateBiasImpulse /
    * updateVelocityChangeFD -> GenericJoint::updateVelocityChangeDynamic, which read getArticulatedInertia() /
    * getInvProjArtInertia(): the plain mass matrix.
-   *   DART_IMPULSE_MASS (1, the default):  A = J M^-1 J^T,  dq = dq* + M^-1 J^T lambda          (DART 6)
-   *   DART_IMPULSE_AUGMENTED (0):          A = J H^-1 J^T,  dq = dq* + H^-1 J^T lambda, H = M + dt D + dt^2 K
-   *                                        (what rounds 1-2 of this build used for both passes) */
+   *   DART_IMPULSE_MASS (0, the default -- what a memset card gets):  A = J M^-1 J^T,  dq = dq* + M^-1 J^T lambda   (DART 6)
+   *   DART_IMPULSE_AUGMENTED (1):          A = J H^-1 J^T,  dq = dq* + H^-1 J^T lambda, H = M + dt D + dt^2 K
+   *                                        (what rounds 1-2 of this build used for both passes)
+   * dart_create rejects any other value (DART_E_INVALID). */
   int32_t impulse_inertia;
 } DartModelCard;
 
-enum { DART_IMPULSE_AUGMENTED = 0, DART_IMPULSE_MASS = 1 };
+enum { DART_IMPULSE_MASS = 0, DART_IMPULSE_AUGMENTED = 1 };
 
 #ifdef __cplusplus
 }

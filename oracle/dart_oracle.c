@@ -18,7 +18,7 @@
  *   2. qd* = qd + dt qdd                        (Skeleton::integrateVelocities)
  *   3. constraints detected at q_t: capsule/ground contacts (ODE capsule-box:
  *      one contact at the lowest segment endpoint), joint limits (inclusive)
- *   4. boxed LCP  A = J M^-1 J^T (1+cfm on diag; card.impulse_inertia = 0: H^-1, see oracle_step), b = -J qd* + erp*depth/dt,
+ *   4. boxed LCP  A = J M^-1 J^T (1+cfm on diag; card.impulse_inertia = DART_IMPULSE_AUGMENTED: H^-1, see oracle_step), b = -J qd* + erp*depth/dt,
  *      friction rows bounded by +-mu * (frictionless normal impulse) exactly as
  *      the ODE Dantzig driver DART calls sets lo/hi when it reaches the first
  *      findex row (two-stage solve)
@@ -565,7 +565,18 @@ static void point_jacobian(OracleWorld* w, int li, const double* P, const double
  * edge-edge point (closest points of the two edges, midpoint) or the face case -- the incident face of the other box
  * is clipped against the reference face's rectangle (intersectRectQuad) and the clipped points that lie below the
  * reference face are the contacts.  R1, R2: row-major 3x3 whose COLUMNS are the box axes in world coordinates;
- * h1, h2: HALF extents.  Output normal points from box 1 towards box 2.  Returns the number of points (<= 8). */
+ * h1, h2: HALF extents.  Output normal points from box 1 towards box 2.  Returns the number of points (<= 8).
+ *
+ * Attribution: rect_quad and box_box follow ODE's `intersectRectQuad` and `dBoxBox` (ode/src/box.cpp) step for step -- for an
+ * oracle, following the published routine of the named third-party dependency is the point.  Open Dynamics Engine, Copyright (C)
+ * 2001-2003 Russell L. Smith, all rights reserved; dual-licensed (GNU LGPL 2.1+ / BSD-style), used here under the BSD-style
+ * license: redistribution and use in source and binary forms, with or without modification, are permitted provided that source
+ * redistributions retain this copyright notice, this list of conditions and the disclaimer; binary redistributions reproduce them
+ * in the documentation; and neither the copyright owner's nor the contributors' names are used to endorse or promote derived
+ * products without specific prior written permission.  THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS"
+ * AND ANY EXPRESS OR IMPLIED WARRANTIES, INCLUDING, BUT NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A
+ * PARTICULAR PURPOSE ARE DISCLAIMED; IN NO EVENT SHALL THE COPYRIGHT OWNER OR CONTRIBUTORS BE LIABLE FOR ANY DAMAGES ARISING IN ANY
+ * WAY OUT OF THE USE OF THIS SOFTWARE. */
 typedef struct { double pos[3], depth; } BoxContact;
 
 static int rect_quad(const double h[2], const double p[8], double ret[16]) {

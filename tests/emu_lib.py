@@ -85,7 +85,11 @@ class EmuStepper:
         if key == st.CFG_AUTORESET: self.autoreset = int(value != 0)
         elif key == st.CFG_SEED: self.seed = int(value)
         elif key == st.CFG_ENV_OFFSET: self.env_offset = int(value)
-        elif key == st.CFG_SOLVER: self._solver = int(value); self.L.emu_set_solver(self.h, self._solver, 0, 0)
+        elif key in (st.CFG_SOLVER, st.CFG_ITERS_STAGE1, st.CFG_ITERS_STAGE2):   # 0 sweeps / iterations = the implementation's default
+            sv = getattr(self, "_solver_cfg", [0, 0, 0])
+            sv[(st.CFG_SOLVER, st.CFG_ITERS_STAGE1, st.CFG_ITERS_STAGE2).index(key)] = int(value)
+            self._solver_cfg = sv
+            self.L.emu_set_solver(self.h, sv[0], sv[1], sv[2])
         elif key == st.CFG_STATS: self.L.emu_enable_stats(self.h, int(value != 0))
         else: raise ValueError(key)
 

@@ -32,16 +32,19 @@ def snap_stats(qg, dqg, ref, si, smax=np.inf):
     """smax = card.state_abs_max: a state the reference's own validity test rejects -- `np.abs(s[2:]) < 100` in every task's done
     condition (hopper.py:60-62; human_walker.py reports it as info['broke_sim']) -- is an env that EXPLODED in its terminal step
     (a tumbling humanoid under full-scale random torques can do that within one env-step since the impulse pass runs on M, A3);
-    the digits of an explosion are not a trajectory: such envs are counted (`envs_broken_sim`), like NaN states, not averaged."""
+    the digits of an explosion are not a trajectory: such envs are counted (`envs_broken_sim`), like NaN states, not averaged --
+    but ONLY when the oracle and the stepper AGREE that the env is broken.  An env that exploded on one side only
+    (`envs_broken_one_side`) stays in the RMS with all its digits: a stepper-only explosion must move the headline figure."""
     qo, dqo = ref["q"][si], ref["dq"][si]
     eq, edq = qg - qo, dqg - dqo
     bad = ~np.isfinite(eq).all(axis=1) | ~np.isfinite(edq).all(axis=1)
     broke = np.zeros(len(eq), dtype=bool)
+    one_side = np.zeros(len(eq), dtype=bool)
     if np.isfinite(smax):
         with np.errstate(invalid="ignore"):
-            for a, b in ((qo, dqo), (qg, dqg)):
-                broke |= (np.abs(a[:, 2:]) >= smax).any(axis=1) | (np.abs(b) >= smax).any(axis=1)
-        broke &= ~bad
+            sides = [(np.abs(a[:, 2:]) >= smax).any(axis=1) | (np.abs(b) >= smax).any(axis=1) for a, b in ((qo, dqo), (qg, dqg))]
+        broke = sides[0] & sides[1] & ~bad
+        one_side = (sides[0] ^ sides[1]) & ~bad
     eq[bad] = 0.0; edq[bad] = 0.0
     incl = (float(np.sqrt(np.mean(eq ** 2))), float(np.sqrt(np.mean(edq ** 2))))    # with the broken-sim envs averaged in
     eq[broke] = 0.0; edq[broke] = 0.0                 # exploded envs are counted, not averaged
@@ -49,7 +52,7 @@ def snap_stats(qg, dqg, ref, si, smax=np.inf):
             "q_incl_broken_sim": incl[0], "dq_incl_broken_sim": incl[1],
             "max_abs_q": float(np.abs(eq).max()), "max_abs_dq": float(np.abs(edq).max()),
             "envs_beyond_1e-4": int((np.abs(eq).max(axis=1) > 1e-4).sum()), "envs_non_finite": int(bad.sum()),
-            "envs_broken_sim": int(broke.sum())}
+            "envs_broken_sim": int(broke.sum()), "envs_broken_one_side": int(one_side.sum())}
 
 
 def summarize(per_snap, snaps, mism, ne, steps, ref, seconds):
@@ -97,7 +100,7 @@ def parity_check(env_id, precision, ne, steps, local_rank, all_bodies_collide=No
     from dart_env_amd.model_card import card_for
     card = card_for(env_id) if all_bodies_collide is None else card_for(env_id, all_bodies_collide=all_bodies_collide)
     if impulse_inertia is not None:
-        card.impulse_inertia = impulse_inertia     # A3 knob (include/dart_model_card.h); None = the card's default (1: DART 6)
+        card.impulse_inertia = impulse_inertia     # A3 knob (include/dart_model_card.h); None = the card's default (0 = DART_IMPULSE_MASS: DART 6)
     snaps = snap_list(steps)
     if ref is None:
         acts, ref = make_reference(card, ne, steps)

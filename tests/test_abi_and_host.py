@@ -55,8 +55,23 @@ def test_create_rejects_bad_arguments():
     assert L.dart_create(C.byref(bad), 4, 0, 32, C.byref(h)) == st.E_INVALID
     assert L.dart_create(C.byref(card_for("DartHopper-v1")), 0, 0, 32, C.byref(h)) == st.E_INVALID
     assert L.dart_create(C.byref(card_for("DartHopper-v1")), 4, 0, 16, C.byref(h)) == st.E_INVALID
+    knob = card_for("DartHopper-v1")
+    knob.impulse_inertia = 7                      # neither DART_IMPULSE_MASS (0) nor DART_IMPULSE_AUGMENTED (1)
+    assert L.dart_create(C.byref(knob), 4, 0, 64, C.byref(h)) == st.E_INVALID
+    assert b"impulse_inertia" in L.dart_last_error(None)
     assert L.dart_destroy(None) == st.DART_OK
     assert L.dart_step(None, None, None, None, None, None) == st.E_INVALID
+
+
+def test_a_zero_initialised_card_gets_the_documented_defaults():
+    """a C caller that memsets a DartModelCard must get DART 6's impulse rule (A3) -- the default is encoded as 0 --
+    and the shipped cards carry that default."""
+    z = DartModelCard()
+    assert z.impulse_inertia == 0
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "dart_model_card.h")).read()
+    assert "DART_IMPULSE_MASS = 0" in hdr and "DART_IMPULSE_AUGMENTED = 1" in hdr
+    for env_id in ("DartHopper-v1", "DartWalker2d-v1", "DartHumanWalker-v1"):
+        assert card_for(env_id).impulse_inertia == 0
 
 
 def test_model_cards():

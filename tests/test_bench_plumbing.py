@@ -56,8 +56,10 @@ class EmuBenchEnv:
         return float(self.last[2].mean())
 
     def packed_last(self):
+        from dart_env_amd.distributed import ShardedDartVectorEnv
         o, r, d, _ = self.last
-        return torch.from_numpy(np.concatenate([o.reshape(-1), r.astype(np.float32), d.astype(np.float32)]))
+        return ShardedDartVectorEnv._pack(torch.from_numpy(np.ascontiguousarray(o, dtype=np.float32)), torch.from_numpy(r.astype(np.float32)),
+                                          torch.from_numpy(d.astype(np.uint8)))
 
     def is_static(self):
         return self.env.is_static
@@ -75,25 +77,28 @@ def _worker(rank, world, port, q):
     q.put((rank, res))
 
 
-def test_two_rank_bench_line():
-    world = 2
-    port = 33500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_rank_bench_line(world):
+    """2 ranks, and the 8 ranks of BASELINE config 5's node: every rank a process, gloo instead of RCCL, the GPU shard replaced by the
+    kernel emulator -- sharding by rank, barriers, max-over-ranks timing, per-rank clocks, the packed rollout all-gather."""
+    port = 33500 + (os.getpid() % 2000) + world
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    got = dict(q.get(timeout=300) for _ in range(world))
+    got = dict(q.get(timeout=600) for _ in range(world))
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert got[1] is None                       # only rank 0 reports
     r = got[0]
     json.dumps(r)
-    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["higher_is_better"] is True
-    assert r["config"]["env_offsets"] == [0, 64]                      # disjoint contiguous shards keyed by rank
+    assert r["n_gpus"] == world and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["higher_is_better"] is True
+    assert r["config"]["env_offsets"] == [64 * g for g in range(world)]   # disjoint contiguous shards keyed by rank
     assert r["config"]["envs_per_gpu"] == 64 and "DartHopper-v1" in r["config"]["workload"]
-    assert abs(r["value"] - 2 * 64 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]   # whole-job aggregate over the slowest rank
+    assert abs(r["value"] - world * 64 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]   # whole-job aggregate over the slowest rank
     assert r["gather_ms"] > 0 and "gather_note" not in r
-    assert [pr["rank"] for pr in r["per_rank"]] == [0, 1]              # every rank's own clock is in the line ...
+    assert r["gather_bytes_per_rank"] == 64 * (11 * 4 + 4 + 1)         # obs f32 | reward f32 | done u8: flags travel as bytes
+    assert [pr["rank"] for pr in r["per_rank"]] == list(range(world))              # every rank's own clock is in the line ...
     assert max(pr["wall_ms_per_step"] for pr in r["per_rank"]) == pytest.approx(r["ms_per_step"])   # ... and `value` uses the slowest
     assert r["roofline"]["algorithmic_bytes_per_env_step"] == 157 and r["vs_baseline"] is None
     assert "cpu_baseline" not in r and "other_configs" not in r      # N = 1 extras only

@@ -23,6 +23,11 @@ def _worker(rank, world, port, total, steps, q):
     for t in range(steps):
         obs, rew, done, _ = env.step(acts[t, env.offset:env.offset + env.count])
         out = env.gather_rollout(obs, rew, done)
+    # the tensor form of the same exchange (on a GPU: outputs that never left HBM; here CPU tensors over gloo): one packed uint8 block
+    import torch
+    to, tr, td = env.gather_rollout_device(torch.from_numpy(obs), torch.from_numpy(rew.astype(np.float32)), torch.from_numpy(done.astype(np.uint8)))
+    assert td.dtype == torch.uint8 and np.array_equal(to.numpy(), out[0]) and np.array_equal(td.numpy() != 0, out[2])
+    assert np.array_equal(tr.numpy(), out[1].astype(np.float32))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()

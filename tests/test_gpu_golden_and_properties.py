@@ -56,17 +56,38 @@ def test_golden_long_episodes_fp64_kernel(tag):
 
 
 @pytest.mark.parametrize("tag", ["hopper", "walker2d"])
-def test_golden_vector_env_fp32_kernel(tag):
-    """Product precision: SyncVectorEnv fixture, teacher-forced by its own done flags (episodes are short)."""
+def test_golden_vector_env_product_default_fp64(tag):
+    """The product default (`vector.make` = fp64 kernels, device MT19937 resets) against the SyncVectorEnv fixture of the reference's
+    Python: EVERY step, done flags exact (so the per-env reset streams never desynchronise), obs to float32 rounding, rewards 1e-4."""
     d = np.load(os.path.join(G, "%s_vector4_seed3.npz" % tag))
     venv = dart_env_amd.vector.make(IDS[tag], 4)
+    assert venv.precision == 64
+    venv.seed(3)
+    ob = venv.reset()
+    assert ob.dtype == np.float32 and np.allclose(ob, d["obs0"], atol=1e-6)
+    assert d["done"].any()                               # the fixture does exercise SyncVectorEnv's auto-reset
+    for t in range(len(d["done"])):
+        ob, r, done, infos = venv.step(d["actions"][t])
+        assert ob.dtype == np.float32 and r.dtype == np.float64 and done.dtype == np.bool_
+        assert np.array_equal(done, d["done"][t]), t
+        assert np.allclose(ob, d["obs"][t], rtol=0, atol=5e-6), (t, np.abs(ob - d["obs"][t]).max())
+        assert np.allclose(r, d["reward"][t], rtol=0, atol=1e-4), (t, np.abs(r - d["reward"][t]).max())
+    venv.close()
+
+
+@pytest.mark.parametrize("tag", ["hopper", "walker2d"])
+def test_golden_vector_env_fp32_fast_mode(tag):
+    """The explicit fast mode (`precision=32`) on the same fixture, held to what fp32 delivers: until the first done flag that fp32
+    rounding flips (which desynchronises that env's reset stream) everything matches to 2e-2, and that is at least 60 steps."""
+    d = np.load(os.path.join(G, "%s_vector4_seed3.npz" % tag))
+    venv = dart_env_amd.vector.make(IDS[tag], 4, precision=32)
+    assert venv.precision == 32
     venv.seed(3)
     ob = venv.reset()
     assert ob.dtype == np.float32 and np.allclose(ob, d["obs0"], atol=1e-6)
     agree = 0
     for t in range(len(d["done"])):
         ob, r, done, infos = venv.step(d["actions"][t])
-        assert ob.dtype == np.float32 and r.dtype == np.float64 and done.dtype == np.bool_
         if not np.array_equal(done, d["done"][t]):
             break  # an fp32 done flip desynchronises the RNG streams; everything before must match
         agree += 1
@@ -113,9 +134,13 @@ def _run(n, steps, block=64, precision=32, env_id="DartHopper-v1", seed=9, x_shi
     return outs, q, dq, el, ep
 
 
-def test_full_batch_determinism_and_batch_independence():
+@pytest.mark.parametrize("precision", [64, 32])
+def test_full_batch_determinism_and_batch_independence(precision):
     """Run-to-run bitwise determinism at N=65 536, and env i's trajectory is independent of the batch it sits in
-    (wave-level votes only end loops early, they never change a lane's result) and of the workgroup width."""
+    (wave-level votes only end loops early, they never change a lane's result) and of the workgroup width.  precision=64 is the
+    product default -- the kernel bench.py times; 32 the fast mode."""
+    import functools
+    _run = functools.partial(globals()["_run"], precision=precision)
     o1, q1, dq1, el1, ep1 = _run(N_FULL, 12)
     o2, q2, dq2, el2, ep2 = _run(N_FULL, 12)
     assert np.array_equal(q1, q2) and np.array_equal(dq1, dq2) and np.array_equal(ep1, ep2)
@@ -129,10 +154,12 @@ def test_full_batch_determinism_and_batch_independence():
     assert ep1.max() > 1 and ep1.min() >= 1              # episodes end and restart on device
 
 
-def test_full_batch_outputs_are_consistent():
-    """obs/reward/done at N=65 536 obey the task definition: obs = [height, q[2:], clip(dq)], done envs restart."""
+@pytest.mark.parametrize("precision", [64, 32])
+def test_full_batch_outputs_are_consistent(precision):
+    """obs/reward/done at N=65 536 obey the task definition: obs = [height, q[2:], clip(dq)], done envs restart (64 = the product
+    default and the kernel bench.py times, 32 = the fast mode)."""
     card = card_for("DartHopper-v1")
-    s = st.HipStepper(card, N_FULL, precision=32)
+    s = st.HipStepper(card, N_FULL, precision=precision)
     s.configure(st.CFG_SEED, 3)
     s.reset(None, None, None, want_obs=False)
     rng = np.random.RandomState(2)
@@ -146,7 +173,7 @@ def test_full_batch_outputs_are_consistent():
         assert np.allclose(ob[:, 5:], np.clip(dq, -10, 10), atol=1e-4)
         pen = 0.75 * ((card.lower[4] - q[:, 4]) > -0.05) + 0.75 * ((card.upper[4] - q[:, 4]) < 0.05)
         rew = (q[:, 0] - q0[:, 0]) / 0.008 + 1.0 - 1e-3 * np.sum(a.astype(np.float64) ** 2, axis=1) - pen
-        assert np.allclose(r, rew, atol=2e-2)            # fp32 x-difference / 0.008
+        assert np.allclose(r, rew, atol=2e-2 if precision == 32 else 2e-4)   # fp32: x-difference / 0.008 in single precision; the reward leaves the device as float32
         ok = np.isfinite(q).all(1) & np.isfinite(dq).all(1) & (np.abs(q[:, 2:]) < 100).all(1) & \
             (np.abs(dq) < 100).all(1) & (ob[:, 0] > .7) & (ob[:, 0] < 1.8) & (np.abs(q[:, 2]) < .2)
         border = (np.abs(ob[:, 0] - .7) < 1e-5) | (np.abs(np.abs(q[:, 2]) - .2) < 1e-5)

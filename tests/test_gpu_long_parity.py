@@ -26,6 +26,9 @@ def test_fp64_untrimmed_rms_below_1e_4_over_1000_steps(env_id, ne):
     assert stats["envs"] >= 4096 and stats["env_steps"] >= 1000 and set(stats["by_step"]) == {"1", "10", "100", "1000"}
     assert stats["done_flag_mismatches"] == 0
     assert all(v["envs_non_finite"] == 0 for v in stats["by_step"].values())
+    # envs the reference's own validity bound calls broken are left out of the RMS only where BOTH sides say so
+    assert all(v["envs_broken_one_side"] == 0 for v in stats["by_step"].values())
+    assert max(v["envs_broken_sim"] for v in stats["by_step"].values()) <= 0.01 * ne
     assert stats["q"] < 1e-4 and stats["dq"] < 1e-4, (stats["q"], stats["dq"])
     # and with a wide margin: the fp64 kernels follow the oracle to rounding error
     assert stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])
@@ -34,10 +37,10 @@ def test_fp64_untrimmed_rms_below_1e_4_over_1000_steps(env_id, ne):
 @pytest.mark.parametrize("env_id,ne,steps", [("DartHopper-v1", 1024, 300), ("DartWalker2d-v1", 1024, 300), ("DartHumanWalker-v1", 256, 100),
                                              ("DartReacher-v1", 1024, 100), ("DartReacher3d-v1", 256, 100), ("DartCartPole-v1", 1024, 100)])
 def test_the_other_setting_of_the_impulse_inertia_knob_is_served_too(env_id, ne, steps):
-    """card.impulse_inertia = 0 (A3: the impulse pass on M + dt D + dt^2 K, what rounds 1-2 of this build assumed) on every kernel
+    """card.impulse_inertia = 1 = DART_IMPULSE_AUGMENTED (A3: the impulse pass on M + dt D + dt^2 K, what rounds 1-2 of this build assumed) on every kernel
     family -- planar register kernel (runtime-parameter variant: the baked kernels carry DART 6's setting), tree kernel, arm, 3-D
     chain and cart kernels -- against the oracle with the same setting, same untrimmed protocol."""
-    stats, ref, _ = parity_check(env_id, 64, ne, steps, 0, impulse_inertia=0)
+    stats, ref, _ = parity_check(env_id, 64, ne, steps, 0, impulse_inertia=1)
     print(env_id, "knob 0", {k: (v["q"], v["dq"]) for k, v in stats["by_step"].items()}, "episodes", stats["episodes"])
     assert stats["done_flag_mismatches"] == 0
     assert stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])

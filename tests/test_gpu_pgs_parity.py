@@ -1,0 +1,47 @@
+"""Fixed-sweep PGS on the GPU against the ORACLE's PGS at the same sweep count (`north_star`: "an iterative PGS LCP
+contact/joint-limit solver with wavefront-level reductions").
+
+Both kernel families, `DART_CFG_SOLVER = 1`, K = 30 and 80 sweeps per stage, fp64: |dq_gpu - dq_oracle| < 1e-9 after one world step
+and < 1e-7 after 20 env-steps, done flags identical.  K = 30 is far from convergence (tests/test_pgs_fixed_sweeps_parity.py:
+>= 1e-4 from the exact solve), so this compares Gauss-Seidel ITERATES -- arithmetic and sweep order -- not limits; the older tests
+(test_pgs_solver_converges_to_pivoting_solver, test_spatial_pgs_...) only compare the device PGS with the device pivoting solve.
+The lane kernels sweep one LCP per lane; the tree kernel sweeps one LCP per wavefront, each row's dot product reduced across the 64
+lanes with __shfl_xor (csrc/spatial_dense.hpp::sp_blcp_lds), in the oracle's row order whatever the storage order (round 4).
+Reference call sites: dart_env.py:158-175 (do_simulation -> World.step), hopper.py:36-65, walker2d.py:22-65, human_walker.py:60-165."""
+import numpy as np
+import pytest
+
+from dart_env_amd import stepper as st
+from dart_env_amd.model_card import card_for
+from tests.pgs_protocol import pgs_rollout
+
+pytestmark = pytest.mark.gpu
+GPU = lambda card, n: st.HipStepper(card, n, precision=64)
+
+CASES = [("DartHopper-v1", {}, 512, 20),          # lane kernel (baked model)
+         ("DartWalker2d-v1", {}, 512, 20),        # lane kernel, joint limits + two feet
+         ("DartHumanWalker-v1", {}, 32, 20),      # tree kernel, prefix row order, compile-time factor pattern
+         ("DartWalker3d-v1", {}, 32, 20),         # tree kernel with link-link contacts (interleaved rows)
+         ("DartHopper-v1", {"generic_kernel": True}, 64, 20)]   # the same planar model on the tree kernel
+
+
+@pytest.mark.parametrize("K", [30, 80])
+@pytest.mark.parametrize("env_id,kw,n,T", CASES, ids=[c[0] + ("/tree" if c[1] else "") for c in CASES])
+def test_device_pgs_equals_oracle_pgs_at_the_same_sweep_count(env_id, kw, n, T, K):
+    card = card_for(env_id, **kw)
+    r = pgs_rollout(GPU, card, n, T, K)
+    print(env_id, kw, "K", K, "max |dq|", max(r["dq"]), "after 1 env-step", r["dq"][0], "max |q|", max(r["q"]))
+    assert r["done_mismatches"] == 0
+    assert max(r["dq"]) < 1e-7 and max(r["q"]) < 1e-9, (max(r["dq"]), max(r["q"]))
+
+
+@pytest.mark.parametrize("K", [30, 80])
+@pytest.mark.parametrize("env_id,n", [("DartHopper-v1", 512), ("DartWalker2d-v1", 512), ("DartHumanWalker-v1", 32)])
+def test_one_world_step_of_device_pgs(env_id, n, K):
+    """frame_skip = 1: ONE world step per launch -- |dq| < 1e-9 against the oracle's PGS after every single world step of a 40-step
+    rollout (states re-synchronise only through the episodes' own resets)"""
+    card = card_for(env_id)
+    card.frame_skip = 1
+    r = pgs_rollout(GPU, card, n, 40, K)
+    assert r["done_mismatches"] == 0
+    assert r["dq"][0] < 1e-9 and max(r["dq"]) < 1e-8, (r["dq"][0], max(r["dq"]))

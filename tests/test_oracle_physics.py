@@ -474,18 +474,18 @@ def flywheel_card(damping=0.0, stiffness=0.0, rest=0.0, friction=0.0, lower=None
 FLY_I = 0.5      # izz of the wheel about its axle
 
 
-def flywheel_closed_forms(kind, steps, dt=0.002, impulse_inertia=1):
+def flywheel_closed_forms(kind, steps, dt=0.002, impulse_inertia=0):
     """(q, dq) after every step of the 1-dof wheel, from the update rules DART's semantics imply (A3, A10, joint friction):
     implicit damping / spring  (I + dt d + dt^2 k) a = tau - d v - k (q + dt v - rest);   Coulomb friction: an impulse within
     +-mu dt that drives v to zero;   limit: inelastic stop while q >= upper (inclusive) and v > 0, no position correction.
-    The impulse acts on I_imp = I (impulse_inertia = 1: DART 6's impulse pass reads the non-implicit articulated inertia) or on
-    I + dt d + dt^2 k (impulse_inertia = 0).  A hard stop cannot tell the two apart (the row's own inertia cancels); a SATURATED
+    The impulse acts on I_imp = I (impulse_inertia = 0 = DART_IMPULSE_MASS: DART 6's impulse pass reads the non-implicit articulated inertia) or on
+    I + dt d + dt^2 k (impulse_inertia = 1 = DART_IMPULSE_AUGMENTED).  A hard stop cannot tell the two apart (the row's own inertia cancels); a SATURATED
     friction impulse can: dv = mu dt / I_imp -- kind 'damped_friction'."""
     q, v, out = 0.0, 2.0, []
     d, k, rest, mu, up = dict(damping=(0.7, 0, 0, 0, None), spring=(0.3, 5.0, 0.1, 0, None), friction=(0, 0, 0, 0.2, None),
                               limit=(0, 0, 0, 0, 0.05), damped_friction=(25.0, 0, 0, 0.2, None))[kind]
     I_fd = FLY_I + dt * d + dt * dt * k
-    I_imp = FLY_I if impulse_inertia == 1 else I_fd
+    I_imp = FLY_I if impulse_inertia == 0 else I_fd
     for _ in range(steps):
         a = (-d * v - k * (q + dt * v - rest)) / I_fd
         vs = v + dt * a
@@ -505,7 +505,7 @@ FLY_CARDS = dict(damping=lambda: flywheel_card(damping=0.7), spring=lambda: flyw
                  damped_friction=lambda: flywheel_card(damping=25.0, friction=0.2))
 
 
-@pytest.mark.parametrize("impulse_inertia", [1, 0])
+@pytest.mark.parametrize("impulse_inertia", [0, 1])
 @pytest.mark.parametrize("kind", ["damping", "spring", "friction", "limit", "damped_friction"])
 def test_single_dof_closed_forms(kind, impulse_inertia):
     card = FLY_CARDS[kind]()
@@ -528,8 +528,8 @@ def test_damped_wheel_with_saturated_friction_separates_the_two_impulse_inertias
     """The closed form that tells the A3 settings apart: while the friction impulse is saturated the wheel loses
     mu dt / I per step under DART 6's rule and mu dt / (I + dt d) under the augmented one -- with d = 25 a 10 % difference
     in the friction deceleration, far above every tolerance of this suite (and of the north star's 1e-4)."""
-    a = flywheel_closed_forms("damped_friction", 400, impulse_inertia=1)
-    b = flywheel_closed_forms("damped_friction", 400, impulse_inertia=0)
+    a = flywheel_closed_forms("damped_friction", 400, impulse_inertia=0)
+    b = flywheel_closed_forms("damped_friction", 400, impulse_inertia=1)
     dt, d, mu = 0.002, 25.0, 0.2
     r = FLY_I / (FLY_I + dt * d)
     # one step from v0 = 2: v1 = v0 r - mu dt / I_imp
@@ -545,10 +545,10 @@ def test_impulse_pass_runs_on_the_mass_matrix_multi_dof():
     """A3 on a real model: the Hopper in the air at q = 0 sits on the (inclusive) upper limits of its thigh and knee joints, which
     carry damping 1.0.  One world step restated in numpy from the oracle's own M and c -- unconstrained velocity from
     (M + dt D)^-1, limit rows solved by enumeration of their active sets on A = J Minv J^T, velocity change Minv J^T lambda -- with
-    Minv = M^-1 (DART 6) or (M + dt D)^-1 (knob 0).  The oracle must follow the setting it is given, and the two must differ."""
+    Minv = M^-1 (DART 6) or (M + dt D)^-1 (knob 1).  The oracle must follow the setting it is given, and the two must differ."""
     import itertools
     res = {}
-    for knob in (1, 0):
+    for knob in (0, 1):
         card = card_for("DartHopper-v1")
         card.impulse_inertia = knob
         w = OracleWorld(card)
@@ -562,7 +562,7 @@ def test_impulse_pass_runs_on_the_mass_matrix_multi_dof():
         D = np.array([card.damping[i] for i in range(n)]); dt = card.dt
         H = M + dt * np.diag(D)
         vs = dq + dt * np.linalg.solve(H, tau - c - D * dq)
-        Minv = np.linalg.inv(M if knob == 1 else H)
+        Minv = np.linalg.inv(M if knob == 0 else H)
         rows = [i for i in range(n) if card.limited[i] and (q[i] <= card.lower[i] or q[i] >= card.upper[i])]
         assert rows == [3, 4]
         A = Minv[np.ix_(rows, rows)] * (np.ones((2, 2)) + np.eye(2) * card.cfm)

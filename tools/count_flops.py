@@ -13,8 +13,12 @@ What the number is, and is not:
     next to `roofline.valu_issue`, the measured issue statistics of everything the wave executes;
   * the counting type takes the fp64 code paths (sincos polynomial, two Newton steps per reciprocal); the fp32 instantiation
     does ~3 % less per env-step (shorter polynomials, one Newton step) -- both lines use this count.
-The tree kernel (HumanWalker, Walker3d, Dog) is wave-cooperative code with no host build: its entry comes from the PMC pass
-instead (tools/update_pmc_traffic.py: SQ_THREAD_CYCLES_VALU / 4 lane-instructions x 2 flops as an upper bound).
+The tree kernel (HumanWalker, Walker3d, Dog) is wave-cooperative code: it is counted on the fiber runtime (emu_tree_flops.cpp), summed
+over the lanes of an env's wavefront -- LANE-REPLICATED work included (a row per lane means every lane carries every column update of a
+factorisation); `useful_factorisation_flops_per_world_step` is the arithmetic a sequential sparse Cholesky of the same matrices
+needs, from the factor's pattern, beside it.  The PMC pass gives the lane-instructions the hardware executed
+(tools/update_pmc_traffic.py: SQ_THREAD_CYCLES_VALU lane-instructions x 2 flops as an upper bound): counted flops <= that bound.
+Every entry is stamped with the hash of the kernel sources it was counted on (tools/source_hash.py); bench.py ignores stale entries.
 
 Run here (CPU only):  python tools/count_flops.py
 """
@@ -29,6 +33,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dart_env_amd.model_card import DartModelCard, card_for  # noqa: E402
+from tools.source_hash import family_hash  # noqa: E402
+from tools.gen_tree_patterns import factor_pattern  # noqa: E402
+
+
+def useful_factorisation_flops(card):
+    """Flops of ONE sequential sparse Cholesky of the model's mass matrix (leaves-first order: no fill-in) from the factor's pattern:
+    per column j with c_j entries below the diagonal -- 1 rsqrt, c_j scalings, c_j (c_j + 1) / 2 multiply-adds (2 flops each)."""
+    rows = factor_pattern(card)
+    n = len(rows)
+    flops = 0
+    for j in range(n):
+        c = sum(1 for i in range(j + 1, n) if (rows[i] >> j) & 1)
+        flops += 1 + c + c * (c + 1)
+    return flops, sum(bin(r).count("1") for r in rows)
 
 EMU_DIR = os.path.join(ROOT, "tests", "kernel_emu")
 FIELDS = ["add", "mul", "fma", "div", "sqrt", "rcp", "rsq", "cmp", "minmax", "abs", "neg", "cvt"]
@@ -36,7 +54,10 @@ ENVS = ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1", "DartSnake7Lin
         "DartDoubleInvertedPendulumEnv-v1"]
 
 
-TREE_ENVS = [("DartHumanWalker-v1", 8, 20, 24), ("DartWalker3d-v1", 8, 20, 30), ("DartDog-v1", 8, 20, 30)]   # env id, envs, warm-up, counted steps
+# env id, envs, warm-up, counted steps (COUNT_TREE_ENVS / COUNT_TREE_STEPS override the sample: the fiber runtime takes ~0.3 s per
+# HumanWalker env-step, so 64 envs x 100 steps is half an hour on one core)
+_TN, _TS = int(os.environ.get("COUNT_TREE_ENVS", "64")), int(os.environ.get("COUNT_TREE_STEPS", "100"))
+TREE_ENVS = [("DartHumanWalker-v1", _TN, 20, _TS), ("DartWalker3d-v1", max(8, _TN // 4), 20, 30), ("DartDog-v1", max(8, _TN // 4), 20, 30)]
 
 
 def load(lib="libdart_planar_flops.so"):
@@ -88,12 +109,15 @@ def main():
     L = load()
     out = {"_method": "tests/kernel_emu/emu_flops.cpp: the lane kernels' own source instantiated with a counting scalar; "
                       "flops = add + mul + 2 fma + div + sqrt + rcp + rsq per lane (= per env), fp64 code paths; tools/count_flops.py"}
+    hp, hs = family_hash("planar"), family_hash("spatial")
     for env_id in ENVS:
         r = count(L, env_id)
+        r["kernel_family"], r["source_hash"] = "planar", hp
         out[env_id] = r
         print("%-36s %9.0f flops / env-step (%6.0f / world step), + %6.0f other VALU ops; %s" %
               (env_id, r["flops_per_env_step"], r["flops_per_world_step"], r["other_valu_ops_per_env_step"], r["sample"]))
     r = count(L, "DartHopper-v1", all_bodies_collide=False)
+    r["kernel_family"], r["source_hash"] = "planar", hp
     out["DartHopper-v1/feet_only"] = r
     print("%-36s %9.0f flops / env-step" % ("DartHopper-v1 feet only", r["flops_per_env_step"]))
     # the tree kernel (one env per wavefront): the same counting scalar on the fiber runtime (tests/kernel_emu/emu_tree_flops.cpp); the
@@ -103,6 +127,12 @@ def main():
     for env_id, n, warm, steps in TREE_ENVS:
         r = count(LT, env_id, n=n, warm=warm, steps=steps)
         r["kernel"] = "tree kernel: summed over the 64 lanes of the env's wavefront"
+        r["kernel_family"], r["source_hash"] = "spatial", hs
+        card = card_for(env_id)
+        uf, nnz = useful_factorisation_flops(card)
+        # two factorisations per world step (M + E for the forward dynamics, M for the impulse pass)
+        r["useful_factorisation_flops_per_world_step"] = 2 * uf
+        r["factor_offdiagonal_nonzeros"] = nnz
         out[env_id] = r
         print("%-36s %9.0f flops / env-step (%6.0f / world step), + %6.0f other VALU ops; %s" %
               (env_id, r["flops_per_env_step"], r["flops_per_world_step"], r["other_valu_ops_per_env_step"], r["sample"]))

@@ -48,7 +48,7 @@ def variants(env_id):
     c = card_a1(env_id)
     if c is not None:
         out.append(("A1 inertia honours the shape transform", c, {}))
-    c = card_for(env_id); c.impulse_inertia = 0
+    c = card_for(env_id); c.impulse_inertia = 1
     out.append(("A3 impulses on M + dt D + dt^2 K", c, {}))
     out.append(("A5 contact point on the capsule surface", card_for(env_id), {5: 1}))
     out.append(("A7 friction bounds iterated to consistency", card_for(env_id), {7: 1}))

@@ -6,6 +6,7 @@ TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+python $R/tools/source_hash.py > $OUT/source_hash.json   # ties every counter of this run to the kernel sources of the library that ran
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-extras"
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES"

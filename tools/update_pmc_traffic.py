@@ -15,6 +15,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.source_hash import all_hashes, family_of_kernel  # noqa: E402
 CFG = {"hopper": ("DartHopper-v1", 65536), "walker2d": ("DartWalker2d-v1", 65536), "humanwalker": ("DartHumanWalker-v1", 16384)}
 
 
@@ -36,6 +38,14 @@ def main():
     cite = sys.argv[2] if len(sys.argv) > 2 else src
     S = parse(src)
     out = {}
+    # the hash of the kernel sources the profiled library was built from: written on the GPU box by tools/profile_round.sh next to the
+    # raw passes (gpurun_out/<tag>/source_hash.json); a summary without one is stamped with the current tree's (run this right after
+    # the profile, before editing kernels)
+    hashes = all_hashes()
+    side = os.path.join(os.path.dirname(os.path.abspath(src)), os.path.basename(src).replace("_rocprof.txt", ""), "source_hash.json")
+    if os.path.exists(side):
+        hashes = json.load(open(side))
+        print("source hashes from", side, hashes)
     for name in S:
         m = re.match(r"^(\w+?)_(f32|f64)_pmc_fetch$", name)
         if not m or m.group(1) not in CFG:
@@ -61,15 +71,22 @@ def main():
                 "source": "%s %s_%s_pmc_sq (SQ_* count quad-cycles)" % (os.path.relpath(cite, ROOT), cfg, dt)}
         lanes = S.get("%s_%s_pmc_lanes" % (cfg, dt), {})
         if "SQ_THREAD_CYCLES_VALU" in lanes and "SQ_ACTIVE_INST_VALU" in lanes:
-            # SQ_THREAD_CYCLES_VALU counts active lanes x quad-cycles of every VALU instruction: / 4 = lane-instructions per launch; an
-            # upper bound of the flops they can carry is 2 per lane-instruction (every one an FMA).  The tree kernel has no host build
-            # to count useful flops on, so this bound is what bench.py reports for it (roofline.valu, method "pmc upper bound").
-            lane_instr = lanes["SQ_THREAD_CYCLES_VALU"][1] / 4.0
+            # SQ_THREAD_CYCLES_VALU sums the ACTIVE LANES of every VALU instruction, in the same unit SQ_ACTIVE_INST_VALU counts
+            # instructions in (one per issued instruction: for every kernel of the r03 passes whose lanes are all busy or all on lane 0
+            # SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU, e.g. sp_reset_kernel 89 948 160 both) -- so it IS the number of lane-instructions, and
+            # SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) is the mean fraction of active lanes.  (Round 3 divided by 4 once more --
+            # "quad-cycles" -- which made the bound 4x too small: 2.86 M flops per HumanWalker env-step, below the 3.85 M the counting build
+            # counts; VERDICT r3 weak 3.  Cross-check: lanes_active x 64 x SQ_INSTS_VALU of the SQ pass = 92.0e9 = SQ_THREAD_CYCLES_VALU
+            # 93.8e9 of the lanes pass.)  An upper bound of the flops they can carry is 2 per lane-instruction (every one an FMA).
+            lane_instr = lanes["SQ_THREAD_CYCLES_VALU"][1]
             entry["valu_lanes"] = {
                 "lanes_active_per_valu_instruction": lanes["SQ_THREAD_CYCLES_VALU"][1] / (64.0 * lanes["SQ_ACTIVE_INST_VALU"][1]),
                 "valu_lane_instructions_per_launch": lane_instr,
                 "flops_upper_bound_per_env_step": 2.0 * lane_instr / n,
                 "source": "%s %s_%s_pmc_lanes" % (os.path.relpath(cite, ROOT), cfg, dt)}
+        fam = family_of_kernel(entry["kernel"])
+        entry["kernel_family"] = fam
+        entry["source_hash"] = hashes[fam]      # bench.py uses the entry only while the tree's kernel sources still hash to this
         out["%s/%d/%s" % (env_id, n, dt)] = entry
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     with open(path, "w") as f:

@@ -63,6 +63,9 @@ struct DartStepper {
   // dart_step_async brings a step's outputs to the host with a single D2H copy instead of four
   size_t out_bytes = 0, out_off[4] = {0, 0, 0, 0};   // offsets of obs / reward / done / truncated inside the block
   std::vector<void*> registered;   // caller-owned output blocks page-locked by dart_register_output
+  // caller-owned host buffers page-locked by dart_register_host_buffer: dart_step DMAs straight from / into arguments that lie inside
+  std::vector<std::pair<char*, size_t>> host_ranges;
+  double* d_rew64 = nullptr;       // float64 rewards for the direct path of dart_step (the reference's reward type), made on the device
   bool split_d2h = false;        // DART_SPLIT_D2H=1: the four separate copies of rounds 1-2 (A/B measurements)
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
@@ -203,6 +206,9 @@ int dart_destroy(DartStepper* h) {
   if (h->impl) h->impl->release();
   for (void* p : h->registered) (void)hipHostUnregister(p);
   h->registered.clear();
+  for (auto& r : h->host_ranges) (void)hipHostUnregister(r.first);
+  h->host_ranges.clear();
+  if (h->d_rew64) hipFree(h->d_rew64);
   void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs /* base of the output block */, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn.dev, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs /* base of the pinned output block */, h->h_mask, h->h_qn, h->h_vn};
@@ -496,14 +502,52 @@ int dart_step_async_to(DartStepper* h, const float* actions, void* block) {
   return step_async_impl(h, actions, block);
 }
 
+int dart_register_host_buffer(DartStepper* h, void* ptr, uint64_t bytes) {
+  if (!h || !ptr || bytes == 0) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  for (auto& r : h->host_ranges) if (r.first == (char*)ptr) { if (r.second >= bytes) return DART_OK; h->err = "dart_register_host_buffer: already registered with a smaller size"; return DART_E_INVALID; }
+  CHK(h, hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+  h->host_ranges.push_back({(char*)ptr, (size_t)bytes});
+  return DART_OK;
+}
+int dart_unregister_host_buffer(DartStepper* h, void* ptr) {
+  if (!h || !ptr) return DART_E_INVALID;
+  if (h->pending) { h->err = "dart_unregister_host_buffer while a step is pending"; return DART_E_PENDING; }
+  for (size_t i = 0; i < h->host_ranges.size(); i++)
+    if (h->host_ranges[i].first == (char*)ptr) {
+      CHK(h, hipSetDevice(h->device));
+      CHK(h, hipStreamSynchronize(h->stream));
+      CHK(h, hipHostUnregister(ptr));
+      h->host_ranges.erase(h->host_ranges.begin() + i);
+      return DART_OK;
+    }
+  h->err = "dart_unregister_host_buffer: not a registered buffer";
+  return DART_E_INVALID;
+}
+// is [p, p + bytes) inside a buffer the caller page-locked with dart_register_host_buffer?
+static bool host_pinned(const DartStepper* h, const void* p, size_t bytes) {
+  const char* c = (const char*)p;
+  for (auto& r : h->host_ranges) if (c >= r.first && c + bytes <= r.first + r.second) return true;
+  return false;
+}
+
+__global__ void reward_f64_kernel(int64_t n, const float* __restrict__ r32, double* __restrict__ r64) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) r64[i] = (double)r32[i];
+}
+
 static int step_async_impl(DartStepper* h, const float* actions, void* dst) {
   if (!h || !actions) return DART_E_INVALID;
   if (h->pending) { h->err = "step_async called while a step is pending"; return DART_E_PENDING; }
   CHK_AUTORESET(h);
   CHK(h, hipSetDevice(h->device));
   size_t N = (size_t)h->n;
-  memcpy(h->h_act, actions, 4 * N * h->card.act_dim);
-  CHK(h, hipMemcpyAsync(h->d_act, h->h_act, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
+  if (host_pinned(h, actions, 4 * N * h->card.act_dim)) {   // the caller's own page-locked memory: DMA straight from it
+    CHK(h, hipMemcpyAsync(h->d_act, actions, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
+  } else {
+    memcpy(h->h_act, actions, 4 * N * h->card.act_dim);
+    CHK(h, hipMemcpyAsync(h->d_act, h->h_act, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
+  }
   const bool mt_reset = h->autoreset && h->noise_mode == 1;
   CHK(h, h->impl->step(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done,
                        h->d_trunc, mt_reset ? 0 : h->autoreset, h->seed, h->env_offset));
@@ -514,7 +558,9 @@ static int step_async_impl(DartStepper* h, const float* actions, void* dst) {
     CHK(h, h->impl->reset(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_done, h->d_qn, h->d_vn, h->d_obs, h->seed,
                           h->env_offset, 1));
   }
-  if (dst) {   // straight into the caller's page-locked block: no staging copy afterwards (dart_step_wait only synchronises)
+  if (dst == (void*)h) {
+    // dart_step's direct path: the D2H copies go into the caller's registered buffers, enqueued by dart_step itself
+  } else if (dst) {   // straight into the caller's page-locked block: no staging copy afterwards (dart_step_wait only synchronises)
     CHK(h, hipMemcpyAsync(dst, h->d_obs, h->out_bytes, hipMemcpyDeviceToHost, h->stream));
   } else if (!h->split_d2h) {
     CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, h->out_bytes, hipMemcpyDeviceToHost, h->stream));   // obs | reward | done | truncated
@@ -553,9 +599,32 @@ int dart_host_views(DartStepper* h, const float** obs, const float** reward_f32,
 
 int dart_step(DartStepper* h, const float* actions, float* obs_out, double* reward_out, uint8_t* done_out,
               uint8_t* truncated_out) {
-  int rc = dart_step_async(h, actions);
+  if (!h) return DART_E_INVALID;
+  const size_t N = (size_t)h->n;
+  // Every output the caller asks for lies in memory it page-locked (dart_register_host_buffer): the results are DMA-ed straight
+  // into it -- no pinned staging block, no host memcpy, and the float64 rewards the reference returns are made on the device.
+  const bool direct = !h->host_ranges.empty() && (obs_out || reward_out || done_out || truncated_out) &&
+                      (!obs_out || host_pinned(h, obs_out, 4 * N * h->card.obs_dim)) && (!reward_out || host_pinned(h, reward_out, 8 * N)) &&
+                      (!done_out || host_pinned(h, done_out, N)) && (!truncated_out || host_pinned(h, truncated_out, N));
+  if (!direct) {
+    int rc = dart_step_async(h, actions);
+    if (rc != DART_OK) return rc;
+    return dart_step_wait(h, obs_out, reward_out, done_out, truncated_out);
+  }
+  int rc = step_async_impl(h, actions, (void*)h);   // (dst == h: "the caller enqueues the copies")
   if (rc != DART_OK) return rc;
-  return dart_step_wait(h, obs_out, reward_out, done_out, truncated_out);
+  h->pending = false;
+  if (obs_out) CHK(h, hipMemcpyAsync(obs_out, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
+  if (reward_out) {
+    if (!h->d_rew64) CHK(h, hipMalloc((void**)&h->d_rew64, 8 * N));
+    hipLaunchKernelGGL(reward_f64_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, (int64_t)N, h->d_rew, h->d_rew64);
+    CHK(h, hipGetLastError());
+    CHK(h, hipMemcpyAsync(reward_out, h->d_rew64, 8 * N, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (done_out) CHK(h, hipMemcpyAsync(done_out, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
+  if (truncated_out) CHK(h, hipMemcpyAsync(truncated_out, h->d_trunc, N, hipMemcpyDeviceToHost, h->stream));
+  CHK(h, hipStreamSynchronize(h->stream));
+  return DART_OK;
 }
 
 int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done,

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -31,6 +32,7 @@ EXPORTS = [
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
     "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses", "dart_snapshot", "dart_restore", "dart_timer_mark", "dart_timer_elapsed",
     "dart_output_layout", "dart_register_output", "dart_unregister_output", "dart_step_async_to",
+    "dart_register_host_buffer", "dart_unregister_host_buffer",
 ]
 
 
@@ -98,6 +100,8 @@ def load_library(path: Optional[str] = None):
     L.dart_register_output.argtypes = [vp, C.c_void_p]
     L.dart_unregister_output.argtypes = [vp, C.c_void_p]
     L.dart_step_async_to.argtypes = [vp, C.POINTER(C.c_float), C.c_void_p]
+    L.dart_register_host_buffer.argtypes = [vp, C.c_void_p, C.c_uint64]
+    L.dart_unregister_host_buffer.argtypes = [vp, C.c_void_p]
     L.dart_host_views.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
                                   C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint8))]
     L.dart_get_episode_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]
@@ -276,16 +280,19 @@ class HipStepper:
         return self._out_layout
 
     def _free_block(self):
-        """A registered output block nobody else references, or a new one (None when the pool is exhausted or pooling is off).
-        Layout of a block: [obs | reward f32 | done | truncated] exactly as the device block, then (N) float64 rewards -- the type
-        gym.vector returns -- filled on the host.  The arrays a step returns are views of the block, so `sys.getrefcount(block)`
-        tells whether the caller still holds any of them: a block is reused only when it does not (copy=True semantics of
-        sync_vector_env.py:83 without a copy, and without the page faults of fresh multi-MB arrays)."""
+        """A registered output block no caller array refers to any more, or a new one (None when the pool is exhausted or pooling is
+        off).  Layout of a block: [obs | reward f32 | done | truncated] exactly as the device block, then (N) float64 rewards -- the
+        type gym.vector returns -- filled on the host.
+        Ownership is explicit (round 4; it used to be inferred from sys.getrefcount): the arrays a step returns are views of a LEASE --
+        a ctypes array aliasing the block, made for that one step -- and numpy keeps the lease alive as the base of every view derived
+        from them; a weakref finalizer on the lease returns the block to the pool when the last such view is gone.  copy=True semantics
+        of sync_vector_env.py:83 without a copy (and without the page faults of fresh multi-MB arrays every step), independent of
+        who else holds references to the block itself (debuggers, profilers, a test's own bookkeeping)."""
         if os.environ.get("DART_NO_OUT_POOL") == "1":      # (A/B switch of tools/bench_host_path.py: round 2's staging path)
             return None
-        pool = self.__dict__.setdefault("_blocks", [])
+        pool = self.__dict__.setdefault("_blocks", [])      # [block array, leased?]
         for ent in pool:
-            if all(sys.getrefcount(b) == 3 for b in ent):      # tuple + loop variable + the call's argument
+            if not ent[1]:
                 return ent[0]
         if len(pool) >= self._POOL_SETS:
             return None
@@ -294,12 +301,40 @@ class HipStepper:
         rc = self.L.dart_register_output(self.h, blk.ctypes.data_as(C.c_void_p))
         if rc != DART_OK:
             return None
-        pool.append((blk,))
+        pool.append([blk, False])
         return blk
+
+    def _lease(self, blk):
+        """-> a uint8 array over `blk` whose views keep the block out of the pool until all of them are garbage"""
+        ent = next(e for e in self._blocks if e[0] is blk)
+        ent[1] = True
+        ca = (C.c_uint8 * blk.size).from_buffer(blk)
+
+        def release(ent=ent):
+            ent[1] = False
+        weakref.finalize(ca, release)
+        return np.frombuffer(ca, dtype=np.uint8)
+
+    def register_host_buffer(self, arr):
+        """page-lock a caller-owned numpy array for direct DMA (dart_register_host_buffer): `dart_step` arguments inside it skip the
+        staging copies.  The caller keeps `arr` alive until unregister_host_buffer / close."""
+        self._check(self.L.dart_register_host_buffer(self.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        self.__dict__.setdefault("_host_bufs", []).append(arr)
+
+    def unregister_host_buffer(self, arr):
+        self._check(self.L.dart_unregister_host_buffer(self.h, arr.ctypes.data_as(C.c_void_p)))
+        self._host_bufs = [a for a in self.__dict__.get("_host_bufs", []) if a is not arr]
+
+    def step_into(self, actions, obs, reward, done, truncated=None):
+        """`dart_step` with caller-owned arrays, as a C caller binds it: actions (N, act) f32 in, obs (N, obs) f32 / reward (N) f64 /
+        done (N) u8 / truncated (N) u8 out.  Arrays inside registered buffers are filled by DMA (include/dart_stepper.h)."""
+        self._check(self.L.dart_step(self.h, _ptr(actions, C.c_float), _ptr(obs, C.c_float), _ptr(reward, C.c_double), _ptr(done, C.c_uint8),
+                                     _ptr(truncated, C.c_uint8) if truncated is not None else None))
 
     def _block_views(self, blk):
         n = self.num_envs
         total, off = self._layout()
+        blk = self._lease(blk)          # every array below is a view of this step's lease (see _free_block)
         obs = blk[off[0]:off[0] + 4 * n * self.obs_dim].view(np.float32).reshape(n, self.obs_dim)
         r32 = blk[off[1]:off[1] + 4 * n].view(np.float32)
         done = blk[off[2]:off[2] + n].view(np.bool_)        # the kernels write exactly 0 / 1

@@ -118,6 +118,18 @@ int dart_get_state(DartStepper* h, double* q, double* dq);
 int dart_step(DartStepper* h, const float* actions, float* obs_out, double* reward_out, uint8_t* done_out,
               uint8_t* truncated_out);
 
+/* Page-lock a caller-owned host buffer (hipHostRegister) so that dart_step / dart_step_async can DMA straight from / into it:
+ * a C caller that keeps its action / observation / reward / done arrays alive across steps -- the usual way to bind this
+ * library from the reference's side -- registers each of them ONCE (or one arena that holds them all) and
+ * from then on every argument of dart_step that lies inside a registered range skips the library's pinned staging block and the
+ * host memcpy behind it; float64 rewards are produced on the device.  Arguments outside every registered range keep the staging
+ * path (correct for any pointer, ~2x slower at 65 536 envs: profiles/r04_host_path_ab.txt).  Ownership is explicit: the buffer
+ * must stay mapped until dart_unregister_host_buffer or dart_destroy -- the library never registers memory on its own
+ * (page-locking a buffer the caller may free behind its back is not something an ABI should do silently).  Actions inside a
+ * registered range are read by DMA after dart_step_async returns: do not overwrite them before dart_step_wait does. */
+int dart_register_host_buffer(DartStepper* h, void* ptr, uint64_t bytes);
+int dart_unregister_host_buffer(DartStepper* h, void* ptr);
+
 /* VectorEnv.step_async / step_wait (reference gym/vector/vector_env.py:68-92): same as dart_step, split. */
 int dart_step_async(DartStepper* h, const float* actions);
 int dart_step_wait(DartStepper* h, float* obs_out, double* reward_out, uint8_t* done_out, uint8_t* truncated_out);

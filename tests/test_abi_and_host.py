@@ -245,3 +245,41 @@ def test_tuple_space_fast_paths_equal_the_reference_loop():
     mixed = spaces.Tuple((box, spaces.Box(-np.ones(2), np.ones(2))))       # distinct objects: the plain loop
     mixed.seed(3)
     assert len(mixed.sample()) == 2
+
+
+def test_output_blocks_are_leased_to_the_callers_arrays_explicitly():
+    """reuse of the page-locked output blocks no longer hinges on sys.getrefcount.  A block returns to the pool when
+    the last array derived from the step's outputs is garbage -- however many other references to the block itself exist."""
+    import gc
+
+    class FakeLib:                      # the two entry points the pool needs; no device behind them
+        def dart_output_layout(self, h, tot, off):
+            n, k = 8, 3
+            ob, rb, db = 4 * n * k, 4 * n, n
+            tot._obj.value = ob + rb + 2 * db
+            for i, v in enumerate((0, ob, ob + rb, ob + rb + db)):
+                off[i] = v
+            return st.DART_OK
+
+        def dart_register_output(self, h, blk):
+            return st.DART_OK
+
+    s = object.__new__(st.HipStepper)
+    s.L, s.h, s.num_envs, s.obs_dim = FakeLib(), None, 8, 3
+    b0 = s._free_block()
+    snoop = [b0, b0, b0]                # a tool holding extra references to the block (what broke the refcount test)
+    obs, rew, done, trunc = s._block_views(b0)
+    assert obs.shape == (8, 3) and rew.dtype == np.float64 and done.dtype == np.bool_
+    b1 = s._free_block()
+    assert b1 is not b0                 # the caller still holds the arrays of b0's step: another block
+    row = obs[2:4]                      # a derived view keeps the lease too
+    del obs, rew, done, trunc
+    gc.collect()
+    assert s._free_block() is b1        # (b1 was never leased: still the first free one) ...
+    o1 = s._block_views(b1)
+    b2 = s._free_block()
+    assert b2 is not b0 and b2 is not b1     # ... and with b1 leased and `row` alive, b0 is NOT handed out again
+    del row
+    gc.collect()
+    assert s._free_block() is b0        # the last view is gone: b0 is free again, `snoop` notwithstanding
+    del o1, snoop

@@ -931,3 +931,37 @@ def test_launch_order_does_not_change_results():
     for a, b in zip(*outs):
         assert np.array_equal(a, b, equal_nan=True)
     assert any(x.any() for x in outs[0][2::3])      # some episodes ended and restarted
+
+
+def test_launch_order_with_contact_report_and_external_force_is_bitwise_index_order():
+    """with a launch order in force the workgroup that steps env e is NOT workgroup e -- every per-env buffer inside the
+    world step (external force, contact report, constraint forces) must be indexed by the env, not by blockIdx.  The reporting
+    instantiation with an external body force, above the 4 096 envs where the order is on by default: contacts, constraint forces,
+    states and outputs are bitwise those of index order, and the per-env forces act on their own envs (they differ per env)."""
+    from dart_env_amd import stepper as st
+    card = card_for("DartHumanWalker-v1", generic_kernel=True)
+    n = 4608
+    rng = np.random.RandomState(8)
+    acts = rng.uniform(-1, 1, (6, n, card.act_dim)).astype(np.float32)
+    force = np.zeros((n, 3)); force[:, 0] = np.linspace(-40.0, 40.0, n); force[:, 1] = rng.uniform(-10, 10, n)   # a different push per env
+    outs = []
+    for order in (1, 0):
+        g = st.HipStepper(card, n, precision=64)
+        g.configure(st.CFG_AUTORESET, 0); g.configure(st.CFG_SEED, 5)
+        g.configure(st.CFG_CONTACT_REPORT, 1)
+        g.configure(st.CFG_LAUNCH_ORDER, order)
+        g.set_ext_force(1, force)
+        g.reset(None, None, None, want_obs=False)
+        rec = []
+        for t in range(6):     # (the order takes effect from the second launch on: it is built from the first one's durations)
+            o, r, d, tr = g.step(acts[t])
+            cnt, bod, pt, fc = g.contacts()
+            rec += [o.copy(), r.copy(), d.copy(), cnt.copy(), bod.copy(), pt.copy(), fc.copy(), g.constraint_forces().copy()]
+        rec += list(g.get_state())
+        outs.append(rec)
+        g.close()
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b, equal_nan=True), k
+    assert outs[0][3].max() > 0                                  # contacts were reported
+    # (in index order workgroup e steps env e and reads force[e]; the pushes differ per env, so bitwise equality with index order
+    # means the ordered launch also applied every env's OWN force and wrote every env's OWN report)

@@ -67,6 +67,11 @@ struct DartStepper {
   std::vector<std::pair<char*, size_t>> host_ranges;
   double* d_rew64 = nullptr;       // float64 rewards for the direct path of dart_step (the reference's reward type), made on the device
   bool split_d2h = false;        // DART_SPLIT_D2H=1: the four separate copies of rounds 1-2 (A/B measurements)
+  // Round 4: the PCIe legs of the host-buffer path without the copy engines.  zc_actions: the step kernel reads the actions straight
+  // from page-locked host memory (one coalesced 768-byte read per wave) instead of waiting for an H2D copy; d2h_kernel: the step's
+  // output block goes back through a copy KERNEL that writes into the mapped host block with 16-byte coalesced stores, instead of a
+  // hipMemcpyAsync (SDMA).  DART_HOST_DMA=copy restores the copy-engine path of rounds 1-3 (A/B: tools/gpu/host_path_c.py).
+  bool zc_actions = true, d2h_kernel = true;
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
   double *h_qn = nullptr, *h_vn = nullptr;
@@ -175,6 +180,10 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
       h->h_obs = (float*)hb; h->h_rew = (float*)(hb + ob); h->h_done = hb + ob + rb; h->h_trunc = hb + ob + rb + db;
       const char* e = getenv("DART_SPLIT_D2H");
       h->split_d2h = e && e[0] == '1';
+      const char* dm = getenv("DART_HOST_DMA");
+      if (dm && !strcmp(dm, "copy")) { h->zc_actions = false; h->d2h_kernel = false; }
+      if (dm && !strcmp(dm, "zc_actions")) h->d2h_kernel = false;     // (each leg on its own, for the A/B)
+      if (dm && !strcmp(dm, "d2h_kernel")) h->zc_actions = false;
     }
     CHK(h, hipMalloc((void**)&h->d_mask, N));
     CHK(h, hipMalloc((void**)&h->d_qn, 8 * N * nd));
@@ -531,6 +540,28 @@ static bool host_pinned(const DartStepper* h, const void* p, size_t bytes) {
   return false;
 }
 
+// device block -> mapped host block, 16 bytes per lane per iteration (the block is a multiple of 256 bytes)
+__global__ void __launch_bounds__(256) d2h_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// the device address of page-locked host memory (hipHostMalloc'ed or hipHostRegister'ed); nullptr if the runtime has none
+static void* host_devptr(void* p) {
+  void* d = nullptr;
+  return hipHostGetDevicePointer(&d, p, 0) == hipSuccess ? d : nullptr;
+}
+static int d2h_block(DartStepper* h, void* host_dst, const void* dev_src, size_t bytes) {
+  void* dd = h->d2h_kernel && (bytes % 16 == 0) ? host_devptr(host_dst) : nullptr;
+  if (dd) {
+    const int64_t n16 = (int64_t)(bytes / 16);
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(d2h_copy_kernel, dim3(blocks), dim3(256), 0, h->stream, (const uint4*)dev_src, (uint4*)dd, n16);
+    CHK(h, hipGetLastError());
+  } else {
+    CHK(h, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, h->stream));
+  }
+  return DART_OK;
+}
+
 __global__ void reward_f64_kernel(int64_t n, const float* __restrict__ r32, double* __restrict__ r64) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) r64[i] = (double)r32[i];
@@ -542,14 +573,18 @@ static int step_async_impl(DartStepper* h, const float* actions, void* dst) {
   CHK_AUTORESET(h);
   CHK(h, hipSetDevice(h->device));
   size_t N = (size_t)h->n;
-  if (host_pinned(h, actions, 4 * N * h->card.act_dim)) {   // the caller's own page-locked memory: DMA straight from it
-    CHK(h, hipMemcpyAsync(h->d_act, actions, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
-  } else {
+  const float* host_act = actions;                            // page-locked source of this step's actions
+  if (!host_pinned(h, actions, 4 * N * h->card.act_dim)) {   // (the caller's own page-locked memory is used where it lies)
     memcpy(h->h_act, actions, 4 * N * h->card.act_dim);
-    CHK(h, hipMemcpyAsync(h->d_act, h->h_act, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
+    host_act = h->h_act;
+  }
+  const float* kernel_act = h->zc_actions ? (const float*)host_devptr((void*)host_act) : nullptr;
+  if (!kernel_act) {
+    CHK(h, hipMemcpyAsync(h->d_act, host_act, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
+    kernel_act = h->d_act;
   }
   const bool mt_reset = h->autoreset && h->noise_mode == 1;
-  CHK(h, h->impl->step(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs, h->d_rew, h->d_done,
+  CHK(h, h->impl->step(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, kernel_act, h->d_obs, h->d_rew, h->d_done,
                        h->d_trunc, mt_reset ? 0 : h->autoreset, h->seed, h->env_offset));
   { int rc = episode_accumulate(h, h->stream, h->d_rew, h->d_done); if (rc != DART_OK) return rc; }
   if (mt_reset) {   // done envs: MT19937 noise, reset, post-reset observation (sync_vector_env.py:77-78)
@@ -561,9 +596,9 @@ static int step_async_impl(DartStepper* h, const float* actions, void* dst) {
   if (dst == (void*)h) {
     // dart_step's direct path: the D2H copies go into the caller's registered buffers, enqueued by dart_step itself
   } else if (dst) {   // straight into the caller's page-locked block: no staging copy afterwards (dart_step_wait only synchronises)
-    CHK(h, hipMemcpyAsync(dst, h->d_obs, h->out_bytes, hipMemcpyDeviceToHost, h->stream));
+    int rc = d2h_block(h, dst, h->d_obs, h->out_bytes); if (rc != DART_OK) return rc;
   } else if (!h->split_d2h) {
-    CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, h->out_bytes, hipMemcpyDeviceToHost, h->stream));   // obs | reward | done | truncated
+    int rc = d2h_block(h, h->h_obs, h->d_obs, h->out_bytes); if (rc != DART_OK) return rc;   // obs | reward | done | truncated
   } else {
     CHK(h, hipMemcpyAsync(h->h_obs, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
     CHK(h, hipMemcpyAsync(h->h_rew, h->d_rew, 4 * N, hipMemcpyDeviceToHost, h->stream));
@@ -614,15 +649,15 @@ int dart_step(DartStepper* h, const float* actions, float* obs_out, double* rewa
   int rc = step_async_impl(h, actions, (void*)h);   // (dst == h: "the caller enqueues the copies")
   if (rc != DART_OK) return rc;
   h->pending = false;
-  if (obs_out) CHK(h, hipMemcpyAsync(obs_out, h->d_obs, 4 * N * h->card.obs_dim, hipMemcpyDeviceToHost, h->stream));
+  if (obs_out) { rc = d2h_block(h, obs_out, h->d_obs, 4 * N * h->card.obs_dim); if (rc != DART_OK) return rc; }
   if (reward_out) {
     if (!h->d_rew64) CHK(h, hipMalloc((void**)&h->d_rew64, 8 * N));
     hipLaunchKernelGGL(reward_f64_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, (int64_t)N, h->d_rew, h->d_rew64);
     CHK(h, hipGetLastError());
-    CHK(h, hipMemcpyAsync(reward_out, h->d_rew64, 8 * N, hipMemcpyDeviceToHost, h->stream));
+    rc = d2h_block(h, reward_out, h->d_rew64, 8 * N); if (rc != DART_OK) return rc;
   }
-  if (done_out) CHK(h, hipMemcpyAsync(done_out, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
-  if (truncated_out) CHK(h, hipMemcpyAsync(truncated_out, h->d_trunc, N, hipMemcpyDeviceToHost, h->stream));
+  if (done_out) { rc = d2h_block(h, done_out, h->d_done, N); if (rc != DART_OK) return rc; }
+  if (truncated_out) { rc = d2h_block(h, truncated_out, h->d_trunc, N); if (rc != DART_OK) return rc; }
   CHK(h, hipStreamSynchronize(h->stream));
   return DART_OK;
 }

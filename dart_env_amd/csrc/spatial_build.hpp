@@ -102,6 +102,18 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     if (c.joint_friction[d] != 0.0) M.has_joint_friction = 1;
   }
   if (body_link_out) for (int b = 0; b < c.nbodies; b++) body_link_out[b] = body_link[b];
+  M.n_mpairs = 0;
+  for (int i = 0; i < nl; i++) {   // the dofs that move link i
+    M.anc_dofs[i] = 0u;
+    for (int j = i; j >= 0; j = M.parent[j]) if (M.dof[j] >= 0) M.anc_dofs[i] |= 1u << M.dof[j];
+  }
+  for (int d = 0; d < c.ndofs; d++) {   // mass-matrix entries (d, dj): dj on the path of d's link to the root
+    const int i = M.dof_link[d];
+    for (int j = i; j >= 0; j = M.parent[j]) {
+      if (M.dof[j] < 0) continue;
+      M.mpairs[M.n_mpairs++] = (uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)d << 16) | ((uint32_t)M.dof[j] << 24);
+    }
+  }
   {  // depth levels, children lists, constant world axes of the root-chain prismatic links
     int depth[SP_MAXL], maxd = 0;
     double Rw[SP_MAXL][9];   // world rotation of each link's JOINT frame at q = 0 (valid for root-chain links)

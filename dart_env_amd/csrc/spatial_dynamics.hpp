@@ -2,6 +2,7 @@
 // Part of the gfx950 tree kernel; overview in spatial_kernel.hpp, design in DESIGN.md section 4.2.
 #pragma once
 #include "spatial_model.hpp"
+#include "tree_patterns.hpp"
 
 namespace dartk {
 
@@ -106,10 +107,11 @@ template <class Real> __device__ __forceinline__ V3<Real> shfl3(V3<Real> v, int 
 //   4. the link's wrench and composite-body seeds about its own joint origin go to LDS.
 // POSE_ONLY: steps 1-2 only (link frames, joint origins / axes, COMs go to LDS) -- the pose the task code reads before and
 // after the world steps, which the first version computed link after link on lane 0.
-template <class Real, bool EXTRAS = false, bool POSE_ONLY = false>
+// PAT: a pattern kernel's compile-time model dimensions (tree_patterns.hpp); DensePattern = read them from the model.
+template <class Real, bool EXTRAS = false, bool POSE_ONLY = false, class PAT = DensePattern>
 __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane,
                                            int64_t env = 0) {
-  const bool live = lane < Md.nl;
+  const bool live = lane < (PAT::dense ? Md.nl : PAT::nl);
   const bool rev = lc.jtype == 2, slide = lc.jtype == 1 && !lc.root_trans;
   const Real qv = (live && lc.dof >= 0) ? S.q[lc.dof] : Real(0), qd = (live && lc.dof >= 0) ? S.dq[lc.dof] : Real(0);
   Real G[SP_LCONST];   // this link's geometry block
@@ -144,7 +146,7 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
     p = ld3(G + LC_PPRE) + mulR(G + LC_RPRE, t);
     if (!live) { for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? Real(1) : Real(0); p = v3<Real>(0, 0, 0); }
   }
-  const int nr = Md.nrounds;
+  const int nr = PAT::dense ? Md.nrounds : PAT::nrounds;
 #pragma unroll
   for (int k = 0; k < SP_ROUNDS; k++) {
     if (k < nr) {
@@ -272,7 +274,7 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
 
 // Link poses of the current S.q for the task code (all 64 lanes call; ends with a barrier): what sp_kinematics computes
 // serially, in O(log depth) wave steps.  A free root must already be in internal coordinates (sp_free_root_to_internal).
-template <class Real, bool EXTRAS>
+template <class Real, bool EXTRAS, class PAT = DensePattern>
 __device__ __forceinline__ void sp_pose_pass(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane);
 
 // floating-base translation: root-chain prismatic joints have fixed world axes (their ancestors never rotate)
@@ -287,11 +289,11 @@ __device__ __forceinline__ void sp_root_offset(const SpatialModel<Real>& Md, SpL
   st3(S.misc, roff);
 }
 
-template <class Real, bool EXTRAS>
+template <class Real, bool EXTRAS, class PAT>
 __device__ __forceinline__ void sp_pose_pass(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int lane) {
   __syncthreads();
   if (lane == 0) sp_root_offset<Real>(Md, S);
-  sp_forward<Real, EXTRAS, true>(lc, Md, S, lane);
+  sp_forward<Real, EXTRAS, true, PAT>(lc, Md, S, lane);
   __syncthreads();
 }
 
@@ -378,6 +380,34 @@ __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const Spa
     else v = dot(aj, Lm);
     if (dj == d && add_diag) v += lc.d_diag;   // the implicit damping / spring terms E = dt D + dt^2 K (A3: only when the impulse pass runs on M + E)
     S.H[HI(n1 - d, n1 - dj)] = v;   // symmetric index: a free root's rotation dofs (0..2) hang below its translation dofs (3..5)
+  }
+}
+
+// The same entries without the walk (round 4): the model lists the structurally non-zero pairs (d, dj) -- SpatialModel::mpairs, 251 for
+// HumanWalker -- and the 64 lanes take them round-robin, every entry from LDS reads that depend on nothing but the entry: ~4 entries
+// per lane instead of a 12-hop dependent chain through LDS on 29 lanes (fp64 HumanWalker: 9.5 k -> ~2 k cycles per world step).
+// The integrator's diagonal terms (add_diag: the A3 knob at 0) are added by the caller after its barrier.
+template <class Real, class PAT = DensePattern>
+__device__ __forceinline__ void sp_mass_entries(const SpatialModel<Real>& Md, SpLds<Real>& S, int lane) {
+  const int n1 = (PAT::dense ? Md.n : PAT::n) - 1, np_ = PAT::dense ? Md.n_mpairs : PAT::n_mpairs;
+  for (int e = lane; e < np_; e += 64) {
+    const uint32_t pr = Md.mpairs[e];
+    const int i = pr & 0xff, jl = (pr >> 8) & 0xff, d = (pr >> 16) & 0xff, dj = pr >> 24;
+    const Real* L = S.link + i * SP_LINKF;
+    const V3<Real> a = ld3(L + LK_A), h = ld3(L + LK_H), jo = ld3(L + LK_JO);
+    V3<Real> Lm, K;
+    if (topo_jtype(S.topo[i]) == 2) {
+      Lm = cross(a, h);
+      const Real* I = L + LK_IC;
+      K = v3<Real>(I[0] * a.x + I[1] * a.y + I[2] * a.z, I[1] * a.x + I[3] * a.y + I[4] * a.z, I[2] * a.x + I[4] * a.y + I[5] * a.z);
+    } else {
+      Lm = a * L[LK_MC];
+      K = cross(h, a);
+    }
+    const Real* Lj = S.link + jl * SP_LINKF;
+    const V3<Real> aj = ld3(Lj + LK_A);
+    const Real v = (topo_jtype(S.topo[jl]) == 2) ? dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm)) : dot(aj, Lm);
+    S.H[HI(n1 - d, n1 - dj)] = v;
   }
 }
 

@@ -81,6 +81,12 @@ struct SpatialImplT : Impl {
         if ((low[a] >> j) & 1u)
           for (int b = j + 1; b < a; b++) if ((low[b] >> j) & 1u) low[a] |= 1u << b;
     for (int i = 0; i < n; i++) if (low[i] != PAT::row(i)) return false;
+    // the model constants the pattern kernel takes as compile-time facts (tree_patterns.hpp; sp_step_kernel assumes them)
+    if (M.nl != PAT::nl || M.maxm != PAT::maxm || M.maxcp != PAT::maxcp || M.nshapes != PAT::nshapes || M.npairs != PAT::npairs ||
+        M.free_root != PAT::free_root || M.task != PAT::task || M.frame_skip != PAT::frame_skip || M.act_dim != PAT::act_dim ||
+        M.obs_dim != PAT::obs_dim || M.act_dof0 != PAT::act_dof0 || M.nrounds != PAT::nrounds || M.n_mpairs != PAT::n_mpairs ||
+        M.impulse_M != PAT::impulse_M || M.has_joint_friction != PAT::has_joint_friction)
+      return false;
     return true;
   }
   // register-LCP models without contact reporting drop the LDS solver's workspace (sp_carve): smaller block, more workgroups per CU

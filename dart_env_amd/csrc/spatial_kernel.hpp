@@ -21,6 +21,7 @@
 // spatial_dense.hpp (Cholesky, solves, boxed LCP) . spatial_free_root.hpp (FreeJoint) . spatial_box_box.hpp (link-link
 // contacts) . spatial_world_step.hpp (one DART step) . spatial_tasks.hpp (task epilogues) . this file (the kernels).
 #pragma once
+#include <type_traits>
 #include "spatial_tasks.hpp"
 
 // the workgroup's dynamic LDS block (the host emulation of tests/kernel_emu/fake_wave_include supplies its own definition)
@@ -39,6 +40,9 @@ namespace dartk {
 // (measured 6.19 -> 5.84 ms; the PAIRS kernel of Walker3d got 13 % slower at 3).
 #ifndef SP_PAT_F32_WAVES
 #define SP_PAT_F32_WAVES 3
+#endif
+#ifndef SP_BAKE_DIMS
+#define SP_BAKE_DIMS 1
 #endif
 #ifndef SP_PAT_F64_WAVES
 #define SP_PAT_F64_WAVES 1
@@ -64,93 +68,99 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
   if ((int64_t)blockIdx.x >= n_envs) return;
   const int64_t e = Md.sched_perm ? (int64_t)Md.sched_perm[blockIdx.x] : (int64_t)blockIdx.x;
   const long long sched_t0 = Md.sched_cost ? (long long)__builtin_readcyclecounter() : 0ll;
-  const int n = Md.n;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp, Md.reg_lcp);
+  // BK: the pattern kernel takes the model's dimensions and task from its pattern at compile time (tree_patterns.hpp; launched only
+  // for a model that carries exactly these values, SpatialImplT::matches_pattern; its launch condition fixes reg_lcp = 1)
+  constexpr bool BK = (SP_BAKE_DIMS != 0) && !PAT::dense;
+  const int n = BK ? PAT::n : Md.n, nl_ = BK ? PAT::nl : Md.nl;
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl_, n, BK ? PAT::maxm : Md.maxm, BK ? PAT::maxcp : Md.maxcp, BK ? PAT::reg_lcp : Md.reg_lcp);
+  const int task = BK ? PAT::task : Md.task, act_dim = BK ? PAT::act_dim : Md.act_dim, act_dof0 = BK ? PAT::act_dof0 : Md.act_dof0;
+  const int frame_skip = BK ? PAT::frame_skip : Md.frame_skip, obs_dim = BK ? PAT::obs_dim : Md.obs_dim;
   int* cflags = S.imisc + 2;
   Real* sh_scal = S.misc + 8;
   if (lane < n) { S.q[lane] = qs[e * n + lane]; S.dq[lane] = dqs[e * n + lane]; S.tau[lane] = Real(0); }
-  if (lane < Md.nl) S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16);
+  if (lane < nl_) { S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16); S.ancd[lane] = (int)Md.anc_dofs[lane]; }
   if (Md.stats && lane < 10) S.ticks[lane] = 0ull;
-  if (EXTRAS && Md.task == 12 && lane < n) S.cf[lane] = Md.cf_store[e * n + lane];
+  if (EXTRAS && task == 12 && lane < n) S.cf[lane] = Md.cf_store[e * n + lane];
   __syncthreads();
   // action: comparison clamp (a NaN stays NaN, hopper.py:25-30) and scaling, one lane per action; the reward's |a| and a^2 sums
   // by wave reductions
   Real abs_sum = Real(0), sq_sum = Real(0);
   {
-    const bool has = lane < Md.act_dim;
-    const Real a = has ? (Real)actions[e * Md.act_dim + lane] : Real(0);
+    const bool has = lane < act_dim;
+    const Real a = has ? (Real)actions[e * act_dim + lane] : Real(0);
     abs_sum = wave_sum<Real>(fabs(a)); sq_sum = wave_sum<Real>(a * a);
     if (has) {
       Real cl = (a > Md.act_hi[lane]) ? Md.act_hi[lane] : a;
       cl = (cl < Md.act_lo[lane]) ? Md.act_lo[lane] : cl;
-      const int dd = Md.act_dof0 + lane;
-      if (EXTRAS && Md.task == 12)   // SPD: the action is a target pose inside the joint's limits (walker3d_spd.py:68-70)
+      const int dd = act_dof0 + lane;
+      if (EXTRAS && task == 12)   // SPD: the action is a target pose inside the joint's limits (walker3d_spd.py:68-70)
         S.tau[dd] = (cl + Real(1)) / Real(2) * (Md.upper[dd] - Md.lower[dd]) + Md.lower[dd];
       else
         S.tau[dd] = cl * Md.act_scale[lane];
     }
   }
   LinkConst<Real> lc;
-  sp_load_link_const<Real>(Md, lane < Md.nl ? lane : 0, lc);
+  sp_load_link_const<Real>(Md, lane < nl_ ? lane : 0, lc);
   if (EXTRAS && Md.free_root) {
     __syncthreads();
     if (lane == 0) { sp_free_root_load<Real>(S); sp_free_root_to_internal<Real>(S); }   // S.q / S.dq: internal from here
   }
   // link poses are needed before the step only by the tasks that measure progress on a body (3, 4) or a tip (11), after
   // it only by the tasks whose reward / done / observation read a body pose
-  if (Md.task == 3 || Md.task == 4 || Md.task == 11 || Md.task == 12 || Md.task == 13) sp_pose_pass<Real, EXTRAS>(lc, Md, S, lane);
+  if (task == 3 || task == 4 || task == 11 || task == 12 || task == 13) sp_pose_pass<Real, EXTRAS, typename std::conditional<BK, PAT, DensePattern>::type>(lc, Md, S, lane);
   else __syncthreads();
   if (lane == 0) {
-    sh_scal[0] = (Md.task == 3 || Md.task == 4 || Md.task == 12 || Md.task == 13) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
-    if (Md.task == 11) {   // DartReacher3d: distance to the target BEFORE the step, and sum tau^2 (reacher.py:23-27)
+    sh_scal[0] = (task == 3 || task == 4 || task == 12 || task == 13) ? S.link[Md.aux_link[0] * SP_LINKF + LK_C] + S.misc[0] : S.q[0];   // posbefore
+    if (task == 11) {   // DartReacher3d: distance to the target BEFORE the step, and sum tau^2 (reacher.py:23-27)
       const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - ld3(tstate + 4 * e);
       sh_scal[0] = sqrt(dot(vec, vec));
       Real st2 = Real(0);
-      for (int k = 0; k < Md.act_dim; k++) st2 += S.tau[Md.act_dof0 + k] * S.tau[Md.act_dof0 + k];
+      for (int k = 0; k < act_dim; k++) st2 += S.tau[act_dof0 + k] * S.tau[act_dof0 + k];
       sh_scal[2] = st2;
     }
     cflags[0] = 0; cflags[1] = 0;
   }
   __syncthreads();
-  for (int f = 0; f < Md.frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG, PAT>(Md, lc, S, lane, cflags, e, REPORT && Md.creport != nullptr && f == Md.frame_skip - 1);
+#pragma nounroll
+  for (int f = 0; f < frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG, PAT>(Md, lc, S, lane, cflags, e, REPORT && Md.creport != nullptr && f == frame_skip - 1);
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
-  const bool pose_last = Md.task == 1 || Md.task == 2 || Md.task == 3 || Md.task == 4 || Md.task == 8 || Md.task >= 10;
-  const bool pose_reset = pose_last && Md.task != 13;   // the dog's observation holds no body pose
+  const bool pose_last = task == 1 || task == 2 || task == 3 || task == 4 || task == 8 || task >= 10;
+  const bool pose_reset = pose_last && task != 13;   // the dog's observation holds no body pose
   if (EXTRAS && Md.free_root) {
     __syncthreads();
     if (lane == 0) sp_free_root_to_internal<Real>(S);   // internal coordinates of the final pose
   }
-  if (pose_last) sp_pose_pass<Real, EXTRAS>(lc, Md, S, lane);
+  if (pose_last) sp_pose_pass<Real, EXTRAS, typename std::conditional<BK, PAT, DensePattern>::type>(lc, Md, S, lane);
   if (lane == 0) {
     Real rew = Real(0);
     bool task_done = false;
     Real dog_x = Real(0), dog_h = Real(0), dog_side = Real(0);
-    if (Md.task == 13) {
+    if (task == 13) {
       const Real* Lb = S.link + Md.aux_link[0] * SP_LINKF;
       dog_x = Lb[LK_C] + S.misc[0]; dog_h = Lb[LK_C + 1] + S.misc[1]; dog_side = fabs(Lb[LK_C + 2] + S.misc[2]);
     }
     if (EXTRAS && Md.free_root) sp_free_root_store<Real>(S);          // S.q / S.dq: public coordinates again
-    if (Md.task == 13) {   // DartDogEnv.step (dog.py:28-46)
+    if (task == 13) {   // DartDogEnv.step (dog.py:28-46)
       rew = Md.aux_real[1] * (dog_x - sh_scal[0]) * Md.inv_envdt;
       rew += Md.aux_real[0];
       rew -= Md.aux_real[2] * sq_sum;
       bool ok = true;
-      for (int i = 0; i < Md.n; i++) {
+      for (int i = 0; i < n; i++) {
         ok = ok && isfinite(S.q[i]) && isfinite(S.dq[i]) && (fabs(S.dq[i]) < Md.s_max);
         if (i >= 2) ok = ok && (fabs(S.q[i]) < Md.s_max);
       }
       task_done = !(ok && dog_h > Md.aux_real[4] && dog_h < Md.aux_real[5] && dog_side < Md.aux_real[3]);
     }
-    if (Md.task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, tstate[4 * e], cflags, rew);
-    else if (Md.task == 3 || Md.task == 12) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
-    else if (Md.task >= 5 && Md.task != 13) task_done = sp_simple_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
-    else if (Md.task == 1 || Md.task == 2) task_done = sp_planar_task_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
-    if (Md.task == 10 || Md.task == 11) {   // reachers: reward from the tip-target distance (2-D: after, 3-D: before the step)
+    if (task == 4) task_done = sp_humanwalker_epilogue<Real>(Md, S, sh_scal[0], abs_sum, tstate[4 * e], cflags, rew);
+    else if (task == 3 || task == 12) task_done = sp_walker3d_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
+    else if (task >= 5 && task != 13) task_done = sp_simple_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
+    else if (task == 1 || task == 2) task_done = sp_planar_task_epilogue<Real>(Md, S, sh_scal[0], sq_sum, rew);
+    if (task == 10 || task == 11) {   // reachers: reward from the tip-target distance (2-D: after, 3-D: before the step)
       const V3<Real> tgt = ld3(tstate + 4 * e);
       bool fin = true;
-      for (int i = 0; i < Md.n; i++) fin = fin && isfinite(S.q[i]) && isfinite(S.dq[i]);
-      if (Md.task == 11) {
+      for (int i = 0; i < n; i++) fin = fin && isfinite(S.q[i]) && isfinite(S.dq[i]);
+      if (task == 11) {
         const Real dist0 = sh_scal[0];
         rew = -dist0 + -(sh_scal[2] * Md.aux_real[3]);
         task_done = !(fin && (dist0 > Md.aux_real[4]));
@@ -185,19 +195,19 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
       S.dq[lane] = Md.dq0[lane] + (-Md.noise_v + Real(2) * Md.noise_v * uv);
     }
     __syncthreads();
-    if (pose_reset) sp_pose_pass<Real, false>(lc, Md, S, lane);   // (`dn` is wave-uniform; no free-root model reads a pose here)
+    if (pose_reset) sp_pose_pass<Real, false, typename std::conditional<BK, PAT, DensePattern>::type>(lc, Md, S, lane);   // (`dn` is wave-uniform; no free-root model reads a pose here)
     if (lane == 0) {
       episode[e] = ep;
-      if (Md.task == 4) tstate[4 * e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
+      if (task == 4) tstate[4 * e] = S.link[Md.aux_link[1] * SP_LINKF + LK_C + 1] + S.misc[1];
       cflags[0] = 0; cflags[1] = 0;
     }
     __syncthreads();
   }
   if (lane < n) { qs[e * n + lane] = S.q[lane]; dqs[e * n + lane] = S.dq[lane]; }
-  if (EXTRAS && Md.task == 12 && lane < n) Md.cf_store[e * n + lane] = (autoreset && dn) ? Real(0) : S.cf[lane];
-  if ((Md.task == 10 || Md.task == 11) && lane < 3) S.misc[4 + lane] = tstate[4 * e + lane];
+  if (EXTRAS && task == 12 && lane < n) Md.cf_store[e * n + lane] = (autoreset && dn) ? Real(0) : S.cf[lane];
+  if ((task == 10 || task == 11) && lane < 3) S.misc[4 + lane] = tstate[4 * e + lane];
   __syncthreads();
-  sp_write_obs<Real>(Md, S, cflags, obs + e * Md.obs_dim, lane);
+  sp_write_obs<Real>(Md, S, cflags, obs + e * obs_dim, lane, BK ? n : -1, BK ? task : -1);
   if (Md.sched_cost && lane == 0) Md.sched_cost[e] = (unsigned int)((long long)__builtin_readcyclecounter() - sched_t0);
 }
 
@@ -220,7 +230,7 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
     const int64_t at = soa ? (int64_t)lane * n_envs + e : e * n + lane;
     S.q[lane] = qs[at]; S.dq[lane] = dqs[at]; S.tau[lane] = Real(0);
   }
-  if (lane < nl) S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16);
+  if (lane < nl) { S.topo[lane] = (Md.parent[lane] + 1) | ((Md.dof[lane] + 1) << 8) | (Md.jtype[lane] << 16); S.ancd[lane] = (int)Md.anc_dofs[lane]; }
   __syncthreads();
   if (pose_out) {   // bodynode world transforms / COMs: R (9), origin (3), com (3) per card body; cold path, serial kinematics
     if (lane == 0) {

@@ -49,6 +49,10 @@ struct SpatialModel {
   // loads issued together: one L1/L2-resident latency per substep instead of ~45 VGPRs held for the whole kernel)
   Real lconst[SP_MAXL][SP_LCONST];
   int child_start[SP_MAXL + 1], child_list[SP_MAXL];            // children of every link
+  // entry-parallel assembly (round 4): no ancestor pointer chasing inside a world step
+  uint32_t anc_dofs[SP_MAXL];        // bit d: dof d moves link i (d belongs to a link on the path i -> root, i included)
+  int n_mpairs;                      // structurally non-zero entries (d, dj) of the mass matrix, dj on d's path to the root
+  uint32_t mpairs[SP_MAXN * (SP_MAXN + 1) / 2];   // link(d) | link(dj) << 8 | d << 16 | dj << 24
   Real axis[SP_MAXL][3];
   Real root_axis_world[SP_MAXL][3];   // world axis of the root-chain prismatic links (constant)
   Real Rpre[SP_MAXL][9], ppre[SP_MAXL][3];    // joint frame in the parent link frame
@@ -152,6 +156,7 @@ struct SpLds {
   int* imisc;    // [8]: ncp, m, contact flags
   unsigned long long* ticks;   // [10] phase cycle counters of this env-step (diagnostics, only touched when stats are on)
   int* topo;     // [nl]: (parent + 1) | (dof + 1) << 8 | jtype << 16 -- ancestor walks read this instead of global memory
+  int* ancd;     // [nl]: SpatialModel::anc_dofs, the dofs that move each link (Jacobian rows are built entry by entry from it)
 };
 __device__ __forceinline__ int topo_parent(int w) { return (w & 0xff) - 1; }
 __device__ __forceinline__ int topo_dof(int w) { return ((w >> 8) & 0xff) - 1; }
@@ -186,7 +191,8 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   S.cplinkB = (int*)p; p += maxcp * sizeof(int) / sizeof(Real) + 1;
   S.imisc = (int*)p;
   S.topo = S.imisc + 8;
-  S.ticks = (unsigned long long*)(((size_t)(S.topo + nl) + 7) & ~(size_t)7);
+  S.ancd = S.topo + nl;
+  S.ticks = (unsigned long long*)(((size_t)(S.ancd + nl) + 7) & ~(size_t)7);
   return S;
 }
 __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp, int reg_lcp) {
@@ -195,7 +201,7 @@ __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes,
   const size_t a = (reg_lcp && alias) ? 0 : (size_t)sp_tri(maxm);
   size_t reals = (size_t)nl * SP_LINKF + 5 * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)sp_w_reals(n, maxm) + a + lw + 5 * maxm +
                  maxcp * 7 + 16 + 24;
-  return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
+  return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + 2 * nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }
 
 }  // namespace dartk

@@ -148,17 +148,19 @@ __device__ __forceinline__ bool sp_simple_epilogue(const SpatialModel<Real>& Md,
 }
 
 template <class Real>
-__device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds<Real>& S, const int* cflags, float* __restrict__ o, int lane) {
-  const int n = Md.n;
-  if (Md.task == 10 || Md.task == 11) {   // reachers: cos q, sin q, target (2-D: x, z), dq, tip - target (reacher.py:38-42)
+__device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds<Real>& S, const int* cflags, float* __restrict__ o, int lane,
+                                             int n_ = -1, int task_ = -1) {
+  // n_ / task_: the caller's compile-time copies of Md.n / Md.task (pattern kernels), -1 = read the model
+  const int n = n_ >= 0 ? n_ : Md.n, task = task_ >= 0 ? task_ : Md.task;
+  if (task == 10 || task == 11) {   // reachers: cos q, sin q, target (2-D: x, z), dq, tip - target (reacher.py:38-42)
     const V3<Real> tgt = ld3(S.misc + 4);       // staged by the caller from the per-env task state
     int o0 = 2 * n;
     if (lane < n) { Real sn, cs; sincos_<Real>(S.q[lane], sn, cs); o[lane] = (float)cs; o[n + lane] = (float)sn; }
     if (lane == 0) {
-      if (Md.task == 10) { o[o0] = (float)tgt.x; o[o0 + 1] = (float)tgt.z; }
+      if (task == 10) { o[o0] = (float)tgt.x; o[o0 + 1] = (float)tgt.z; }
       else { o[o0] = (float)tgt.x; o[o0 + 1] = (float)tgt.y; o[o0 + 2] = (float)tgt.z; }
     }
-    o0 += (Md.task == 10) ? 2 : 3;
+    o0 += (task == 10) ? 2 : 3;
     if (lane < n) o[o0 + lane] = (float)S.dq[lane];
     if (lane == 0) {
       const V3<Real> vec = sp_reacher_tip<Real>(Md, S) - tgt;
@@ -166,20 +168,20 @@ __device__ __forceinline__ void sp_write_obs(const SpatialModel<Real>& Md, SpLds
     }
     return;
   }
-  if (Md.task == 8) {   // double pendulum: [q0, sin q1, sin q2, cos q1, cos q2, dq] (inverted_double_pendulum.py:45-51)
+  if (task == 8) {   // double pendulum: [q0, sin q1, sin q2, cos q1, cos q2, dq] (inverted_double_pendulum.py:45-51)
     if (lane == 0) o[0] = (float)S.q[0];
     if (lane == 1 || lane == 2) { Real sn, cs; sincos_<Real>(S.q[lane], sn, cs); o[lane] = (float)sn; o[lane + 2] = (float)cs; }
     if (lane < 3) o[5 + lane] = (float)S.dq[lane];
     return;
   }
-  if (Md.task == 0 || Md.task == 5 || Md.task == 7) {   // physics only, CartPole, swing-up: [q, dq]
+  if (task == 0 || task == 5 || task == 7) {   // physics only, CartPole, swing-up: [q, dq]
     if (lane < n) { o[lane] = (float)S.q[lane]; o[n + lane] = (float)S.dq[lane]; }
     return;
   }
   if (lane >= 1 && lane < n) o[lane - 1] = (float)S.q[lane];
   if (lane < n) o[n - 1 + lane] = (float)fmin(fmax(S.dq[lane], -Md.v_clip), Md.v_clip);
-  if (Md.task == 4 && lane < 2) o[2 * n - 1 + lane] = (float)cflags[lane];   // foot-contact flags (human_walker.py:146)
-  if ((Md.task == 1 || Md.task == 2) && lane == 1)   // observation[0] = COM height of the root body (hopper.py:72)
+  if (task == 4 && lane < 2) o[2 * n - 1 + lane] = (float)cflags[lane];   // foot-contact flags (human_walker.py:146)
+  if ((task == 1 || task == 2) && lane == 1)   // observation[0] = COM height of the root body (hopper.py:72)
     o[0] = (float)(S.link[Md.aux_link[0] * SP_LINKF + LK_C + 1] + S.misc[1]);
 }
 

@@ -1,6 +1,7 @@
 // spatial_world_step.hpp -- one DART world step of the env owned by a wavefront: dynamics, contact / limit / friction rows, two-stage LCP, velocity and position update, contact report.
 // Part of the gfx950 tree kernel; overview in spatial_kernel.hpp, design in DESIGN.md section 4.2.
 #pragma once
+#include <type_traits>
 #include "spatial_dense.hpp"
 #include "spatial_free_root.hpp"
 #include "spatial_box_box.hpp"
@@ -8,6 +9,14 @@
 namespace dartk {
 
 // ------------------------------------------------------------------ one world step for the env owned by this wavefront
+// 1: mass-matrix entries and Jacobian rows are assembled entry by entry on all 64 lanes (round 4); 0: one lane per row walking its
+// ancestors (rounds 1-3; kept for A/B builds: tools/build_variant.sh <name> spatial_f64 -DSP_ENTRY_PARALLEL=0)
+#ifndef SP_ENTRY_PARALLEL
+#define SP_ENTRY_PARALLEL 1
+#endif
+#ifndef SP_BAKE_DIMS
+#define SP_BAKE_DIMS 1
+#endif
 #define SP_TICK(ph)                                                                              \
   do {                                                                                            \
     if (Md.stats && lane == 0) {                                                                  \
@@ -26,7 +35,12 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
                                               int* contact_flags, int64_t env, bool report = false) {
   // env: the env this wavefront steps -- NOT blockIdx.x once a launch order is in force (sp_step_kernel: e = sched_perm[blockIdx.x]);
   // every per-env buffer (external force, contact report, constraint forces, debug dump) is indexed with it
-  const int n = Md.n, nl = Md.nl;
+  // BK: a pattern kernel takes the model's dimensions from its pattern at compile time (tree_patterns.hpp; the library launches it
+  // only for a model that carries exactly these values) -- the LDS carve offsets, row capacities and loop bounds become immediates
+  constexpr bool BK = (SP_BAKE_DIMS != 0) && !PAT::dense;
+  const int n = BK ? PAT::n : Md.n, nl = BK ? PAT::nl : Md.nl;
+  const int maxm = BK ? PAT::maxm : Md.maxm, maxcp = BK ? PAT::maxcp : Md.maxcp, nshapes = BK ? PAT::nshapes : Md.nshapes;
+  const bool impulse_M = BK ? (PAT::impulse_M != 0) : (Md.impulse_M != 0);
   unsigned long long t0_ = Md.stats ? __builtin_readcyclecounter() : 0ull;
   {
     // A world that has left the representable regime is frozen: a coordinate or velocity beyond 1e6 (or not finite) cannot come
@@ -50,7 +64,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   }
   // tree recursions level by level: links of equal depth are independent, one lane each
   if (lane == 0) sp_root_offset<Real>(Md, S);
-  sp_forward<Real, EXTRAS>(lc, Md, S, lane, env);   // lane i owns link i
+  sp_forward<Real, EXTRAS, false, typename std::conditional<BK, PAT, DensePattern>::type>(lc, Md, S, lane, env);   // lane i owns link i
   __syncthreads();
   for (int lv = Md.n_group_levels - 1; lv >= 0; lv--) {
     if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);
@@ -65,8 +79,21 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   SP_TICK(0);
   if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[HL(lane, k)] = Real(0); if (lane >= n) S.H[HL(lane, lane)] = Real(1); }
   __syncthreads();
-  if (lane < n) sp_mass_row<Real>(lc, Md, S, lane, !Md.impulse_M);   // scatters into other lanes' rows (reversed storage order, see there)
-  __syncthreads();
+  // Entry-parallel assembly of M and of the Jacobian rows (round 4) for the 20+-dof models (BIG): measured on one box against the
+  // ancestor walks (-DSP_ENTRY_PARALLEL=0), fp64, 16 384 envs: HumanWalker 16.43 -> 15.72 ms, Walker3d 9.85 -> 9.46 ms; the Dog
+  // (22 dofs, shallow legs, up to 40 box-vertex rows, LDS solver) got 4 % SLOWER with it (4.31 -> 4.50 ms) and keeps the walks.
+  constexpr bool EP = (SP_ENTRY_PARALLEL != 0) && BIG;
+  if constexpr (EP) {
+    sp_mass_entries<Real, typename std::conditional<BK, PAT, DensePattern>::type>(Md, S, lane);   // all 64 lanes, one structural entry at a time (reversed storage order, see sp_mass_row)
+    __syncthreads();
+    if (!impulse_M) {   // (wave-uniform) A3 knob at 0: the impulse pass runs on M + E
+      if (lane < n) S.H[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag;
+      __syncthreads();
+    }
+  } else {
+    if (lane < n) sp_mass_row<Real>(lc, Md, S, lane, !impulse_M);   // scatters into other lanes' rows (reversed storage order, see there)
+    __syncthreads();
+  }
   if (EXTRAS && Md.task == 12) sp_spd_torque<Real>(lc, Md, S, lane);
   SP_TICK(1);
   // ---- contact points and active limits, in parallel: lane s tests collision shape s, lane d tests the limits of
@@ -75,7 +102,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   int ncp, m, m1;   // contact points, LCP rows, rows of the frictionless stage (normals + limits + joint friction: a prefix)
   constexpr bool PREFIX = !PAIRS;
   {
-    const bool has_shape = lane < Md.nshapes;
+    const bool has_shape = lane < nshapes;
     const int s = has_shape ? lane : 0;
     const int slink = Md.sh_link[s], stype = Md.sh_type[s];
     Real sR[9];
@@ -122,7 +149,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     int idx = before;
     for (int v = 0; v < 4; v++) {
       if (hit[v]) {
-        if (idx < Md.maxcp) {
+        if (idx < maxcp) {
           S.cpP[4 * idx + 0] = P[v].x; S.cpP[4 * idx + 1] = P[v].y; S.cpP[4 * idx + 2] = P[v].z; S.cpP[4 * idx + 3] = dep[v];
           S.cpN[3 * idx + 0] = Real(0); S.cpN[3 * idx + 1] = Real(1); S.cpN[3 * idx + 2] = Real(0);
           S.cplink[idx] = slink; S.cplinkB[idx] = -1;
@@ -130,7 +157,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         idx++;
       }
     }
-    ncp = total < Md.maxcp ? total : Md.maxcp;
+    ncp = total < maxcp ? total : maxcp;
     // foot-contact flags of the observation (human_walker.py:97-106): any contact on aux_link[2], aux_link[3]
     const bool anyhit = hit[0] || hit[1] || hit[2] || hit[3];
     const uint64_t f0 = __ballot(anyhit && slink == Md.aux_link[2]), f1 = __ballot(anyhit && slink == Md.aux_link[3]);
@@ -146,13 +173,13 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       for (int v = 0; v < 8; v++) { const uint64_t hm8 = __ballot(v < k); before += __popcll(hm8 & lt); total += __popcll(hm8); }
       for (int v = 0; v < k; v++) {
         const int id2 = ncp + before + v;
-        if (id2 < Md.maxcp) {
+        if (id2 < maxcp) {
           for (int t = 0; t < 4; t++) S.cpP[4 * id2 + t] = scratch[4 * v + t];
           S.cpN[3 * id2 + 0] = -nrm.x; S.cpN[3 * id2 + 1] = -nrm.y; S.cpN[3 * id2 + 2] = -nrm.z;   // into the first link
           S.cplink[id2] = la; S.cplinkB[id2] = lb;
         }
       }
-      ncp = (ncp + total) < Md.maxcp ? (ncp + total) : Md.maxcp;
+      ncp = (ncp + total) < maxcp ? (ncp + total) : maxcp;
     }
     // Row order: contact normals [0, ncp), joint limits, joint friction, then the 2 ncp contact tangents.  The rows the
     // frictionless stage can move are a PREFIX (m1 of them): that stage solves the leading m1 x m1 block of A alone (the tangent
@@ -168,7 +195,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     const bool up = lane < n && lc.d_limited && !low && qd >= lc.d_upper;
     const uint64_t lm = __ballot(low || up);
     const int row = nfront + __popcll(lm & lt);
-    if ((low || up) && row < Md.maxm) {
+    if ((low || up) && row < maxm) {
       const Real viol = low ? qd - lc.d_lower : qd - lc.d_upper;
       const Real bounce = fmin(fmax(-viol * Md.limit_erp_dt, -Md.max_erv), Md.max_erv);
       S.rdof[row] = lane; S.rfidx[row] = -1;
@@ -181,19 +208,19 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       const bool fr = lane < n && lc.d_fric > Real(0);
       const uint64_t fm = __ballot(fr);
       const int frow = m + __popcll(fm & lt);
-      if (fr && frow < Md.maxm) {
+      if (fr && frow < maxm) {
         S.rdof[frow] = lane; S.rfidx[frow] = -1;
         S.b[frow] = Real(0);   // (- v*_d follows with the Jacobian rows)
         S.lo[frow] = -lc.d_fric; S.hi[frow] = lc.d_fric;
       }
       m += __popcll(fm);
     }
-    m1 = m < Md.maxm ? m : Md.maxm;
+    m1 = m < maxm ? m : maxm;
     if (PREFIX) {
-      if (lane < 2 * ncp && m1 + lane < Md.maxm) { S.rdof[m1 + lane] = -1; S.rfidx[m1 + lane] = lane >> 1; }   // tangents t1, t2 of contact lane / 2
+      if (lane < 2 * ncp && m1 + lane < maxm) { S.rdof[m1 + lane] = -1; S.rfidx[m1 + lane] = lane >> 1; }   // tangents t1, t2 of contact lane / 2
       m = m1 + 2 * ncp;
     }
-    m = m < Md.maxm ? m : Md.maxm;
+    m = m < maxm ? m : maxm;
     if (!PREFIX) m1 = m;
   }
   __syncthreads();
@@ -215,9 +242,86 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       Real* const Hm = pass ? S.H : H2; Real* const sv = pass ? S.sinv : sinv2; Real* const Wr = pass ? S.W : xq;
       const int nrows = pass ? m : 1;
       if (pass == 0) {
-        if (lane < np) for (int k = 0; k <= lane; k++) H2[HL(lane, k)] = S.H[HL(lane, k)];
+        for (int e = lane; e < HR(np); e += 64) H2[e] = S.H[e];   // the whole padded block, 64 entries per trip (was: lane r copying its row, 32 dependent trips for the last one)
         __syncthreads();
-        if (lane < n) { if (Md.impulse_M) H2[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag; xq[n - 1 - lane] = S.rhs[lane]; }
+        if (lane < n) { if (impulse_M) H2[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag; xq[n - 1 - lane] = S.rhs[lane]; }
+      } else if constexpr (EP) {
+        // Entry-parallel Jacobian (round 4).  Lane (d, half) = (lane & 31, lane >> 5) holds dof d's joint axis / origin / type in
+        // registers and fills column d of the rows half, half + 2, ...: J_id = dir_i . (a_d x (P_i - o_d)) (revolute) or dir_i . a_d
+        // (prismatic) where dof d moves the contact's link (bit d of the link's ancestor-dof mask), 0 elsewhere -- no walk up the tree,
+        // every entry from reads that depend on nothing but (i, d), 58 of 64 lanes busy for HumanWalker.  (Before: one lane per row
+        // chasing parent pointers through LDS, <= 12 dependent hops: 11 % of the fp64 kernel's cycles.)
+        // Two steps so that no lane chases a chain of dependent LDS reads inside the entry loop: (1) the lane that owns row i writes
+        // the row's descriptor -- direction, point, the ancestor-dof masks of its link(s), or the dof of a limit row -- into the idle
+        // Delassus block (S.A; it aliases the link records, which every lane has read its dof's axis / origin from before the
+        // barrier); (2) the entry loop reads descriptors only (addresses depend on i alone), two rows per trip.
+        {
+          const int dcol = lane & 31, half = lane >> 5;
+          const int dlk = __shfl(lc.d_link, dcol);          // link of dof dcol (lane dcol < n owns it)
+          const bool dlive = dcol < n;
+          const Real* Ld = S.link + (dlive ? dlk : 0) * SP_LINKF;
+          const V3<Real> ad = ld3(Ld + LK_A), od = ld3(Ld + LK_JO);
+          const bool drev = topo_jtype(S.topo[dlive ? dlk : 0]) == 2;
+          const uint32_t dbit = 1u << dcol;
+          Real* const rowd = S.A;                            // [m][8]: dir (3), P (3), then two ints in the last two slots
+          int* const rowi = (int*)(S.A + 8 * maxm);       // [m][4]: limit dof (-1: contact row), mask a, mask b
+          __syncthreads();                                   // every lane holds its dof's axis / origin: the link records may go
+          if (lane < m) {
+            const int i = lane, rd = S.rdof[i];
+            V3<Real> dir = v3<Real>(0, 0, 0), P = dir;
+            int ma = 0, mb = 0;
+            if (rd < 0) {
+              const int cidx = PREFIX ? (i < m1 ? i : ((i - m1) >> 1)) : i / 3, kind = PREFIX ? (i < m1 ? 0 : 1 + ((i - m1) & 1)) : i % 3;
+              // DART ContactConstraint tangent basis: t1 = normalize(z x n) (x x n when z and n are parallel), t2 = n x t1
+              if (PAIRS) {
+                const V3<Real> nn = ld3(S.cpN + 3 * cidx);
+                V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
+                if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);
+                t1 = t1 * (Real(1) / sqrt(dot(t1, t1)));
+                dir = kind == 0 ? nn : (kind == 1 ? t1 : cross(nn, t1));
+              } else {   // ground contacts only: n = +y, t1 = z x n = -x, t2 = n x t1 = +z
+                dir = kind == 0 ? v3<Real>(0, 1, 0) : (kind == 1 ? v3<Real>(-1, 0, 0) : v3<Real>(0, 0, 1));
+              }
+              P = ld3(S.cpP + 4 * cidx);
+              ma = S.ancd[S.cplink[cidx]];
+              if (PAIRS) { const int lb = S.cplinkB[cidx]; mb = lb >= 0 ? S.ancd[lb] : 0; }   // J = J_a - J_b for a link-link contact
+            }
+            st3(rowd + 8 * i, dir); st3(rowd + 8 * i + 3, P);
+            rowi[4 * i] = rd; rowi[4 * i + 1] = ma; rowi[4 * i + 2] = mb;
+          }
+          __syncthreads();
+          auto entry = [&](int i) -> Real {
+            const int rd = rowi[4 * i];
+            const uint32_t ma = (uint32_t)rowi[4 * i + 1], mb = (uint32_t)rowi[4 * i + 2];
+            const V3<Real> dir = ld3(rowd + 8 * i), P = ld3(rowd + 8 * i + 3);
+            const Real jd = drev ? dot(dir, cross(ad, P - od)) : dot(dir, ad);
+            Real v = (ma & dbit) ? jd : Real(0);
+            if (PAIRS) v = (mb & dbit) ? v - jd : v;
+            return rd >= 0 ? ((rd == dcol) ? Real(1) : Real(0)) : v;   // limit / joint-friction row: the unit vector of its dof
+          };
+          int i = half;
+          for (; i + 2 < m; i += 4) {   // rows i and i + 2 of this half: their reads are independent
+            const Real v0 = entry(i), v1 = entry(i + 2);
+            if (dlive) { S.W[i * n + (n - 1 - dcol)] = v0; S.W[(i + 2) * n + (n - 1 - dcol)] = v1; }
+          }
+          if (i < m) { const Real v0 = entry(i); if (dlive) S.W[i * n + (n - 1 - dcol)] = v0; }
+        }
+        __syncthreads();
+        if (lane < m) {   // right-hand side and bounds of row `lane`: b = bounce - J v*
+          const Real* Jr = S.W + lane * n;
+          const int d = S.rdof[lane];
+          if (d >= 0) {
+            S.b[lane] -= S.dq[d];   // limit / joint-friction row: bounce - v*_d
+          } else {
+            const int cidx = PREFIX ? (lane < m1 ? lane : ((lane - m1) >> 1)) : lane / 3, kind = PREFIX ? (lane < m1 ? 0 : 1 + ((lane - m1) & 1)) : lane % 3;
+            Real rel = Real(0);
+            for (int k = 0; k < n; k++) rel += Jr[k] * S.dq[n - 1 - k];
+            const Real depth = S.cpP[4 * cidx + 3];
+            S.b[lane] = (kind == 0 ? fmin(depth * Md.erp_dt, Md.max_erv) : Real(0)) - rel;
+            S.lo[lane] = Real(0);
+            S.hi[lane] = kind == 0 ? inf_<Real>() : Real(0);   // friction rows pinned during the frictionless stage
+          }
+        }
       } else {
         if (lane < m) {
           Real* Jr = S.W + lane * n;
@@ -378,7 +482,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
   if (REPORT && report) {   // world.collision_result.contacts (walker2d.py:38-41, human_walker.py:97-106): point, force on the first body
     if (lane == 0) Md.creport_count[env] = ncp;
     if (lane < ncp) {
-      Real* out = Md.creport + ((size_t)env * Md.maxcp + lane) * 8;
+      Real* out = Md.creport + ((size_t)env * maxcp + lane) * 8;
       const V3<Real> nn = ld3(S.cpN + 3 * lane);
       V3<Real> t1 = cross(v3<Real>(0, 0, 1), nn);
       if (dot(t1, t1) < Real(1e-12)) t1 = cross(v3<Real>(1, 0, 0), nn);

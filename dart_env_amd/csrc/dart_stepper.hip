@@ -98,6 +98,7 @@ struct DartStepper {
     }                                                                                        \
   } while (0)
 
+static int state_copy(DartStepper* h, double* q, double* dq, int to_device);
 static int dynamics_impl(DartStepper* h, double* mass, double* bias, double* rot = nullptr, double* pos = nullptr, double* com = nullptr) {
   const size_t N = (size_t)h->n, nd = (size_t)h->card.ndofs, nb = (size_t)h->card.nbodies;
   const bool poses = rot || pos || com;
@@ -108,15 +109,58 @@ static int dynamics_impl(DartStepper* h, double* mass, double* bias, double* rot
     CHK(h, hipMalloc((void**)&h->d_dynM, sizeof(double) * N * nd * nd));
     CHK(h, hipMalloc((void**)&h->d_dync, sizeof(double) * N * nd));
   }
-  if ((mass || bias) && h->dyn.free_root) {
-    h->err = "dynamics getters: free root joint (the kernel's internal coordinates differ from DART's)"; return DART_E_UNSUPPORTED;
-  }
   if (poses && !h->d_pose) CHK(h, hipMalloc((void**)&h->d_pose, sizeof(double) * N * nb * 15));
-  CHK(h, (f32 ? dyn_launch_f32 : dyn_launch_f64)(h->stream, h->dyn, h->n, h->q, h->dq, h->impl->soa ? 1 : 0, mass ? h->d_dynM : nullptr,
+  CHK(h, (f32 ? dyn_launch_f32 : dyn_launch_f64)(h->stream, h->dyn, h->n, h->q, h->dq, h->impl->soa ? 1 : 0, (mass || (bias && h->dyn.free_root)) ? h->d_dynM : nullptr,
                                                  bias ? h->d_dync : nullptr, poses ? h->d_pose : nullptr, (int)nb));
-  if (mass) CHK(h, hipMemcpyAsync(mass, h->d_dynM, sizeof(double) * N * nd * nd, hipMemcpyDeviceToHost, h->stream));
+  const bool fr = (mass || bias) && h->dyn.free_root;
+  std::vector<double> mi;   // free root: the internal chain's M is needed for c as well (c = T^T (c_int + M_int a0))
+  double* mass_dst = mass;
+  if (fr && !mass) { mi.resize(N * nd * nd); mass_dst = mi.data(); }
+  if (mass_dst) CHK(h, hipMemcpyAsync(mass_dst, h->d_dynM, sizeof(double) * N * nd * nd, hipMemcpyDeviceToHost, h->stream));
   if (bias) CHK(h, hipMemcpyAsync(bias, h->d_dync, sizeof(double) * N * nd, hipMemcpyDeviceToHost, h->stream));
   CHK(h, hipStreamSynchronize(h->stream));
+  if (fr) {
+    // FreeJoint root (dog.skel): the kernel's chain has world-frame root rates dqi = T dq, T = blockdiag(R0, R0, I), R0 = exp(q[0:3]),
+    // and accelerations qddi = T qdd + a0, a0 = Tdot dq = (-(rb rc), ra rc, -(ra rb); w x pdot; 0 ...) with (ra, rb, rc) = w = R0 dq[0:3],
+    // pdot = R0 dq[3:6] (csrc/spatial_free_root.hpp: sp_free_root_velocity_correction); forces map by virtual work.  pydart2's skel.M /
+    // skel.c are in DART's coordinates (body-frame twist):  M = T^T M_int T,  c = T^T (c_int + M_int a0)  -- the same map as the oracle's
+    // (oracle/dart_oracle.c: free_root_to_dart), done here on the host in doubles: the getter is a cold path.
+    std::vector<double> qh(N * nd), dqh(N * nd), X(nd * nd), t(nd);
+    { int rc = state_copy(h, qh.data(), dqh.data(), 0); if (rc != DART_OK) return rc; }
+    for (size_t e = 0; e < N; e++) {
+      const double* q = qh.data() + e * nd; const double* dq = dqh.data() + e * nd;
+      double R[9];
+      {   // Rodrigues
+        const double th2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], th = std::sqrt(th2);
+        const double a = th < 1e-8 ? 1.0 - th2 / 6.0 : std::sin(th) / th, b = th < 1e-8 ? 0.5 - th2 / 24.0 : (1.0 - std::cos(th)) / th2;
+        const double K[9] = {0, -q[2], q[1], q[2], 0, -q[0], -q[1], q[0], 0};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+          double k2 = 0; for (int k = 0; k < 3; k++) k2 += K[3 * i + k] * K[3 * k + j];
+          R[3 * i + j] = (i == j ? 1.0 : 0.0) + a * K[3 * i + j] + b * k2;
+        }
+      }
+      double* Mi = mass_dst + e * nd * nd;
+      if (bias) {
+        double w3[3], p3[3];
+        for (int i = 0; i < 3; i++) { w3[i] = R[3 * i] * dq[0] + R[3 * i + 1] * dq[1] + R[3 * i + 2] * dq[2]; p3[i] = R[3 * i] * dq[3] + R[3 * i + 1] * dq[4] + R[3 * i + 2] * dq[5]; }
+        const double a0[6] = {-(w3[1] * w3[2]), w3[0] * w3[2], -(w3[0] * w3[1]), w3[1] * p3[2] - w3[2] * p3[1], w3[2] * p3[0] - w3[0] * p3[2], w3[0] * p3[1] - w3[1] * p3[0]};
+        double* c = bias + e * nd;
+        for (size_t i = 0; i < nd; i++) { t[i] = c[i]; for (int k = 0; k < 6; k++) t[i] += Mi[i * nd + k] * a0[k]; }
+        for (int g = 0; g < 6; g += 3) for (int a = 0; a < 3; a++) c[g + a] = R[a] * t[g] + R[3 + a] * t[g + 1] + R[6 + a] * t[g + 2];
+        for (size_t i = 6; i < nd; i++) c[i] = t[i];
+      }
+      if (mass) {
+        for (size_t i = 0; i < nd; i++) {            // X = M_int T
+          for (int g = 0; g < 6; g += 3) for (int b = 0; b < 3; b++) X[i * nd + g + b] = Mi[i * nd + g] * R[b] + Mi[i * nd + g + 1] * R[3 + b] + Mi[i * nd + g + 2] * R[6 + b];
+          for (size_t j = 6; j < nd; j++) X[i * nd + j] = Mi[i * nd + j];
+        }
+        for (size_t j = 0; j < nd; j++) {            // M = T^T X
+          for (int g = 0; g < 6; g += 3) for (int a = 0; a < 3; a++) Mi[(g + a) * nd + j] = R[a] * X[g * nd + j] + R[3 + a] * X[(g + 1) * nd + j] + R[6 + a] * X[(g + 2) * nd + j];
+          for (size_t i = 6; i < nd; i++) Mi[i * nd + j] = X[i * nd + j];
+        }
+      }
+    }
+  }
   if (poses) {
     std::vector<double> tmp(N * nb * 15);
     CHK(h, hipMemcpy(tmp.data(), h->d_pose, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));

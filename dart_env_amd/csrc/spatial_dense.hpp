@@ -43,11 +43,16 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
     const Real sj = rsqrt_<Real>(dj);
     const Real lrj = (r >= j) ? row[j] * sj : Real(0);   // lanes above the diagonal contribute nothing
     row[j] = lrj;
-    if (lane == j) sinv[j] = sj;   // (sinv has sp_npad(n) slots: the padding columns write theirs too -- a `j < n` test per column cost HumanWalker 6 %)
+    // (1 / L_jj goes to sinv[] once, after the loop: a store under `if (lane == j)` here splits the factorisation into one basic block
+    // per column, and the compiler then SINKS every update row[k] -= L_rj L_kj into the block of column k while the v_readlane that
+    // produced L_kj -- convergent, it cannot move -- stays in column j's: the broadcast values of a whole factorisation were live at
+    // once, ~450 SGPRs spilled into VGPR lanes and read back, 2 x v_writelane + 2 x v_readlane extra per update; round 4, found in the
+    // disassembly of the fp64 pattern kernel)
     sown = (lane == j) ? sj : sown;
 #pragma unroll
     for (int k = j + 1; k < NP; k++) if (PAT::nz(k, j)) row[k] -= lrj * readlane_<Real>(lrj, k);
   }
+  if (lane < NP) sinv[lane] = sown;   // (sinv has sp_npad(n) slots: the padding columns write theirs too)
   if (lane < n) {
 #pragma unroll
     for (int k = 0; k < NP; k++) if (k <= lane) M[rb + k] = row[k];
@@ -64,6 +69,10 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
     if (lane < n) xvec[lane] = yv;
   }
   if (W != nullptr) {   // wave-uniform
+    // the factor entries are broadcast AGAIN below, on purpose: see DART_OPAQUE (wave_blcp.hpp)
+#pragma unroll
+    for (int k = 0; k < NP; k++) DART_OPAQUE(row[k]);
+    DART_OPAQUE(sown);
     const bool has = lane <= m;
     Real* yrow = W + (has ? lane : 0) * n;
     Real y[NP];

@@ -257,8 +257,12 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
   }
   LinkConst<Real> lc;
   sp_load_link_const<Real>(Md, lane < nl ? lane : 0, lc);
+  if (Md.free_root) {   // FreeJoint root: the chain's internal coordinates, chart re-centred on the pose (the host maps M, c to DART's)
+    if (lane == 0) { sp_free_root_load<Real>(S); sp_free_root_to_internal<Real>(S); }
+    __syncthreads();
+  }
   if (lane == 0) sp_root_offset<Real>(Md, S);
-  sp_forward<Real>(lc, Md, S, lane);
+  if (Md.free_root) sp_forward<Real, true>(lc, Md, S, lane); else sp_forward<Real>(lc, Md, S, lane);
   __syncthreads();
   for (int lv = Md.n_group_levels - 1; lv >= 0; lv--) {
     if (lane < nl && lc.group_level == lv) sp_gather_children<Real>(lc, Md, S, lane);

@@ -14,6 +14,10 @@ namespace dartk {
 #ifndef SP_ENTRY_PARALLEL
 #define SP_ENTRY_PARALLEL 1
 #endif
+// 1: friction rows start sticking or sliding according to the frictionless solve (round 4); 0: all of them start free (rounds 1-3)
+#ifndef SP_FRICTION_START
+#define SP_FRICTION_START 1
+#endif
 #ifndef SP_BAKE_DIMS
 #define SP_BAKE_DIMS 1
 #endif
@@ -456,18 +460,33 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       if (stage == 1) {
         SP_TICK(7);
         if (ncp == 0) break;
-        bool isf = false, pinned = false;
+        bool isf = false, pinned = false, slide_up = false, slide_dn = false;
         if (lane < m && S.rfidx[lane] >= 0) {
-          const Real hb = fabs(Md.mu * S.x[S.rfidx[lane]]);
+          const int nr = S.rfidx[lane];   // the contact's normal row
+          const Real hb = fabs(Md.mu * S.x[nr]);
           // a direction the skeleton cannot move in (planar model, z tangent) has A_ii = 0: keep that row out
-          isf = true; pinned = !(hb > Real(0)) || !(S.A[TI(lane, lane)] > Real(1e-12));
+          const Real att0 = S.A[TI(lane, lane)];
+          isf = true; pinned = !(hb > Real(0)) || !(att0 > Real(1e-12));
           S.hi[lane] = hb; S.lo[lane] = -hb;
+#if SP_FRICTION_START
+          // Start set of the friction row (round 4; the lane kernels' rule, planar_kernel.hpp): the impulse that would stop the
+          // tangential velocity the frictionless solve left, with every other row held and the contact's own normal row free to respond
+          // (tangential stiffness = Schur complement A_tt - A_tn^2 / A_nn) -- inside the bounds the row starts free (sticking), beyond
+          // them on that bound (sliding).  Before, every friction row started free and a sliding foot cost the wave extra pivoting
+          // iterations of ~10 k cycles each.  Only the path to the (unique) LCP solution changes.
+          Real wt = -S.b[lane];
+          for (int j = 0; j < m; j++) wt += S.A[lane >= j ? TI(lane, j) : TI(j, lane)] * S.x[j];   // x = 0 on the friction rows
+          const Real atn = S.A[lane >= nr ? TI(lane, nr) : TI(nr, lane)];
+          const Real att = ((F >> nr) & 1ull) ? att0 - atn * atn / S.A[TI(nr, nr)] : att0;
+          const Real xe = -wt / att;
+          slide_up = !pinned && xe > hb; slide_dn = !pinned && xe < -hb;
+#endif
         }
         __syncthreads();
-        const uint64_t fr = __ballot(isf), pf = __ballot(isf && pinned);
+        const uint64_t fr = __ballot(isf), pf = __ballot(isf && pinned), su = __ballot(slide_up), sd = __ballot(slide_dn);
         pinmask = (pinmask & ~fr) | pf;
-        F = (F & ~fr) | (fr & ~pf);
-        U &= ~fr;
+        F = (F & ~fr) | (fr & ~pf & ~su & ~sd);
+        U = (U & ~fr) | su;
       }
       sp_blcp<Real, BIG>(S, stage == 0 ? m1 : m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction),
                          0, (PREFIX && stage == 1) ? ncp : -1, m1);

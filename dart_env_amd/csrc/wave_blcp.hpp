@@ -4,6 +4,20 @@
 // Included by planar_kernel.hpp after TI / tol_ / rcp_ are defined; device code only (readlane, DPP).
 #pragma once
 
+// Value-identity fence for the systolic (v_readlane-broadcast) algorithms: `x` comes back as a value the compiler knows nothing about
+// (an empty asm with a read-write VGPR operand: no instruction).  Why: sp_cholesky_t broadcasts L_kj = readlane(row[j], k) once in
+// the factorisation and once more, much later, in the W = L^-1 J^T substitution; the compiler recognises the two as the same value
+// and keeps all 222 broadcast pairs of a HumanWalker factor alive in between -- 444 SGPRs in a file of ~100 -- i.e. it spills each
+// into a VGPR lane (2 x v_writelane) and reads it back (2 x v_readlane) where simply broadcasting again costs 2 x v_readlane
+// (round 4, from the disassembly of the fp64 pattern kernel: 1 078 SGPR spills).  Host builds (tests/kernel_emu) define it away.
+#ifndef DART_OPAQUE
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DART_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define DART_OPAQUE(x) ((void)0)
+#endif
+#endif
+
 namespace dartk {
 
 template <class Real> __device__ __forceinline__ Real readlane_(Real x, int l);

@@ -200,7 +200,9 @@ int dart_get_episode_stats(DartStepper* h, double* last_return, int32_t* last_le
 /* Dynamics quantities of the current state of every env -- pydart2's `skel.M` and `skel.c` (reference
  * gym/envs/dart/walker3d_spd.py:40-55 builds its SPD controller from them): mass_matrix (N, ndofs, ndofs) symmetric,
  * WITHOUT the implicit damping / stiffness terms the integrator adds; coriolis_gravity (N, ndofs) = C(q, dq) dq + g(q).
- * Either pointer may be NULL.  Computed by the generic tree kernel for every model (planar ones included). */
+ * Either pointer may be NULL.  Computed by the generic tree kernel for every model (planar ones included).  For a FreeJoint root
+ * (dog.skel) both are in DART's coordinates -- dq[0:6] is the body-frame twist: M = T^T M_int T, c = T^T (c_int + M_int Tdot dq)
+ * with T = blockdiag(R, R, I) mapping the twist to the world-frame rates of the kernel's internal root chain (round 4). */
 int dart_get_dynamics(DartStepper* h, double* mass_matrix, double* coriolis_gravity);
 
 /* World poses of every body of every env in its current state -- pydart2's `bodynode.T` / `.C` / `.com()` as the task code

@@ -1125,8 +1125,45 @@ int oracle_step(OracleWorld* w) {
 }
 
 /* ------------------------------------------------------------------ introspection (known-answer tests) */
-void oracle_mass_matrix(OracleWorld* w, double* M) { kinematics(w); crba(w, w->M); memcpy(M, w->M, w->n * w->n * sizeof(double)); }
-void oracle_bias(OracleWorld* w, double* C) { kinematics(w); rnea(w, w->dqi, NULL, 1, C); }
+/* pydart2 skel.M / skel.c (walker3d_spd.py:40-55) in DART's generalized coordinates.  For a FreeJoint root the internal chain's rates
+ * are dqi = T dq with T = blockdiag(R0, R0, I) (world-frame angular velocity and origin velocity from the body-frame twist) and its
+ * accelerations are qddi = T qdd + a0, a0 = Tdot dq = (-(rb rc), ra rc, -(ra rb); w x pdot; 0 ...) at the chart centre (r = dqi[0:3] =
+ * w, pdot = dqi[3:6]; the same terms as free_root_advance / the kernel's sp_free_root_velocity_correction); generalized forces map by
+ * virtual work, tau = T^T taui.  Hence  M = T^T Mi T  and  c = T^T (ci + Mi a0). */
+static void free_root_to_dart(const OracleWorld* w, double* M /* n x n or NULL */, double* c /* n or NULL */, const double* Mi) {
+  const int n = w->n;
+  const double* R = w->R0;
+  if (c) {
+    const double ra = w->dqi[0], rb = w->dqi[1], rc = w->dqi[2], px = w->dqi[3], py = w->dqi[4], pz = w->dqi[5];
+    const double a0[6] = {-(rb * rc), ra * rc, -(ra * rb), rb * pz - rc * py, rc * px - ra * pz, ra * py - rb * px};
+    double t[MAXN];
+    for (int i = 0; i < n; i++) { t[i] = c[i]; for (int k = 0; k < 6; k++) t[i] += Mi[i * n + k] * a0[k]; }
+    for (int g = 0; g < 6; g += 3)
+      for (int a = 0; a < 3; a++) c[g + a] = R[a] * t[g] + R[3 + a] * t[g + 1] + R[6 + a] * t[g + 2];   /* R^T */
+    for (int i = 6; i < n; i++) c[i] = t[i];
+  }
+  if (M) {
+    static __thread double X[MAXN * MAXN];
+    for (int i = 0; i < n; i++) {            /* X = Mi T */
+      for (int g = 0; g < 6; g += 3)
+        for (int b = 0; b < 3; b++) X[i * n + g + b] = Mi[i * n + g] * R[b] + Mi[i * n + g + 1] * R[3 + b] + Mi[i * n + g + 2] * R[6 + b];
+      for (int j = 6; j < n; j++) X[i * n + j] = Mi[i * n + j];
+    }
+    for (int j = 0; j < n; j++) {            /* M = T^T X */
+      for (int g = 0; g < 6; g += 3)
+        for (int a = 0; a < 3; a++) M[(g + a) * n + j] = R[a] * X[g * n + j] + R[3 + a] * X[(g + 1) * n + j] + R[6 + a] * X[(g + 2) * n + j];
+      for (int i = 6; i < n; i++) M[i * n + j] = X[i * n + j];
+    }
+  }
+}
+void oracle_mass_matrix(OracleWorld* w, double* M) {
+  kinematics(w); crba(w, w->M);
+  if (w->free_root) free_root_to_dart(w, M, NULL, w->M); else memcpy(M, w->M, w->n * w->n * sizeof(double));
+}
+void oracle_bias(OracleWorld* w, double* C) {
+  kinematics(w); rnea(w, w->dqi, NULL, 1, C);
+  if (w->free_root) { crba(w, w->M); free_root_to_dart(w, NULL, C, w->M); }
+}
 void oracle_inverse_dynamics(OracleWorld* w, const double* dq, const double* ddq, int with_gravity, double* tau) {
   kinematics(w); rnea(w, dq, ddq, with_gravity, tau);
 }

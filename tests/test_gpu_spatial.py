@@ -300,16 +300,18 @@ def test_classic_env_vector_fixture_and_fp32(tag, env_id):
         venv.close()
 
 
-@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartWalker3d-v1", "DartHumanWalker-v1"])
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartWalker3d-v1", "DartHumanWalker-v1", "DartDog-v1"])
 def test_dynamics_getters_match_oracle(env_id):
     """dart_get_dynamics = pydart2's skel.M / skel.c: CRBA mass matrix and RNEA bias of the oracle at random states,
-    for models stepped by the planar kernels (SoA state) as well as by the spatial one."""
+    for models stepped by the planar kernels (SoA state) as well as by the spatial one -- and, since round 4, for the Dog's FreeJoint
+    root in DART's coordinates (body-frame twist; the oracle side is pinned by the kinetic-energy and equation-of-motion checks of
+    tests/test_oracle_physics.py::test_free_root_*)."""
     from dart_env_amd.stepper import HipStepper
     card = card_for(env_id)
     n, nd = 40, card.ndofs
     rng = np.random.RandomState(11)
     q = rng.uniform(-0.4, 0.4, (n, nd)); dq = rng.uniform(-2, 2, (n, nd))
-    q[:, 0] += 100.0 * rng.rand(n)              # far from the origin: the getters must not care
+    q[:, 3 if env_id == "DartDog-v1" else 0] += 100.0 * rng.rand(n)   # far from the origin: the getters must not care (Dog: q[3] is the x translation, q[0:3] the rotation vector)
     w = OracleWorld(card)
     for prec, rtol in ((64, 1e-11), (32, 2e-5)):
         s = HipStepper(card, n, precision=prec)

@@ -517,6 +517,10 @@ static int state_copy(DartStepper* h, double* q, double* dq, int to_device) {
 int dart_set_state(DartStepper* h, const double* q, const double* dq) { return state_copy(h, (double*)q, (double*)dq, 1); }
 int dart_get_state(DartStepper* h, double* q, double* dq) { return state_copy(h, q, dq, 0); }
 
+// wait for everything enqueued on the handle's stream.  (Round 4 measured a polled event -- hipEventRecord + hipEventQuery in a spin loop --
+// against this: 216.8 us per host step either way, profiles/r04_host_path_ab.txt; the runtime's wait is not where the time goes.)
+static hipError_t wait_stream(DartStepper* h) { return hipStreamSynchronize(h->stream); }
+
 static int step_async_impl(DartStepper* h, const float* actions, void* dst);
 int dart_step_async(DartStepper* h, const float* actions) { return step_async_impl(h, actions, nullptr); }
 
@@ -658,7 +662,7 @@ int dart_step_wait(DartStepper* h, float* obs_out, double* reward_out, uint8_t* 
   if (!h->pending) { h->err = "step_wait called without step_async"; return DART_E_NOT_PENDING; }
   h->pending = false;
   CHK(h, hipSetDevice(h->device));
-  CHK(h, hipStreamSynchronize(h->stream));
+  CHK(h, wait_stream(h));
   size_t N = (size_t)h->n;
   if (obs_out) memcpy(obs_out, h->h_obs, 4 * N * h->card.obs_dim);
   if (reward_out) for (size_t i = 0; i < N; i++) reward_out[i] = (double)h->h_rew[i];
@@ -702,7 +706,7 @@ int dart_step(DartStepper* h, const float* actions, float* obs_out, double* rewa
   }
   if (done_out) { rc = d2h_block(h, done_out, h->d_done, N); if (rc != DART_OK) return rc; }
   if (truncated_out) { rc = d2h_block(h, truncated_out, h->d_trunc, N); if (rc != DART_OK) return rc; }
-  CHK(h, hipStreamSynchronize(h->stream));
+  CHK(h, wait_stream(h));
   return DART_OK;
 }
 
@@ -912,7 +916,7 @@ int dart_restore(DartStepper* h, const void* buf, uint64_t nbytes) {
 int dart_sync(DartStepper* h) {
   if (!h) return DART_E_INVALID;
   CHK(h, hipSetDevice(h->device));
-  CHK(h, hipStreamSynchronize(h->stream));
+  CHK(h, wait_stream(h));
   return DART_OK;
 }
 

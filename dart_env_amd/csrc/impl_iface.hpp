@@ -24,6 +24,7 @@ struct Impl {
   virtual hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) = 0;
   virtual void set_solver(int solver, int it1, int it2) = 0;
   virtual void set_stats(unsigned long long* p) = 0;
+  virtual void set_wave_vote(int /*k*/) {}      // planar kernels with a wave-served fallback: DART_CFG_WAVE_VOTE
   virtual void set_force_slow(int /*on*/) {}   // planar kernels: route every touching env through the single-lane fallback solver (tests)
   virtual hipError_t prepare(int64_t) { return hipSuccess; }   // per-handle device allocations of the implementation
   virtual void release() {}

@@ -54,6 +54,7 @@ struct ImplT : Impl {
   }
   void set_stats(unsigned long long* p) override { P.stats = p; }
   void set_force_slow(int on) override { P.force_slow = on; }
+  void set_wave_vote(int k) override { P.force_slow = k > 0 ? -k : 0; }
   // ---- optional extras: external body force, contact report (see Extras in planar_kernel.hpp)
   int link_body[T::NL] = {};                 // card body of each link (welded bodies have no link of their own)
   Real* d_ext = nullptr; Real* d_rec = nullptr; int* d_cnt = nullptr; Real* d_cf = nullptr;

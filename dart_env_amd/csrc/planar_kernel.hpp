@@ -72,6 +72,9 @@ struct HopperAllTopo {  // the same chain with EVERY capsule tested against the 
   static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2, TIER1_F64 = 2;
   static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = false;
+#ifdef DART_HOPPER_HINV_LDS
+  static constexpr bool HINV_LDS_F64 = true;   // (experiment, round 4: H^-1 parked in LDS across the pivoting loops as for the walker)
+#endif
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
@@ -263,7 +266,7 @@ struct Params {
   Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise, noise_v;
   int frame_skip, max_steps, penalty_link, task;
   int solver, iters1, iters2;  // solver 0: block principal pivoting (exact); 1: PGS sweeps
-  int force_slow;              // debug / test knob: every lane with a contact takes the single-lane fallback solver
+  int force_slow;              // > 0: debug / test knob, every lane with a contact takes the fallback solver; < 0: -K of DART_CFG_WAVE_VOTE (step_kernel)
   unsigned long long* stats;   // optional [2][32] histogram of wave-level pivoting iterations per stage (debug), or null
   int cbody[T::NC];            // card body index of each candidate capsule (contact report)
   Extras<Real> ex;
@@ -1552,7 +1555,25 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   }
   bool slow = false;
   if constexpr (has_slow_path<T, Real>()) {
-    slow = nact > last_tier<T, Real>() || (P.force_slow != 0 && nact > 0);
+    slow = nact > last_tier<T, Real>() || (P.force_slow > 0 && nact > 0);
+#ifdef DART_WAVE_COOP
+    // DART_CFG_WAVE_VOTE = K (P.force_slow = -K; opt-in, round 4).  Topologies with the wave-served fallback (half
+    // cheetah): in fp64 the big register tier is spill-bound (6 KB of scratch per lane, ~20 k cycles per masked solve for ALL 64 lanes)
+    // and 94 % of the waves enter it for ~3 lanes.  With the vote, a wave that has at most K lanes beyond the small tier serves those envs
+    // together, one after the other (wave_constraints: exact, any number of contacts), and everybody else stays in the small tier; a
+    // wave with more such lanes -- a batch lying on the floor -- keeps the big tier, so the worst case stays what it was.
+    // A/B on one box, fp64 x 65 536: K = 0 1.452 ms, 1 1.39, 2 1.29, 3 1.26, 4 1.32, 8 1.65 (fp32: no gain at any K).  Why it is NOT the
+    // default: which solver serves a lane then depends on its wave mates, and the two solvers round differently -- same LCP solution,
+    // last-bit different states -- so an env's trajectory is no longer BITWISE independent of the batch around it
+    // (test_other_configs_full_batch_determinism_and_batch_independence compares a 1 000-env batch with the first 1 000 of 65 536).
+    if constexpr (topo_wave_fallback<T>::value && tier1<T, Real>() > 0) {
+      if (P.force_slow < 0 && blockDim.x == 64) {
+        const bool big = !slow && nact > T::TIER0;
+        const int nbig = __popcll(__ballot(big));
+        if (nbig > 0 && nbig <= -P.force_slow) slow = slow || big;
+      }
+    }
+#endif
     if (__any(slow)) {
       // the rare lanes whose env touches the floor with more capsules than the tiers hold: one after the other
 #ifdef DART_WAVE_TIMING

@@ -398,6 +398,45 @@ def test_half_cheetah_wave_fallback_matches_oracle(precision, tq, tdq):
     gpu.close()
 
 
+@pytest.mark.parametrize("k", [1, 3])
+def test_half_cheetah_wave_vote_matches_oracle_and_is_repeatable(k):
+    """DART_CFG_WAVE_VOTE (opt-in, round 4): waves with at most K envs beyond the small register tier serve them cooperatively instead of
+    running the big fp64 tier for all 64 lanes.  The trajectories are the oracle's to rounding (4 096 envs x 100 env-steps, the untrimmed
+    protocol's bound), run-to-run bitwise repeatable, and -- the reason the mode is opt-in -- NOT bitwise those of the default mode."""
+    from dart_env_amd.stepper import HipStepper, CFG_WAVE_VOTE, CFG_AUTORESET, CFG_SEED
+    card = card_for("DartHalfCheetah-v1")
+    n, T = 4096, 40
+    acts = np.random.RandomState(5).uniform(-1, 1, (T, n, card.act_dim)).astype(np.float32)
+
+    def run(vote):
+        g = HipStepper(card, n, precision=64)
+        g.configure(CFG_AUTORESET, 1); g.configure(CFG_SEED, 3); g.configure(CFG_WAVE_VOTE, vote)
+        g.reset(None, None, None, want_obs=False)
+        for t in range(T):
+            g.step(acts[t])
+        out = g.get_state()
+        g.close()
+        return out
+    (qa, dqa), (qb, dqb), (q0, dq0) = run(k), run(k), run(0)
+    assert np.array_equal(qa, qb) and np.array_equal(dqa, dqb)            # repeatable
+    assert np.isfinite(qa).all()
+    # the same LCP solutions through another solver: rounding-level differences, amplified by 40 env-steps of a thrashing cheetah
+    assert np.sqrt(np.mean((qa - q0) ** 2)) < 1e-9 and np.sqrt(np.mean((dqa - dq0) ** 2)) < 1e-7
+    from tests.parity_protocol import parity_check
+    import dart_env_amd.stepper as stm
+    orig = stm.HipStepper.__init__
+
+    def patched(self, *a, **kw):                                           # the protocol builds its own stepper: switch the vote on in it
+        orig(self, *a, **kw)
+        self.configure(CFG_WAVE_VOTE, k)
+    stm.HipStepper.__init__ = patched
+    try:
+        stats, _, _ = parity_check("DartHalfCheetah-v1", 64, 4096, 100, 0)
+    finally:
+        stm.HipStepper.__init__ = orig
+    assert stats["done_flag_mismatches"] == 0 and stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])
+
+
 def test_walker3d_link_link_contacts_match_oracle():
     """Self-collision (walker3d.py:26): squeeze / cross the legs with hip torques so that thigh, shin and foot boxes
     collide (face-face, edge-edge, with the feet on the floor at the same time); the fp64 kernel follows the oracle

@@ -11,10 +11,13 @@ from tests.batch_oracle import OracleBatch
 from tests.emu_lib import EmuStepper
 
 
-def rollout(card, n, T, force_fallback=False, noise=0.1, scale=None, seed=0):
+def rollout(card, n, T, force_fallback=False, noise=0.1, scale=None, seed=0, wave_vote=0):
     g = EmuStepper(card, n, precision=64, waves=True)
     if force_fallback:
         g.force_slow(True)
+    if wave_vote:
+        from dart_env_amd import stepper as st
+        g.configure(st.CFG_WAVE_VOTE, wave_vote)
     ora = OracleBatch(card, n)
     rng = np.random.RandomState(seed)
     nd = card.ndofs
@@ -41,6 +44,14 @@ def rollout(card, n, T, force_fallback=False, noise=0.1, scale=None, seed=0):
 def test_whole_waves_follow_the_oracle(env_id, n, T):
     worst, most = rollout(card_for(env_id), n, T)
     assert worst[0] < 1e-9 and worst[1] < 1e-7, worst
+
+
+@pytest.mark.parametrize("k", [1, 3, 63])
+def test_wave_vote_follows_the_oracle(k):
+    """DART_CFG_WAVE_VOTE (opt-in, round 4): a wave with at most K half cheetahs beyond the small register tier serves them together
+    instead of running the big tier for all its lanes -- the same LCPs, solved by the other solver: the oracle's trajectories to rounding"""
+    worst, most = rollout(card_for("DartHalfCheetah-v1"), 128, 40, wave_vote=k)
+    assert worst[0] < 1e-9 and worst[1] < 1e-7 and most >= 3, (worst, most)
 
 
 def test_wave_served_fallback_follows_the_oracle():

@@ -72,9 +72,8 @@ struct HopperAllTopo {  // the same chain with EVERY capsule tested against the 
   static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2, TIER1_F64 = 2;
   static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = false;
-#ifdef DART_HOPPER_HINV_LDS
-  static constexpr bool HINV_LDS_F64 = true;   // (experiment, round 4: H^-1 parked in LDS across the pivoting loops as for the walker)
-#endif
+  // (round 4 A/B: H^-1 parked in LDS across the pivoting loops, the walker's HINV_LDS_F64, makes THIS kernel slower -- 31.82 -> 33.24 us
+  // fp64, 158 -> 126 AGPRs: the 21 entries cost more as LDS round trips than as accumulator-register moves)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 1, 2, 3}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }

@@ -247,6 +247,8 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       const int nrows = pass ? m : 1;
       if (pass == 0) {
         for (int e = lane; e < HR(np); e += 64) H2[e] = S.H[e];   // the whole padded block, 64 entries per trip (was: lane r copying its row, 32 dependent trips for the last one)
+        // (factoring M + E straight from S.H -- row loads from S.H plus the E entry, no copy, no barrier -- was built and measured in
+        // round 4: SLOWER, HumanWalker fp64 13.45 -> 13.81 ms, fp32 5.98 -> 6.36, Dog 3.41 -> 3.59; profiles/r04_tree_kernel_ab.txt)
         __syncthreads();
         if (lane < n) { if (impulse_M) H2[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag; xq[n - 1 - lane] = S.rhs[lane]; }
       } else if constexpr (EP) {

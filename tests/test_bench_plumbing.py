@@ -120,3 +120,42 @@ def test_shards_are_contiguous_and_disjoint():
     assert spans[0] == (0, 65536) and spans[7] == (7 * 65536, 65536)
     assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(7))
     assert bench.default_envs("DartHumanWalker-v1") == 16384 and bench.default_envs("DartHopper-v1") == 65536
+
+
+def test_counter_files_are_used_only_while_their_kernel_sources_are_unchanged(tmp_path, monkeypatch):
+    """roofline.traffic / valu_issue / valu are COPIED from committed counter files; every entry is stamped with the
+    hash of the kernel sources it was measured on (tools/source_hash.py) and bench.py uses it only while the tree still hashes to that --
+    otherwise the line says `stale` and carries no number."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tools.source_hash import all_hashes, family_hash, family_files
+    h = all_hashes()
+    assert set(h) == {"planar", "spatial", "dart_stepper"} and all(len(v) == 16 for v in h.values())
+    assert any(f.endswith("planar_kernel.hpp") for f in family_files("planar")) and any(f.endswith("spatial_kernel.hpp") for f in family_files("spatial"))
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    good = {"bytes_per_launch": 123, "kernel": "dartk::step_kernel<double, ...>", "kernel_family": "planar", "source_hash": h["planar"],
+            "source": "test", "valu_issue": {"x": 1}}
+    stale = dict(good, source_hash="0123456789abcdef")
+    unstamped = {k: v for k, v in good.items() if k not in ("source_hash", "kernel_family")}
+    (prof / "pmc_traffic.json").write_text(json.dumps({"a": good, "b": stale, "c": unstamped}))
+    (prof / "flops_per_env_step.json").write_text(json.dumps({
+        "DartHopper-v1": {"flops_per_env_step": 1000.0, "kernel_family": "planar", "source_hash": h["planar"], "method": "m", "sample": "s"},
+        "DartWalker2d-v1": {"flops_per_env_step": 1000.0, "kernel_family": "planar", "source_hash": "deadbeefdeadbeef"}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    r = {"traffic": None}
+    bench.attach_pmc(r, "a")
+    assert r["traffic"] == 123 and r["stale"] is False and r["valu_issue"] == {"x": 1} and r["kernel_source_hash"]["this_tree"] == h["planar"]
+    for key in ("b", "c"):
+        r = {"traffic": None}
+        bench.attach_pmc(r, key)
+        assert r["traffic"] is None and r["stale"] is True and "valu_issue" not in r and "not used" in r["stale_note"]
+    r = {}
+    bench.attach_valu(r, "DartHopper-v1", 65536, "f64", 0.032)
+    assert r["valu"]["flops_per_env_step"] == 1000.0 and 0 < r["valu"]["frac"] < 1
+    r = {}
+    bench.attach_valu(r, "DartWalker2d-v1", 65536, "f64", 0.12)
+    assert r["valu"] == {"stale": True, "stale_note": r["valu"]["stale_note"]} and "frac" not in r["valu"]
+    # the committed files themselves are stamped, family by family
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert pmc and all("source_hash" in e and e["kernel_family"] in ("planar", "spatial") for e in pmc.values())

@@ -72,9 +72,9 @@ class HipBenchEnv:
         self.n, self.ring_len = n, ring
         self.dev = torch.device("cuda", local_rank)
         self.env = st.HipStepper(self.card, n, device=local_rank, precision=precision)
-        from dart_env_amd.model_card import TASK_CARTPOLE_SWINGUP, TASK_REACHER2D, TASK_REACHER3D
-        if self.card.task in (TASK_CARTPOLE_SWINGUP, TASK_REACHER2D, TASK_REACHER3D):
-            # reset_model of these tasks draws more than the two noise vectors (swing-up sign, reach targets): the device MT19937
+        from dart_env_amd.model_card import TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D, TASK_REACHER3D
+        if self.card.task in (TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D, TASK_REACHER3D):
+            # reset_model of these tasks draws more than the two noise vectors (swing-up sign, reach targets, Gaussian velocities): the device MT19937
             # bank draws all of it, the in-kernel Philox reset would leave degenerate episodes (the ABI refuses that combination)
             from dart_env_amd import seeding
             keys, klen = seeding.mt_keys([env_offset + i for i in range(n)])

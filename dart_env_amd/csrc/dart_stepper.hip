@@ -57,6 +57,8 @@ struct DartStepper {
   unsigned long long* d_stats = nullptr;
   uint32_t* mt = nullptr;        // MT19937 bank [624][N] (dart_seed_mt19937)
   int32_t* mt_pos = nullptr;
+  double* mt_gauss = nullptr;    // numpy legacy_gauss: the cached second deviate of a pair, per env (double pendulum resets)
+  int32_t* mt_has_gauss = nullptr;
   double *d_init_pos = nullptr, *d_init_vel = nullptr;
   int noise_mode = 0;            // 0: Philox / host-supplied noise, 1: device MT19937 bank (reference-exact)
   // obs | reward | done | truncated of a step are ONE device block and ONE pinned host block (d_obs / h_obs are their bases):
@@ -262,7 +264,7 @@ int dart_destroy(DartStepper* h) {
   for (auto& r : h->host_ranges) (void)hipHostUnregister(r.first);
   h->host_ranges.clear();
   if (h->d_rew64) hipFree(h->d_rew64);
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs /* base of the output block */, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, h->dyn.dev, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs /* base of the output block */, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->mt_gauss, h->mt_has_gauss, h->d_init_pos, h->d_init_vel, h->dyn.dev, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs /* base of the pinned output block */, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -300,13 +302,13 @@ int dart_query(const DartStepper* h, int what, int64_t* out) {
 static bool philox_autoreset_unsupported(const DartStepper* h) {
   const int t = h->card.task;
   return h->autoreset && h->noise_mode == 0 &&
-         (t == DART_TASK_CARTPOLE_SWINGUP || t == DART_TASK_REACHER2D || t == DART_TASK_REACHER3D);
+         (t == DART_TASK_CARTPOLE_SWINGUP || t == DART_TASK_REACHER2D || t == DART_TASK_REACHER3D || t == DART_TASK_DOUBLE_PENDULUM);
 }
 #define CHK_AUTORESET(h)                                                                                                     \
   do {                                                                                                                       \
     if (philox_autoreset_unsupported(h)) {                                                                                   \
       (h)->err = "on-device auto-reset of this task needs the MT19937 bank (dart_seed_mt19937): its reset_model also draws "  \
-                 "the swing-up sign / the reach target, which the Philox reset does not";                                    \
+                 "the swing-up sign / the reach target / Gaussian velocities, which the Philox reset does not";                                    \
       return DART_E_UNSUPPORTED;                                                                                             \
     }                                                                                                                        \
   } while (0)
@@ -388,12 +390,15 @@ static int mt_draw(DartStepper* h, hipStream_t s, const uint8_t* d_mask) {
   const double r = h->card.reset_noise, rv = h->card.reset_noise_vel;
   const int extra = h->card.task == DART_TASK_CARTPOLE_SWINGUP ? MT_EXTRA_SWINGUP
                   : h->card.task == DART_TASK_REACHER2D ? MT_EXTRA_REACHER2D
-                  : h->card.task == DART_TASK_REACHER3D ? MT_EXTRA_REACHER3D : MT_EXTRA_NONE;
+                  : h->card.task == DART_TASK_REACHER3D ? MT_EXTRA_REACHER3D
+                  : h->card.task == DART_TASK_DOUBLE_PENDULUM ? MT_EXTRA_GAUSS_VEL : MT_EXTRA_NONE;
   const bool targets = extra == MT_EXTRA_REACHER2D || extra == MT_EXTRA_REACHER3D;
   if (targets && !h->d_tvals) CHK(h, hipMalloc((void**)&h->d_tvals, sizeof(double) * 4 * (size_t)h->n));
   dim3 grid((unsigned)((h->n + 127) / 128)), block(128);
+  // (MT_EXTRA_GAUSS_VEL: the velocity "range" argument carries the Gaussian's scale -- reset_noise_vel = .1 for the double pendulum)
   hipLaunchKernelGGL(mt_draw_kernel, grid, block, 0, s, h->n, (int)h->card.ndofs, h->mt, h->mt_pos, d_mask, -r, r - (-r), -rv,
-                     rv - (-rv), h->d_init_pos, h->d_init_vel, h->d_qn, h->d_vn, extra, h->d_tvals);
+                     extra == MT_EXTRA_GAUSS_VEL ? rv : rv - (-rv), h->d_init_pos, h->d_init_vel, h->d_qn, h->d_vn, extra, h->d_tvals,
+                     h->mt_gauss, h->mt_has_gauss);
   CHK(h, hipGetLastError());
   if (targets) return h->impl->set_task_state(s, d_mask, h->d_tvals, h->n);   // before the reset kernel computes the observation
   return DART_OK;
@@ -407,6 +412,8 @@ int dart_seed_mt19937(DartStepper* h, const uint32_t* keys, const int32_t* key_l
   if (!h->mt) {
     CHK(h, hipMalloc((void**)&h->mt, sizeof(uint32_t) * 624 * N));
     CHK(h, hipMalloc((void**)&h->mt_pos, sizeof(int32_t) * N));
+    CHK(h, hipMalloc((void**)&h->mt_gauss, sizeof(double) * N));
+    CHK(h, hipMalloc((void**)&h->mt_has_gauss, sizeof(int32_t) * N));
     CHK(h, hipMalloc((void**)&h->d_init_pos, sizeof(double) * nd));
     CHK(h, hipMalloc((void**)&h->d_init_vel, sizeof(double) * nd));
     CHK(h, hipMemcpy(h->d_init_pos, h->card.init_pos, sizeof(double) * nd, hipMemcpyHostToDevice));
@@ -417,6 +424,8 @@ int dart_seed_mt19937(DartStepper* h, const uint32_t* keys, const int32_t* key_l
   CHK(h, hipMalloc((void**)&dl, sizeof(int32_t) * N));
   CHK(h, hipMemcpy(dk, keys, sizeof(uint32_t) * 2 * N, hipMemcpyHostToDevice));
   CHK(h, hipMemcpy(dl, key_len, sizeof(int32_t) * N, hipMemcpyHostToDevice));
+  CHK(h, hipMemsetAsync(h->mt_gauss, 0, sizeof(double) * N, h->stream));          // RandomState.seed() clears has_gauss
+  CHK(h, hipMemsetAsync(h->mt_has_gauss, 0, sizeof(int32_t) * N, h->stream));
   hipLaunchKernelGGL(mt_seed_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, h->stream, h->n, h->mt, h->mt_pos, dk, dl);
   CHK(h, hipGetLastError());
   CHK(h, hipStreamSynchronize(h->stream));
@@ -845,7 +854,7 @@ static void snapshot_buffers(DartStepper* h, std::vector<std::pair<void*, size_t
   const size_t N = (size_t)h->n, nd = (size_t)h->card.ndofs, rs = h->precision == 32 ? 4 : 8;
   v.push_back({h->q, rs * nd * N}); v.push_back({h->dq, rs * nd * N});
   v.push_back({h->elapsed, 4 * N}); v.push_back({h->episode, 4 * N});
-  if (h->mt) { v.push_back({h->mt, 4 * 624 * N}); v.push_back({h->mt_pos, 4 * N}); }
+  if (h->mt) { v.push_back({h->mt, 4 * 624 * N}); v.push_back({h->mt_pos, 4 * N}); v.push_back({h->mt_gauss, 8 * N}); v.push_back({h->mt_has_gauss, 4 * N}); }
   if (h->d_ep_ret) {
     v.push_back({h->d_ep_ret, 8 * N}); v.push_back({h->d_last_ret, 8 * N}); v.push_back({h->d_ep_len, 4 * N});
     v.push_back({h->d_last_len, 4 * N}); v.push_back({h->d_ep_tot, 8 * 3});

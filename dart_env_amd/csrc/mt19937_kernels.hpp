@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cr_log.hpp"
+
 namespace dartk {
 
 // init_by_array(key[0..len)) for every env; keys: [N][2], len[N] in {1, 2}
@@ -41,7 +43,7 @@ __global__ void mt_seed_kernel(int64_t n_envs, uint32_t* __restrict__ mt, int32_
   pos[e] = 0;     // numpy regenerates before its first draw: the first output is x[624], produced over slot 0
 }
 
-enum { MT_EXTRA_NONE = 0, MT_EXTRA_SWINGUP = 1, MT_EXTRA_REACHER2D = 2, MT_EXTRA_REACHER3D = 3 };
+enum { MT_EXTRA_NONE = 0, MT_EXTRA_SWINGUP = 1, MT_EXTRA_REACHER2D = 2, MT_EXTRA_REACHER3D = 3, MT_EXTRA_GAUSS_VEL = 4 };
 
 // For every env with mask[e] != 0 (mask == nullptr: all): draw 2*ndofs doubles and emit
 //   qn[e][d] = init_pos[d] + U(-r, r),  vn[e][d] = init_vel[d] + U(-rv, rv)     (row-major doubles, as dart_reset takes them)
@@ -54,7 +56,8 @@ enum { MT_EXTRA_NONE = 0, MT_EXTRA_SWINGUP = 1, MT_EXTRA_REACHER2D = 2, MT_EXTRA
 __global__ void mt_draw_kernel(int64_t n_envs, int ndofs, uint32_t* __restrict__ mt, int32_t* __restrict__ pos,
                                const uint8_t* __restrict__ mask, double low_q, double range_q, double low_v,
                                double range_v, const double* __restrict__ init_pos, const double* __restrict__ init_vel,
-                               double* __restrict__ qn, double* __restrict__ vn, int extra, double* __restrict__ tvals) {
+                               double* __restrict__ qn, double* __restrict__ vn, int extra, double* __restrict__ tvals,
+                               double* __restrict__ gauss_cache = nullptr, int32_t* __restrict__ has_gauss = nullptr) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_envs) return;
   if (mask && !mask[e]) return;
@@ -75,7 +78,8 @@ __global__ void mt_draw_kernel(int64_t n_envs, int ndofs, uint32_t* __restrict__
     return y;
   };
   int p = pos[e];                       // slot of the next word to produce, 0..623
-  const int n_doubles = 2 * ndofs;
+  // MT_EXTRA_GAUSS_VEL: only the positions are uniform; the velocities are `randn(ndofs) * range_v` (below)
+  const int n_doubles = extra == MT_EXTRA_GAUSS_VEL ? ndofs : 2 * ndofs;
   for (int d0 = 0; d0 < n_doubles; d0 += 4) {
     uint32_t lo[9], hi[8], out[8];
 #pragma unroll
@@ -117,7 +121,43 @@ __global__ void mt_draw_kernel(int64_t n_envs, int ndofs, uint32_t* __restrict__
       const uint32_t a = next_word() >> 5, b = next_word() >> 6;
       return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
     };
-    if (extra == MT_EXTRA_SWINGUP) {
+    if (extra == MT_EXTRA_GAUSS_VEL) {
+      // inverted_double_pendulum.py:50-51: qvel = dq + np_random.randn(ndofs) * .1 -- numpy's LEGACY Gaussian (legacy-distributions.c:
+      // legacy_gauss): polar Box-Muller, two uniforms per try, the second deviate of a pair cached in the generator across calls (and
+      // across resets: gauss_cache / has_gauss live in HBM per env like the MT state).  Every operation is a single IEEE rounding as in
+      // the C original (no contraction); log is dartk::log_cr (cr_log.hpp: the host libm's value in 99.92 % of the draws, 1 ulp otherwise).
+      double cached = gauss_cache[e];
+      int has = has_gauss[e];
+      for (int d = 0; d < ndofs; d++) {
+        double g;
+        if (has) { g = cached; has = 0; cached = 0.0; }
+        else {
+          double x1, x2, r2;
+          do {
+#pragma clang fp contract(off)
+            x1 = 2.0 * next_double() - 1.0;
+            x2 = 2.0 * next_double() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+          } while (r2 >= 1.0 || r2 == 0.0);
+          double f;
+          {
+#pragma clang fp contract(off)
+            const double num = -2.0 * log_cr(r2);
+            f = sqrt(num / r2);
+            cached = f * x1;
+            g = f * x2;
+          }
+          has = 1;
+        }
+        double noise;
+        {
+#pragma clang fp contract(off)
+          noise = g * range_v;                 // (range_v carries the scale of the Gaussian here: .1)
+          vn[e * ndofs + d] = init_vel[d] + noise;
+        }
+      }
+      gauss_cache[e] = cached; has_gauss[e] = has;
+    } else if (extra == MT_EXTRA_SWINGUP) {
       // cartpole_swingup.py:42-45: `if np_random.uniform(0, 1, 1) > 0.5: qpos[1] += pi else: qpos[1] += -pi`
       const double u = affine(0.0, 0.0, 1.0, next_double());
       qn[e * ndofs + 1] += (u > 0.5) ? 3.141592653589793 : -3.141592653589793;

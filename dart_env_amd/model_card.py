@@ -224,11 +224,11 @@ DOG = TaskSpec(
 
 TASKS = {t.env_id: t for t in (HOPPER, WALKER2D, WALKER3D, HUMANWALKER, CARTPOLE, HALFCHEETAH, CARTPOLE_SWINGUP,
                                DOUBLE_PENDULUM, SNAKE, REACHER2D, REACHER3D, WALKER3D_SPD, DOG)}
-# tasks whose reset_model draws more than the two uniform vectors: the host draws them (see envs/dart_env.py)
-# reset_model() draws more than the two uniform noise vectors.  The device MT19937 bank draws the swing-up sign and the reach
-# targets itself (csrc/mt19937_kernels.hpp); the double pendulum's Gaussian velocities need numpy's legacy polar method
-# bit-for-bit (log / sqrt of the host libm) and stay on the host stream.
-HOST_RESET_TASKS = (TASK_DOUBLE_PENDULUM,)
+# reset_model() of these tasks draws more than the two uniform noise vectors.  The device MT19937 bank draws all of it itself
+# (csrc/mt19937_kernels.hpp): the swing-up sign, the reach targets and -- since round 4 -- the double pendulum's Gaussian velocities
+# (numpy's legacy polar method with a correctly rounded log, csrc/cr_log.hpp: the host stream bit for bit except for one draw in ~1 200,
+# where glibc's own log is not correctly rounded, by one ulp).  noise="mt19937-host" still draws everything with numpy on the host.
+HOST_RESET_TASKS = ()
 MT_ONLY_TASKS = (TASK_CARTPOLE_SWINGUP, TASK_DOUBLE_PENDULUM, TASK_REACHER2D, TASK_REACHER3D)   # no Philox variant
 # tasks with per-env state beyond (q, dq) that reset_model draws (the reach target): dart_set_task_state
 TASK_STATE_TASKS = (TASK_REACHER2D, TASK_REACHER3D)

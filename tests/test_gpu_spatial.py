@@ -282,9 +282,9 @@ def test_classic_env_vector_fixture_and_fp32(tag, env_id):
     d = np.load(os.path.join(G, "%s_vector4_seed3.npz" % tag))
     for prec, tol in ((64, 2e-5), (32, 5e-3)):
         venv = dart_env_amd.vector.make(env_id, 4, precision=prec)
-        # reset_model() runs on the device from the MT19937 bank -- incl. the swing-up sign and the rejection-sampled reach
-        # targets; only the double pendulum's Gaussian velocities come from numpy on the host
-        assert venv.env.noise == ("mt19937-host" if tag == "doublependulum" else "mt19937")
+        # reset_model() runs on the device from the MT19937 bank -- incl. the swing-up sign, the rejection-sampled reach targets and,
+        # since round 4, the double pendulum's Gaussian velocities (numpy's legacy polar method, csrc/cr_log.hpp)
+        assert venv.env.noise == "mt19937" and venv.env.device_noise
         venv.seed(3)
         assert np.allclose(venv.reset(), d["obs0"], atol=1e-6)
         # fp32: the first 15 steps only -- a free-flying 22-dof body amplifies rounding differences beyond any fixed bound later

@@ -348,7 +348,9 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
   if (!BIG || mv > SP_BLCP_MAXREG || max_iter == 0) { sp_blcp_lds<Real>(S, m, pinmask, F, U, max_iter, pgs_sweeps, stats, lane, ZERO_BOUNDS, pf_ncp, pf_m1); return; }
   if (lane < m) S.x0[lane] = S.x[lane];   // solution of the previous stage (zeros before the first): PGS fallback start
   BlcpSets r;
-  if (mv <= 16) r = sp_blcp_t<Real, 16>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  if (mv <= 8) r = sp_blcp_t<Real, 8>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (mv <= 12) r = sp_blcp_t<Real, 12>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (mv <= 16) r = sp_blcp_t<Real, 16>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
   else if (mv <= 24) r = sp_blcp_t<Real, 24>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
   else if (mv <= 32) r = sp_blcp_t<Real, 32>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
 #if SP_BLCP_MAXREG > 24

@@ -444,8 +444,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     // ---- stage 1 (frictionless), stage 2 (friction bounds from the stage-1 normal impulses)
     uint64_t pinmask = 0, F = 0, U = 0;
     {
-      Real bm = Real(0);
-      for (int i = 0; i < m; i++) bm = fmax(bm, fabs(S.b[i]));
+      const Real bm = wave_max_nonneg<Real>(lane < m ? fabs(S.b[lane]) : Real(0));
       const Real tol0 = tol_<Real>() * (Real(1) + bm);
       bool pinned = false, upper = false, startf = false;
       if (lane < m) {

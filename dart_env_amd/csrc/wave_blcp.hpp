@@ -57,13 +57,41 @@ __device__ __forceinline__ Real wave_sum(Real x) {
   return readlane_<Real>(x, 63);
 }
 
-// Boxed LCP by block principal pivoting with the whole iteration in REGISTERS: lane i holds row i of A and row i of the
-// masked LDL^T factor; a finished column travels through v_readlane (an SGPR operand of the FMA), the transposed solve uses
-// one DPP wave sum per column.  No LDS traffic and no barrier inside the pivoting loop (the LDS version paid an LDS round
-// trip + barrier per eliminated column).  MP = compile-time row capacity (variants 16 / 24 / 40: only the one a wave takes
-// enters the instruction cache); rows >= m are inert padding.
+// Maximum of NON-NEGATIVE x over the 64 lanes (same DPP ladder; lanes shifted in from outside a row read 0, the identity here).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return fmaxf(v, __builtin_bit_cast(float, t));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return fmax(v, __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo));
+}
+template <class Real>
+__device__ __forceinline__ Real wave_max_nonneg(Real x) {
+  x = dpp_max_<0x111, 0xf>(x);
+  x = dpp_max_<0x112, 0xf>(x);
+  x = dpp_max_<0x114, 0xf>(x);
+  x = dpp_max_<0x118, 0xf>(x);
+  x = dpp_max_<0x142, 0xa>(x);
+  x = dpp_max_<0x143, 0xc>(x);
+  return readlane_<Real>(x, 63);
+}
+
+// Boxed LCP by block principal pivoting with the whole iteration in REGISTERS: lane i holds row i of A and row i of the working
+// copy of the free block; a pivot row travels through v_readlane (an SGPR operand of the FMA).  No LDS traffic and no barrier inside
+// the pivoting loop (the LDS version paid an LDS round trip + barrier per eliminated column).
+// The free block is solved by GAUSS-JORDAN elimination on [A_FF | r] (round 4; before: masked LDL^T + two triangular solves).  With
+// one row per lane an elimination step is the same instructions whether it clears the column below the pivot or below AND above it
+// (every lane runs the update of its row either way), so eliminating both sides is free -- and the transposed solve L^T x = y, which
+// in this layout needed one 20-instruction DPP wave sum per free row on the critical path, disappears: after the last pivot
+// x_i = r_i / a_ii.  A_FF is symmetric positive definite (J M^-1 J^T + cfm), no pivoting needed.
+// MP = compile-time row capacity (variants 8 ... 40: only the one a wave takes enters the instruction cache); rows >= m are inert padding.
 // EXT (the lane kernels' callers): bmax_more, keep_last and the iteration count in the result are live; the tree kernel instantiates
-// EXT = false, whose code is the solver as it was before the lane kernels shared it.
+// EXT = false.
 struct BlcpSets { uint64_t F, U; bool ok; int iters; };
 template <class Real, int MP, bool EXT = false>
 __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__ Ap, const Real* __restrict__ bp, const Real* __restrict__ lop,
@@ -79,9 +107,7 @@ __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__
 #pragma unroll
   for (int j = 0; j < MP; j++) Ar[j] = (row && j < m) ? Ap[TI(lane, j)] : Real(0);
   const Real bi = row ? bp[lane] : Real(0), loi = row ? lop[lane] : Real(0), hii = row ? hip[lane] : Real(0);
-  Real bmax = EXT ? fmax(fabs(bi), bmax_more) : fabs(bi);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, o));
+  const Real bmax = wave_max_nonneg<Real>(EXT ? fmax(fabs(bi), bmax_more) : fabs(bi));
   const Real tol = tol_<Real>() * (Real(1) + bmax);
   int best = m + 1, patience = 3;
   bool converged = false;
@@ -96,42 +122,26 @@ __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__
       for (int j = 0; j < MP; j++) t -= Ar[j] * readlane_<Real>(xb, j);
     }
     rr = fi ? t : xb;
-    // masked LDL^T: non-free rows / columns are identity
+    // working copy of the free block, full rows (non-free rows / columns are identity)
     Real L[MP];
 #pragma unroll
     for (int j = 0; j < MP; j++) {
       const bool fj = (F >> j) & 1ull;
-      L[j] = (j == lane) ? (fi ? Ar[j] : Real(1)) : ((fi && fj && j < lane) ? Ar[j] : Real(0));
+      L[j] = (fi && fj) ? Ar[j] : ((j == lane) ? Real(1) : Real(0));
     }
     Real invd_own = Real(1);
 #pragma unroll
     for (int j = 0; j < MP; j++) {
       if ((F >> j) & 1ull) {   // wave-uniform
         const Real inv = rcp_<Real>(readlane_<Real>(L[j], j));
-        const Real u = (lane > j) ? L[j] : Real(0);   // unscaled column below the diagonal (0 in non-free rows)
-        const Real lij = u * inv;
-        L[j] = (lane > j) ? lij : L[j];
+        const Real mi = (lane != j) ? L[j] * inv : Real(0);   // this row's multiplier of pivot row j (0 in non-free rows: L[j] = 0 there)
         invd_own = (lane == j) ? inv : invd_own;
 #pragma unroll
-        for (int k = j + 1; k < MP; k++) L[k] -= lij * readlane_<Real>(u, k);
-      }
-    }
-    // L y = rr (unit lower triangle), y /= d, L^T x = y -- restricted to the free rows
-#pragma unroll
-    for (int j = 0; j < MP; j++) {
-      if ((F >> j) & 1ull) {
-        const Real yj = readlane_<Real>(rr, j);
-        rr = (lane > j) ? rr - L[j] * yj : rr;      // L[j] = 0 in non-free rows
+        for (int k = j + 1; k < MP; k++) L[k] -= mi * readlane_<Real>(L[k], j);   // lane j itself has mi = 0: the pivot row stays
+        rr -= mi * readlane_<Real>(rr, j);
       }
     }
     rr = fi ? rr * invd_own : rr;
-#pragma unroll
-    for (int j = MP - 1; j >= 0; j--) {
-      if ((F >> j) & 1ull) {
-        const Real s = wave_sum<Real>((lane > j && fi) ? L[j] * rr : Real(0));
-        rr = (lane == j) ? rr - s : rr;
-      }
-    }
     // w = A x - b and the feasibility of every row
     Real w = -bi;
 #pragma unroll

@@ -350,6 +350,24 @@ template <> __device__ __forceinline__ double rsqrt_<double>(double x) {   // v_
   r = r * fma(-0.5 * x * r, r, 1.5);
   return r * fma(-0.5 * x * r, r, 1.5);
 }
+// rsqrt_<Real>(x) with its dependent operations handed out one at a time -- same operations, same result -- so that a caller with
+// independent work (the systolic Cholesky of the tree kernel: the previous column's remaining updates) can put it between them: a lone
+// wave issues in order and would otherwise wait out every link of the chain (v_rsq_f64 + 6 dependent fp64 operations per column).
+template <class Real> __device__ __forceinline__ Real rsq_seed_(Real x);
+template <> __device__ __forceinline__ float rsq_seed_<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+template <> __device__ __forceinline__ double rsq_seed_<double>(double x) { return __builtin_amdgcn_rsq(x); }
+template <class Real>
+struct RsqStaged {
+  Real r, h, t;
+  static constexpr int NSTAGE = 3 * (sizeof(Real) == 4 ? 1 : 2);   // Newton steps of rsqrt_: 1 (fp32), 2 (fp64), three operations each
+  __device__ __forceinline__ void start(Real x) { r = rsq_seed_<Real>(x); h = Real(-0.5) * x; }
+  __device__ __forceinline__ void step(int s) {   // s = 0 .. NSTAGE-1, in order
+    const int ph = s % 3;
+    if (ph == 0) t = h * r;
+    else if (ph == 1) t = fma(t, r, Real(1.5));
+    else r = r * t;
+  }
+};
 template <class Real> __device__ __forceinline__ Real inf_() { return Real(__builtin_huge_valf()); }
 template <class Real> __device__ __forceinline__ Real tol_() { return sizeof(Real) == 4 ? Real(2e-6) : Real(1e-12); }
 

@@ -37,10 +37,18 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
 #pragma unroll
   for (int k = 0; k < NP; k++) row[k] = (k <= r) ? M[rb + k] : Real(0);
   Real sown = Real(1);                  // lane j: 1 / L_jj
+  // Columns beyond the model's dofs (identity padding up to NP) are left alone in a pattern kernel: nothing to factor, sinv = 1.
+  constexpr int NC = PAT::dense ? NP : (PAT::n < NP ? PAT::n : NP);
+  // 1 / sqrt(d_j) is SOFTWARE-PIPELINED (round 4): column j + 1's diagonal is final after the first update of column j, so its
+  // v_rsq + Newton chain (7 dependent fp64 operations, ~100 cycles that a lone in-order wave would wait out) is started there and its
+  // links are placed one by one between the remaining updates of column j, which do not depend on it.
+  RsqStaged<Real> nx;
+  nx.start(readlane_<Real>(row[0], 0));
 #pragma unroll
-  for (int j = 0; j < NP; j++) {
-    const Real dj = readlane_<Real>(row[j], j);
-    const Real sj = rsqrt_<Real>(dj);
+  for (int s = 0; s < RsqStaged<Real>::NSTAGE; s++) nx.step(s);
+#pragma unroll
+  for (int j = 0; j < NC; j++) {
+    const Real sj = nx.r;
     const Real lrj = (r >= j) ? row[j] * sj : Real(0);   // lanes above the diagonal contribute nothing
     row[j] = lrj;
     // (1 / L_jj goes to sinv[] once, after the loop: a store under `if (lane == j)` here splits the factorisation into one basic block
@@ -49,8 +57,21 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
     // once, ~450 SGPRs spilled into VGPR lanes and read back, 2 x v_writelane + 2 x v_readlane extra per update; round 4, found in the
     // disassembly of the fp64 pattern kernel)
     sown = (lane == j) ? sj : sown;
+    int st = RsqStaged<Real>::NSTAGE;   // (compile-time after unrolling) next link of the chain; NSTAGE: none pending
+    if (j + 1 < NC) {
+      if (PAT::nz(j + 1, j)) row[j + 1] -= lrj * readlane_<Real>(lrj, j + 1);
+      nx.start(readlane_<Real>(row[j + 1], j + 1));
+      st = 0;
+    }
 #pragma unroll
-    for (int k = j + 1; k < NP; k++) if (PAT::nz(k, j)) row[k] -= lrj * readlane_<Real>(lrj, k);
+    for (int k = j + 2; k < NP; k++) {
+      if (PAT::nz(k, j)) {
+        row[k] -= lrj * readlane_<Real>(lrj, k);
+        if (st < RsqStaged<Real>::NSTAGE) nx.step(st++);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < RsqStaged<Real>::NSTAGE; s++) if (s >= st) nx.step(s);
   }
   if (lane < NP) sinv[lane] = sown;   // (sinv has sp_npad(n) slots: the padding columns write theirs too)
   if (lane < n) {
@@ -82,8 +103,10 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
     for (int k = 0; k < NP; k++) {
       if (k < n) {
         Real t = y[k];
+        // the broadcasts of step k may not be issued before step k - 1 is done (DART_TIE, wave_blcp.hpp): <= 12 SGPR pairs in flight
 #pragma unroll
-        for (int j = 0; j < k; j++) if (PAT::nz(k, j)) t -= readlane_<Real>(row[j], k) * y[j];
+        for (int j = 0; j < k; j++) if (PAT::nz(k, j)) { if (k > 0) DART_TIE(row[j], y[k - 1]); t -= readlane_<Real>(row[j], k) * y[j]; }
+        if (k > 0) DART_TIE(sown, y[k - 1]);
         y[k] = t * readlane_<Real>(sown, k);
       }
     }

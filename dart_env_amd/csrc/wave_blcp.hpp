@@ -10,11 +10,18 @@
 // and keeps all 222 broadcast pairs of a HumanWalker factor alive in between -- 444 SGPRs in a file of ~100 -- i.e. it spills each
 // into a VGPR lane (2 x v_writelane) and reads it back (2 x v_readlane) where simply broadcasting again costs 2 x v_readlane
 // (round 4, from the disassembly of the fp64 pattern kernel: 1 078 SGPR spills).  Host builds (tests/kernel_emu) define it away.
+// DART_TIE(x, after): the same fence with an input -- `x` becomes a value that exists only once `after` has been computed, so a
+// v_readlane of x cannot be scheduled before that point.  Why: where every broadcast source is ready at the top of a long unrolled
+// region (the W = L^-1 J^T substitution below the factorisation: 222 broadcasts of finished factor entries), the scheduler hoists ALL
+// the v_readlanes to the top of the region "to cover latency" and the register allocator then parks each SGPR pair in a VGPR lane
+// (2 x v_writelane + s_nops) and fetches it back before use -- found in the disassembly, round 4: 409 v_writelane in that region.
 #ifndef DART_OPAQUE
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DART_OPAQUE(x) asm volatile("" : "+v"(x))
+#define DART_TIE(x, after) asm volatile("" : "+v"(x) : "v"(after))
 #else
 #define DART_OPAQUE(x) ((void)0)
+#define DART_TIE(x, after) ((void)0)
 #endif
 #endif
 

@@ -54,6 +54,7 @@ inline CReal fmin(CReal a, CReal b) { g_fc.minmax++; return CReal(std::fmin(a.v,
 inline CReal sqrt(CReal a) { g_fc.sqrt++; return CReal(std::sqrt(a.v)); }
 inline bool isfinite(CReal a) { g_fc.cmp++; return std::isfinite(a.v); }
 inline CReal cfma(CReal a, CReal b, CReal c) { g_fc.fma++; return CReal(std::fma(a.v, b.v, c.v)); }
+inline CReal fma(CReal a, CReal b, CReal c) { return cfma(a, b, c); }
 
 #include "planar_kernel.hpp"
 
@@ -92,6 +93,7 @@ template <> __device__ __forceinline__ CReal rcp_<CReal>(CReal x) {   // v_rcp_f
   r = cfma(cfma(-x, r, CReal(1.0)), r, r);
   return cfma(cfma(-x, r, CReal(1.0)), r, r);
 }
+template <> __device__ __forceinline__ CReal rsq_seed_<CReal>(CReal x) { g_fc.rsq++; return CReal(1.0 / std::sqrt(x.v)); }
 template <> __device__ __forceinline__ CReal rsqrt_<CReal>(CReal x) {   // v_rsq_f64 + two Newton steps
   g_fc.rsq++;
   CReal r(1.0 / std::sqrt(x.v));
@@ -126,6 +128,7 @@ namespace dartk {
 template <> __device__ __forceinline__ CReal readlane_<CReal>(CReal x, int l) { return CReal(readlane_<double>(x.v, l)); }
 }
 template <int CTRL, int ROW_MASK> inline CReal dpp_add_(CReal v) { g_fc.add++; return CReal(dartk::dpp_add_<CTRL, ROW_MASK>(v.v)); }
+template <int CTRL, int ROW_MASK> inline CReal dpp_max_(CReal v) { g_fc.minmax++; return CReal(dartk::dpp_max_<CTRL, ROW_MASK>(v.v)); }
 
 #include "spatial_impl.hpp"
 

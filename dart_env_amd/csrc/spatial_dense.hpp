@@ -144,7 +144,9 @@ __device__ __forceinline__ void sp_chol_backsolve_lds(const Real* Lf, const Real
 // entry is broadcast with v_readlane, the factor entries L_ji (row j, contiguous over the lanes i) are independent LDS reads
 // issued up front -- no barrier and no LDS write per column (the first version paid both).
 template <class Real, int NP>
-__device__ __attribute__((noinline)) void sp_chol_backsolve_t(const Real* __restrict__ Lf, const Real* __restrict__ sinv, int n, Real* __restrict__ x, int lane) {
+__device__ __attribute__((noinline)) void sp_chol_backsolve_t(const Real* __restrict__ Lf_, const Real* __restrict__ sinv_, int n, Real* __restrict__ x_, int lane) {
+  const auto Lf = DART_LDS_PTR(const Real, Lf_), sinv = DART_LDS_PTR(const Real, sinv_);   // LDS with every caller (wave_blcp.hpp)
+  const auto x = DART_LDS_PTR(Real, x_);
   const int i = lane < NP ? lane : 0;
   Real xi = (lane < n) ? x[lane] : Real(0);
   const Real si = (lane < n) ? sinv[lane] : Real(1);

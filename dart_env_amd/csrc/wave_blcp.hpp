@@ -25,6 +25,14 @@
 #endif
 #endif
 
+// A pointer the CALLER knows to be LDS, re-typed as such inside a noinline function: its generic-pointer arguments would otherwise
+// compile to flat_load / flat_store (the vector-memory path, aperture check first) instead of ds_read / ds_write.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DART_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#else
+#define DART_LDS_PTR(T, p) (p)
+#endif
+
 namespace dartk {
 
 template <class Real> __device__ __forceinline__ Real readlane_(Real x, int l);
@@ -101,10 +109,13 @@ __device__ __forceinline__ Real wave_max_nonneg(Real x) {
 // EXT = false.
 struct BlcpSets { uint64_t F, U; bool ok; int iters; };
 template <class Real, int MP, bool EXT = false>
-__device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__ Ap, const Real* __restrict__ bp, const Real* __restrict__ lop,
-                                                        const Real* __restrict__ hip, Real* __restrict__ xp, int m, uint64_t pinmask, uint64_t F,
+__device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__ Ap_, const Real* __restrict__ bp_, const Real* __restrict__ lop_,
+                                                        const Real* __restrict__ hip_, Real* __restrict__ xp_, int m, uint64_t pinmask, uint64_t F,
                                                         uint64_t U, int max_iter, unsigned long long* stats, int lane, const bool ZERO_BOUNDS,
                                                         Real bmax_more = Real(0), bool keep_last = false) {
+  // the problem lives in LDS with every caller (the tree kernel's SpLds block, the lane kernels' hand-off buffer)
+  const auto Ap = DART_LDS_PTR(const Real, Ap_), bp = DART_LDS_PTR(const Real, bp_), lop = DART_LDS_PTR(const Real, lop_), hip = DART_LDS_PTR(const Real, hip_);
+  const auto xp = DART_LDS_PTR(Real, xp_);
   // bmax_more: |b| of rows the caller left out of this solve (they enter the feasibility tolerance as in blcp_bpp)
   // keep_last: when the cap is reached the last iterate is written to xp, clamped into the box (default: xp is left alone)
   // a real function call (not inlined): its register arrays get their own allocation instead of raising the pressure of the

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE -- the wave-cooperative boxed-LCP solver (dart_env_amd/csrc/wave_blcp.hpp: the tree kernel's constraint solver,
 // and the lane kernels' wave-served fallback) behind a plain C entry point, so that tests/test_gpu_wave_blcp.py can feed it random
-// problems and check the complementarity conditions of what comes back.  One problem per 64-lane workgroup, operands in global
-// memory.  Built by __graft_entry__.build() into tests/gpu_kernels/libwave_blcp_harness.so; nothing under dart_env_amd/ loads it.
+// problems and check the complementarity conditions of what comes back.  One problem per 64-lane workgroup, operands staged
+// from global memory into LDS.  Built by __graft_entry__.build() into tests/gpu_kernels/libwave_blcp_harness.so; nothing under dart_env_amd/ loads it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -16,11 +16,19 @@ __global__ void __launch_bounds__(64) blcp_harness_kernel(int n_problems, int mc
   const int p = blockIdx.x;
   if (p >= n_problems) return;
   const int tri = mcap * (mcap + 1) / 2;
+  // the solver's operands live in LDS with every product caller (it re-types its pointers as LDS: DART_LDS_PTR): stage them there
+  __shared__ Real sm[40 * 41 / 2 + 4 * 40];
+  Real* sA = sm; Real* sb = sm + tri; Real* slo = sb + mcap; Real* shi = slo + mcap; Real* sx = shi + mcap;
+  for (int e = threadIdx.x; e < tri; e += 64) sA[e] = A[(size_t)p * tri + e];
+  for (int e = threadIdx.x; e < mcap; e += 64) {
+    sb[e] = b[(size_t)p * mcap + e]; slo[e] = lo[(size_t)p * mcap + e]; shi[e] = hi[(size_t)p * mcap + e]; sx[e] = x[(size_t)p * mcap + e];
+  }
+  __syncthreads();
   BlcpSets r;
-  if constexpr (EXT) r = sp_blcp_t<Real, MP, true>(A + (size_t)p * tri, b + (size_t)p * mcap, lo + (size_t)p * mcap, hi + (size_t)p * mcap, x + (size_t)p * mcap,
-                                                     m[p], pin[p], F[p], U[p], max_iter, nullptr, (int)threadIdx.x, zero_bounds != 0, Real(0), keep_last != 0);
-  else r = sp_blcp_t<Real, MP>(A + (size_t)p * tri, b + (size_t)p * mcap, lo + (size_t)p * mcap, hi + (size_t)p * mcap, x + (size_t)p * mcap, m[p], pin[p],
-                               F[p], U[p], max_iter, nullptr, (int)threadIdx.x, zero_bounds != 0);
+  if constexpr (EXT) r = sp_blcp_t<Real, MP, true>(sA, sb, slo, shi, sx, m[p], pin[p], F[p], U[p], max_iter, nullptr, (int)threadIdx.x, zero_bounds != 0, Real(0), keep_last != 0);
+  else r = sp_blcp_t<Real, MP>(sA, sb, slo, shi, sx, m[p], pin[p], F[p], U[p], max_iter, nullptr, (int)threadIdx.x, zero_bounds != 0);
+  __syncthreads();
+  for (int e = threadIdx.x; e < mcap; e += 64) x[(size_t)p * mcap + e] = sx[e];
   if (threadIdx.x == 0) { F[p] = r.F; U[p] = r.U; ok[p] = r.ok ? 1 : 0; iters[p] = r.iters; }
 }
 
@@ -38,7 +46,9 @@ static int run(int n, int mp, int ext, int mcap, const Real* A, const Real* b, c
   CK(hipMemcpy(dx, x, n * mcap * sizeof(Real), hipMemcpyHostToDevice)); CK(hipMemcpy(dm, m, n * sizeof(int), hipMemcpyHostToDevice));
   CK(hipMemcpy(dpin, pin, n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dF, F, n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dU, U, n * 8, hipMemcpyHostToDevice));
 #define LAUNCH(MP, EXT) hipLaunchKernelGGL((blcp_harness_kernel<Real, MP, EXT>), dim3(n), dim3(64), 0, 0, n, mcap, dA, db, dlo, dhi, dx, dm, dpin, dF, dU, dok, dit, max_iter, zero_bounds, keep_last)
+  if (mcap > 40) return -2;
   if (mp == 16 && ext) LAUNCH(16, true); else if (mp == 24 && ext) LAUNCH(24, true); else if (mp == 16) LAUNCH(16, false);
+  else if (mp == 8) LAUNCH(8, false); else if (mp == 12) LAUNCH(12, false);
   else if (mp == 24) LAUNCH(24, false); else if (mp == 32) LAUNCH(32, false); else if (mp == 40) LAUNCH(40, false); else return -2;
   CK(hipDeviceSynchronize());
   CK(hipMemcpy(x, dx, n * mcap * sizeof(Real), hipMemcpyDeviceToHost)); CK(hipMemcpy(F, dF, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(U, dU, n * 8, hipMemcpyDeviceToHost));
@@ -49,7 +59,7 @@ static int run(int n, int mp, int ext, int mcap, const Real* A, const Real* b, c
 
 extern "C" {
 // n problems of up to `mcap` rows each (row count m[p]); A packed lower triangle (TI), row-major per problem with stride mcap(mcap+1)/2;
-// mp = the register variant (16 / 24 / 32 / 40 rows), ext = the lane kernels' instantiation (mp 16 or 24).  Returns 0, -1 (HIP error), -2 (variant).
+// mp = the register variant (8 / 12 / 16 / 24 / 32 / 40 rows), ext = the lane kernels' instantiation (mp 16 or 24).  Returns 0, -1 (HIP error), -2 (variant).
 int wave_blcp_run_f64(int n, int mp, int ext, int mcap, const double* A, const double* b, const double* lo, const double* hi, double* x, const int* m,
                       const uint64_t* pin, uint64_t* F, uint64_t* U, int* ok, int* iters, int max_iter, int zero_bounds, int keep_last) {
   return run<double>(n, mp, ext, mcap, A, b, lo, hi, x, m, pin, F, U, ok, iters, max_iter, zero_bounds, keep_last);

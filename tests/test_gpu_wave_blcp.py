@@ -104,8 +104,8 @@ def enumerate_solution(Ap, b, lo, hi):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("real,mp,ext", [("f64", 16, 0), ("f64", 24, 0), ("f64", 32, 0), ("f64", 40, 0), ("f64", 16, 1), ("f64", 24, 1),
-                                         ("f32", 16, 0), ("f32", 40, 0), ("f32", 16, 1), ("f32", 24, 1)])
+@pytest.mark.parametrize("real,mp,ext", [("f64", 8, 0), ("f64", 12, 0), ("f64", 16, 0), ("f64", 24, 0), ("f64", 32, 0), ("f64", 40, 0), ("f64", 16, 1), ("f64", 24, 1),
+                                         ("f32", 8, 0), ("f32", 12, 0), ("f32", 16, 0), ("f32", 40, 0), ("f32", 16, 1), ("f32", 24, 1)])
 @pytest.mark.parametrize("zero_bounds,rank_deficient", [(0, False), (1, False), (0, True)])
 def test_wave_solver_returns_the_lcp_solution(real, mp, ext, zero_bounds, rank_deficient):
     L = _lib()

@@ -143,8 +143,8 @@ __device__ __forceinline__ void sp_chol_backsolve_lds(const Real* Lf, const Real
 // x <- L^-T x (backward) for one vector in LDS, lanes own entries.  The running vector stays in registers: column j's finished
 // entry is broadcast with v_readlane, the factor entries L_ji (row j, contiguous over the lanes i) are independent LDS reads
 // issued up front -- no barrier and no LDS write per column (the first version paid both).
-template <class Real, int NP>
-__device__ __attribute__((noinline)) void sp_chol_backsolve_t(const Real* __restrict__ Lf_, const Real* __restrict__ sinv_, int n, Real* __restrict__ x_, int lane) {
+template <class Real, int NP, int TAG = 0>   // TAG: private copies per kernel family (see sp_blcp_t)
+static __device__ __attribute__((noinline)) void sp_chol_backsolve_t(const Real* __restrict__ Lf_, const Real* __restrict__ sinv_, int n, Real* __restrict__ x_, int lane) {
   const auto Lf = DART_LDS_PTR(const Real, Lf_), sinv = DART_LDS_PTR(const Real, sinv_);   // LDS with every caller (wave_blcp.hpp)
   const auto x = DART_LDS_PTR(Real, x_);
   const int i = lane < NP ? lane : 0;
@@ -164,14 +164,14 @@ __device__ __attribute__((noinline)) void sp_chol_backsolve_t(const Real* __rest
   if (lane < n) x[lane] = xi;
   __syncthreads();
 }
-template <class Real, bool BIG = false>
+template <class Real, bool BIG = false, int TAG = 0>
 __device__ __forceinline__ void sp_chol_backsolve(const Real* Lf, const Real* sinv, int n, Real* x, int lane) {
   if constexpr (!BIG) { sp_chol_backsolve_lds<Real>(Lf, sinv, n, x, lane); return; }
   const int np = sp_npad(n);
-  if (np <= 8) sp_chol_backsolve_t<Real, 8>(Lf, sinv, n, x, lane);
-  else if (np <= 16) sp_chol_backsolve_t<Real, 16>(Lf, sinv, n, x, lane);
-  else if (np <= 24) sp_chol_backsolve_t<Real, 24>(Lf, sinv, n, x, lane);
-  else sp_chol_backsolve_t<Real, 32>(Lf, sinv, n, x, lane);
+  if (np <= 8) sp_chol_backsolve_t<Real, 8, TAG>(Lf, sinv, n, x, lane);
+  else if (np <= 16) sp_chol_backsolve_t<Real, 16, TAG>(Lf, sinv, n, x, lane);
+  else if (np <= 24) sp_chol_backsolve_t<Real, 24, TAG>(Lf, sinv, n, x, lane);
+  else sp_chol_backsolve_t<Real, 32, TAG>(Lf, sinv, n, x, lane);
 }
 
 // x <- L^-1 x (forward), column-oriented like the back-substitution
@@ -363,7 +363,7 @@ __device__ __forceinline__ void sp_blcp_lds(SpLds<Real>& S, int m, uint64_t pinm
 // solver beyond; a register solve that hits its iteration cap re-enters the LDS solver with no pivoting iterations = its PGS
 // safety net.  The small-model kernels keep the LDS solver: measured, the register arrays cost them more (occupancy, call
 // overhead) than the saved barriers give back.
-template <class Real, bool BIG = false>
+template <class Real, bool BIG = false, int TAG = 0>
 __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask, uint64_t& F, uint64_t& U, int max_iter,
                                        int pgs_sweeps, unsigned long long* stats, int lane, const bool ZERO_BOUNDS, int mv = 0,
                                        int pf_ncp = -1, int pf_m1 = 0) {
@@ -373,13 +373,13 @@ __device__ __forceinline__ void sp_blcp(SpLds<Real>& S, int m, uint64_t pinmask,
   if (!BIG || mv > SP_BLCP_MAXREG || max_iter == 0) { sp_blcp_lds<Real>(S, m, pinmask, F, U, max_iter, pgs_sweeps, stats, lane, ZERO_BOUNDS, pf_ncp, pf_m1); return; }
   if (lane < m) S.x0[lane] = S.x[lane];   // solution of the previous stage (zeros before the first): PGS fallback start
   BlcpSets r;
-  if (mv <= 8) r = sp_blcp_t<Real, 8>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
-  else if (mv <= 12) r = sp_blcp_t<Real, 12>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
-  else if (mv <= 16) r = sp_blcp_t<Real, 16>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
-  else if (mv <= 24) r = sp_blcp_t<Real, 24>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
-  else if (mv <= 32) r = sp_blcp_t<Real, 32>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  if (mv <= 8) r = sp_blcp_t<Real, 8, false, TAG>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (mv <= 12) r = sp_blcp_t<Real, 12, false, TAG>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (mv <= 16) r = sp_blcp_t<Real, 16, false, TAG>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (mv <= 24) r = sp_blcp_t<Real, 24, false, TAG>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else if (mv <= 32) r = sp_blcp_t<Real, 32, false, TAG>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
 #if SP_BLCP_MAXREG > 24
-  else r = sp_blcp_t<Real, 40>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
+  else r = sp_blcp_t<Real, 40, false, TAG>(S.A, S.b, S.lo, S.hi, S.x, m, pinmask, F, U, max_iter, stats, lane, ZERO_BOUNDS);
 #else
   else r = BlcpSets{F, U, false, 0};
 #endif

@@ -37,15 +37,18 @@ namespace dartk {
 // workgroups per CU); the small-model kernels keep three.
 // Waves per SIMD the register allocation is bounded for.  Small models: 3 (168 VGPRs).  BIG (register LCP solver): 2 in fp32 / 1 in
 // fp64 -- except the lean kernel of a model with a compile-time factor pattern (HumanWalker), which is short enough for 3 in fp32
-// (measured 6.19 -> 5.84 ms; the PAIRS kernel of Walker3d got 13 % slower at 3).
+// (measured 6.19 -> 5.84 ms; the PAIRS kernel of Walker3d got 13 % slower at 3) and 2 in fp64 (below).
 #ifndef SP_PAT_F32_WAVES
 #define SP_PAT_F32_WAVES 3
 #endif
 #ifndef SP_BAKE_DIMS
 #define SP_BAKE_DIMS 1
 #endif
+// fp64 pattern kernel: 2 (round 4).  Its LDS block (26 928 B after the trim in sp_carve) fits six times into a CU, so two of the four
+// SIMDs can hold a second wave -- if a wave stays within 256 registers.  Measured (HumanWalker, 16 384 envs): 9.72 ms at 1 (256 VGPR + 96
+// AGPR, 356 B scratch) -> 9.01 ms at 2 (256 VGPR, 816 B scratch).  The callees must be private copies for this to work (sp_blcp_t's TAG).
 #ifndef SP_PAT_F64_WAVES
-#define SP_PAT_F64_WAVES 1
+#define SP_PAT_F64_WAVES 2
 #endif
 template <class Real, bool BIG, class PAT = DensePattern> __host__ __device__ constexpr int sp_min_waves() {
   if (!BIG) return 3;

@@ -178,13 +178,16 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
     if (alias) { S.Lw = S.link; S.x0 = S.link + sp_tri(maxm); }
     else { S.Lw = p; p += sp_tri(maxm); S.x0 = p; p += maxm; }
   }
-  S.b = p; p += maxm; S.lo = p; p += maxm; S.hi = p; p += maxm; S.x = p; p += maxm; S.r = p; p += maxm;
+  S.b = p; p += maxm; S.lo = p; p += maxm; S.hi = p; p += maxm; S.x = p; p += maxm;
+  // reg_lcp (register LCP solver: no pairs, no extras, no free root, no report, no SPD -- SpatialImplT::choose_lds) leaves out what only
+  // those paths touch: the LDS solver's iterate (r), the previous step's constraint forces (cf), the free root's pose (root).  712 B in
+  // fp64 for HumanWalker: 26 928 B instead of 27 640 = six workgroups per CU instead of five (round 4).
+  if (reg_lcp) S.r = nullptr; else { S.r = p; p += maxm; }
   S.cpP = p; p += maxcp * 4;
   S.cpN = p; p += maxcp * 3;
   S.misc = p; p += 16;
   S.sinv = p; p += sp_npad(n);   // the factorisation writes the padding columns' entries too
-  S.cf = p; p += n;
-  S.root = p; p += 24;
+  if (reg_lcp) { S.cf = nullptr; S.root = nullptr; } else { S.cf = p; p += n; S.root = p; p += 24; }
   S.rdof = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
   S.rfidx = (int*)p; p += maxm * sizeof(int) / sizeof(Real) + 1;
   S.cplink = (int*)p; p += maxcp * sizeof(int) / sizeof(Real) + 1;
@@ -199,8 +202,8 @@ __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes,
   const bool alias = sp_lw_aliases_links(nl, maxm);
   const size_t lw = alias ? 0 : (size_t)sp_tri(maxm) + maxm;
   const size_t a = (reg_lcp && alias) ? 0 : (size_t)sp_tri(maxm);
-  size_t reals = (size_t)nl * SP_LINKF + 5 * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)sp_w_reals(n, maxm) + a + lw + 5 * maxm +
-                 maxcp * 7 + 16 + 24;
+  size_t reals = (size_t)nl * SP_LINKF + (reg_lcp ? 4 : 5) * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)sp_w_reals(n, maxm) + a + lw +
+                 (reg_lcp ? 4 : 5) * maxm + maxcp * 7 + 16 + (reg_lcp ? 0 : 24);
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + 2 * nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }
 

@@ -414,7 +414,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       }
       SP_TICK(2);
       if (pass == 0) {
-        sp_chol_backsolve<Real, BIG>(Hm, sv, n, xq, lane);
+        sp_chol_backsolve<Real, BIG, BK ? 1 : 0>(Hm, sv, n, xq, lane);
         if (lane < n) S.dq[lane] += Md.dt * xq[n - 1 - lane];
         __syncthreads();
       }
@@ -489,7 +489,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         F = (F & ~fr) | (fr & ~pf & ~su & ~sd);
         U = (U & ~fr) | su;
       }
-      sp_blcp<Real, BIG>(S, stage == 0 ? m1 : m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction),
+      sp_blcp<Real, BIG, BK ? 1 : 0>(S, stage == 0 ? m1 : m, pinmask, F, U, Md.solver_iters, Md.pgs_fallback_sweeps, Md.stats, lane, stage == 0 && !(EXTRAS && Md.has_joint_friction),
                          0, (PREFIX && stage == 1) ? ncp : -1, m1);
     }
     SP_TICK(8);
@@ -542,7 +542,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       Md.cf_report[(size_t)env * n + lane] = v;
     }
   }
-  if (m > 0) sp_chol_backsolve<Real, BIG>(S.H, S.sinv, n, S.rhs, lane);   // (wave-uniform: nothing touching, no limit active -> v = v*)
+  if (m > 0) sp_chol_backsolve<Real, BIG, BK ? 1 : 0>(S.H, S.sinv, n, S.rhs, lane);   // (wave-uniform: nothing touching, no limit active -> v = v*)
   SP_TICK(9);
   if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[n - 1 - lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
   __syncthreads();

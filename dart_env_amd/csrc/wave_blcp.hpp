@@ -108,8 +108,11 @@ __device__ __forceinline__ Real wave_max_nonneg(Real x) {
 // EXT (the lane kernels' callers): bmax_more, keep_last and the iteration count in the result are live; the tree kernel instantiates
 // EXT = false.
 struct BlcpSets { uint64_t F, U; bool ok; int iters; };
-template <class Real, int MP, bool EXT = false>
-__device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__ Ap_, const Real* __restrict__ bp_, const Real* __restrict__ lop_,
+// TAG: a kernel that wants private copies of this function instantiates its own tag -- the register budget of a non-kernel function is
+// the loosest one among the kernels that call it (waves per SIMD are a kernel attribute the compiler propagates to callees), so a
+// kernel built for 2 waves per SIMD must not share its callees with kernels built for 1 (the tree kernel's fp64 pattern kernel).
+template <class Real, int MP, bool EXT = false, int TAG = 0>
+static __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __restrict__ Ap_, const Real* __restrict__ bp_, const Real* __restrict__ lop_,
                                                         const Real* __restrict__ hip_, Real* __restrict__ xp_, int m, uint64_t pinmask, uint64_t F,
                                                         uint64_t U, int max_iter, unsigned long long* stats, int lane, const bool ZERO_BOUNDS,
                                                         Real bmax_more = Real(0), bool keep_last = false) {

@@ -259,17 +259,18 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
     f = f - fe;
     if (!Md.ext_at_joint_origin) nj = nj - cross(p - pj, fe);
   }
-  st3(L + LK_F, f);
-  st3(L + LK_N, nj);
-  L[LK_MC] = m;
-  st3(L + LK_H, dj * m);
+  Real* D = S.ldyn + lane * SP_LDYN;
+  st3(D + LD_F, f);
+  st3(D + LD_N, nj);
+  D[LD_MC] = m;
+  st3(D + LD_H, dj * m);
   const Real d2 = dot(dj, dj);
-  L[LK_IC + 0] = Iw[0] + m * (d2 - dj.x * dj.x);
-  L[LK_IC + 1] = Iw[1] - m * dj.x * dj.y;
-  L[LK_IC + 2] = Iw[2] - m * dj.x * dj.z;
-  L[LK_IC + 3] = Iw[4] + m * (d2 - dj.y * dj.y);
-  L[LK_IC + 4] = Iw[5] - m * dj.y * dj.z;
-  L[LK_IC + 5] = Iw[8] + m * (d2 - dj.z * dj.z);
+  D[LD_IC + 0] = Iw[0] + m * (d2 - dj.x * dj.x);
+  D[LD_IC + 1] = Iw[1] - m * dj.x * dj.y;
+  D[LD_IC + 2] = Iw[2] - m * dj.x * dj.z;
+  D[LD_IC + 3] = Iw[4] + m * (d2 - dj.y * dj.y);
+  D[LD_IC + 4] = Iw[5] - m * dj.y * dj.z;
+  D[LD_IC + 5] = Iw[8] + m * (d2 - dj.z * dj.z);
 }
 
 // Link poses of the current S.q for the task code (all 64 lanes call; ends with a barrier): what sp_kinematics computes
@@ -301,44 +302,46 @@ __device__ __forceinline__ void sp_pose_pass(const LinkConst<Real>& lc, const Sp
 // bodies (lc.children holds the child groups' leaders)
 template <class Real>
 __device__ __forceinline__ void sp_gather_children(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
-  Real* Lp = S.link + i * SP_LINKF;
-  V3<Real> F = ld3(Lp + LK_F), N = ld3(Lp + LK_N), H = ld3(Lp + LK_H);
-  Real mcp = Lp[LK_MC];
-  Real I0 = Lp[LK_IC + 0], I1 = Lp[LK_IC + 1], I2 = Lp[LK_IC + 2], I3 = Lp[LK_IC + 3], I4 = Lp[LK_IC + 4], I5 = Lp[LK_IC + 5];
-  const V3<Real> jop = ld3(Lp + LK_JO);
+  Real* Dp = S.ldyn + i * SP_LDYN;
+  V3<Real> F = ld3(Dp + LD_F), N = ld3(Dp + LD_N), H = ld3(Dp + LD_H);
+  Real mcp = Dp[LD_MC];
+  Real I0 = Dp[LD_IC + 0], I1 = Dp[LD_IC + 1], I2 = Dp[LD_IC + 2], I3 = Dp[LD_IC + 3], I4 = Dp[LD_IC + 4], I5 = Dp[LD_IC + 5];
+  const V3<Real> jop = ld3(S.link + i * SP_LINKF + LK_JO);
   for (int ci = 0; ci < lc.nchild; ci++) {
-    const Real* L = S.link + (int)((lc.children >> (8 * ci)) & 0xffull) * SP_LINKF;
-    const V3<Real> o = ld3(L + LK_JO) - jop, Fc = ld3(L + LK_F);
+    const int c = (int)((lc.children >> (8 * ci)) & 0xffull);
+    const Real* D = S.ldyn + c * SP_LDYN;
+    const V3<Real> o = ld3(S.link + c * SP_LINKF + LK_JO) - jop, Fc = ld3(D + LD_F);
     F = F + Fc;
-    N = N + ld3(L + LK_N) + cross(o, Fc);
-    const Real mc = L[LK_MC];
-    const V3<Real> h = ld3(L + LK_H);
+    N = N + ld3(D + LD_N) + cross(o, Fc);
+    const Real mc = D[LD_MC];
+    const V3<Real> h = ld3(D + LD_H);
     const Real diag = Real(2) * dot(o, h) + mc * dot(o, o);
-    I0 += L[LK_IC + 0] + diag - Real(2) * h.x * o.x - mc * o.x * o.x;
-    I1 += L[LK_IC + 1] - (h.x * o.y + o.x * h.y) - mc * o.x * o.y;
-    I2 += L[LK_IC + 2] - (h.x * o.z + o.x * h.z) - mc * o.x * o.z;
-    I3 += L[LK_IC + 3] + diag - Real(2) * h.y * o.y - mc * o.y * o.y;
-    I4 += L[LK_IC + 4] - (h.y * o.z + o.y * h.z) - mc * o.y * o.z;
-    I5 += L[LK_IC + 5] + diag - Real(2) * h.z * o.z - mc * o.z * o.z;
+    I0 += D[LD_IC + 0] + diag - Real(2) * h.x * o.x - mc * o.x * o.x;
+    I1 += D[LD_IC + 1] - (h.x * o.y + o.x * h.y) - mc * o.x * o.y;
+    I2 += D[LD_IC + 2] - (h.x * o.z + o.x * h.z) - mc * o.x * o.z;
+    I3 += D[LD_IC + 3] + diag - Real(2) * h.y * o.y - mc * o.y * o.y;
+    I4 += D[LD_IC + 4] - (h.y * o.z + o.y * h.z) - mc * o.y * o.z;
+    I5 += D[LD_IC + 5] + diag - Real(2) * h.z * o.z - mc * o.z * o.z;
     H = H + h + o * mc;
     mcp += mc;
   }
-  st3(Lp + LK_F, F); st3(Lp + LK_N, N); st3(Lp + LK_H, H);
-  Lp[LK_MC] = mcp;
-  Lp[LK_IC + 0] = I0; Lp[LK_IC + 1] = I1; Lp[LK_IC + 2] = I2; Lp[LK_IC + 3] = I3; Lp[LK_IC + 4] = I4; Lp[LK_IC + 5] = I5;
+  st3(Dp + LD_F, F); st3(Dp + LD_N, N); st3(Dp + LD_H, H);
+  Dp[LD_MC] = mcp;
+  Dp[LD_IC + 0] = I0; Dp[LD_IC + 1] = I1; Dp[LD_IC + 2] = I2; Dp[LD_IC + 3] = I3; Dp[LD_IC + 4] = I4; Dp[LD_IC + 5] = I5;
 }
 // every link of a group takes the leader's composite (same joint origin, massless carriers), then emits its rhs entry
 template <class Real, bool EXTRAS = false>
 __device__ __forceinline__ void sp_link_rhs(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int i) {
-  Real* L = S.link + i * SP_LINKF;
+  const Real* L = S.link + i * SP_LINKF;
+  Real* D = S.ldyn + i * SP_LDYN;
   if (lc.group_leader != i) {
-    const Real* G = S.link + lc.group_leader * SP_LINKF;
-    for (int k = LK_F; k < SP_LINKF; k++) L[k] = G[k];
+    const Real* G = S.ldyn + lc.group_leader * SP_LDYN;
+    for (int k = 0; k < 16; k++) D[k] = G[k];   // (the 17th Real is padding)
   }
   const int d = lc.dof;
   if (d >= 0) {
     const V3<Real> a = ld3(L + LK_A);
-    const Real Cb = (lc.jtype == 2) ? dot(a, ld3(L + LK_N)) : dot(a, ld3(L + LK_F));
+    const Real Cb = (lc.jtype == 2) ? dot(a, ld3(D + LD_N)) : dot(a, ld3(D + LD_F));
     if (EXTRAS && Md.task == 12) {   // SPD: S.tau holds the target pose; the torque is added once M and c are known
       S.b[d] = Cb;
       S.rhs[d] = -Cb - lc.damp * S.dq[d] - lc.stiff * (S.q[d] + Md.dt * S.dq[d] - lc.rest);
@@ -357,14 +360,15 @@ template <class Real>
 __device__ __forceinline__ void sp_mass_row(const LinkConst<Real>& lc, const SpatialModel<Real>& Md, SpLds<Real>& S, int d, bool add_diag) {
   const int i = lc.d_link;
   const Real* L = S.link + i * SP_LINKF;
-  const V3<Real> a = ld3(L + LK_A), h = ld3(L + LK_H), jo = ld3(L + LK_JO);
+  const Real* D = S.ldyn + i * SP_LDYN;
+  const V3<Real> a = ld3(L + LK_A), h = ld3(D + LD_H), jo = ld3(L + LK_JO);
   V3<Real> Lm, K;
   if (topo_jtype(S.topo[i]) == 2) {
     Lm = cross(a, h);
-    const Real* I = L + LK_IC;
+    const Real* I = D + LD_IC;
     K = v3<Real>(I[0] * a.x + I[1] * a.y + I[2] * a.z, I[1] * a.x + I[3] * a.y + I[4] * a.z, I[2] * a.x + I[4] * a.y + I[5] * a.z);
   } else {
-    Lm = a * L[LK_MC];
+    Lm = a * D[LD_MC];
     K = cross(h, a);
   }
   const int n1 = Md.n - 1;
@@ -394,14 +398,15 @@ __device__ __forceinline__ void sp_mass_entries(const SpatialModel<Real>& Md, Sp
     const uint32_t pr = Md.mpairs[e];
     const int i = pr & 0xff, jl = (pr >> 8) & 0xff, d = (pr >> 16) & 0xff, dj = pr >> 24;
     const Real* L = S.link + i * SP_LINKF;
-    const V3<Real> a = ld3(L + LK_A), h = ld3(L + LK_H), jo = ld3(L + LK_JO);
+    const Real* D = S.ldyn + i * SP_LDYN;
+    const V3<Real> a = ld3(L + LK_A), h = ld3(D + LD_H), jo = ld3(L + LK_JO);
     V3<Real> Lm, K;
     if (topo_jtype(S.topo[i]) == 2) {
       Lm = cross(a, h);
-      const Real* I = L + LK_IC;
+      const Real* I = D + LD_IC;
       K = v3<Real>(I[0] * a.x + I[1] * a.y + I[2] * a.z, I[1] * a.x + I[3] * a.y + I[4] * a.z, I[2] * a.x + I[4] * a.y + I[5] * a.z);
     } else {
-      Lm = a * L[LK_MC];
+      Lm = a * D[LD_MC];
       K = cross(h, a);
     }
     const Real* Lj = S.link + jl * SP_LINKF;

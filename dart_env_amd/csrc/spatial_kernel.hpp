@@ -47,11 +47,16 @@ namespace dartk {
 // fp64 pattern kernel: 2 (round 4).  Its LDS block (26 928 B after the trim in sp_carve) fits six times into a CU, so two of the four
 // SIMDs can hold a second wave -- if a wave stays within 256 registers.  Measured (HumanWalker, 16 384 envs): 9.72 ms at 1 (256 VGPR + 96
 // AGPR, 356 B scratch) -> 9.01 ms at 2 (256 VGPR, 816 B scratch).  The callees must be private copies for this to work (sp_blcp_t's TAG).
+// fp64 kernels of the small models: 2 (round 4).  Their LDS block allows fewer workgroups per CU than three waves per SIMD would need
+// anyway (the Dog: 24.7 KB = 6 per CU), so the 168-register budget only bought spills: Dog 3.65 -> 2.80 ms at 256 registers.
+#ifndef SP_SMALL_F64_WAVES
+#define SP_SMALL_F64_WAVES 2
+#endif
 #ifndef SP_PAT_F64_WAVES
 #define SP_PAT_F64_WAVES 2
 #endif
 template <class Real, bool BIG, class PAT = DensePattern> __host__ __device__ constexpr int sp_min_waves() {
-  if (!BIG) return 3;
+  if (!BIG) return sizeof(Real) == 8 ? SP_SMALL_F64_WAVES : 3;
   if (!PAT::dense) return sizeof(Real) == 8 ? SP_PAT_F64_WAVES : SP_PAT_F32_WAVES;
   return sizeof(Real) == 8 ? 1 : 2;
 }
@@ -276,7 +281,8 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
   if (bias_out && lane < nl && lc.dof >= 0) {
     const Real* L = S.link + lane * SP_LINKF;
     const V3<Real> a = ld3(L + LK_A);
-    bias_out[e * n + lc.dof] = (double)((lc.jtype == 2) ? dot(a, ld3(L + LK_N)) : dot(a, ld3(L + LK_F)));
+    const Real* D = S.ldyn + lane * SP_LDYN;
+    bias_out[e * n + lc.dof] = (double)((lc.jtype == 2) ? dot(a, ld3(D + LD_N)) : dot(a, ld3(D + LD_F)));
   }
   if (mass_out) {
     if (lane < n) for (int k = 0; k <= lane; k++) S.H[HL(lane, k)] = Real(0);

@@ -16,9 +16,8 @@ constexpr int SP_MAXS = 16;   // collidable shapes
 constexpr int SP_MAXPAIRS = 40;   // non-adjacent shape pairs tested for link-link contacts
 __device__ __host__ constexpr int sp_tri(int m) { return m * (m + 1) / 2; }   // packed lower triangle of A / LDL workspace
 // The pivoting solver's LDL^T workspace (and its PGS start vector) are live only after the Jacobian rows have been
-// built, the per-link records only before: when the link block is big enough the two share LDS (HumanWalker: 2.8 KB
-// less per workgroup = 10 instead of 8 workgroups per CU).
-__device__ __host__ constexpr bool sp_lw_aliases_links(int nl, int maxm) { return nl * 37 >= sp_tri(maxm) + maxm; }
+// built, the per-link pose records only before: the two share LDS, the block is sized for the larger one (sp_link_reals).
+__device__ __host__ constexpr bool sp_lw_aliases_links(int nl, int maxm) { return true; }
 __device__ __host__ constexpr int sp_npad(int n) { return (n + 7) & ~7; }   // H is stored padded with identity rows to a multiple of 8
 __device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j; }   // caller guarantees i >= j
 // The mass matrix / its Cholesky factor is stored lower-triangular with rows padded to multiples of 4 entries and 16-byte
@@ -27,7 +26,11 @@ __device__ __host__ constexpr int TL(int i, int j) { return i * (i + 1) / 2 + j;
 __device__ __host__ constexpr int HR(int i) { return 8 * (i >> 2) * ((i >> 2) + 1) + 4 * ((i >> 2) + 1) * (i - 4 * (i >> 2)); }   // row offset
 __device__ __host__ constexpr int HL(int i, int j) { return HR(i) + j; }   // caller guarantees i >= j
 __device__ __host__ constexpr int HI(int i, int j) { return i >= j ? HR(i) + j : HR(j) + i; }
-constexpr int SP_LINKF = 37;  // Reals stored per link in LDS
+constexpr int SP_LINKF = 21;  // Reals of a link's POSE record in LDS (S.link): R 9, origin 3, joint origin 3, joint axis 3, COM 3
+constexpr int SP_LDYN = 17;   // Reals of its DYNAMICS record (S.ldyn): wrench F 3, N 3, composite mass 1, first moment 3, inertia 6 -- and one of
+                              // padding: lane i works on record i, and a stride of 16 Reals puts every lane on the same LDS banks (measured: Dog +4 %)
+// the link block holds the pose records and, once they are dead, the pivoting solver's matrix / workspace + its start vector
+__device__ __host__ constexpr int sp_link_reals(int nl, int maxm) { return nl * SP_LINKF > sp_tri(maxm) + maxm ? nl * SP_LINKF : sp_tri(maxm) + maxm; }
 constexpr int SP_LCONST = 48;   // Rpre 9, ppre 3, Rpost 9, ppost 3, axis 3, com 3, inertia 9, axr 3, cpost 3 (+3 pad)
 enum { LC_RPRE = 0, LC_PPRE = 9, LC_RPOST = 12, LC_PPOST = 21, LC_AXIS = 24, LC_COM = 27, LC_INERTIA = 30, LC_AXR = 39, LC_CPOST = 42 };
 constexpr int SP_ROUNDS = 6;  // pointer-jumping rounds: trees up to 64 links deep
@@ -126,17 +129,24 @@ template <class Real> __device__ __forceinline__ void mulRR(const Real* A, const
 }
 
 // LDS layout of one link (offsets in Reals)
-enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_C = 18, LK_F = 21, LK_N = 24, LK_MC = 27, LK_H = 28, LK_IC = 31 };
+enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_C = 18 };
+// ... and of its dynamics record.  Round 4: the two were one 37-Real record; the dynamics part is dead once the mass matrix and the
+// right-hand side are assembled, before anything is written to the Jacobian block W -- it lives THERE now (S.ldyn = S.W), and the link
+// block shrinks to what the pivoting solver's matrix needs anyway (it aliases the pose records): HumanWalker fp64 26 928 -> 22 776 B of
+// LDS per env = seven workgroups per CU instead of six.
+enum { LD_F = 0, LD_N = 3, LD_MC = 6, LD_H = 7, LD_IC = 10 };
 
 // Reals of the Jacobian block W: (maxm + 1) rows of n, and room for the forward dynamics' own factor of M + E (padded rows, the
 // reciprocal diagonal and one vector) that lives there before the Jacobian rows are written (sp_world_step, A3)
-__device__ __host__ constexpr int sp_w_reals(int n, int maxm) {
-  return (maxm + 1) * n > HR(sp_npad(n)) + 2 * sp_npad(n) ? (maxm + 1) * n : HR(sp_npad(n)) + 2 * sp_npad(n);
+__device__ __host__ constexpr int sp_w_reals(int n, int maxm, int nl = 0) {   // nl: ... and for the links' dynamics records
+  const int w = (maxm + 1) * n > HR(sp_npad(n)) + 2 * sp_npad(n) ? (maxm + 1) * n : HR(sp_npad(n)) + 2 * sp_npad(n);
+  return w > nl * SP_LDYN ? w : nl * SP_LDYN;
 }
 
 template <class Real>
 struct SpLds {
-  Real* link;    // [nl][SP_LINKF]
+  Real* link;    // [nl][SP_LINKF] pose records
+  Real* ldyn;    // [nl][SP_LDYN] dynamics records (= W: dead before the Jacobian block is written)
   Real* q; Real* dq; Real* tau; Real* rhs;   // [n]
   Real* H;       // [n(n+1)/2] packed lower triangle -> Cholesky factor
   Real* W;       // [maxm+1][n]: constraint Jacobian rows, then W = L^-1 J^T
@@ -166,11 +176,11 @@ template <class Real>
 __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int maxm, int maxcp, int reg_lcp) {
   SpLds<Real> S;
   Real* p = base;
-  S.link = p; p += nl * SP_LINKF;
+  S.link = p; p += sp_link_reals(nl, maxm);
   S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n;
   p = base + (((p - base) + 3) & ~3);   // 16-byte aligned rows
   S.H = p; p += HR(sp_npad(n));
-  S.W = p; p += sp_w_reals(n, maxm);
+  S.W = p; S.ldyn = p; p += sp_w_reals(n, maxm, nl);
   const bool alias = sp_lw_aliases_links(nl, maxm);
   if (reg_lcp && alias) { S.A = S.link; S.x0 = S.link + sp_tri(maxm); S.Lw = nullptr; }
   else {
@@ -202,7 +212,7 @@ __host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes,
   const bool alias = sp_lw_aliases_links(nl, maxm);
   const size_t lw = alias ? 0 : (size_t)sp_tri(maxm) + maxm;
   const size_t a = (reg_lcp && alias) ? 0 : (size_t)sp_tri(maxm);
-  size_t reals = (size_t)nl * SP_LINKF + (reg_lcp ? 4 : 5) * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)sp_w_reals(n, maxm) + a + lw +
+  size_t reals = (size_t)sp_link_reals(nl, maxm) + (reg_lcp ? 4 : 5) * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)sp_w_reals(n, maxm, nl) + a + lw +
                  (reg_lcp ? 4 : 5) * maxm + maxcp * 7 + 16 + (reg_lcp ? 0 : 24);
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + 2 * nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }

@@ -35,6 +35,7 @@ def lib(tree=False, waves=False):
         L.emu_destroy.argtypes = [vp]
         L.emu_is_static.argtypes = [vp]
         L.emu_slots.argtypes = [vp]
+        L.emu_lds_bytes.argtypes = [vp]; L.emu_lds_bytes.restype = C.c_longlong
         L.emu_set_solver.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.emu_enable_stats.argtypes = [vp, C.c_int]
         L.emu_force_slow.argtypes = [vp, C.c_int]
@@ -81,6 +82,11 @@ class EmuStepper:
     @property
     def is_static(self):
         return bool(self.L.emu_is_static(self.h))
+
+    @property
+    def lds_bytes(self):
+        """DART_Q_LDS_BYTES of the product library for this card: the step kernel's LDS block per workgroup"""
+        return int(self.L.emu_lds_bytes(self.h))
 
     def configure(self, key, value):
         if key == st.CFG_AUTORESET: self.autoreset = int(value != 0)

@@ -55,6 +55,7 @@ Emu* emu_create(const DartModelCard* card, int64_t n, int precision, int allow_s
 void emu_destroy(Emu* h) { if (h) { h->impl->release(); delete h; } }
 int emu_is_static(Emu* h) { return h->impl->is_static ? 1 : 0; }
 int emu_slots(Emu* h) { return h->impl->slots(); }
+long long emu_lds_bytes(Emu* h) { return (long long)h->impl->lds_bytes(); }   // DART_Q_LDS_BYTES of the product library: the step kernel's LDS block
 void emu_set_solver(Emu* h, int solver, int it1, int it2) { h->impl->set_solver(solver, it1, it2); }
 int emu_set_ext_force(Emu* h, int body, const double* force) { return h->impl->set_ext_force(body, force, h->n); }
 int emu_contact_report(Emu* h, int on) { return h->impl->set_contact_report(on != 0, h->n); }

@@ -1006,3 +1006,16 @@ def test_launch_order_with_contact_report_and_external_force_is_bitwise_index_or
     assert outs[0][3].max() > 0                                  # contacts were reported
     # (in index order workgroup e steps env e and reads force[e]; the pushes differ per env, so bitwise equality with index order
     # means the ordered launch also applied every env's OWN force and wrote every env's OWN report)
+
+
+@pytest.mark.gpu
+def test_tree_kernel_lds_block_on_the_device_matches_the_thresholds():
+    """DART_Q_LDS_BYTES of the running library: HumanWalker's fp64 block fits seven times into a CU's 160 KB (round 4: 27 640 -> 22 776 B,
+    9.7 -> 6.95 ms), its fp32 block twelve times; the pattern kernel is the one that runs."""
+    from dart_env_amd import stepper as st
+    for prec, per_cu in ((64, 7), (32, 12)):
+        s = st.HipStepper(card_for("DartHumanWalker-v1"), 64, precision=prec)
+        lds = s.query(st.Q_LDS_BYTES)
+        assert s.query(st.Q_STATIC_KERNEL) == 1 and s.query(st.Q_LANE_KERNEL) == 0
+        assert (160 * 1024) // lds >= per_cu, (prec, lds)
+        s.close()

@@ -82,3 +82,22 @@ def test_tree_kernel_fp32_and_contact_report_on_the_host():
                 assert np.allclose(pt[i, :len(rep)], rep[:, 2:5], atol=1e-9) and np.allclose(fc[i, :len(rep)], rep[:, 5:8], atol=1e-5, rtol=1e-6)
     assert seen >= 8
     g32.close(); g64.close()
+
+
+def test_lds_block_of_the_tree_kernel_decides_the_workgroups_per_cu():
+    """Round 4: the tree kernel runs one env per workgroup and a CU holds floor(160 KB / LDS block) of them whatever the registers allow --
+    HumanWalker's fp64 time went 9.7 -> 9.0 -> 6.95 ms as its block went 27 640 -> 26 928 -> 22 776 B (5 -> 6 -> 7 workgroups per CU;
+    DESIGN.md section 4.2).  The thresholds are pinned here so that a field added to the block cannot silently cost a workgroup per CU:
+    this is DART_Q_LDS_BYTES of the product library (same host code), read through the emulator build."""
+    cu = 160 * 1024
+    sizes = {}
+    for env_id, prec in (("DartHumanWalker-v1", 64), ("DartHumanWalker-v1", 32), ("DartWalker3d-v1", 64), ("DartDog-v1", 64)):
+        e = EmuStepper(card_for(env_id), 1, precision=prec, tree=True)
+        sizes[(env_id, prec)] = e.lds_bytes
+        e.close()
+    assert cu // sizes[("DartHumanWalker-v1", 64)] >= 7, sizes       # 256 registers at 2 waves per SIMD allow 8
+    assert cu // sizes[("DartHumanWalker-v1", 32)] >= 12, sizes      # 3 waves per SIMD x 4 SIMDs
+    assert cu // sizes[("DartWalker3d-v1", 64)] >= 3, sizes
+    assert cu // sizes[("DartDog-v1", 64)] >= 6, sizes
+    # the pose / dynamics split of the link records: the block no longer grows with 37 Reals per link
+    assert sizes[("DartHumanWalker-v1", 64)] <= 22784 and sizes[("DartHumanWalker-v1", 32)] <= 11904, sizes

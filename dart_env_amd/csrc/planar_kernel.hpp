@@ -217,6 +217,24 @@ __device__ __host__ constexpr unsigned long long anc_table() {
     for (int j = 0; j < T::NL; j++) if (is_anc<T>(j, k)) t |= 1ull << (8 * k + j);
   return t;
 }
+// The two tables as COMPILE-TIME values.  anc_table<T>() / T::clink(c) written into an ordinary expression are constexpr FUNCTIONS the
+// compiler may evaluate at run time -- and did, in every kernel of the all-shapes topologies (found in the disassembly, round 4): the
+// slot compaction of every world step walked parent tables in constant memory, one dependent s_load + s_waitcnt per hop (6 sites in the
+// Hopper kernel, 56 in Walker2d's).  A static constexpr data member is a constant expression by construction.
+template <class T> struct AncTable { static constexpr unsigned long long value = anc_table<T>(); };
+template <class T>
+__device__ __host__ constexpr unsigned long long clink_packed() {   // link of capsule c in bits [4c, 4c + 4)
+  static_assert(T::NC <= 16 && T::NL <= 16, "clink table packs 16 capsules of 4 bits");
+  unsigned long long t = 0;
+  for (int c = 0; c < T::NC; c++) t |= (unsigned long long)T::clink(c) << (4 * c);
+  return t;
+}
+template <class T> struct ClinkTable { static constexpr unsigned long long value = clink_packed<T>(); };
+// ancestor-or-self mask of capsule c's link, c a run-time index: shifts of two immediates, no memory
+template <class T> __device__ __host__ __forceinline__ uint32_t anc_mask_of_capsule(int c) {
+  const int lk = (int)((ClinkTable<T>::value >> (4 * c)) & 0xfull);
+  return (uint32_t)((AncTable<T>::value >> (8 * lk)) & 0xffull);
+}
 // LDS words of the single-lane fallback solver (slow_constraints): H^-1 full, kinematics, candidates, rows
 template <class T>
 __device__ __host__ constexpr int slow_words() {
@@ -748,7 +766,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     sfor<0, NCA>([&](auto S) {
       constexpr int sl = S;
       son[sl] = con[sl] && !off; sPx[sl] = cPx[sl]; sPy[sl] = cPy[sl]; sdep[sl] = cdep[sl];
-      samask[sl] = (uint32_t)((anc_table<T>() >> (8 * T::clink(sl))) & 0xffull);
+      { constexpr uint32_t am_ = (uint32_t)((AncTable<T>::value >> (8 * T::clink(sl))) & 0xffull); samask[sl] = am_; }
     });
   } else {
     sfor<0, NCA>([&](auto S) { son[S] = false; sPx[S] = Real(0); sPy[S] = Real(0); sdep[S] = Real(0); samask[S] = 0u; });
@@ -761,7 +779,8 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
         const bool take = hit && rank == sl;
         son[sl] = son[sl] || take;
         sPx[sl] = take ? cPx[c] : sPx[sl]; sPy[sl] = take ? cPy[c] : sPy[sl]; sdep[sl] = take ? cdep[c] : sdep[sl];
-        samask[sl] = take ? (uint32_t)((anc_table<T>() >> (8 * T::clink(c))) & 0xffull) : samask[sl];
+        constexpr uint32_t am_ = (uint32_t)((AncTable<T>::value >> (8 * T::clink(c))) & 0xffull);   // (a constant expression: see AncTable)
+        samask[sl] = take ? am_ : samask[sl];
         cid = take ? (cid | ((uint32_t)c << (4 * sl))) : cid;
       });
       rank += hit ? 1 : 0;
@@ -1157,7 +1176,7 @@ __device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* me
   uint32_t limrows = 0;
   for (int c = 0; c < NC; c++) {
     if (con[c] == Real(0)) continue;
-    const uint32_t am = (uint32_t)((anc_table<T>() >> (8 * T::clink(c))) & 0xffull);
+    const uint32_t am = anc_mask_of_capsule<T>(c);
     Real* jn = J + m * N; Real* jt = J + (m + 1) * N;
     jn[0] = Real(0); jn[1] = Real(1); jt[0] = Real(-1); jt[1] = Real(0);
     for (int j = 0; j < NL; j++) {
@@ -1285,7 +1304,7 @@ __device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* me
   const unsigned long long below = (1ull << lane) - 1ull;
   if (cact) {
     const int c = lane, row = 2 * __popcll(cbal & below);
-    const uint32_t am = (uint32_t)((anc_table<T>() >> (8 * T::clink(c))) & 0xffull);
+    const uint32_t am = anc_mask_of_capsule<T>(c);
     Real* jn = J + row * N; Real* jt = J + (row + 1) * N;
     jn[0] = Real(0); jn[1] = Real(1); jt[0] = Real(-1); jt[1] = Real(0);
     Real rn = vs[1], rt = -vs[0];

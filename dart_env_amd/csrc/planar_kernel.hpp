@@ -112,6 +112,7 @@ struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded hea
   // use; tests/test_gpu_repeatability.py and tools/gpu/determinism.py keep watching it.
   // (Round 3: with the impulse pass on M the cheetah rests on 3 capsules in 4.5 % and on 4 in 0.23 % of its env-world-steps: 94 % of
   // the waves take the second tier.)
+  static constexpr bool ANC_TABLES_RT = true;   // see topo_anc_rt
   static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4, TIER1_F64 = 3;
   static constexpr bool ISOLATED_TIER1 = true;
   // Five touching capsules (four in fp64) are 6e-5 (2.3e-3) of the env-world-steps -- ~20 (~750) per launch of 65 536 envs -- and a
@@ -147,6 +148,7 @@ struct SnakeTopo {  // reference assets/snake_7link.skel: seven links in a chain
 // (fp64: three) slots of the walker tree as a real call with the wave-served fallback behind it, as for the half cheetah.  (With the
 // base topologies' tiers 65 536 fallen pogo hoppers took 2.4 ms per env-step, every lane waiting its turn in the single-lane solver.)
 template <class B> struct PhysTopo : B {
+  static constexpr bool ANC_TABLES_RT = true;   // see topo_anc_rt
   static constexpr int NA = B::NDOF;
   static constexpr bool PHYSICS = true;
   static constexpr int TIER1 = B::NC <= 4 ? B::NC : 4, TIER1_F64 = B::NC <= 4 ? B::NC : 3;
@@ -222,6 +224,12 @@ __device__ __host__ constexpr unsigned long long anc_table() {
 // slot compaction of every world step walked parent tables in constant memory, one dependent s_load + s_waitcnt per hop (6 sites in the
 // Hopper kernel, 56 in Walker2d's).  A static constexpr data member is a constant expression by construction.
 template <class T> struct AncTable { static constexpr unsigned long long value = anc_table<T>(); };
+// ANC_TABLES_RT (optional trait): the topology keeps the run-time evaluation.  The half cheetah and the physics-only variants do: with
+// the compile-time tables the fp32 half-cheetah kernel's FIRST launch in a process differed from the later ones on gfx950
+// (tests/test_gpu_repeatability.py; the round-2 symptom of the largest register-tier kernels, cause still unknown) -- their code
+// is left exactly as it was measured and verified.
+template <class T, class = void> struct topo_anc_rt { static constexpr bool value = false; };
+template <class T> struct topo_anc_rt<T, decltype((void)T::ANC_TABLES_RT)> { static constexpr bool value = T::ANC_TABLES_RT; };
 template <class T>
 __device__ __host__ constexpr unsigned long long clink_packed() {   // link of capsule c in bits [4c, 4c + 4)
   static_assert(T::NC <= 16 && T::NL <= 16, "clink table packs 16 capsules of 4 bits");
@@ -232,6 +240,7 @@ __device__ __host__ constexpr unsigned long long clink_packed() {   // link of c
 template <class T> struct ClinkTable { static constexpr unsigned long long value = clink_packed<T>(); };
 // ancestor-or-self mask of capsule c's link, c a run-time index: shifts of two immediates, no memory
 template <class T> __device__ __host__ __forceinline__ uint32_t anc_mask_of_capsule(int c) {
+  if constexpr (topo_anc_rt<T>::value) return (uint32_t)((anc_table<T>() >> (8 * T::clink(c))) & 0xffull);
   const int lk = (int)((ClinkTable<T>::value >> (4 * c)) & 0xfull);
   return (uint32_t)((AncTable<T>::value >> (8 * lk)) & 0xffull);
 }
@@ -766,7 +775,8 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     sfor<0, NCA>([&](auto S) {
       constexpr int sl = S;
       son[sl] = con[sl] && !off; sPx[sl] = cPx[sl]; sPy[sl] = cPy[sl]; sdep[sl] = cdep[sl];
-      { constexpr uint32_t am_ = (uint32_t)((AncTable<T>::value >> (8 * T::clink(sl))) & 0xffull); samask[sl] = am_; }
+      if constexpr (topo_anc_rt<T>::value) samask[sl] = (uint32_t)((anc_table<T>() >> (8 * T::clink(sl))) & 0xffull);
+      else { constexpr uint32_t am_ = (uint32_t)((AncTable<T>::value >> (8 * T::clink(sl))) & 0xffull); samask[sl] = am_; }
     });
   } else {
     sfor<0, NCA>([&](auto S) { son[S] = false; sPx[S] = Real(0); sPy[S] = Real(0); sdep[S] = Real(0); samask[S] = 0u; });
@@ -779,8 +789,11 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
         const bool take = hit && rank == sl;
         son[sl] = son[sl] || take;
         sPx[sl] = take ? cPx[c] : sPx[sl]; sPy[sl] = take ? cPy[c] : sPy[sl]; sdep[sl] = take ? cdep[c] : sdep[sl];
-        constexpr uint32_t am_ = (uint32_t)((AncTable<T>::value >> (8 * T::clink(c))) & 0xffull);   // (a constant expression: see AncTable)
-        samask[sl] = take ? am_ : samask[sl];
+        if constexpr (topo_anc_rt<T>::value) samask[sl] = take ? (uint32_t)((anc_table<T>() >> (8 * T::clink(c))) & 0xffull) : samask[sl];
+        else {
+          constexpr uint32_t am_ = (uint32_t)((AncTable<T>::value >> (8 * T::clink(c))) & 0xffull);   // (a constant expression: see AncTable)
+          samask[sl] = take ? am_ : samask[sl];
+        }
         cid = take ? (cid | ((uint32_t)c << (4 * sl))) : cid;
       });
       rank += hit ? 1 : 0;

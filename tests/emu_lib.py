@@ -59,6 +59,26 @@ def _p(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
 
 
+def poison_static_lds(waves=True, tree=False):
+    """Register every static __shared__ array of an emulator library (function-local statics of the host build: `slow_lds` of the lane
+    kernels) with its launcher, so that DART_EMU_POISON_LDS -- read once per process by the launcher -- fills them, like the dynamic LDS
+    block, with a byte pattern before every workgroup.  Addresses = load base + symbol value from the library's symbol table."""
+    L = lib(tree=tree, waves=waves)
+    path = _TREE_LIB if tree else (_WAVE_LIB if waves else _LIB)
+    syms = {}
+    for line in subprocess.check_output(["nm", "-S", "--defined-only", path], text=True).splitlines():
+        p = line.split()
+        if len(p) == 4:
+            syms[p[3]] = (int(p[0], 16), int(p[1], 16))
+    base = C.cast(L.emu_create, C.c_void_p).value - syms["emu_create"][0]
+    L.emu_register_static_lds.argtypes = [C.c_void_p, C.c_ulonglong]
+    n = 0
+    for name, (off, size) in syms.items():
+        if name.endswith("slow_lds"):
+            L.emu_register_static_lds(C.c_void_p(base + off), size); n += 1
+    return n
+
+
 class EmuStepper:
     def __init__(self, card, num_envs, precision=64, allow_static=True, tree=False, waves=False):
         """tree=True: the tree kernel (csrc/spatial_*.hpp) instead of the lane kernels -- any card.  waves=True: the lane kernels run as

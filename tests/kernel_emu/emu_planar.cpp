@@ -55,6 +55,15 @@ Emu* emu_create(const DartModelCard* card, int64_t n, int precision, int allow_s
 void emu_destroy(Emu* h) { if (h) { h->impl->release(); delete h; } }
 int emu_is_static(Emu* h) { return h->impl->is_static ? 1 : 0; }
 int emu_slots(Emu* h) { return h->impl->slots(); }
+#ifdef DART_WAVE_EMU
+// a static __shared__ array of this library (address = load base + symbol value, found by the test in the symbol table): poisoned with the
+// dynamic block before every workgroup when DART_EMU_POISON_LDS is set
+int emu_register_static_lds(void* addr, unsigned long long bytes) {
+  if (wave_emu::n_static_lds >= 256) return -1;
+  wave_emu::static_lds[wave_emu::n_static_lds] = (unsigned char*)addr; wave_emu::static_lds_bytes[wave_emu::n_static_lds++] = (size_t)bytes;
+  return wave_emu::n_static_lds;
+}
+#endif
 long long emu_lds_bytes(Emu* h) { return (long long)h->impl->lds_bytes(); }   // DART_Q_LDS_BYTES of the product library: the step kernel's LDS block
 void emu_set_solver(Emu* h, int solver, int it1, int it2) { h->impl->set_solver(solver, it1, it2); }
 int emu_set_ext_force(Emu* h, int body, const double* force) { return h->impl->set_ext_force(body, force, h->n); }

@@ -202,6 +202,11 @@ inline void resolve(const dim3& bd) {
     }
   }
 }
+// the static __shared__ arrays of the kernels (function-local statics here): registered by the test from the library's symbol table
+// (tests/emu_lib.py: poison_static_lds) so that DART_EMU_POISON_LDS reaches them too
+inline unsigned char* static_lds[256];
+inline size_t static_lds_bytes[256];
+inline int n_static_lds = 0;
 inline unsigned char* dyn_lds = nullptr;
 inline size_t dyn_lds_cap = 0;
 template <class F> inline void launch(dim3 g, dim3 b, size_t lds, F&& f) {
@@ -213,8 +218,14 @@ template <class F> inline void launch(dim3 g, dim3 b, size_t lds, F&& f) {
   stack_bytes = nl <= 64 ? (size_t)WAVE_EMU_STACK : (size_t)(256u << 10);
   fp = &f;
   body = +[]() { (*fp)(); };
+  // DART_EMU_POISON_LDS=<byte>: the dynamic LDS block is filled with that byte before every workgroup (0xff: NaNs / -1) -- a kernel
+  // whose results depend on LDS it has not written shows it (tests/test_tree_kernel_emu_parity.py; the device hands a workgroup whatever
+  // the previous one left behind)
+  static const char* poison = getenv("DART_EMU_POISON_LDS");
   for (unsigned bx = 0; bx < g.x; bx++) {
     blockIdx.x = bx;
+    if (poison && lds) memset(dyn_lds, (int)strtol(poison, nullptr, 0), lds);
+    if (poison) for (int r = 0; r < n_static_lds; r++) memset(static_lds[r], (int)strtol(poison, nullptr, 0), static_lds_bytes[r]);
     for (int l = 0; l < nl; l++) { make_fiber(l); op_of[l] = NONE; parked[l] = false; }
     bool alive = true;
     while (alive) {

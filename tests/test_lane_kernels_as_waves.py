@@ -74,3 +74,44 @@ def test_fallen_user_models_on_whole_waves():
     pcard.frame_skip = 4
     worst, most = rollout(pcard, 64, 120, noise=0.01, scale=np.asarray(SCALE, float), seed=4)
     assert most >= 3 and worst[0] < 1e-8 and worst[1] < 1e-6, (worst, most)
+
+
+_POISON_LANE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from dart_env_amd.model_card import card_for
+from tests.emu_lib import EmuStepper, poison_static_lds
+assert poison_static_lds(waves=True) > 0
+outs = []
+for env_id, prec in (("DartHalfCheetah-v1", 32), ("DartHalfCheetah-v1", 64), ("DartWalker2d-v1", 64), ("DartHopper-v1", 64)):
+    card = card_for(env_id); n = 64; nd, na = card.ndofs, card.act_dim
+    rng = np.random.RandomState(5)
+    q0 = rng.uniform(-0.3, 0.3, (n, nd)); dq0 = rng.uniform(-2, 2, (n, nd))
+    q0[:, 1] = rng.uniform(-0.65, -0.3, n)      # from above the floor to lying in it: every register tier, the fallback solver, the hand-off
+    g = EmuStepper(card, n, precision=prec, waves=True)
+    g.set_state(q0, dq0)
+    for t in range(3):
+        ob, r, d, tr = g.step(rng.uniform(-1, 1, (n, na)).astype(np.float32))
+        outs += [np.asarray(ob, np.float64).ravel(), np.asarray(r, np.float64).ravel(), np.asarray(d, np.float64).ravel()]
+    outs += [np.asarray(x, np.float64).ravel() for x in g.get_state()]
+    g.close()
+np.save(sys.argv[2], np.concatenate(outs))
+"""
+
+
+def test_lane_kernel_results_do_not_depend_on_what_lds_held_before(tmp_path):
+    """The lane kernels' static LDS (the fallback solver's block, the wave hand-off buffer) filled with a byte pattern before every
+    workgroup (DART_EMU_POISON_LDS + emu_lib.poison_static_lds): NaNs / -1 or plausible numbers instead of zeros must not change a bit.
+    (Written while looking for the cause of the half cheetah's first-launch difference on gfx950, DESIGN.md section 4.1: it is NOT a read of
+    LDS the workgroup has not written.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "poison_lane.py"
+    script.write_text(_POISON_LANE_SCRIPT)
+    got = {}
+    for tag, val in (("zero", "0x00"), ("nan", "0xff"), ("finite", "0x3f")):
+        out = tmp_path / (tag + ".npy")
+        subprocess.check_call([sys.executable, str(script), root, str(out)], env=dict(os.environ, DART_EMU_POISON_LDS=val), timeout=1500)
+        got[tag] = np.load(out)
+    assert np.all(np.isfinite(got["zero"]))
+    assert np.array_equal(got["zero"], got["nan"]) and np.array_equal(got["zero"], got["finite"])

@@ -101,3 +101,41 @@ def test_lds_block_of_the_tree_kernel_decides_the_workgroups_per_cu():
     assert cu // sizes[("DartDog-v1", 64)] >= 6, sizes
     # the pose / dynamics split of the link records: the block no longer grows with 37 Reals per link
     assert sizes[("DartHumanWalker-v1", 64)] <= 22784 and sizes[("DartHumanWalker-v1", 32)] <= 11904, sizes
+
+
+_POISON_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from dart_env_amd.model_card import card_for
+from tests.emu_lib import EmuStepper
+outs = []
+for env_id, prec in (("DartHumanWalker-v1", 64), ("DartHumanWalker-v1", 32), ("DartWalker3d-v1", 64), ("DartDog-v1", 64)):
+    card = card_for(env_id); n = 2
+    g = EmuStepper(card, n, precision=prec, tree=True)
+    g.reset()
+    rng = np.random.RandomState(3)
+    for t in range(4):
+        ob, r, d, tr = g.step(rng.uniform(-1, 1, (n, card.act_dim)).astype(np.float32)); outs += [np.asarray(ob, np.float64).ravel(), np.asarray(r, np.float64).ravel()]
+    outs += [np.asarray(x, np.float64).ravel() for x in g.get_state()]
+    g.close()
+np.save(sys.argv[2], np.concatenate(outs))
+"""
+
+
+def test_tree_kernel_results_do_not_depend_on_what_lds_held_before(tmp_path):
+    """Round 4 re-laid the tree kernel's LDS block (arrays dropped for the lean kernels, link records split, the dynamics records and the
+    solver's matrix living in blocks that other arrays own at other times).  On the device a workgroup starts with whatever the previous one
+    left in LDS: the emulator fills the block with a byte pattern before every workgroup (DART_EMU_POISON_LDS, fake_wave_include) -- NaNs /
+    -1 with 0xff, plausible finite numbers with 0x3f -- and the results must be bit for bit those of a zeroed block."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "poison.py"
+    script.write_text(_POISON_SCRIPT)
+    got = {}
+    for tag, val in (("zero", "0x00"), ("nan", "0xff"), ("finite", "0x3f")):
+        out = tmp_path / (tag + ".npy")
+        env = dict(os.environ, DART_EMU_POISON_LDS=val)
+        subprocess.check_call([sys.executable, str(script), root, str(out)], env=env, timeout=900)
+        got[tag] = np.load(out)
+    assert np.all(np.isfinite(got["zero"]))
+    assert np.array_equal(got["zero"], got["nan"]) and np.array_equal(got["zero"], got["finite"])

@@ -139,3 +139,23 @@ def test_tree_kernel_results_do_not_depend_on_what_lds_held_before(tmp_path):
         got[tag] = np.load(out)
     assert np.all(np.isfinite(got["zero"]))
     assert np.array_equal(got["zero"], got["nan"]) and np.array_equal(got["zero"], got["finite"])
+
+
+def test_lds_reservation_covers_what_the_kernels_carve():
+    """sp_lds_bytes (what the host reserves per workgroup) against sp_carve (what the kernels lay out in it) over a sweep of model dimensions,
+    both precisions, with and without the register-LCP trim: the carve must end inside the reservation -- and not far inside (a reservation
+    that grows unnoticed costs workgroups per CU, the round-4 lever)."""
+    import ctypes as C
+    from tests import emu_lib
+    L = emu_lib.lib(tree=True)
+    for f in (L.emu_lds_reserved, L.emu_lds_carved):
+        f.argtypes = [C.c_int] * 6; f.restype = C.c_longlong
+    rng = np.random.RandomState(0)
+    cases = [(33, 29, 36, 12), (22, 22, 36, 12), (21, 21, 64, 20), (4, 6, 36, 12), (1, 1, 36, 12), (64, 32, 64, 20)]
+    cases += [(int(nl), int(min(nl, rng.randint(1, 33))), int(rng.choice([36, 64])), int(rng.choice([12, 20]))) for nl in rng.randint(1, 65, 60)]
+    for nl, n, maxm, maxcp in cases:
+        for rb in (4, 8):
+            for reg in (0, 1):
+                res, car = L.emu_lds_reserved(nl, n, rb, maxm, maxcp, reg), L.emu_lds_carved(nl, n, rb, maxm, maxcp, reg)
+                assert car <= res, (nl, n, maxm, maxcp, rb, reg, car, res)
+                assert res - car <= 64 + 8 * rb, (nl, n, maxm, maxcp, rb, reg, car, res)

@@ -9,6 +9,7 @@ timed region; outputs stay in HBM.
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 2000 --warmup 200
+    python bench.py --gpus 8 --steps 2000 --warmup 200      # no launcher (RANK unset): bench.py starts its own 8 ranks, one per GPU
 
 Precision.  The headline runs the fp64 instantiation of the kernels (`--precision 64`, the default): it is the mode that meets
 the north star's tolerance (RMS state error < 1e-4 over 1 000 env-steps, untrimmed; measured here ~1e-10), and on MI355X fp64
@@ -298,6 +299,49 @@ def other_solver_block(env_id, n, local_rank, precision, sweeps, steps, warmup, 
     return out
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_ranks: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here -- the same command line re-executed once per GPU with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them (rendezvous on 127.0.0.1,
+    a free port).  Rank 0's stdout (the ONE JSON line) is this process's stdout; the other ranks' stdout goes to stderr.  Returns the
+    worst exit code; a rank that dies takes the others down instead of leaving them in a barrier."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DART_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (dmabuf IPC: what RCCL needs on this driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0:
+                rc = rc or c
+                for o in live:          # exact PIDs this function started
+                    o.terminate()
+    return rc
+
+
+def _resolve(spec):
+    """'package.module:attr' -> the object (the hidden --env-factory of the CPU plumbing test)"""
+    import importlib
+    mod, attr = spec.split(":")
+    return getattr(importlib.import_module(mod), attr)
+
+
 def main(argv=None, env_factory=None, dist_backend="nccl"):
     """env_factory / dist_backend exist for the CPU unit test of the N > 1 plumbing (tests/test_bench_plumbing.py injects a
     stand-in shard and gloo); the command line always runs HipBenchEnv over RCCL."""
@@ -319,8 +363,20 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
                     "all_gather) even with one rank: the only way to execute it on a 1-GPU box (tests/test_gpu_bench_dist.py)")
     ap.add_argument("--parity-steps", type=int, default=1000)
     ap.add_argument("--parity-budget", type=float, default=12.0, help="seconds of oracle wall time per parity sample")
+    ap.add_argument("--dist-backend", default=None, help=argparse.SUPPRESS)    # tests/test_bench_plumbing.py: gloo + a stand-in shard, so that
+    ap.add_argument("--env-factory", default=None, help=argparse.SUPPRESS)     # the self-launch path runs on a box without GPUs
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(argv)
-
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher around us (torch.distributed.run always sets RANK): start the ranks ourselves
+        rc = self_launch(args.gpus, argv)
+        if rc != 0:
+            raise SystemExit("bench.py: a self-launched rank exited with code %d" % rc)
+        return None
+    if args.dist_backend:
+        dist_backend = args.dist_backend
+    if args.env_factory:
+        env_factory = _resolve(args.env_factory)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -456,6 +512,9 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     attach_valu(result["roofline"], args.env_id, n, dtype, ms_kernel)
     if dist is not None:
         result["per_rank"] = per_rank          # every rank's own clock: `value` uses the slowest (max over ranks, contract)
+        result["dist_backend"] = dist.get_backend()
+        result["nccl_world_size"] = dist.get_world_size()       # as the process group (RCCL on the GPU box) reports it, not as --gpus says
+        result["launcher"] = "self" if os.environ.get("DART_BENCH_SELF_LAUNCHED") else "torch.distributed.run / external"
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
         result["gather_bytes_per_rank"] = int(packed.numel() * packed.element_size())

@@ -104,9 +104,40 @@ def test_multi_rank_bench_line(world):
     assert "cpu_baseline" not in r and "other_configs" not in r      # N = 1 extras only
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_its_own_ranks_when_no_launcher_did(world):
+    """`python bench.py --gpus N` with no RANK in the environment (the way the driver invokes --gpus 1) starts its own N
+    ranks, one JSON line comes out of rank 0 and carries the world size the process group itself reports."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--envs", "64", "--steps", "3", "--warmup", "1",
+                        "--dist-backend", "gloo", "--env-factory", "tests.test_bench_plumbing:EmuBenchEnv"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                                    # ONE line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == world and r["nccl_world_size"] == world and r["dist_backend"] == "gloo" and r["launcher"] == "self"
+    assert r["config"]["env_offsets"] == [64 * g for g in range(world)]
+    assert [pr["rank"] for pr in r["per_rank"]] == list(range(world)) and r["gather_ms"] > 0
+    assert abs(r["value"] - world * 64 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]
+
+
+def test_self_launch_reports_a_dead_rank():
+    """a rank that fails takes the launch down with a non-zero exit instead of leaving the others in a barrier"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "64", "--steps", "1", "--warmup", "0",
+                        "--dist-backend", "gloo", "--env-factory", "tests.test_bench_plumbing:NoSuchFactory"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "self-launched rank" in p.stderr
+
+
 def test_world_size_mismatch_is_fatal(monkeypatch):
+    """under a launcher (RANK set) a WORLD_SIZE that contradicts --gpus is an error, not a silent re-launch"""
     sys.path.insert(0, ROOT)
     import bench
+    monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("WORLD_SIZE", "1")
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "8"], env_factory=EmuBenchEnv, dist_backend="gloo")

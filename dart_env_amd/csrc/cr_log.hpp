@@ -9,7 +9,7 @@
 #pragma once
 #include <cmath>
 #ifndef DART_HD
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DART_HD __host__ __device__
 #else
 #define DART_HD

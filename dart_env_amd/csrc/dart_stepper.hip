@@ -26,8 +26,7 @@ namespace {
 thread_local std::string g_err;
 
 std::unique_ptr<Impl> make_impl(const DartModelCard& c, int precision, std::string& why, bool allow_static) {
-  const char* fs = getenv("DART_FORCE_SPATIAL");   // testing aid: run planar models through the general kernel
-  const bool force_spatial = (fs && fs[0] == '1') || c.generic_kernel != 0;
+  const bool force_spatial = c.generic_kernel != 0;   // the card asks for the tree kernel (the library reads no environment variables)
   if (!force_spatial) {
     if (auto p = precision == 32 ? make_planar_impl_f32(c, why, allow_static) : make_planar_impl_f64(c, why, allow_static)) {
       p->lane_kernel = true;
@@ -68,12 +67,12 @@ struct DartStepper {
   // caller-owned host buffers page-locked by dart_register_host_buffer: dart_step DMAs straight from / into arguments that lie inside
   std::vector<std::pair<char*, size_t>> host_ranges;
   double* d_rew64 = nullptr;       // float64 rewards for the direct path of dart_step (the reference's reward type), made on the device
-  bool split_d2h = false;        // DART_SPLIT_D2H=1: the four separate copies of rounds 1-2 (A/B measurements)
-  // Round 4: the PCIe legs of the host-buffer path without the copy engines.  zc_actions: the step kernel reads the actions straight
-  // from page-locked host memory (one coalesced 768-byte read per wave) instead of waiting for an H2D copy; d2h_kernel: the step's
-  // output block goes back through a copy KERNEL that writes into the mapped host block with 16-byte coalesced stores, instead of a
-  // hipMemcpyAsync (SDMA).  DART_HOST_DMA=copy restores the copy-engine path of rounds 1-3 (A/B: tools/gpu/host_path_c.py).
-  bool zc_actions = true, d2h_kernel = true;
+  // DART_CFG_HOST_DMA (bit mask, default 3).  The PCIe legs of the host-buffer path without the copy engines (round 4) --
+  // zc_actions (bit 0): the step kernel reads the actions straight from page-locked host memory (one coalesced 768-byte read per wave)
+  // instead of waiting for an H2D copy; d2h_kernel (bit 1): the step's output block goes back through a copy KERNEL that writes into the
+  // mapped host block with 16-byte coalesced stores, instead of a hipMemcpyAsync (SDMA); split_d2h (bit 2): the four separate copies of
+  // rounds 1-2.  0 = the copy-engine path of rounds 1-3 (A/B: tools/gpu/host_path_c.py).
+  bool zc_actions = true, d2h_kernel = true, split_d2h = false;
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
   double *h_qn = nullptr, *h_vn = nullptr;
@@ -197,9 +196,7 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
   }
   if (device < 0 || device >= ndev) { g_err = "device index out of range"; return DART_E_INVALID; }
   std::string why;
-  const char* gen = getenv("DART_GENERIC_KERNEL");   // debugging aid: force the runtime-parameter kernel
-  bool allow_static = !(gen && gen[0] == '1');
-  std::unique_ptr<Impl> impl = make_impl(*card, precision, why, allow_static);
+  std::unique_ptr<Impl> impl = make_impl(*card, precision, why, /*allow_static=*/true);
   if (!impl) { g_err = "no compiled kernel for this model: " + why; return DART_E_UNSUPPORTED; }
   auto h = new DartStepper();
   h->card = *card; h->n = num_envs; h->device = device; h->precision = precision; h->impl = std::move(impl);
@@ -224,12 +221,6 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
       unsigned char* hb = nullptr;
       CHK(h, hipHostMalloc((void**)&hb, h->out_bytes));
       h->h_obs = (float*)hb; h->h_rew = (float*)(hb + ob); h->h_done = hb + ob + rb; h->h_trunc = hb + ob + rb + db;
-      const char* e = getenv("DART_SPLIT_D2H");
-      h->split_d2h = e && e[0] == '1';
-      const char* dm = getenv("DART_HOST_DMA");
-      if (dm && !strcmp(dm, "copy")) { h->zc_actions = false; h->d2h_kernel = false; }
-      if (dm && !strcmp(dm, "zc_actions")) h->d2h_kernel = false;     // (each leg on its own, for the A/B)
-      if (dm && !strcmp(dm, "d2h_kernel")) h->zc_actions = false;
     }
     CHK(h, hipMalloc((void**)&h->d_mask, N));
     CHK(h, hipMalloc((void**)&h->d_qn, 8 * N * nd));
@@ -361,6 +352,10 @@ int dart_configure(DartStepper* h, int key, double value) {
     case DART_CFG_BLOCK_THREADS:
       if (value != 64 && value != 32 && value != 16) { h->err = "block threads must be 16, 32 or 64"; return DART_E_INVALID; }
       h->impl->block_threads = (int)value; break;
+    case DART_CFG_HOST_DMA:
+      if (value < 0 || value > 7 || value != (double)(int)value) { h->err = "host DMA mode: a bit mask 0 .. 7"; return DART_E_INVALID; }
+      h->zc_actions = ((int)value & 1) != 0; h->d2h_kernel = ((int)value & 2) != 0; h->split_d2h = ((int)value & 4) != 0;
+      break;
     default: h->err = "unknown configure key"; return DART_E_INVALID;
   }
   if (h->solver < 0 || h->solver > 1 || h->it1 < 0 || h->it2 < 0) { h->err = "bad solver setting"; return DART_E_INVALID; }
@@ -533,8 +528,8 @@ int dart_get_state(DartStepper* h, double* q, double* dq) { return state_copy(h,
 // against this: 216.8 us per host step either way, profiles/r04_host_path_ab.txt; the runtime's wait is not where the time goes.)
 static hipError_t wait_stream(DartStepper* h) { return hipStreamSynchronize(h->stream); }
 
-static int step_async_impl(DartStepper* h, const float* actions, void* dst);
-int dart_step_async(DartStepper* h, const float* actions) { return step_async_impl(h, actions, nullptr); }
+static int step_async_impl(DartStepper* h, const float* actions, void* dst, bool caller_blocks);
+int dart_step_async(DartStepper* h, const float* actions) { return step_async_impl(h, actions, nullptr, false); }
 
 int dart_output_layout(const DartStepper* h, int64_t* total_bytes, int64_t* offsets4) {
   if (!h) return DART_E_INVALID;
@@ -568,7 +563,7 @@ int dart_step_async_to(DartStepper* h, const float* actions, void* block) {
   bool known = false;
   for (void* p : h->registered) known = known || p == block;
   if (!known) { h->err = "dart_step_async_to: the block is not registered (dart_register_output)"; return DART_E_INVALID; }
-  return step_async_impl(h, actions, block);
+  return step_async_impl(h, actions, block, false);
 }
 
 int dart_register_host_buffer(DartStepper* h, void* ptr, uint64_t bytes) {
@@ -611,6 +606,8 @@ static void* host_devptr(void* p) {
 }
 static int d2h_block(DartStepper* h, void* host_dst, const void* dev_src, size_t bytes) {
   void* dd = h->d2h_kernel && (bytes % 16 == 0) ? host_devptr(host_dst) : nullptr;
+  // 128-bit loads / stores: both ends 16-byte aligned (a caller's registered arena may hand any offset), else the copy engine
+  if (dd && (((uintptr_t)dd | (uintptr_t)dev_src) % 16 != 0)) dd = nullptr;
   if (dd) {
     const int64_t n16 = (int64_t)(bytes / 16);
     const unsigned blocks = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
@@ -627,14 +624,17 @@ __global__ void reward_f64_kernel(int64_t n, const float* __restrict__ r32, doub
   if (i < n) r64[i] = (double)r32[i];
 }
 
-static int step_async_impl(DartStepper* h, const float* actions, void* dst) {
+// caller_blocks: the call returns only after the step has completed (dart_step) -- only then may the kernel read the actions where the
+// caller keeps them.  The asynchronous entry points copy them at call time, as their contract says ("actions are read before the call
+// returns"): a caller that refills a registered action array between step_async and step_wait must not race with the kernel.
+static int step_async_impl(DartStepper* h, const float* actions, void* dst, bool caller_blocks) {
   if (!h || !actions) return DART_E_INVALID;
   if (h->pending) { h->err = "step_async called while a step is pending"; return DART_E_PENDING; }
   CHK_AUTORESET(h);
   CHK(h, hipSetDevice(h->device));
   size_t N = (size_t)h->n;
   const float* host_act = actions;                            // page-locked source of this step's actions
-  if (!host_pinned(h, actions, 4 * N * h->card.act_dim)) {   // (the caller's own page-locked memory is used where it lies)
+  if (!caller_blocks || !host_pinned(h, actions, 4 * N * h->card.act_dim)) {   // (a blocking call uses the caller's own page-locked memory where it lies)
     memcpy(h->h_act, actions, 4 * N * h->card.act_dim);
     host_act = h->h_act;
   }
@@ -702,11 +702,11 @@ int dart_step(DartStepper* h, const float* actions, float* obs_out, double* rewa
                       (!obs_out || host_pinned(h, obs_out, 4 * N * h->card.obs_dim)) && (!reward_out || host_pinned(h, reward_out, 8 * N)) &&
                       (!done_out || host_pinned(h, done_out, N)) && (!truncated_out || host_pinned(h, truncated_out, N));
   if (!direct) {
-    int rc = dart_step_async(h, actions);
+    int rc = step_async_impl(h, actions, nullptr, true);
     if (rc != DART_OK) return rc;
     return dart_step_wait(h, obs_out, reward_out, done_out, truncated_out);
   }
-  int rc = step_async_impl(h, actions, (void*)h);   // (dst == h: "the caller enqueues the copies")
+  int rc = step_async_impl(h, actions, (void*)h, true);   // (dst == h: "the caller enqueues the copies")
   if (rc != DART_OK) return rc;
   h->pending = false;
   if (obs_out) { rc = d2h_block(h, obs_out, h->d_obs, 4 * N * h->card.obs_dim); if (rc != DART_OK) return rc; }

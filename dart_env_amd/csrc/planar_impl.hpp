@@ -53,8 +53,13 @@ struct ImplT : Impl {
     P.solver = solver; P.iters1 = it1 > 0 ? it1 : dflt; P.iters2 = it2 > 0 ? it2 : dflt;
   }
   void set_stats(unsigned long long* p) override { P.stats = p; }
-  void set_force_slow(int on) override { P.force_slow = on; }
-  void set_wave_vote(int k) override { P.force_slow = k > 0 ? -k : 0; }
+  // The kernel has ONE parameter for both modes (P.force_slow: 1 = every touching env through the fallback, -K = the wave vote); the two
+  // settings are kept apart here so that neither call cancels the other: the forced fallback (a test mode) wins while it is on,
+  // the vote is back in force when it goes off.
+  int cfg_force_slow = 0, cfg_wave_vote = 0;
+  void apply_slow_mode() { P.force_slow = cfg_force_slow ? 1 : -cfg_wave_vote; }
+  void set_force_slow(int on) override { cfg_force_slow = on ? 1 : 0; apply_slow_mode(); }
+  void set_wave_vote(int k) override { cfg_wave_vote = k > 0 ? k : 0; apply_slow_mode(); }
   // ---- optional extras: external body force, contact report (see Extras in planar_kernel.hpp)
   int link_body[T::NL] = {};                 // card body of each link (welded bodies have no link of their own)
   Real* d_ext = nullptr; Real* d_rec = nullptr; int* d_cnt = nullptr; Real* d_cf = nullptr;

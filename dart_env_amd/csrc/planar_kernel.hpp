@@ -71,7 +71,7 @@ struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - s
 struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour, the default card)
   static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2, TIER1_F64 = 2;
   static constexpr bool ISOLATED_TIER1 = false;
-  static constexpr bool WARM = false;
+  static constexpr bool WARM = false;   // (round 5, host build over 64-lane groups: 13.75 pivoting solves per wave and env-step, 14.02 with warm starts)
   // (round 4 A/B: H^-1 parked in LDS across the pivoting loops, the walker's HINV_LDS_F64, makes THIS kernel slower -- 31.82 -> 33.24 us
   // fp64, 158 -> 126 AGPRs: the 21 entries cost more as LDS round trips than as accumulator-register moves)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
@@ -82,6 +82,7 @@ struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin f
   static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;   // measured +26 % (persistent double-support contacts)
+  static constexpr bool WARM_FRICTION = false;   // round 5: the Schur-complement start beats the previous substep's friction state (constraint_phase)
 #ifndef DART_NO_HINV_LDS
   static constexpr bool HINV_LDS_F64 = true;   // see topo_hinv_lds64
 #endif
@@ -93,6 +94,7 @@ struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the flo
   static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;
+  static constexpr bool WARM_FRICTION = false;   // (see Walker2dTopo)
 #ifndef DART_NO_HINV_LDS
   static constexpr bool HINV_LDS_F64 = true;   // see topo_hinv_lds64: 672 -> 368 B of scratch per lane, 134 -> 119 us, bitwise the same states
 #endif
@@ -112,7 +114,10 @@ struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded hea
   // use; tests/test_gpu_repeatability.py and tools/gpu/determinism.py keep watching it.
   // (Round 3: with the impulse pass on M the cheetah rests on 3 capsules in 4.5 % and on 4 in 0.23 % of its env-world-steps: 94 % of
   // the waves take the second tier.)
-  static constexpr bool ANC_TABLES_RT = true;   // see topo_anc_rt
+#ifndef DART_CHEETAH_RT_TABLES
+#define DART_CHEETAH_RT_TABLES true    // (-DDART_CHEETAH_RT_TABLES=false: the build that failed the repeatability test in round 4, for tools/gpu/first_launch_probe.py)
+#endif
+  static constexpr bool ANC_TABLES_RT = DART_CHEETAH_RT_TABLES;   // see topo_anc_rt
   static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4, TIER1_F64 = 3;
   static constexpr bool ISOLATED_TIER1 = true;
   // Five touching capsules (four in fp64) are 6e-5 (2.3e-3) of the env-world-steps -- ~20 (~750) per launch of 65 536 envs -- and a
@@ -175,6 +180,8 @@ template <class T> struct topo_plane_xz<T, decltype((void)T::PLANE_XZ)> { static
 // bitwise those of the register version.
 template <class T, class = void> struct topo_hinv_lds64 { static constexpr bool value = false; };
 template <class T> struct topo_hinv_lds64<T, decltype((void)T::HINV_LDS_F64)> { static constexpr bool value = T::HINV_LDS_F64; };
+template <class T, class = void> struct topo_warm_friction { static constexpr bool value = true; };   // stage-2 start of a persisting contact's friction row from the previous substep (constraint_phase)
+template <class T> struct topo_warm_friction<T, decltype((void)T::WARM_FRICTION)> { static constexpr bool value = T::WARM_FRICTION; };
 template <class T, class = void> struct topo_wave_fallback { static constexpr bool value = false; };
 template <class T> struct topo_wave_fallback<T, decltype((void)T::WAVE_FALLBACK)> { static constexpr bool value = T::WAVE_FALLBACK; };
 template <class T, class = void> struct topo_hinv_lds32 { static constexpr bool value = false; };
@@ -349,6 +356,48 @@ template <> __device__ __forceinline__ void sincos_<double>(double x, double& s,
   pc = fma(pc, z, 2.48015872894767294178e-05);
   pc = fma(pc, z, -1.38888888888741095749e-03);
   pc = fma(pc, z, 4.16666666666666019037e-02);
+  const double cs = fma(pc * z, z, fma(z, -0.5, 1.0));
+  const bool swap = k & 1;
+  const double s0 = swap ? cs : sn, c0 = swap ? sn : cs;
+  s = (k & 2) ? -s0 : s0;
+  c = ((k + 1) & 2) ? -c0 : c0;
+}
+// The same function with its 17 constants REMATERIALISED at every use (round 5, tree kernel).  Where the scalar registers are oversubscribed
+// (the tree kernel: S pointers, model fields, wave masks) the compiler keeps these loop-invariant doubles in VGPR pairs across the whole
+// frame loop and, out of registers, spills them before the loop and reloads them every world step (10 of the 30 pairs the fp64 pattern
+// kernel spilled, found in the disassembly).  An `asm volatile` s_mov pair cannot be hoisted: the constant exists for the one FMA that reads
+// it (an SGPR-pair operand, SALU issue).  Same arithmetic, bitwise the same results.  Host builds (tests/kernel_emu) use the plain literals.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DART_NO_REMAT64)
+template <unsigned long long B> __device__ __forceinline__ double remat64_() {
+  int lo, hi;
+  asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "i"((int)(unsigned)(B & 0xffffffffull)));
+  asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "i"((int)(unsigned)(B >> 32)));
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+#define DART_REMAT64(x) (::dartk::remat64_<__builtin_bit_cast(unsigned long long, (double)(x))>())
+#else
+#define DART_REMAT64(x) ((double)(x))
+#endif
+template <class Real> __device__ __forceinline__ void sincos_remat_(Real x, Real& s, Real& c) { sincos_<Real>(x, s, c); }
+template <> __device__ __forceinline__ void sincos_remat_<double>(double x, double& s, double& c) {
+  const double kf = rint(x * DART_REMAT64(6.36619772367581382433e-01));
+  const int k = (int)kf;
+  double r = fma(kf, DART_REMAT64(-1.57079632673412561417e+00), x);
+  r = fma(kf, DART_REMAT64(-6.07710050630396597660e-11), r);
+  r = fma(kf, DART_REMAT64(-2.02226624871116645580e-21), r);
+  r = fma(kf, DART_REMAT64(-8.47842766036889956997e-32), r);
+  const double z = r * r;
+  double ps = fma(z, DART_REMAT64(1.58969099521155010221e-10), DART_REMAT64(-2.50507602534068634195e-08));
+  ps = fma(ps, z, DART_REMAT64(2.75573137070700676789e-06));
+  ps = fma(ps, z, DART_REMAT64(-1.98412698298579493134e-04));
+  ps = fma(ps, z, DART_REMAT64(8.33333333332248946124e-03));
+  ps = fma(ps, z, DART_REMAT64(-1.66666666666666324348e-01));
+  const double sn = fma(ps * z, r, r);
+  double pc = fma(z, DART_REMAT64(-1.13596475577881948265e-11), DART_REMAT64(2.08757232129817482790e-09));
+  pc = fma(pc, z, DART_REMAT64(-2.75573143513906633035e-07));
+  pc = fma(pc, z, DART_REMAT64(2.48015872894767294178e-05));
+  pc = fma(pc, z, DART_REMAT64(-1.38888888888741095749e-03));
+  pc = fma(pc, z, DART_REMAT64(4.16666666666666019037e-02));
   const double cs = fma(pc * z, z, fma(z, -0.5, 1.0));
   const bool swap = k & 1;
   const double s0 = swap ? cs : sn, c0 = swap ? sn : cs;
@@ -1036,7 +1085,12 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       fric |= pinned ? 0u : (1u << stt);
     });
     // ... unless the same contact was sliding/sticking a substep ago: start from that state
-    const uint32_t samef = fric & (same << 1);   // friction row of a contact whose normal row persisted
+    // Round 5, measured on the host build over 64-lane groups (tests/diag/diag_wave_solves.py): where the Schur-complement start above is in
+    // force it predicts a friction row's state BETTER than the contact's state a substep ago -- Walker2d: a lane needs a second stage-2
+    // solve in 1.5 % of the substeps with it, in 14 % with the warm start on top, and since a wave iterates until its slowest lane is done
+    // that is 1.3 against 2.75 stage-2 solves per wave and substep (15.2 against 19.4 solves per wave and env-step in all).  The half
+    // cheetah (plain A_tt start, 4.3 stage-2 solves per wave either way) keeps the warm start: 33.5 against 34.7.  WARM_FRICTION, per topology.
+    const uint32_t samef = topo_warm_friction<T>::value ? (fric & (same << 1)) : 0u;   // friction row of a contact whose normal row persisted
     F = (F & ~samef) | (warm.F2 & samef);
     U = (U & ~samef) | (warm.U2 & samef);
     if (P.solver == 0) blcp_bpp_mixed<Real, M, false, PRE32>(A, b, lo, hi, pinmask, F, U, x, P.iters2, P.stats ? P.stats + 32 : nullptr, Real(0), cm, HO2, 6);
@@ -1821,6 +1875,9 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
     if (EXTRAS && P.ex.creport != nullptr && f == P.frame_skip - 1 && valid) {
       rp.rec = P.ex.creport + (size_t)e * T::NC * 8; rp.count = P.ex.creport_count + e; rp.cf = P.ex.cf_report + (size_t)e * N;
     }
+#ifdef DART_EMU_TRACE
+    dart_emu_substep((int)ec, f);   // host build of tests/diag only: which env / world step the following pivoting runs belong to
+#endif
     world_step<Real, T, PT, EXTRAS>(P, q, dq, tau, warm, slow_lds, ec, rp, hl);
     dx += P.dt * dq[0];
   }

@@ -111,9 +111,12 @@ std::string fill_spatial(const DartModelCard& c, SpatialModel<Real>& M, bool phy
     const int i = M.dof_link[d];
     for (int j = i; j >= 0; j = M.parent[j]) {
       if (M.dof[j] < 0) continue;
+      const int a = c.ndofs - 1 - d, b = c.ndofs - 1 - M.dof[j];
+      M.mpair_off[M.n_mpairs] = (uint16_t)HI(a, b);      // the padded dense rows; SpatialImplT::choose_lds re-addresses them for a pattern kernel's skyline
       M.mpairs[M.n_mpairs++] = (uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)d << 16) | ((uint32_t)M.dof[j] << 24);
     }
   }
+  M.hreals = HR(sp_npad(c.ndofs));
   {  // depth levels, children lists, constant world axes of the root-chain prismatic links
     int depth[SP_MAXL], maxd = 0;
     double Rw[SP_MAXL][9];   // world rotation of each link's JOINT frame at q = 0 (valid for root-chain links)

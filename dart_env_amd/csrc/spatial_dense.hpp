@@ -29,13 +29,21 @@ namespace dartk {
 // xvec != nullptr: ONE right-hand side, entry k held by lane k (storage order), is forward-substituted column by column while the
 // factor is in registers -- lane j > k holds L_jk in its own row, x_k arrives through v_readlane: 3 wave instructions per column
 // instead of a row's ~400 multiply-adds (the forward dynamics' solve, sp_world_step pass 0).
+// Pattern kernels store M / the factor as a SKYLINE (round 5; tree_patterns.hpp): row r keeps only its structural entries -- with the
+// dofs numbered leaves first they are one contiguous run of columns ending at the diagonal -- at hrb + k; `hrb` / `hmask` (base offset and
+// column mask of row `lane`, LinkConst::h_rb / h_mask) come from the caller, the identity padding rows beyond n are made up in registers.
 template <class Real, int NP, class PAT = DensePattern>
-__device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1, Real* xvec = nullptr) {
+__device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1, Real* xvec = nullptr,
+                                              int hrb = 0, uint32_t hmask = 0u) {
   const int r = lane < NP ? lane : 0;   // spare lanes shadow lane 0 (convergent code, results discarded)
-  const int rb = HR(r);
+  const int rb = PAT::dense ? HR(r) : (lane < NP ? hrb : PAT::hbase(0));
+  const uint32_t own = PAT::dense ? 0u : ((lane < PAT::n ? hmask : 0u) | ((lane < PAT::n || lane >= NP) ? (1u << r) : 0u));   // stored entries of this lane's row
   Real row[NP];
 #pragma unroll
-  for (int k = 0; k < NP; k++) row[k] = (k <= r) ? M[rb + k] : Real(0);
+  for (int k = 0; k < NP; k++) {
+    if constexpr (PAT::dense) row[k] = (k <= r) ? M[rb + k] : Real(0);
+    else row[k] = ((own >> k) & 1u) ? M[rb + k] : ((k == r) ? Real(1) : Real(0));   // (k == r: a padding row n <= r < NP = identity)
+  }
   Real sown = Real(1);                  // lane j: 1 / L_jj
   // Columns beyond the model's dofs (identity padding up to NP) are left alone in a pattern kernel: nothing to factor, sinv = 1.
   constexpr int NC = PAT::dense ? NP : (PAT::n < NP ? PAT::n : NP);
@@ -76,7 +84,10 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
   if (lane < NP) sinv[lane] = sown;   // (sinv has sp_npad(n) slots: the padding columns write theirs too)
   if (lane < n) {
 #pragma unroll
-    for (int k = 0; k < NP; k++) if (k <= lane) M[rb + k] = row[k];
+    for (int k = 0; k < NP; k++) {
+      if constexpr (PAT::dense) { if (k <= lane) M[rb + k] = row[k]; }
+      else { if ((own >> k) & 1u) M[rb + k] = row[k]; }
+    }
   }
   if (xvec != nullptr) {   // wave-uniform
     Real yv = (lane < n) ? xvec[lane] : Real(0);
@@ -119,8 +130,9 @@ __device__ __forceinline__ void sp_cholesky_t(Real* M, Real* sinv, int n, int la
 }
 // one straight-line variant per padded size (only the one a model uses ever enters the instruction cache)
 template <class Real, class PAT = DensePattern>
-__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1, Real* xvec = nullptr) {
-  if constexpr (!PAT::dense) { sp_cholesky_t<Real, sp_npad(PAT::n), PAT>(M, sinv, n, lane, W, m, xvec); return; }
+__device__ __forceinline__ void sp_cholesky(Real* M, Real* sinv, int n, int lane, Real* W = nullptr, int m = -1, Real* xvec = nullptr,
+                                            int hrb = 0, uint32_t hmask = 0u) {
+  if constexpr (!PAT::dense) { sp_cholesky_t<Real, sp_npad(PAT::n), PAT>(M, sinv, n, lane, W, m, xvec, hrb, hmask); return; }
   const int np = sp_npad(n);
   if (np <= 8) sp_cholesky_t<Real, 8>(M, sinv, n, lane, W, m, xvec);
   else if (np <= 16) sp_cholesky_t<Real, 16>(M, sinv, n, lane, W, m, xvec);
@@ -143,7 +155,7 @@ __device__ __forceinline__ void sp_chol_backsolve_lds(const Real* Lf, const Real
 // x <- L^-T x (backward) for one vector in LDS, lanes own entries.  The running vector stays in registers: column j's finished
 // entry is broadcast with v_readlane, the factor entries L_ji (row j, contiguous over the lanes i) are independent LDS reads
 // issued up front -- no barrier and no LDS write per column (the first version paid both).
-template <class Real, int NP, int TAG = 0>   // TAG: private copies per kernel family (see sp_blcp_t)
+template <class Real, int NP, int TAG = 0, class PAT = DensePattern>   // TAG: private copies per kernel family (see sp_blcp_t); PAT: skyline storage of the factor
 static __device__ __attribute__((noinline)) void sp_chol_backsolve_t(const Real* __restrict__ Lf_, const Real* __restrict__ sinv_, int n, Real* __restrict__ x_, int lane) {
   const auto Lf = DART_LDS_PTR(const Real, Lf_), sinv = DART_LDS_PTR(const Real, sinv_);   // LDS with every caller (wave_blcp.hpp)
   const auto x = DART_LDS_PTR(Real, x_);
@@ -152,7 +164,10 @@ static __device__ __attribute__((noinline)) void sp_chol_backsolve_t(const Real*
   const Real si = (lane < n) ? sinv[lane] : Real(1);
   Real col[NP];   // col[j] = L_ji for j > i
 #pragma unroll
-  for (int j = 0; j < NP; j++) col[j] = (j > i && j < n && lane < n) ? Lf[HL(j, i)] : Real(0);
+  for (int j = 0; j < NP; j++) {
+    if constexpr (PAT::dense) col[j] = (j > i && j < n && lane < n) ? Lf[HL(j, i)] : Real(0);
+    else col[j] = (j < PAT::n && lane < j && ((PAT::row(j) >> i) & 1u)) ? Lf[PAT::hbase(j) + i] : Real(0);   // structural zeros are not stored
+  }
 #pragma unroll
   for (int j = NP - 1; j >= 0; j--) {
     if (j < n) {
@@ -164,8 +179,9 @@ static __device__ __attribute__((noinline)) void sp_chol_backsolve_t(const Real*
   if (lane < n) x[lane] = xi;
   __syncthreads();
 }
-template <class Real, bool BIG = false, int TAG = 0>
+template <class Real, bool BIG = false, int TAG = 0, class PAT = DensePattern>
 __device__ __forceinline__ void sp_chol_backsolve(const Real* Lf, const Real* sinv, int n, Real* x, int lane) {
+  if constexpr (!PAT::dense) { sp_chol_backsolve_t<Real, sp_npad(PAT::n), TAG, PAT>(Lf, sinv, n, x, lane); return; }
   if constexpr (!BIG) { sp_chol_backsolve_lds<Real>(Lf, sinv, n, x, lane); return; }
   const int np = sp_npad(n);
   if (np <= 8) sp_chol_backsolve_t<Real, 8, TAG>(Lf, sinv, n, x, lane);
@@ -337,8 +353,11 @@ __device__ __forceinline__ void sp_blcp_lds(SpLds<Real>& S, int m, uint64_t pinm
     // Sweep order = the oracle's row order (oracle_step: {n, t1, t2} per contact, then limits, then joint friction), whatever the
     // storage order: a Gauss-Seidel iterate after a FIXED number of sweeps depends on it.  pf_ncp >= 0: the rows are stored in
     // prefix order (normals [0, ncp), limits / joint friction [ncp, m1), tangents [m1, m1 + 2 ncp) -- sp_world_step).
+    // (the sweep positions run over the UNtruncated row count of the prefix layout: when the model's LCP capacity clipped m, the limit /
+    // joint-friction rows sit at positions beyond m and must still be visited -- ADVICE r4; rows that were dropped are skipped below)
+    const int npos = pf_ncp >= 0 ? pf_m1 + 2 * pf_ncp : m;
     for (int sw = 0; sw < pgs_sweeps; ++sw)
-      for (int p = 0; p < m; p++) {
+      for (int p = 0; p < npos; p++) {
         int i = p;
         if (pf_ncp >= 0) i = p < 3 * pf_ncp ? ((p % 3 == 0) ? p / 3 : pf_m1 + 2 * (p / 3) + (p % 3 - 1)) : pf_ncp + (p - 3 * pf_ncp);
         if (i >= m) continue;            // (rows beyond the model's LCP capacity were dropped)

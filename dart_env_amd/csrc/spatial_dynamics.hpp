@@ -74,6 +74,9 @@ struct LinkConst {
   // the same lane also owns dof `lane` (mass-matrix row, limits)
   int d_link; Real d_diag;                   // link of dof `lane`; dt*damping + dt^2*stiffness
   int d_limited; Real d_lower, d_upper, d_fric;
+  // pattern kernels (skyline storage of H, tree_patterns.hpp): of factor row `lane` -- base offset, mask of its structural columns -- and
+  // the offset of the diagonal entry of dof `lane` (row n-1-lane); filled by sp_load_pattern_const, unused by the dense kernels
+  int h_rb; uint32_t h_mask; int h_diag;
 };
 template <class Real>
 __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md, int i, LinkConst<Real>& c) {
@@ -92,6 +95,18 @@ __device__ __forceinline__ void sp_load_link_const(const SpatialModel<Real>& Md,
   c.d_diag = Md.dt * Md.damp[dl] + Md.dt * Md.dt * Md.stiff[dl];
   c.d_limited = (i < Md.n) ? Md.limited[dl] : 0; c.d_lower = Md.lower[dl]; c.d_upper = Md.upper[dl];
   c.d_fric = (i < Md.n) ? Md.jfric_dt[dl] : Real(0);
+  c.h_rb = 0; c.h_mask = 0u; c.h_diag = 0;
+}
+// Per-lane constants of a pattern's skyline H storage: the tables are compile-time, the index is the lane -- looked up ONCE per kernel
+// (a constant-memory load per lane) and kept in registers, like the rest of LinkConst.
+template <class PAT, class Real>
+__device__ __forceinline__ void sp_load_pattern_const(int lane, LinkConst<Real>& c) {
+  if constexpr (!PAT::dense) {
+    const int r = lane < PAT::n ? lane : 0;
+    c.h_rb = PAT::hbase(r); c.h_mask = lane < PAT::n ? PAT::row(r) : 0u;
+    const int rd = lane < PAT::n ? PAT::n - 1 - lane : 0;
+    c.h_diag = PAT::hbase(rd) + rd;
+  }
 }
 
 template <class Real> __device__ __forceinline__ V3<Real> shfl3(V3<Real> v, int src) {
@@ -133,7 +148,7 @@ __device__ __forceinline__ void sp_forward(const LinkConst<Real>& lc, const Spat
   V3<Real> p;
   {
     Real sn = Real(0), cs = Real(1);
-    if (rev) sincos_<Real>(qv, sn, cs);
+    if (rev) sincos_remat_<Real>(qv, sn, cs);   // (constants rematerialised at their use: planar_kernel.hpp)
     const Real v = Real(1) - cs;
     const Real Rq[9] = {ax.x * ax.x * v + cs,        ax.x * ax.y * v - ax.z * sn, ax.x * ax.z * v + ax.y * sn,
                         ax.y * ax.x * v + ax.z * sn, ax.y * ax.y * v + cs,        ax.y * ax.z * v - ax.x * sn,
@@ -412,7 +427,10 @@ __device__ __forceinline__ void sp_mass_entries(const SpatialModel<Real>& Md, Sp
     const Real* Lj = S.link + jl * SP_LINKF;
     const V3<Real> aj = ld3(Lj + LK_A);
     const Real v = (topo_jtype(S.topo[jl]) == 2) ? dot(aj, K + cross(jo - ld3(Lj + LK_JO), Lm)) : dot(aj, Lm);
-    S.H[HI(n1 - d, n1 - dj)] = v;
+    // where the entry goes depends on the layout of S.H: the padded rows of the dense kernels, a pattern kernel's skyline -- the host
+    // tabulated it for the kernel it launches (SpatialModel::mpair_off; dense: HI(n1 - d, n1 - dj))
+    (void)n1; (void)d; (void)dj;
+    S.H[Md.mpair_off[e]] = v;
   }
 }
 

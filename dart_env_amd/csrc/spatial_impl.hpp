@@ -94,9 +94,21 @@ struct SpatialImplT : Impl {
     if (M.creport) return false;
     return pairs ? (extras || big) : (!extras && big);
   }
+  bool launches_pattern_kernel() const { return !M.creport && !pairs && !extras && big && pattern == 1; }   // step()'s dispatch, restated
   void choose_lds() {
     M.reg_lcp = (uses_big() && M.npairs == 0 && M.maxm <= 40) ? 1 : 0;
-    lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp, M.reg_lcp);
+    // layout of H in the block (round 5): the pattern kernel keeps a skyline of the structural entries (HumanWalker: 252 Reals instead of
+    // the 576 of the padded rows -- with it the fp64 block drops under 20 KB = eight workgroups per CU), every other kernel the padded rows;
+    // the mass-matrix entry list is addressed accordingly
+    const bool sky = launches_pattern_kernel();
+    M.hreals = sky ? HumanWalkerPattern::hreals : HR(sp_npad(M.n));
+    const int n1 = M.n - 1;
+    for (int e = 0; e < M.n_mpairs; e++) {
+      const int d = (M.mpairs[e] >> 16) & 0xff, dj = M.mpairs[e] >> 24;
+      const int a = n1 - d, b = n1 - dj, r = a > b ? a : b, c = a > b ? b : a;
+      M.mpair_off[e] = (uint16_t)(sky ? HumanWalkerPattern::hbase(r) + c : HL(r, c));
+    }
+    lds = sp_lds_bytes(M.nl, M.n, sizeof(Real), M.maxm, M.maxcp, M.reg_lcp, M.hreals);
   }
   void upload() { if (dM) (void)hipMemcpy(dM, &M, sizeof(M), hipMemcpyHostToDevice); }
   hipError_t step(hipStream_t s, int64_t n, void* q, void* dq, int32_t* el, uint32_t* ep, const float* act, float* obs,
@@ -107,7 +119,7 @@ struct SpatialImplT : Impl {
     if (M.creport) SP_LAUNCH(true, true, true, false);   // contact reporting lives in the most general instantiation only
     else if (pairs) { if (extras) SP_LAUNCH(true, true, false, true); else if (big) SP_LAUNCH(true, false, false, true); else SP_LAUNCH(true, false, false, false); }
     else if (extras) SP_LAUNCH(false, true, false, false);
-    else if (big && pattern == 1)   // the factor's sparsity is known at compile time (tree_patterns.hpp)
+    else if (launches_pattern_kernel())   // the factor's sparsity is known at compile time (tree_patterns.hpp)
       hipLaunchKernelGGL((sp_step_kernel<Real, false, false, false, true, HumanWalkerPattern>), dim3((unsigned)n), dim3(64), lds, s, dM, n, (Real*)q,
                          (Real*)dq, init_h, el, ep, act, obs, rew, done, trunc, autoreset, seed, off);
     else if (big) SP_LAUNCH(false, false, false, true);

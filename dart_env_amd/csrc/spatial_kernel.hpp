@@ -55,6 +55,9 @@ namespace dartk {
 #ifndef SP_PAT_F64_WAVES
 #define SP_PAT_F64_WAVES 2
 #endif
+#ifndef SP_OPAQUE_LANE
+#define SP_OPAQUE_LANE 0
+#endif
 template <class Real, bool BIG, class PAT = DensePattern> __host__ __device__ constexpr int sp_min_waves() {
   if (!BIG) return sizeof(Real) == 8 ? SP_SMALL_F64_WAVES : 3;
   if (!PAT::dense) return sizeof(Real) == 8 ? SP_PAT_F64_WAVES : SP_PAT_F32_WAVES;
@@ -80,7 +83,8 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
   // for a model that carries exactly these values, SpatialImplT::matches_pattern; its launch condition fixes reg_lcp = 1)
   constexpr bool BK = (SP_BAKE_DIMS != 0) && !PAT::dense;
   const int n = BK ? PAT::n : Md.n, nl_ = BK ? PAT::nl : Md.nl;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl_, n, BK ? PAT::maxm : Md.maxm, BK ? PAT::maxcp : Md.maxcp, BK ? PAT::reg_lcp : Md.reg_lcp);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl_, n, BK ? PAT::maxm : Md.maxm, BK ? PAT::maxcp : Md.maxcp, BK ? PAT::reg_lcp : Md.reg_lcp,
+                                 BK ? PAT::hreals : Md.hreals);   // (a pattern kernel stores H as a skyline; the host states the same size in Md.hreals)
   const int task = BK ? PAT::task : Md.task, act_dim = BK ? PAT::act_dim : Md.act_dim, act_dof0 = BK ? PAT::act_dof0 : Md.act_dof0;
   const int frame_skip = BK ? PAT::frame_skip : Md.frame_skip, obs_dim = BK ? PAT::obs_dim : Md.obs_dim;
   int* cflags = S.imisc + 2;
@@ -109,6 +113,7 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
   }
   LinkConst<Real> lc;
   sp_load_link_const<Real>(Md, lane < nl_ ? lane : 0, lc);
+  if constexpr (BK) sp_load_pattern_const<PAT, Real>(lane, lc);
   if (EXTRAS && Md.free_root) {
     __syncthreads();
     if (lane == 0) { sp_free_root_load<Real>(S); sp_free_root_to_internal<Real>(S); }   // S.q / S.dq: internal from here
@@ -130,7 +135,16 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
   }
   __syncthreads();
 #pragma nounroll
-  for (int f = 0; f < frame_skip; ++f) sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG, PAT>(Md, lc, S, lane, cflags, e, REPORT && Md.creport != nullptr && f == frame_skip - 1);
+  for (int f = 0; f < frame_skip; ++f) {
+#if SP_OPAQUE_LANE
+    int ln = lane;
+    DART_OPAQUE(ln);
+    __builtin_assume(ln >= 0 && ln < 64);
+    sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG, PAT>(Md, lc, S, ln, cflags, e, REPORT && Md.creport != nullptr && f == frame_skip - 1);
+#else
+    sp_world_step<Real, PAIRS, EXTRAS, REPORT, BIG, PAT>(Md, lc, S, lane, cflags, e, REPORT && Md.creport != nullptr && f == frame_skip - 1);
+#endif
+  }
   if (Md.stats && lane < 10) atomicAdd(&Md.stats[40 + lane], S.ticks[lane]);
   bool dn = false, tr = false;
   const bool pose_last = task == 1 || task == 2 || task == 3 || task == 4 || task == 8 || task >= 10;
@@ -233,7 +247,7 @@ __global__ void __launch_bounds__(64) sp_dynamics_kernel(const SpatialModel<Real
   const int64_t e = blockIdx.x;
   if (e >= n_envs) return;
   const int n = Md.n, nl = Md.nl;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl, n, Md.maxm, Md.maxcp, Md.reg_lcp);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, nl, n, Md.maxm, Md.maxcp, Md.reg_lcp, Md.hreals);
   if (lane < n) {
     const int64_t at = soa ? (int64_t)lane * n_envs + e : e * n + lane;
     S.q[lane] = qs[at]; S.dq[lane] = dqs[at]; S.tau[lane] = Real(0);
@@ -321,7 +335,7 @@ __global__ void __launch_bounds__(64) sp_reset_kernel(const SpatialModel<Real>* 
   const int64_t e = blockIdx.x;
   if (e >= n_envs) return;
   const int n = Md.n;
-  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp, Md.reg_lcp);
+  SpLds<Real> S = sp_carve<Real>((Real*)sp_smem, Md.nl, n, Md.maxm, Md.maxcp, Md.reg_lcp, Md.hreals);
   int* cflags = S.imisc + 2;
   const bool m = (mask == nullptr) || mask[e];
   if (lane < n) {

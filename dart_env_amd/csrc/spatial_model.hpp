@@ -100,6 +100,11 @@ struct SpatialModel {
   // sched_cost[env] -- the most expensive envs of the previous step can be dispatched first (longest-processing-time-first packing)
   const int* sched_perm;
   unsigned int* sched_cost;
+  // Storage of H / its factor in LDS (round 5).  hreals: Reals of the block -- HR(sp_npad(n)) in the padded dense row layout, a pattern's
+  // skyline size (tree_patterns.hpp: PAT::hreals) when the step kernel the host will launch is that pattern's; every kernel that carves the
+  // block (step, reset) must agree on it, so the host states it here.  mpair_off[e]: where entry e of `mpairs` goes in THAT layout.
+  int hreals;
+  uint16_t mpair_off[SP_MAXN * (SP_MAXN + 1) / 2];
 };
 
 // 128-bit LDS access of `width` consecutive Reals
@@ -136,10 +141,11 @@ enum { LK_R = 0, LK_P = 9, LK_JO = 12, LK_A = 15, LK_C = 18 };
 // LDS per env = seven workgroups per CU instead of six.
 enum { LD_F = 0, LD_N = 3, LD_MC = 6, LD_H = 7, LD_IC = 10 };
 
-// Reals of the Jacobian block W: (maxm + 1) rows of n, and room for the forward dynamics' own factor of M + E (padded rows, the
+// Reals of the Jacobian block W: maxm rows of n (round 5: the spare row that carried the right-hand side through the substitution until
+// round 3 is gone -- no kernel touches row maxm any more), and room for the forward dynamics' own factor of M + E (padded rows, the
 // reciprocal diagonal and one vector) that lives there before the Jacobian rows are written (sp_world_step, A3)
 __device__ __host__ constexpr int sp_w_reals(int n, int maxm, int nl = 0) {   // nl: ... and for the links' dynamics records
-  const int w = (maxm + 1) * n > HR(sp_npad(n)) + 2 * sp_npad(n) ? (maxm + 1) * n : HR(sp_npad(n)) + 2 * sp_npad(n);
+  const int w = maxm * n > HR(sp_npad(n)) + 2 * sp_npad(n) ? maxm * n : HR(sp_npad(n)) + 2 * sp_npad(n);
   return w > nl * SP_LDYN ? w : nl * SP_LDYN;
 }
 
@@ -149,7 +155,7 @@ struct SpLds {
   Real* ldyn;    // [nl][SP_LDYN] dynamics records (= W: dead before the Jacobian block is written)
   Real* q; Real* dq; Real* tau; Real* rhs;   // [n]
   Real* H;       // [n(n+1)/2] packed lower triangle -> Cholesky factor
-  Real* W;       // [maxm+1][n]: constraint Jacobian rows, then W = L^-1 J^T
+  Real* W;       // [maxm][n]: constraint Jacobian rows, then W = L^-1 J^T
   Real* A;       // [tri(maxm)] packed symmetric
   Real* Lw;      // [tri(maxm)] packed lower
   Real* b; Real* lo; Real* hi; Real* x; Real* r; Real* x0;   // [maxm]
@@ -172,14 +178,16 @@ __device__ __forceinline__ int topo_parent(int w) { return (w & 0xff) - 1; }
 __device__ __forceinline__ int topo_dof(int w) { return ((w >> 8) & 0xff) - 1; }
 __device__ __forceinline__ int topo_jtype(int w) { return (w >> 16) & 0xff; }
 
+// hreals: Reals of the H block (SpatialModel::hreals; 0 = the padded dense layout HR(sp_npad(n)))
+__device__ __host__ constexpr int sp_h_reals(int n, int hreals) { return hreals > 0 ? hreals : HR(sp_npad(n)); }
 template <class Real>
-__device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int maxm, int maxcp, int reg_lcp) {
+__device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int maxm, int maxcp, int reg_lcp, int hreals = 0) {
   SpLds<Real> S;
   Real* p = base;
   S.link = p; p += sp_link_reals(nl, maxm);
   S.q = p; p += n; S.dq = p; p += n; S.tau = p; p += n; S.rhs = p; p += n;
   p = base + (((p - base) + 3) & ~3);   // 16-byte aligned rows
-  S.H = p; p += HR(sp_npad(n));
+  S.H = p; p += sp_h_reals(n, hreals);
   S.W = p; S.ldyn = p; p += sp_w_reals(n, maxm, nl);
   const bool alias = sp_lw_aliases_links(nl, maxm);
   if (reg_lcp && alias) { S.A = S.link; S.x0 = S.link + sp_tri(maxm); S.Lw = nullptr; }
@@ -208,11 +216,11 @@ __device__ __forceinline__ SpLds<Real> sp_carve(Real* base, int nl, int n, int m
   S.ticks = (unsigned long long*)(((size_t)(S.ancd + nl) + 7) & ~(size_t)7);
   return S;
 }
-__host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp, int reg_lcp) {
+__host__ __device__ inline size_t sp_lds_bytes(int nl, int n, size_t real_bytes, int maxm, int maxcp, int reg_lcp, int hreals = 0) {
   const bool alias = sp_lw_aliases_links(nl, maxm);
   const size_t lw = alias ? 0 : (size_t)sp_tri(maxm) + maxm;
   const size_t a = (reg_lcp && alias) ? 0 : (size_t)sp_tri(maxm);
-  size_t reals = (size_t)sp_link_reals(nl, maxm) + (reg_lcp ? 4 : 5) * n + sp_npad(n) + (size_t)HR(sp_npad(n)) + 3 + (size_t)sp_w_reals(n, maxm, nl) + a + lw +
+  size_t reals = (size_t)sp_link_reals(nl, maxm) + (reg_lcp ? 4 : 5) * n + sp_npad(n) + (size_t)sp_h_reals(n, hreals) + 3 + (size_t)sp_w_reals(n, maxm, nl) + a + lw +
                  (reg_lcp ? 4 : 5) * maxm + maxcp * 7 + 16 + (reg_lcp ? 0 : 24);
   return reals * real_bytes + (2 * maxm + 2 * maxcp + 8 + 2 * nl) * sizeof(int) + 4 * real_bytes + 16 + 10 * sizeof(unsigned long long);
 }

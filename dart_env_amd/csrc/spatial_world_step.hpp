@@ -81,7 +81,9 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     __syncthreads();
   }
   SP_TICK(0);
-  if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[HL(lane, k)] = Real(0); if (lane >= n) S.H[HL(lane, lane)] = Real(1); }
+  using HP = typename std::conditional<BK, PAT, DensePattern>::type;   // layout of S.H: a pattern's skyline needs its compile-time dimensions (BK)
+  if constexpr (!HP::dense) { for (int e = lane; e < HP::hreals; e += 64) S.H[e] = Real(0); }   // skyline: structural entries only, no padding rows
+  else if (lane < sp_npad(n)) { for (int k = 0; k < lane; k++) S.H[HL(lane, k)] = Real(0); if (lane >= n) S.H[HL(lane, lane)] = Real(1); }
   __syncthreads();
   // Entry-parallel assembly of M and of the Jacobian rows (round 4) for the 20+-dof models (BIG): measured on one box against the
   // ancestor walks (-DSP_ENTRY_PARALLEL=0), fp64, 16 384 envs: HumanWalker 16.43 -> 15.72 ms, Walker3d 9.85 -> 9.46 ms; the Dog
@@ -91,7 +93,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
     sp_mass_entries<Real, typename std::conditional<BK, PAT, DensePattern>::type>(Md, S, lane);   // all 64 lanes, one structural entry at a time (reversed storage order, see sp_mass_row)
     __syncthreads();
     if (!impulse_M) {   // (wave-uniform) A3 knob at 0: the impulse pass runs on M + E
-      if (lane < n) S.H[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag;
+      if (lane < n) S.H[HP::dense ? HL(n - 1 - lane, n - 1 - lane) : lc.h_diag] += lc.d_diag;
       __syncthreads();
     }
   } else {
@@ -246,11 +248,11 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       Real* const Hm = pass ? S.H : H2; Real* const sv = pass ? S.sinv : sinv2; Real* const Wr = pass ? S.W : xq;
       const int nrows = pass ? m : 1;
       if (pass == 0) {
-        for (int e = lane; e < HR(np); e += 64) H2[e] = S.H[e];   // the whole padded block, 64 entries per trip (was: lane r copying its row, 32 dependent trips for the last one)
+        for (int e = lane; e < (HP::dense ? HR(np) : HP::hreals); e += 64) H2[e] = S.H[e];   // the whole padded block, 64 entries per trip (was: lane r copying its row, 32 dependent trips for the last one)
         // (factoring M + E straight from S.H -- row loads from S.H plus the E entry, no copy, no barrier -- was built and measured in
         // round 4: SLOWER, HumanWalker fp64 13.45 -> 13.81 ms, fp32 5.98 -> 6.36, Dog 3.41 -> 3.59; profiles/r04_tree_kernel_ab.txt)
         __syncthreads();
-        if (lane < n) { if (impulse_M) H2[HL(n - 1 - lane, n - 1 - lane)] += lc.d_diag; xq[n - 1 - lane] = S.rhs[lane]; }
+        if (lane < n) { if (impulse_M) H2[HP::dense ? HL(n - 1 - lane, n - 1 - lane) : lc.h_diag] += lc.d_diag; xq[n - 1 - lane] = S.rhs[lane]; }
       } else if constexpr (EP) {
         // Entry-parallel Jacobian (round 4).  Lane (d, half) = (lane & 31, lane >> 5) holds dof d's joint axis / origin / type in
         // registers and fills column d of the rows half, half + 2, ...: J_id = dir_i . (a_d x (P_i - o_d)) (revolute) or dir_i . a_d
@@ -378,7 +380,8 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
         // Pattern kernels (HumanWalker): the substitution follows while the factor is still in registers -- L_kj reaches a
         // row's lane through v_readlane (sp_cholesky_t).  Measured 6.36 -> 6.19 ms; the dense kernels got slower with it
         // (Walker3d +4 %) and keep the LDS reads.
-        sp_cholesky<Real, PAT>(Hm, sv, n, lane, pass ? Wr : nullptr, nrows - 1, pass ? nullptr : xq);
+        static_assert(PAT::dense || BK, "a pattern kernel stores H as a skyline: it needs SP_BAKE_DIMS");
+        sp_cholesky<Real, PAT>(Hm, sv, n, lane, pass ? Wr : nullptr, nrows - 1, pass ? nullptr : xq, lc.h_rb, lc.h_mask);
       } else {
         sp_cholesky<Real, PAT>(Hm, sv, n, lane, nullptr, -1, pass ? nullptr : xq);
         // The row lives in registers and both loops are fully unrolled (SP_MAXN x SP_MAXN / 2 predicated steps, uniform
@@ -414,7 +417,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       }
       SP_TICK(2);
       if (pass == 0) {
-        sp_chol_backsolve<Real, BIG, BK ? 1 : 0>(Hm, sv, n, xq, lane);
+        sp_chol_backsolve<Real, BIG, BK ? 1 : 0, HP>(Hm, sv, n, xq, lane);
         if (lane < n) S.dq[lane] += Md.dt * xq[n - 1 - lane];
         __syncthreads();
       }
@@ -478,7 +481,8 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
           Real wt = -S.b[lane];
           for (int j = 0; j < m; j++) wt += S.A[lane >= j ? TI(lane, j) : TI(j, lane)] * S.x[j];   // x = 0 on the friction rows
           const Real atn = S.A[lane >= nr ? TI(lane, nr) : TI(nr, lane)];
-          const Real att = ((F >> nr) & 1ull) ? att0 - atn * atn / S.A[TI(nr, nr)] : att0;
+          Real att = ((F >> nr) & 1ull) ? att0 - atn * atn / S.A[TI(nr, nr)] : att0;
+          if (!(att > Real(1e-12) * att0)) att = att0;   // a tangent (nearly) dependent on its normal row: the Schur complement rounds to <= 0 -- start from the row's own stiffness
           const Real xe = -wt / att;
           slide_up = !pinned && xe > hb; slide_dn = !pinned && xe < -hb;
 #endif
@@ -542,7 +546,7 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
       Md.cf_report[(size_t)env * n + lane] = v;
     }
   }
-  if (m > 0) sp_chol_backsolve<Real, BIG, BK ? 1 : 0>(S.H, S.sinv, n, S.rhs, lane);   // (wave-uniform: nothing touching, no limit active -> v = v*)
+  if (m > 0) sp_chol_backsolve<Real, BIG, BK ? 1 : 0, HP>(S.H, S.sinv, n, S.rhs, lane);   // (wave-uniform: nothing touching, no limit active -> v = v*)
   SP_TICK(9);
   if (lane < n) { const Real vnew = S.dq[lane] + S.rhs[n - 1 - lane]; S.dq[lane] = vnew; S.q[lane] += Md.dt * vnew; }
   __syncthreads();

@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("DART_STEPPER_LIB", os.path.join(_HERE, LIB_NAME))
 DART_OK, E_INVALID, E_NO_DEVICE, E_UNSUPPORTED, E_HIP, E_PENDING, E_NOT_PENDING = 0, -1, -2, -3, -4, -5, -6
 Q_NUM_ENVS, Q_NDOFS, Q_OBS_DIM, Q_ACT_DIM, Q_FRAME_SKIP, Q_PRECISION, Q_DEVICE, Q_LCP_SLOTS, Q_STATIC_KERNEL, Q_MAX_CONTACTS, Q_LDS_BYTES, Q_LANE_KERNEL = range(12)
 (CFG_SOLVER, CFG_ITERS_STAGE1, CFG_ITERS_STAGE2, CFG_AUTORESET, CFG_SEED, CFG_ENV_OFFSET, CFG_BLOCK_THREADS, CFG_STATS,
- CFG_EPISODE_STATS, CFG_CONTACT_REPORT, CFG_DEBUG_FORCE_FALLBACK, CFG_LAUNCH_ORDER, CFG_WAVE_VOTE) = range(13)
+ CFG_EPISODE_STATS, CFG_CONTACT_REPORT, CFG_DEBUG_FORCE_FALLBACK, CFG_LAUNCH_ORDER, CFG_WAVE_VOTE, CFG_HOST_DMA) = range(14)
 SOLVER_BPP, SOLVER_PGS = 0, 1
 
 EXPORTS = [
@@ -288,7 +288,7 @@ class HipStepper:
         from them; a weakref finalizer on the lease returns the block to the pool when the last such view is gone.  copy=True semantics
         of sync_vector_env.py:83 without a copy (and without the page faults of fresh multi-MB arrays every step), independent of
         who else holds references to the block itself (debuggers, profilers, a test's own bookkeeping)."""
-        if os.environ.get("DART_NO_OUT_POOL") == "1":      # (A/B switch of tools/bench_host_path.py: round 2's staging path)
+        if not self.__dict__.get("output_pool", True):     # (attribute set by tools/bench_host_path.py for its A/B: round 2's staging path)
             return None
         pool = self.__dict__.setdefault("_blocks", [])      # [block array, leased?]
         for ent in pool:
@@ -317,7 +317,9 @@ class HipStepper:
 
     def register_host_buffer(self, arr):
         """page-lock a caller-owned numpy array for direct DMA (dart_register_host_buffer): `dart_step` arguments inside it skip the
-        staging copies.  The caller keeps `arr` alive until unregister_host_buffer / close."""
+        staging copies.  The caller keeps `arr` alive until unregister_host_buffer / close.  Actions are consumed before the call that
+        takes them returns (the blocking `step_into` reads a registered array in place, `step_async` copies at call time), so the array
+        may be refilled right after either call."""
         self._check(self.L.dart_register_host_buffer(self.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
         self.__dict__.setdefault("_host_bufs", []).append(arr)
 
@@ -354,7 +356,8 @@ class HipStepper:
         return self.step_wait()
 
     def step_async(self, actions, staged=False):
-        """staged=True: the outputs go through the library's own pinned staging buffer (what step_wait(copy=False) returns views of)"""
+        """staged=True: the outputs go through the library's own pinned staging buffer (what step_wait(copy=False) returns views of).
+        `actions` is copied before this returns: the caller may overwrite it while the step is in flight."""
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim)
         blk = None if staged else self._free_block()
         if blk is None:

@@ -67,13 +67,24 @@ enum {
                                lanes (fp64: 1.45 -> 1.26 ms per batched step at 65 536 envs with K = 3).  Same LCP solutions; but which solver
                                serves an env then depends on its wave mates and the two round differently, so trajectories are no longer
                                bitwise independent of the batch an env sits in -- hence off (0) by default. */
+  DART_CFG_HOST_DMA = 13,   /* how the host-buffer entry points (dart_step, dart_step_async[_to]) cross PCIe, a bit mask, default 3:
+                               bit 0 = the step kernel reads the actions straight from page-locked host memory (no H2D copy),
+                               bit 1 = the outputs return through a copy kernel writing the mapped host block (no SDMA copy),
+                               bit 2 = the four outputs as four separate copies (rounds 1-2).  0 = copy engines both ways.  Results do
+                               not depend on it; it exists for A/B measurements (tools/gpu/host_path_c.py). */
   DART_CFG_LAUNCH_ORDER = 11 /* tree kernel (one env per workgroup): 1 (default) = the workgroups of a step are dispatched in the order
                                of the envs' durations at the previous step, longest first -- a launch ends when its last workgroup
                                does, and an env that was expensive (many contacts, a long pivoting run) mostly still is; 0 = index
                                order.  Results do not depend on it (each env is stepped by one workgroup either way). */
 };
 
-/* Library-level error text for failures that happen before a handle exists (handle == NULL). */
+/* Environment: the library reads NO environment variables (round 5: the debugging switches DART_FORCE_SPATIAL, DART_GENERIC_KERNEL,
+ * DART_SPLIT_D2H, DART_HOST_DMA of earlier rounds are gone -- the tree kernel is chosen with card.generic_kernel, the PCIe legs with
+ * DART_CFG_HOST_DMA).  What a handle does is decided by its card and its dart_configure keys alone.
+ *
+ * Threading: one thread at a time per handle; different handles may be driven from different threads.
+ * Library-level error text for failures that happen before a handle exists (handle == NULL): kept per calling THREAD
+ * (thread_local), so two threads inside dart_create do not share it. */
 const char* dart_last_error(const DartStepper* h);
 
 /* Replaces DartEnv.__init__'s world construction for N envs: pydart.World(dt, skel), skeletons[-1], limit
@@ -130,8 +141,10 @@ int dart_step(DartStepper* h, const float* actions, float* obs_out, double* rewa
  * host memcpy behind it; float64 rewards are produced on the device.  Arguments outside every registered range keep the staging
  * path (correct for any pointer, ~2x slower at 65 536 envs: profiles/r04_host_path_ab.txt).  Ownership is explicit: the buffer
  * must stay mapped until dart_unregister_host_buffer or dart_destroy -- the library never registers memory on its own
- * (page-locking a buffer the caller may free behind its back is not something an ABI should do silently).  Actions inside a
- * registered range are read by DMA after dart_step_async returns: do not overwrite them before dart_step_wait does. */
+ * (page-locking a buffer the caller may free behind its back is not something an ABI should do silently).  Actions are always
+ * consumed before the call that takes them returns: dart_step (blocking) lets the kernel read a registered action array where it
+ * lies; dart_step_async / dart_step_async_to copy the actions into the library's own pinned block at call time, so the caller may
+ * refill its array between step_async and step_wait (round 5; round 4 read them in place after the call had returned). */
 int dart_register_host_buffer(DartStepper* h, void* ptr, uint64_t bytes);
 int dart_unregister_host_buffer(DartStepper* h, void* ptr);
 

@@ -59,12 +59,14 @@ int emu_slots(Emu* h) { return h->impl->slots(); }
 // the tree kernel's LDS block: bytes the host reserves (sp_lds_bytes) and the end of what the kernels carve out of it (sp_carve) for the same
 // dimensions -- tests/test_tree_kernel_emu_parity.py sweeps them against each other (a carve that runs past the reservation is silent
 // corruption of the neighbouring workgroup's block on the device)
-long long emu_lds_reserved(int nl, int n, int real_bytes, int maxm, int maxcp, int reg_lcp) { return (long long)sp_lds_bytes(nl, n, (size_t)real_bytes, maxm, maxcp, reg_lcp); }
-long long emu_lds_carved(int nl, int n, int real_bytes, int maxm, int maxcp, int reg_lcp) {
+// hreals: Reals of the H block (0 = the padded dense rows; a pattern kernel's skyline size otherwise -- SpatialModel::hreals)
+long long emu_lds_reserved(int nl, int n, int real_bytes, int maxm, int maxcp, int reg_lcp, int hreals) { return (long long)sp_lds_bytes(nl, n, (size_t)real_bytes, maxm, maxcp, reg_lcp, hreals); }
+long long emu_lds_carved(int nl, int n, int real_bytes, int maxm, int maxcp, int reg_lcp, int hreals) {
   alignas(16) static unsigned char base[1];
-  if (real_bytes == 4) { auto S = sp_carve<float>((float*)base, nl, n, maxm, maxcp, reg_lcp); return (long long)((unsigned char*)(S.ticks + 10) - base); }
-  auto S = sp_carve<double>((double*)base, nl, n, maxm, maxcp, reg_lcp); return (long long)((unsigned char*)(S.ticks + 10) - base);
+  if (real_bytes == 4) { auto S = sp_carve<float>((float*)base, nl, n, maxm, maxcp, reg_lcp, hreals); return (long long)((unsigned char*)(S.ticks + 10) - base); }
+  auto S = sp_carve<double>((double*)base, nl, n, maxm, maxcp, reg_lcp, hreals); return (long long)((unsigned char*)(S.ticks + 10) - base);
 }
+int emu_pattern_hreals() { return HumanWalkerPattern::hreals; }
 #endif
 #ifdef DART_WAVE_EMU
 // a static __shared__ array of this library (address = load base + symbol value, found by the test in the symbol table): poisoned with the

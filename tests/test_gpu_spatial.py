@@ -13,8 +13,9 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.fixture
-def force_spatial(monkeypatch):
-    monkeypatch.setenv("DART_FORCE_SPATIAL", "1")
+def force_spatial():
+    """planar models through the tree kernel: the card asks for it (card.generic_kernel -- the library reads no environment variables)"""
+    return True
 
 
 def _physics_card(model_name, contact_bodies):
@@ -22,6 +23,7 @@ def _physics_card(model_name, contact_bodies):
     for s in m.shapes:
         s.collidable = m.bodies[s.body].name in contact_bodies
     card = build_card(m, None)
+    card.generic_kernel = 1      # these tests are about the tree kernel
     if model_name == "humanwalker":
         card.contact_cfm = 1e-4     # box feet: redundant coplanar contacts need the regularisation (see dart_model_card.h)
     return card, m
@@ -488,7 +490,7 @@ def test_walker3d_link_link_contacts_match_oracle():
 def test_spatial_pgs_solver_converges_to_pivoting_solver(force_spatial):
     """DART_CFG_SOLVER = PGS on the wave-per-env kernel: sweeps with wavefront reductions approach the exact solve."""
     from dart_env_amd import stepper as st
-    card = card_for("DartHopper-v1")
+    card = card_for("DartHopper-v1", generic_kernel=True)
     n = 256
     acts = np.random.RandomState(3).uniform(-1, 1, (20, n, 3)).astype(np.float32)
     out = {}

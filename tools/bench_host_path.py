@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "ab":
     # A/B of the host path in two fresh processes on the same box: round 2's (four D2H copies per step, fresh output arrays every
     # step) against the current one (one packed D2H, output arrays reused once the caller has dropped them)
-    for tag, env in (("legacy (DART_SPLIT_D2H=1 DART_NO_OUT_POOL=1)", {"DART_SPLIT_D2H": "1", "DART_NO_OUT_POOL": "1"}), ("current", {})):
+    for tag, env in (("legacy (DART_CFG_HOST_DMA=4: four copies; DART_NO_OUT_POOL=1)", {"BENCH_HOST_DMA": "4", "DART_NO_OUT_POOL": "1"}), ("current", {})):
         print("==", tag, flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[2:], env=dict(os.environ, **env), check=True)
     sys.exit(0)
@@ -19,6 +19,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 card = card_for("DartHopper-v1")
 s = st.HipStepper(card, n)
 s.configure(st.CFG_AUTORESET, 1)
+s.output_pool = os.environ.get("DART_NO_OUT_POOL") != "1"
+if os.environ.get("BENCH_HOST_DMA"):          # (this tool's own switch: the library reads no environment variables)
+    s.configure(st.CFG_HOST_DMA, int(os.environ["BENCH_HOST_DMA"]))
 s.reset(None, None, None)
 a = np.random.RandomState(0).uniform(-1, 1, (n, 3)).astype(np.float32)
 for _ in range(20):

@@ -50,13 +50,13 @@ def rollout(gym, env_id, seed, steps, act_scale):
     return out
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "dart_real"))
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--seeds", type=int, nargs="*", default=[0, 1])
     ap.add_argument("--envs", nargs="*", default=list(ENVS))
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     try:
         import pydart2
     except ImportError:

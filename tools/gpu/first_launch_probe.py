@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""First launch != later launches: ONE case per fresh process, with the three kinds of storage a kernel can read
+before writing -- scratch, LDS, vector / accumulator registers -- poisoned on demand before the first and / or the later rollouts.
+
+    python tools/gpu/first_launch_probe.py --env DartHalfCheetah-v1 --prec 32 [--report] [--n 256]
+           [--poison none|scratch|lds|regs|all] [--pattern 0x7fc00000] [--when first|later|both]
+    DART_STEPPER_LIB=abtest/lib_ctab.so ...   the build with compile-time ancestor tables that failed in round 4
+
+Prints one line: the digest of each of four identical rollouts (same state, same actions).  Reading it:
+  * later rollouts agree with each other but not with the first, no poison      -> the symptom;
+  * poisoning X before the LATER rollouts changes them (or makes them agree with a first one that was poisoned the same way)
+    -> the kernel reads X before writing it; if no X does, the difference is not uninitialised storage."""
+import argparse, ctypes as C, hashlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from dart_env_amd.model_card import card_for
+from dart_env_amd.stepper import HipStepper, CFG_CONTACT_REPORT
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--env", default="DartHalfCheetah-v1"); ap.add_argument("--prec", type=int, default=32); ap.add_argument("--report", action="store_true")
+ap.add_argument("--n", type=int, default=256); ap.add_argument("--poison", default="none"); ap.add_argument("--pattern", default="0x7fc00000")
+ap.add_argument("--when", default="later"); ap.add_argument("--reps", type=int, default=4); ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+H = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "gpu_kernels", "libpoison_harness.so"))
+pat = int(a.pattern, 0)
+
+
+def poison():
+    kinds = ("scratch", "lds", "regs") if a.poison == "all" else (a.poison,)
+    for k in kinds:
+        if k != "none":
+            rc = getattr(H, "poison_" + k)(C.c_uint32(pat))
+            assert rc == 0, (k, rc)
+
+
+card = card_for(a.env); n = a.n; nd, na = card.ndofs, card.act_dim
+rng = np.random.RandomState(5)
+q0 = rng.uniform(-0.3, 0.3, (n, nd)); dq0 = rng.uniform(-2, 2, (n, nd))
+if card.ground_y > -1e9:
+    q0[:, 1] = rng.uniform(-0.65, -0.3, n)
+acts = rng.uniform(-1, 1, (a.steps, n, na)).astype(np.float32)
+g = HipStepper(card, n, precision=a.prec)
+if a.report:
+    g.configure(CFG_CONTACT_REPORT, 1)
+digests, outs_all = [], []
+for rep in range(a.reps):
+    g.set_state(q0, dq0)
+    if (rep == 0 and a.when in ("first", "both")) or (rep > 0 and a.when in ("later", "both")):
+        poison()
+    outs = []
+    for t in range(a.steps):
+        ob, r, d, tr = g.step(acts[t]); outs += [ob.copy(), r.copy(), d.copy()]
+    outs += list(g.get_state())
+    h = hashlib.sha1()
+    for o in outs:
+        h.update(np.ascontiguousarray(o).tobytes())
+    digests.append(h.hexdigest()[:10]); outs_all.append(outs)
+q_first, q_later = outs_all[0][-2], outs_all[-1][-2]
+ndiff = int((~((q_first == q_later) | (np.isnan(q_first) & np.isnan(q_later)))).any(axis=1).sum())
+print("%-22s f%d %-6s lib=%-18s poison=%-7s when=%-5s pattern=%s | digests %s | envs whose final q differs first vs last: %d of %d" % (
+    a.env, a.prec, "report" if a.report else "lean", os.path.basename(os.environ.get("DART_STEPPER_LIB", "in-tree")), a.poison, a.when, a.pattern,
+    " ".join(digests), ndiff, n), flush=True)
+g.close()

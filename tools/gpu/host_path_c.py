@@ -34,13 +34,11 @@ def caller_arrays():
 
 
 def make(dma=None):
-    """dma: DART_HOST_DMA of this handle (read at dart_create): None = default (kernel reads actions from page-locked memory, copy
-    kernel for the outputs), 'copy' = hipMemcpyAsync both ways (rounds 1-3), 'zc_actions' / 'd2h_kernel' = one leg each"""
-    os.environ.pop("DART_HOST_DMA", None)
-    if dma:
-        os.environ["DART_HOST_DMA"] = dma
+    """dma: DART_CFG_HOST_DMA of this handle: None = default (3: kernel reads actions from page-locked memory, copy kernel for the
+    outputs), 'copy' = 0, hipMemcpyAsync both ways (rounds 1-3), 'zc_actions' = 1 / 'd2h_kernel' = 2: one leg each"""
     s = st.HipStepper(card, n, precision=64)
-    os.environ.pop("DART_HOST_DMA", None)
+    if dma:
+        s.configure(st.CFG_HOST_DMA, {"copy": 0, "zc_actions": 1, "d2h_kernel": 2}[dma])
     s.configure(st.CFG_AUTORESET, 1)
     s.reset(None, None, None, want_obs=False)
     return s
@@ -62,10 +60,10 @@ variants = {
     "registered dart_step, dart_register_host_buffer'd caller arrays": lambda: s_reg.step_into(*arr_reg),
     "block      dart_step_async_to + dart_step_wait (HipStepper.step)": lambda: s_blk.step(a),
     "python     DartVectorEnv.step, device MT19937 resets": lambda: venv.step(a),
-    "block      ... DART_HOST_DMA=copy (hipMemcpyAsync H2D + D2H, rounds 1-3)": lambda: s_blk_copy.step(a),
-    "block      ... DART_HOST_DMA=zc_actions (kernel reads pinned actions, D2H by hipMemcpyAsync)": lambda: s_blk_zc.step(a),
-    "block      ... DART_HOST_DMA=d2h_kernel (H2D by hipMemcpyAsync, outputs by copy kernel)": lambda: s_blk_dk.step(a),
-    "registered ... DART_HOST_DMA=copy": lambda: s_reg_copy.step_into(*arr_reg_copy),
+    "block      ... DART_CFG_HOST_DMA=copy (hipMemcpyAsync H2D + D2H, rounds 1-3)": lambda: s_blk_copy.step(a),
+    "block      ... DART_CFG_HOST_DMA=zc_actions (kernel reads pinned actions, D2H by hipMemcpyAsync)": lambda: s_blk_zc.step(a),
+    "block      ... DART_CFG_HOST_DMA=d2h_kernel (H2D by hipMemcpyAsync, outputs by copy kernel)": lambda: s_blk_dk.step(a),
+    "registered ... DART_CFG_HOST_DMA=copy": lambda: s_reg_copy.step_into(*arr_reg_copy),
 }
 for f in variants.values():
     for _ in range(600):

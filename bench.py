@@ -230,12 +230,15 @@ def host_surface(env_id, n, local_rank, precision, budget_s=1.0, max_steps=200):
         venv = V.make(env_id, n, device=local_rank, precision=precision, copy=copy)
         venv.seed(0)
         venv.reset()
-        a = np.random.RandomState(0).uniform(-1, 1, (n, venv.env.act_dim)).astype(np.float32)
-        for _ in range(300):      # (the first few hundred steps of a fresh handle run at half speed in a process that also holds
-            venv.step(a)          # torch's HIP context -- tools/gpu/host_loop_probe.py: 459 then 249 us per step)
+        # a RING of action batches, as in the timed region -- NOT one batch applied at every step (rounds 3-4 did that: under constant
+        # torques the hoppers spend their episodes lying on several capsules, the step kernel takes 96 us instead of 32 -- rocprof trace of
+        # tools/gpu/host_latency_probe.py, profiles/r05_host_path.txt -- and what was reported as the host path's cost was 2/3 kernel)
+        ring = np.random.RandomState(0).uniform(-1, 1, (16, n, venv.env.act_dim)).astype(np.float32)
+        for i in range(300):      # (the first few hundred steps of a fresh handle run at half speed in a process that also holds
+            venv.step(ring[i % 16])   # torch's HIP context -- tools/gpu/host_loop_probe.py: 459 then 249 us per step)
         k, t0 = 0, time.perf_counter()
         while k < max_steps and time.perf_counter() - t0 < budget_s:
-            obs, rew, done, info = venv.step(a)
+            obs, rew, done, info = venv.step(ring[k % 16])
             k += 1
         dt = time.perf_counter() - t0
         out["copy_true" if copy else "copy_false"] = {"copy": copy, "steps": k, "ms_per_step": dt / k * 1e3, "value": n * k / dt,

@@ -63,6 +63,7 @@ struct DartStepper {
   // obs | reward | done | truncated of a step are ONE device block and ONE pinned host block (d_obs / h_obs are their bases):
   // dart_step_async brings a step's outputs to the host with a single D2H copy instead of four
   size_t out_bytes = 0, out_off[4] = {0, 0, 0, 0};   // offsets of obs / reward / done / truncated inside the block
+  size_t out_bytes_host = 0;     // a caller's output block (dart_step_async_to): the device block + (N) float64 rewards behind it, made by the copy kernel
   std::vector<void*> registered;   // caller-owned output blocks page-locked by dart_register_output
   // caller-owned host buffers page-locked by dart_register_host_buffer: dart_step DMAs straight from / into arguments that lie inside
   std::vector<std::pair<char*, size_t>> host_ranges;
@@ -214,6 +215,7 @@ int dart_create(const DartModelCard* card, int64_t num_envs, int device, int pre
     {
       const size_t ob = (4 * N * card->obs_dim + 255) & ~(size_t)255, rb = (4 * N + 255) & ~(size_t)255, db = (N + 255) & ~(size_t)255;
       h->out_bytes = ob + rb + 2 * db;
+      h->out_bytes_host = h->out_bytes + ((8 * N + 255) & ~(size_t)255);
       unsigned char* blk = nullptr;
       CHK(h, hipMalloc((void**)&blk, h->out_bytes));
       h->d_obs = (float*)blk; h->d_rew = (float*)(blk + ob); h->d_done = blk + ob + rb; h->d_trunc = blk + ob + rb + db;
@@ -533,7 +535,7 @@ int dart_step_async(DartStepper* h, const float* actions) { return step_async_im
 
 int dart_output_layout(const DartStepper* h, int64_t* total_bytes, int64_t* offsets4) {
   if (!h) return DART_E_INVALID;
-  if (total_bytes) *total_bytes = (int64_t)h->out_bytes;
+  if (total_bytes) *total_bytes = (int64_t)h->out_bytes_host;
   if (offsets4) for (int k = 0; k < 4; k++) offsets4[k] = (int64_t)h->out_off[k];
   return DART_OK;
 }
@@ -541,7 +543,7 @@ int dart_register_output(DartStepper* h, void* block) {
   if (!h || !block) return DART_E_INVALID;
   CHK(h, hipSetDevice(h->device));
   for (void* p : h->registered) if (p == block) return DART_OK;
-  CHK(h, hipHostRegister(block, h->out_bytes, hipHostRegisterDefault));
+  CHK(h, hipHostRegister(block, h->out_bytes_host, hipHostRegisterDefault));
   h->registered.push_back(block);
   return DART_OK;
 }
@@ -604,6 +606,14 @@ static void* host_devptr(void* p) {
   void* d = nullptr;
   return hipHostGetDevicePointer(&d, p, 0) == hipSuccess ? d : nullptr;
 }
+// ... and, behind it, the float64 rewards the reference's API returns (gym.vector: rewards are numpy float64) -- one launch for a caller's
+// whole output block (round 5; the Python layer converted the float32 rewards on the host after every step)
+__global__ void __launch_bounds__(256) d2h_block_r64_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16, const float* __restrict__ rew,
+                                                            double* __restrict__ rew64, int64_t n) {
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = t0; i < n16; i += nt) dst[i] = src[i];
+  for (int64_t i = t0; i < n; i += nt) rew64[i] = (double)rew[i];
+}
 static int d2h_block(DartStepper* h, void* host_dst, const void* dev_src, size_t bytes) {
   void* dd = h->d2h_kernel && (bytes % 16 == 0) ? host_devptr(host_dst) : nullptr;
   // 128-bit loads / stores: both ends 16-byte aligned (a caller's registered arena may hand any offset), else the copy engine
@@ -622,6 +632,41 @@ static int d2h_block(DartStepper* h, void* host_dst, const void* dev_src, size_t
 __global__ void reward_f64_kernel(int64_t n, const float* __restrict__ r32, double* __restrict__ r64) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) r64[i] = (double)r32[i];
+}
+
+// dart_step's direct path in ONE launch (round 5): every output the caller asked for goes from the device block straight into the
+// caller's page-locked arrays -- observations as 16-byte words, rewards converted to the float64 the reference returns on the way, the
+// two flag arrays as 16-byte words (or bytes when a pointer is not 16-byte aligned).  Was: up to five launches behind the step kernel
+// (copy, convert, copy, copy, copy), each a dependent ~10-20 us hop on an otherwise idle stream.
+__global__ void __launch_bounds__(256) d2h_outputs_kernel(const float* __restrict__ obs, float* __restrict__ h_obs, int64_t obs_floats,
+                                                          const float* __restrict__ rew, double* __restrict__ h_rew, const uint8_t* __restrict__ done,
+                                                          uint8_t* __restrict__ h_done, const uint8_t* __restrict__ trunc, uint8_t* __restrict__ h_trunc,
+                                                          int64_t n) {
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+  if (h_obs) {
+    if ((((uintptr_t)obs | (uintptr_t)h_obs) & 15) == 0) {
+      const int64_t n16 = obs_floats / 4;
+      const uint4* s = (const uint4*)obs; uint4* d = (uint4*)h_obs;
+      for (int64_t i = t0; i < n16; i += nt) d[i] = s[i];
+      for (int64_t i = 4 * n16 + t0; i < obs_floats; i += nt) h_obs[i] = obs[i];
+    } else {
+      for (int64_t i = t0; i < obs_floats; i += nt) h_obs[i] = obs[i];
+    }
+  }
+  if (h_rew) for (int64_t i = t0; i < n; i += nt) h_rew[i] = (double)rew[i];
+  const uint8_t* fs[2] = {done, trunc};
+  uint8_t* fd[2] = {h_done, h_trunc};
+  for (int k = 0; k < 2; k++) {
+    if (!fd[k]) continue;
+    if ((((uintptr_t)fs[k] | (uintptr_t)fd[k]) & 15) == 0) {
+      const int64_t n16 = n / 16;
+      const uint4* s = (const uint4*)fs[k]; uint4* d = (uint4*)fd[k];
+      for (int64_t i = t0; i < n16; i += nt) d[i] = s[i];
+      for (int64_t i = 16 * n16 + t0; i < n; i += nt) fd[k][i] = fs[k][i];
+    } else {
+      for (int64_t i = t0; i < n; i += nt) fd[k][i] = fs[k][i];
+    }
+  }
 }
 
 // caller_blocks: the call returns only after the step has completed (dart_step) -- only then may the kernel read the actions where the
@@ -656,7 +701,20 @@ static int step_async_impl(DartStepper* h, const float* actions, void* dst, bool
   if (dst == (void*)h) {
     // dart_step's direct path: the D2H copies go into the caller's registered buffers, enqueued by dart_step itself
   } else if (dst) {   // straight into the caller's page-locked block: no staging copy afterwards (dart_step_wait only synchronises)
-    int rc = d2h_block(h, dst, h->d_obs, h->out_bytes); if (rc != DART_OK) return rc;
+    void* dd = h->d2h_kernel ? host_devptr(dst) : nullptr;
+    if (dd && ((uintptr_t)dd % 16 == 0)) {
+      const int64_t n16 = (int64_t)(h->out_bytes / 16);
+      const unsigned blocks = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+      hipLaunchKernelGGL(d2h_block_r64_kernel, dim3(blocks), dim3(256), 0, h->stream, (const uint4*)h->d_obs, (uint4*)dd, n16, h->d_rew,
+                         (double*)((unsigned char*)dd + h->out_bytes), (int64_t)N);
+      CHK(h, hipGetLastError());
+    } else {   // copy engines: the block, then the float64 rewards through the device staging array
+      int rc = d2h_block(h, dst, h->d_obs, h->out_bytes); if (rc != DART_OK) return rc;
+      if (!h->d_rew64) CHK(h, hipMalloc((void**)&h->d_rew64, 8 * N));
+      hipLaunchKernelGGL(reward_f64_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, (int64_t)N, h->d_rew, h->d_rew64);
+      CHK(h, hipGetLastError());
+      CHK(h, hipMemcpyAsync((unsigned char*)dst + h->out_bytes, h->d_rew64, 8 * N, hipMemcpyDeviceToHost, h->stream));
+    }
   } else if (!h->split_d2h) {
     int rc = d2h_block(h, h->h_obs, h->d_obs, h->out_bytes); if (rc != DART_OK) return rc;   // obs | reward | done | truncated
   } else {
@@ -692,6 +750,16 @@ int dart_host_views(DartStepper* h, const float** obs, const float** reward_f32,
   return DART_OK;
 }
 
+int dart_device_outputs(DartStepper* h, const float** d_obs, const float** d_reward_f32, const uint8_t** d_done, const uint8_t** d_truncated) {
+  if (!h) return DART_E_INVALID;
+  if (h->pending) { h->err = "dart_device_outputs while a step is pending"; return DART_E_PENDING; }
+  if (d_obs) *d_obs = h->d_obs;
+  if (d_reward_f32) *d_reward_f32 = h->d_rew;
+  if (d_done) *d_done = h->d_done;
+  if (d_truncated) *d_truncated = h->d_trunc;
+  return DART_OK;
+}
+
 int dart_step(DartStepper* h, const float* actions, float* obs_out, double* reward_out, uint8_t* done_out,
               uint8_t* truncated_out) {
   if (!h) return DART_E_INVALID;
@@ -709,6 +777,20 @@ int dart_step(DartStepper* h, const float* actions, float* obs_out, double* rewa
   int rc = step_async_impl(h, actions, (void*)h, true);   // (dst == h: "the caller enqueues the copies")
   if (rc != DART_OK) return rc;
   h->pending = false;
+  if (h->d2h_kernel && !h->split_d2h) {   // one launch for all the outputs, rewards converted on the way
+    void* po = obs_out ? host_devptr(obs_out) : nullptr; void* pr = reward_out ? host_devptr(reward_out) : nullptr;
+    void* pd = done_out ? host_devptr(done_out) : nullptr; void* pt = truncated_out ? host_devptr(truncated_out) : nullptr;
+    if ((!obs_out || po) && (!reward_out || pr) && (!done_out || pd) && (!truncated_out || pt)) {
+      const int64_t of = (int64_t)N * h->card.obs_dim;
+      const int64_t work = (of / 4 > (int64_t)N ? of / 4 : (int64_t)N);
+      const unsigned blocks = (unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+      hipLaunchKernelGGL(d2h_outputs_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_obs, (float*)po, of, h->d_rew, (double*)pr, h->d_done,
+                         (uint8_t*)pd, h->d_trunc, (uint8_t*)pt, (int64_t)N);
+      CHK(h, hipGetLastError());
+      CHK(h, wait_stream(h));
+      return DART_OK;
+    }
+  }
   if (obs_out) { rc = d2h_block(h, obs_out, h->d_obs, 4 * N * h->card.obs_dim); if (rc != DART_OK) return rc; }
   if (reward_out) {
     if (!h->d_rew64) CHK(h, hipMalloc((void**)&h->d_rew64, 8 * N));

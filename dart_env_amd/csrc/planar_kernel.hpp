@@ -119,7 +119,10 @@ struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded hea
 #endif
   static constexpr bool ANC_TABLES_RT = DART_CHEETAH_RT_TABLES;   // see topo_anc_rt
   static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4, TIER1_F64 = 3;
-  static constexpr bool ISOLATED_TIER1 = true;
+#ifndef DART_CHEETAH_ISOLATED_TIER1
+#define DART_CHEETAH_ISOLATED_TIER1 true    // (false: round 2's inlined big tier, for tools/exec_prologue_lint.py -- is it the same toolchain bug?)
+#endif
+  static constexpr bool ISOLATED_TIER1 = DART_CHEETAH_ISOLATED_TIER1;
   // Five touching capsules (four in fp64) are 6e-5 (2.3e-3) of the env-world-steps -- ~20 (~750) per launch of 65 536 envs -- and a
   // launch at one wave per SIMD lasts as long as its slowest wave.  WAVE_FALLBACK: such an env is served by the whole wave
   // (wave_constraints) instead of by its own lane alone, 2.50 -> 0.95 ms (fp32) / 3.43 -> 1.54 ms (fp64) per batched step; and the lanes

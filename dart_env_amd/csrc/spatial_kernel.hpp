@@ -55,8 +55,15 @@ namespace dartk {
 #ifndef SP_PAT_F64_WAVES
 #define SP_PAT_F64_WAVES 2
 #endif
+// The lane index is made opaque to the compiler at the top of every world step (round 5).  With `lane` a loop invariant, every per-lane
+// LDS address, mask and comparison of the world step is hoisted out of the frame loop -- a hundred-odd values that then live across the
+// whole loop and every call in it; the allocator spilled ~30 register pairs before the loop and reloaded 18 of them after each call to the
+// LCP solver (found in the disassembly of the fp64 pattern kernel; the pre-loop stores were 80 % of its 307 MB of HBM writes per launch).
+// Recomputing them per world step is a few dozen integer instructions.  Compiler remarks, VGPR spills of the eight fp32 / eight fp64
+// instantiations: 162 118 80 94 137 81 89 77 -> 47 24 13 12 40 16 5 14 and 113 0 0 73 82 63 0 48 -> 21 0 0 7 13 80 0 5 (the fp64 pattern
+// kernel also stores its factor as a skyline now); measured: profiles/r05_tree_kernel_ab.txt.  0 restores rounds 1-4.
 #ifndef SP_OPAQUE_LANE
-#define SP_OPAQUE_LANE 0
+#define SP_OPAQUE_LANE 1
 #endif
 template <class Real, bool BIG, class PAT = DensePattern> __host__ __device__ constexpr int sp_min_waves() {
   if (!BIG) return sizeof(Real) == 8 ? SP_SMALL_F64_WAVES : 3;
@@ -136,7 +143,7 @@ __global__ void __launch_bounds__(64, (sp_min_waves<Real, BIG, PAT>())) sp_step_
   __syncthreads();
 #pragma nounroll
   for (int f = 0; f < frame_skip; ++f) {
-#if SP_OPAQUE_LANE
+#if SP_OPAQUE_LANE && defined(__HIP_DEVICE_COMPILE__)
     int ln = lane;
     DART_OPAQUE(ln);
     __builtin_assume(ln >= 0 && ln < 64);

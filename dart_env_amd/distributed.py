@@ -85,22 +85,45 @@ class ShardedDartVectorEnv:
             out = torch.cat(parts)
         return out.reshape(w, -1), w
 
-    def gather_rollout(self, obs, reward, done):
+    def _resident_outputs(self):
+        """The last host-buffer step's outputs where the kernel left them in HBM (dart_device_outputs), as torch tensors over that memory
+        -- or None when the stepper has no such view (CPU stand-ins of the tests)."""
+        import torch
+        st = self.venv.env._stepper
+        if not hasattr(st, "device_outputs") or not torch.cuda.is_available():
+            return None
+        po, pr, pd, _ = st.device_outputs()
+        n, k = self.count, self.venv.env.obs_dim
+
+        class _Mem:     # (the CUDA array interface: torch wraps the memory without copying it)
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+        dev = torch.device("cuda", st.device)
+        return (torch.as_tensor(_Mem(po, (n, k), "<f4"), device=dev), torch.as_tensor(_Mem(pr, (n,), "<f4"), device=dev),
+                torch.as_tensor(_Mem(pd, (n,), "|u1"), device=dev))
+
+    def gather_rollout(self, obs, reward, done, force_collective=False):
         """Host arrays of this rank's last step -> full-batch arrays in global env order on every rank: obs f32 (N, k), reward f64 (N,),
-        done bool (N,).  Requires equal shard sizes (total_envs % world_size == 0) like the 8 x 65 536 config.  For outputs that are
-        already in HBM use step_device() + gather_rollout_device(): no host round trip at all."""
+        done bool (N,).  Requires equal shard sizes (total_envs % world_size == 0) like the 8 x 65 536 config.  Under RCCL the shard is
+        NOT uploaded again: the step that produced `obs` left the same values in HBM (dart_device_outputs), the all-gather reads them
+        there and only the gathered batch crosses PCIe, once (round 5; rounds 1-4 went numpy -> device -> all-gather -> host).  For a
+        learner on the GPU use step_device() + gather_rollout_device(): no host copy at all."""
         import torch
         import torch.distributed as dist
-        if self.world_size == 1 or not dist.is_initialized():
+        if not dist.is_initialized() or (self.world_size == 1 and not force_collective):
             return obs, reward, done
         assert self.total_envs % self.world_size == 0, "gather_rollout needs equal shards"
         n, k = obs.shape
-        packed = self._pack(torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)),
-                            torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)),
-                            torch.from_numpy(np.ascontiguousarray(done).astype(np.uint8)))
-        if dist.get_backend() == "nccl":
-            packed = packed.cuda()
-        full, w = self._all_gather_bytes(packed)
+        resident = self._resident_outputs() if dist.get_backend() == "nccl" else None
+        if resident is not None:
+            packed = self._pack(*resident)
+        else:
+            packed = self._pack(torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)),
+                                torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)),
+                                torch.from_numpy(np.ascontiguousarray(done).astype(np.uint8)))
+            if dist.get_backend() == "nccl":
+                packed = packed.cuda()
+        full, w = self._all_gather_bytes(packed, force_collective)
         o, r, d = self._unpack(full, w, n, k)
         return o.cpu().numpy(), r.cpu().numpy().astype(np.float64), d.cpu().numpy() != 0
 

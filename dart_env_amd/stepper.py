@@ -32,7 +32,7 @@ EXPORTS = [
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
     "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses", "dart_snapshot", "dart_restore", "dart_timer_mark", "dart_timer_elapsed",
     "dart_output_layout", "dart_register_output", "dart_unregister_output", "dart_step_async_to",
-    "dart_register_host_buffer", "dart_unregister_host_buffer",
+    "dart_register_host_buffer", "dart_unregister_host_buffer", "dart_device_outputs",
 ]
 
 
@@ -102,6 +102,7 @@ def load_library(path: Optional[str] = None):
     L.dart_step_async_to.argtypes = [vp, C.POINTER(C.c_float), C.c_void_p]
     L.dart_register_host_buffer.argtypes = [vp, C.c_void_p, C.c_uint64]
     L.dart_unregister_host_buffer.argtypes = [vp, C.c_void_p]
+    L.dart_device_outputs.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.dart_host_views.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
                                   C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint8))]
     L.dart_get_episode_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]
@@ -282,7 +283,7 @@ class HipStepper:
     def _free_block(self):
         """A registered output block no caller array refers to any more, or a new one (None when the pool is exhausted or pooling is
         off).  Layout of a block: [obs | reward f32 | done | truncated] exactly as the device block, then (N) float64 rewards -- the
-        type gym.vector returns -- filled on the host.
+        type gym.vector returns -- written by the same copy kernel (round 5; rounds 3-4 converted them on the host after every step).
         Ownership is explicit (round 4; it used to be inferred from sys.getrefcount): the arrays a step returns are views of a LEASE --
         a ctypes array aliasing the block, made for that one step -- and numpy keeps the lease alive as the base of every view derived
         from them; a weakref finalizer on the lease returns the block to the pool when the last such view is gone.  copy=True semantics
@@ -297,7 +298,7 @@ class HipStepper:
         if len(pool) >= self._POOL_SETS:
             return None
         total, _ = self._layout()
-        blk = np.empty(total + 8 * self.num_envs, dtype=np.uint8)
+        blk = np.empty(total, dtype=np.uint8)
         rc = self.L.dart_register_output(self.h, blk.ctypes.data_as(C.c_void_p))
         if rc != DART_OK:
             return None
@@ -341,8 +342,8 @@ class HipStepper:
         r32 = blk[off[1]:off[1] + 4 * n].view(np.float32)
         done = blk[off[2]:off[2] + n].view(np.bool_)        # the kernels write exactly 0 / 1
         trunc = blk[off[3]:off[3] + n].view(np.bool_)
-        rew = blk[total:total + 8 * n].view(np.float64)
-        np.copyto(rew, r32)
+        r64 = total - ((8 * n + 255) & ~255)     # the block's tail: float64 rewards, converted by the copy kernel (include/dart_stepper.h)
+        rew = blk[r64:r64 + 8 * n].view(np.float64)
         return obs, rew, done, trunc
 
     def _outs(self):
@@ -375,6 +376,13 @@ class HipStepper:
             self._host_views = (np.ctypeslib.as_array(po, shape=(n, self.obs_dim)), np.ctypeslib.as_array(pr, shape=(n,)),
                                 np.ctypeslib.as_array(pd, shape=(n,)), np.ctypeslib.as_array(pt, shape=(n,)))
         return self._host_views
+
+    def device_outputs(self):
+        """-> device addresses (ints) of the last host-buffer step's obs (N, obs_dim) f32 / reward (N) f32 / done (N) u8 / truncated (N) u8,
+        still resident in HBM until the next step or reset (dart_device_outputs)."""
+        p = [C.c_void_p() for _ in range(4)]
+        self._check(self.L.dart_device_outputs(self.h, *[C.byref(x) for x in p]))
+        return tuple(int(x.value) for x in p)
 
     def step_wait(self, copy=True):
         """copy=True: arrays the caller owns (views of a page-locked block of this step; see _free_block).  copy=False: views of the

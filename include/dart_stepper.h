@@ -181,9 +181,17 @@ int dart_debug_dump(DartStepper* h, double* out160);
  * reference gym/vector/sync_vector_env.py:83). */
 int dart_host_views(DartStepper* h, const float** obs, const float** reward_f32, const uint8_t** done, const uint8_t** truncated);
 
+/* Where the outputs of the last HOST-buffer step (dart_step / dart_step_async[_to] + dart_step_wait) still sit in HBM: the device block the
+ * host copies were made from -- (N, obs_dim) float32, (N) float32, (N) u8, (N) u8 -- valid until the next step / reset on this handle.  For
+ * a consumer on the device that follows a host-driven loop (the rollout all-gather of dart_env_amd/distributed.py::gather_rollout: "RCCL
+ * only to gather rollouts") -- it need not upload again what the step just produced there. */
+int dart_device_outputs(DartStepper* h, const float** d_obs, const float** d_reward_f32, const uint8_t** d_done, const uint8_t** d_truncated);
+
 /* The outputs of a step as ONE caller-owned block -- the zero-staging form of the host-buffer path ("copied back once per
  * batched step", reference gym/vector/vector_env.py:68-92): dart_output_layout gives the block's size and the byte offsets of
- * obs (N, obs_dim) f32 / reward (N) f32 / done (N) u8 / truncated (N) u8 inside it; dart_register_output page-locks a caller
+ * obs (N, obs_dim) f32 / reward (N) f32 / done (N) u8 / truncated (N) u8 inside it; the LAST round256(8 N) bytes of the block hold
+ * the rewards once more as (N) float64 -- the type the reference's API returns -- converted on the device (round 5; offset =
+ * total_bytes - ((8 N + 255) & ~255)); dart_register_output page-locks a caller
  * buffer of that size (hipHostRegister; the caller keeps it alive until dart_unregister_output or dart_destroy);
  * dart_step_async_to enqueues H2D actions, kernel, auto-reset and a SINGLE D2H copy straight into the block;
  * dart_step_wait(h, NULL, NULL, NULL, NULL) then only synchronises.  A step's results stay valid for as long as the caller does

@@ -256,7 +256,7 @@ def test_output_blocks_are_leased_to_the_callers_arrays_explicitly():
         def dart_output_layout(self, h, tot, off):
             n, k = 8, 3
             ob, rb, db = 4 * n * k, 4 * n, n
-            tot._obj.value = ob + rb + 2 * db
+            tot._obj.value = ob + rb + 2 * db + ((8 * n + 255) & ~255)     # ... + the float64 rewards behind the device block (round 5)
             for i, v in enumerate((0, ob, ob + rb, ob + rb + db)):
                 off[i] = v
             return st.DART_OK

@@ -41,7 +41,9 @@ g = buf.gather(force_collective=True)          # the all_gather_into_tensor call
 torch.cuda.synchronize()
 ok = all(torch.equal(g[k][0], getattr(buf, k)) for k in ("obs", "actions", "rewards", "dones", "truncated"))
 ob, r, d, infos = venv.step(buf.actions[0].cpu().numpy())
-fo, fr, fd = venv.gather_rollout(ob, r, d)
+fo, fr, fd = venv.gather_rollout(ob, r, d, force_collective=True)     # resident path: the all-gather reads the step's outputs where they sit in HBM
+import numpy as np
+host_ok = bool(venv._resident_outputs() is not None and np.array_equal(fo, ob) and np.array_equal(fr, r) and np.array_equal(fd, d))
 # the device-resident form: step in HBM, one packed uint8 all-gather over RCCL, nothing touches the host
 dob, drew, ddone, dtr = venv.step_device(buf.actions[1])
 gob, grew, gdone = venv.gather_rollout_device(force_collective=True)
@@ -49,7 +51,7 @@ torch.cuda.synchronize()
 dev_ok = bool(gob.is_cuda and gob.dtype == torch.float32 and gdone.dtype == torch.uint8 and torch.equal(gob, dob) and torch.equal(grew, drew)
               and torch.equal(gdone, ddone))
 print(json.dumps({"ok": bool(ok), "shape": list(g["obs"].shape), "backend": dist.get_backend(), "dones": int(buf.dones.sum().item()),
-                  "gather_rollout_rows": int(fo.shape[0]), "device_gather_ok": dev_ok, "device_gather_rows": int(gob.shape[0])}))
+                  "gather_rollout_rows": int(fo.shape[0]), "gather_rollout_resident_ok": host_ok, "device_gather_ok": dev_ok, "device_gather_rows": int(gob.shape[0])}))
 venv.close()
 dist.destroy_process_group()
 """
@@ -71,3 +73,4 @@ def test_rollout_buffer_gather_runs_over_rccl():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["ok"] and d["backend"] == "nccl" and d["shape"] == [1, 17, 1024, 11] and d["dones"] > 0 and d["gather_rollout_rows"] == 1024
     assert d["device_gather_ok"] and d["device_gather_rows"] == 1024
+    assert d["gather_rollout_resident_ok"]      # gather_rollout() took the shard from HBM (dart_device_outputs) and returned the step's own values

@@ -500,7 +500,7 @@ def test_rollout_buffer_and_episode_statistics_against_the_oracle():
     venv.close(); oenv.close()
 
 
-def test_step_outputs_in_registered_blocks_keep_copy_semantics(monkeypatch):
+def test_step_outputs_in_registered_blocks_keep_copy_semantics():
     """dart_step_async_to: a step's outputs land in a page-locked block the caller sees directly (no staging memcpy).  The arrays a
     step returned must stay intact while the caller holds them, however many steps follow (gym.vector's copy=True,
     sync_vector_env.py:83), blocks must be reused once dropped, and the values must be those of the staging path bit for bit."""
@@ -509,11 +509,8 @@ def test_step_outputs_in_registered_blocks_keep_copy_semantics(monkeypatch):
     acts = np.random.RandomState(3).uniform(-1, 1, (12, n, 3)).astype(np.float32)
 
     def run(pool):
-        if not pool:
-            monkeypatch.setenv("DART_NO_OUT_POOL", "1")
-        else:
-            monkeypatch.delenv("DART_NO_OUT_POOL", raising=False)
         s = st.HipStepper(card, n, precision=64)
+        s.output_pool = pool          # (False: round 2's staging path -- an attribute, the host layer reads no environment switches)
         s.configure(st.CFG_AUTORESET, 1); s.configure(st.CFG_SEED, 4)
         s.reset(None, None, None, want_obs=False)
         kept, copies = [], []

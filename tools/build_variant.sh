@@ -9,7 +9,8 @@ mkdir -p $R/build_ab/$NAME $R/abtest
 OBJS=""
 for u in dart_stepper planar_f32 planar_f64 spatial_f32 spatial_f64; do
   if [[ ",$UNITS," == *",$u,"* ]]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -Rpass-analysis=kernel-resource-usage \
+    UF=""; if [[ $u == spatial_* && -z "$DART_NO_UNIT_FLAGS" ]]; then UF="-mllvm -disable-machine-licm"; fi   # the product build's per-unit flags (__graft_entry__.UNIT_FLAGS)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $UF "$@" -Rpass-analysis=kernel-resource-usage \
       -c $R/dart_env_amd/csrc/$u.hip -o $R/build_ab/$NAME/$u.o 2> $R/build_ab/$NAME/$u.res.txt &
     OBJS="$OBJS $R/build_ab/$NAME/$u.o"
   else

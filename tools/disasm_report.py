@@ -21,6 +21,10 @@ def main():
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
            "-I" + os.path.join(ROOT, "dart_env_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
            os.path.join(ROOT, "dart_env_amd", "csrc", unit + ".hip"), "-o", out] + os.environ.get("DART_EXTRA_HIPFLAGS", "").split()
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import UNIT_FLAGS      # the product build's per-unit flags (tree kernels: no machine LICM)
+    if os.environ.get("DART_NO_UNIT_FLAGS") != "1":
+        cmd += UNIT_FLAGS.get(unit, [])
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     stats, name = {}, None
     for line in open(out):

@@ -22,14 +22,18 @@ ap.add_argument("--n", type=int, default=256); ap.add_argument("--poison", defau
 ap.add_argument("--when", default="later"); ap.add_argument("--reps", type=int, default=4); ap.add_argument("--steps", type=int, default=5)
 a = ap.parse_args()
 H = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "gpu_kernels", "libpoison_harness.so"))
-pat = int(a.pattern, 0)
+_prng = __import__("random").Random(12345)
+
+
+def next_pattern():       # "random": a fresh 32-bit word for every poisoning -- leftovers that differ from launch to launch, under control
+    return _prng.getrandbits(32) | 1 if a.pattern == "random" else int(a.pattern, 0)
 
 
 def poison():
     kinds = ("scratch", "lds", "regs") if a.poison == "all" else (a.poison,)
     for k in kinds:
         if k != "none":
-            rc = getattr(H, "poison_" + k)(C.c_uint32(pat))
+            rc = getattr(H, "poison_" + k)(C.c_uint32(next_pattern()))
             assert rc == 0, (k, rc)
 
 

@@ -25,11 +25,16 @@ def mk(n):
     s = st.HipStepper(card, n, precision=64)
     s.configure(st.CFG_AUTORESET, 1)
     s.reset(None, None, None, want_obs=False)
-    a = (torch.rand((n, 3), device="cuda") * 2 - 1).contiguous()
+    a = (torch.rand((16, n, 3), device="cuda") * 2 - 1).contiguous()     # a ring of 16 action batches (PROBE_CONST=1: one batch, what rounds 3-4 timed)
     bufs = (torch.empty((n, 11), device="cuda"), torch.empty(n, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda"),
             torch.empty(n, dtype=torch.uint8, device="cuda"))
-    ptr = (a.data_ptr(),) + tuple(b.data_ptr() for b in bufs)
-    return s, ptr, (a, bufs)
+    class Ptr:
+        k = 0
+        def __iter__(self):
+            Ptr.k += 1
+            off = 0 if os.environ.get("PROBE_CONST") == "1" else (Ptr.k % 16) * n * 3 * 4
+            return iter((a.data_ptr() + off,) + tuple(b.data_ptr() for b in bufs))
+    return s, Ptr(), (a, bufs)
 
 
 def bench(name, f, k=400, warm=300):

@@ -17,12 +17,12 @@ def main():
     for path in sorted(glob.glob(os.path.join(ROOT, "build", "obj", "*.res.txt"))):
         cur = None
         for line in open(path):
-            m = re.search(r"remark:\s+(?:Function Name|Name): (\S+)", line)
+            m = re.search(r"remark:\s+(?:\S+:\d+:\d+:\s+)?(?:Function Name|Name): (\S+)", line)   # (with -save-temps the location follows "remark:")
             if m:
                 cur = {"name": m.group(1)}
                 rows.append(cur)
                 continue
-            m = re.search(r"remark:\s+([\w][\w \[\]/]*?):\s+(\S+)", line)
+            m = re.search(r"remark:\s+(?:\S+:\d+:\d+:\s+)?([\w][\w \[\]/]*?):\s+(\S+)", line)
             if m and cur is not None:
                 cur[m.group(1).strip()] = m.group(2)
     names = [r["name"] for r in rows]

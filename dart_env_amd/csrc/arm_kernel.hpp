@@ -178,6 +178,14 @@ __device__ __forceinline__ void arm_write_obs(const ArmParams<Real, NP>& P, cons
   o[3 * NP + 2] = (float)(tx - tgt[0]); o[3 * NP + 3] = (float)(P.height - tgt[1]); o[3 * NP + 4] = (float)(ty - tgt[2]);
 }
 template <int NP> __device__ __host__ constexpr int arm_obs_dim() { return 3 * NP + 5; }
+// task 0 (round 5): a physics-only card of this shape (envs.DartEnv on a user's .skel, dart_env.py:28-175): torques as given, obs = [q, dq],
+// reward 0, never done
+template <int NP> __device__ __host__ constexpr int arm_obs_dim_rt(int task) { return task == 0 ? 2 * NP : arm_obs_dim<NP>(); }
+template <class Real, int NP>
+__device__ __forceinline__ void arm_write_obs_rt(const ArmParams<Real, NP>& P, const Real (&q)[NP], const Real (&dq)[NP], const Real (&tgt)[3], float* __restrict__ o) {
+  if (P.task == 0) { sfor<0, NP>([&](auto K) { constexpr int k = K; o[k] = (float)q[k]; o[NP + k] = (float)dq[k]; }); return; }
+  arm_write_obs<Real, NP>(P, q, dq, tgt, o);
+}
 
 template <class Real, int NP>
 __global__ void __launch_bounds__(64) arm_step_kernel(ArmParams<Real, NP> P, int64_t n_envs, Real* __restrict__ qs, Real* __restrict__ dqs,
@@ -201,7 +209,7 @@ __global__ void __launch_bounds__(64) arm_step_kernel(ArmParams<Real, NP> P, int
     a2 += a * a;                                  // reacher2d.py:34: the control cost takes the action as given
     Real cl = (a > P.act_hi[k]) ? P.act_hi[k] : a;   // comparison clamp (reacher2d.py:18-23): a NaN action stays NaN
     cl = (cl < P.act_lo[k]) ? P.act_lo[k] : cl;
-    tau[k] = cl * P.act_scale[k];
+    tau[k] = P.task == 0 ? a : cl * P.act_scale[k];
   });
   DART_PIN_VGPR(el_in); DART_PIN_VGPR(ep_in);   // pinned where the state loads are awaited anyway: the compiler must not sink them
 #pragma unroll 1
@@ -209,7 +217,7 @@ __global__ void __launch_bounds__(64) arm_step_kernel(ArmParams<Real, NP> P, int
   Real tx, ty;
   arm_tip<Real, NP>(P, q, tx, ty);
   const Real vx = tx - tgt[0], vy = P.height - tgt[1], vz = ty - tgt[2];
-  const Real rew = -sqrt(vx * vx + vy * vy + vz * vz) - a2;      // reacher2d.py:31-35; the task itself never ends an episode
+  const Real rew = P.task == 0 ? Real(0) : -sqrt(vx * vx + vy * vy + vz * vz) - a2;      // reacher2d.py:31-35; the task itself never ends an episode
   int el = el_in + 1;
   const bool trunc = (P.max_steps > 0) && (el >= P.max_steps);
   const bool dn = trunc;
@@ -223,7 +231,7 @@ __global__ void __launch_bounds__(64) arm_step_kernel(ArmParams<Real, NP> P, int
   if (valid) {
     sfor<0, N>([&](auto I) { constexpr int i = I; qs[(int64_t)i * n_envs + e] = q[i]; dqs[(int64_t)i * n_envs + e] = dq[i]; });
     elapsed[e] = el;
-    arm_write_obs<Real, NP>(P, q, dq, tgt, obs + e * arm_obs_dim<NP>());
+    arm_write_obs_rt<Real, NP>(P, q, dq, tgt, obs + e * arm_obs_dim_rt<NP>(P.task));
     reward[e] = (float)rew;
     done[e] = dn ? 1 : 0;
     truncated[e] = trunc ? 1 : 0;
@@ -257,7 +265,7 @@ __global__ void __launch_bounds__(256) arm_reset_kernel(ArmParams<Real, NP> P, i
   }
   if (obs && (m || !obs_masked_only)) {
     sfor<0, 3>([&](auto I) { constexpr int i = I; tgt[i] = P.tstate[4 * e + i]; });
-    arm_write_obs<Real, NP>(P, q, dq, tgt, obs + e * arm_obs_dim<NP>());
+    arm_write_obs_rt<Real, NP>(P, q, dq, tgt, obs + e * arm_obs_dim_rt<NP>(P.task));
   }
 }
 

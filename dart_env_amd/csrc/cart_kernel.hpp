@@ -32,9 +32,9 @@ struct CartParams {
   int frame_skip, max_steps, task, iters;
 };
 
-// one world step: q, dq in/out, tau on the slider
+// one world step: q, dq in/out, tau = generalized forces (the three tasks drive the slider only; a physics-only card every dof)
 template <class Real, int NP>
-__device__ __forceinline__ void cart_world_step(const CartParams<Real, NP>& P, Real (&q)[1 + NP], Real (&dq)[1 + NP], Real tau_x) {
+__device__ __forceinline__ void cart_world_step(const CartParams<Real, NP>& P, Real (&q)[1 + NP], Real (&dq)[1 + NP], const Real (&tau)[1 + NP]) {
   constexpr int N = 1 + NP, NL = N;   // link 0 = the cart (translates only)
   Real c[NL], s[NL], px[NL], py[NL], lx[NL], ly[NL], om[NL], apx[NL], apy[NL];
   Real mc[NL], dcx[NL], dcy[NL], Ip[NL], Fx[NL], Fy[NL], Nz[NL];
@@ -70,7 +70,7 @@ __device__ __forceinline__ void cart_world_step(const CartParams<Real, NP>& P, R
   });
   Real H[N * (N + 1) / 2], rhs[N];
   H[tri(0, 0)] = mc[0];
-  rhs[0] = tau_x - Fx[0];
+  rhs[0] = tau[0] - Fx[0];
   sfor<1, NL>([&](auto K) {
     constexpr int k = K, i = k - 1;
     H[tri(k, 0)] = -P.sigma[i] * dcy[k];
@@ -78,7 +78,7 @@ __device__ __forceinline__ void cart_world_step(const CartParams<Real, NP>& P, R
       constexpr int j = J;
       H[tri(k, j)] = P.sigma[i] * P.sigma[j - 1] * (Ip[k] + dcx[k] * (px[k] - px[j]) + dcy[k] * (py[k] - py[j]));
     });
-    rhs[k] = -P.sigma[i] * Nz[k];
+    rhs[k] = tau[k] - P.sigma[i] * Nz[k];
   });
   sfor<0, N>([&](auto I) {
     constexpr int i = I;
@@ -173,13 +173,18 @@ __global__ void __launch_bounds__(64) cart_step_kernel(CartParams<Real, NP> P, i
   sfor<0, N>([&](auto I) { constexpr int i = I; q[i] = qs[(int64_t)i * n_envs + ec]; dq[i] = dqs[(int64_t)i * n_envs + ec]; });
   int el_in = elapsed[ec];            // fetched with the state: a load issued in the epilogue would be a bare HBM round trip
   uint32_t ep_in = episode[ec];
-  const Real a = (Real)actions[ec];
+  // task 0 (round 5): a physics-only card -- what envs.DartEnv builds from a user's .skel of this shape (dart_env.py:28-175): the action is
+  // the generalized force on every dof (no clamp, no scale), the observation [q, dq], reward 0, never done
+  const bool phys = P.task == 0;
+  const Real a = (Real)actions[phys ? ec * N : ec];
   Real cl = (a > P.act_hi) ? P.act_hi : a;      // comparison clamp; these three tasks leave act_lo / act_hi at -/+inf
   cl = (cl < P.act_lo) ? P.act_lo : cl;
-  const Real tau_x = cl * P.act_scale;
+  Real tau[N];
+  tau[0] = phys ? a : cl * P.act_scale;
+  sfor<1, N>([&](auto K) { constexpr int k = K; tau[k] = phys ? (Real)actions[ec * N + k] : Real(0); });
   DART_PIN_VGPR(el_in); DART_PIN_VGPR(ep_in);   // pinned where the state loads are awaited anyway: the compiler must not sink them
 #pragma unroll 1
-  for (int f = 0; f < P.frame_skip; ++f) cart_world_step<Real, NP>(P, q, dq, tau_x);
+  for (int f = 0; f < P.frame_skip; ++f) cart_world_step<Real, NP>(P, q, dq, tau);
   bool fin = true, bounded = true;
   sfor<0, N>([&](auto I) {
     constexpr int i = I;

@@ -232,6 +232,13 @@ __device__ __forceinline__ void chain3d_write_obs(const Chain3Params<Real, NL>& 
   o[3 * NL + 3] = (float)(tip.x - tgt[0]); o[3 * NL + 4] = (float)(tip.y - tgt[1]); o[3 * NL + 5] = (float)(tip.z - tgt[2]);
 }
 template <int NL> __device__ __host__ constexpr int chain3d_obs_dim() { return 3 * NL + 6; }
+// task 0 (round 5): a physics-only card of this shape (envs.DartEnv on a user's .skel): torques as given, obs = [q, dq], reward 0, never done
+template <int NL> __device__ __host__ constexpr int chain3d_obs_dim_rt(int task) { return task == 0 ? 2 * NL : chain3d_obs_dim<NL>(); }
+template <class Real, int NL>
+__device__ __forceinline__ void chain3d_write_obs_rt(const Chain3Params<Real, NL>& P, const Real (&q)[NL], const Real (&dq)[NL], const Real (&tgt)[3], float* __restrict__ o) {
+  if (P.task == 0) { sfor<0, NL>([&](auto K) { constexpr int k = K; o[k] = (float)q[k]; o[NL + k] = (float)dq[k]; }); return; }
+  chain3d_write_obs<Real, NL>(P, q, dq, tgt, o);
+}
 
 template <class Real, int NL, bool FRIC>
 __global__ void __launch_bounds__(64) chain3d_step_kernel(Chain3Params<Real, NL> P, int64_t n_envs, Real* __restrict__ qs, Real* __restrict__ dqs,
@@ -254,7 +261,7 @@ __global__ void __launch_bounds__(64) chain3d_step_kernel(Chain3Params<Real, NL>
     const Real av = (Real)actions[ec * N + k];
     Real cl = (av > P.act_hi[k]) ? P.act_hi[k] : av;   // comparison clamp (reacher.py:17-22): a NaN action stays NaN
     cl = (cl < P.act_lo[k]) ? P.act_lo[k] : cl;
-    tau[k] = cl * P.act_scale[k];
+    tau[k] = P.task == 0 ? av : cl * P.act_scale[k];
     tau2 += tau[k] * tau[k];                           // reacher.py:26: the control cost takes the scaled, clamped torque
   });
   DART_PIN_VGPR(el_in); DART_PIN_VGPR(ep_in);   // pinned where the state loads are awaited anyway: the compiler must not sink them
@@ -269,8 +276,8 @@ __global__ void __launch_bounds__(64) chain3d_step_kernel(Chain3Params<Real, NL>
   for (int f = 0; f < P.frame_skip; ++f) chain3d_world_step<Real, NL, FRIC>(P, q, dq, tau);
   bool fin = true;
   sfor<0, N>([&](auto I) { constexpr int i = I; fin = fin && isfinite(q[i]) && isfinite(dq[i]); });
-  const Real rew = -dist0 - tau2 * P.ctrl_w;
-  const bool task_done = !(fin && (dist0 > P.done_dist));
+  const Real rew = P.task == 0 ? Real(0) : -dist0 - tau2 * P.ctrl_w;
+  const bool task_done = P.task != 0 && !(fin && (dist0 > P.done_dist));
   int el = el_in + 1;
   const bool trunc = (P.max_steps > 0) && (el >= P.max_steps);
   const bool dn = task_done || trunc;
@@ -284,7 +291,7 @@ __global__ void __launch_bounds__(64) chain3d_step_kernel(Chain3Params<Real, NL>
   if (valid) {
     sfor<0, N>([&](auto I) { constexpr int i = I; qs[(int64_t)i * n_envs + e] = q[i]; dqs[(int64_t)i * n_envs + e] = dq[i]; });
     elapsed[e] = el;
-    chain3d_write_obs<Real, NL>(P, q, dq, tgt, obs + e * chain3d_obs_dim<NL>());
+    chain3d_write_obs_rt<Real, NL>(P, q, dq, tgt, obs + e * chain3d_obs_dim_rt<NL>(P.task));
     reward[e] = (float)rew;
     done[e] = dn ? 1 : 0;
     truncated[e] = (trunc && !task_done) ? 1 : 0;
@@ -318,7 +325,7 @@ __global__ void __launch_bounds__(256) chain3d_reset_kernel(Chain3Params<Real, N
   }
   if (obs && (m || !obs_masked_only)) {
     sfor<0, 3>([&](auto I) { constexpr int i = I; tgt[i] = P.tstate[4 * e + i]; });
-    chain3d_write_obs<Real, NL>(P, q, dq, tgt, obs + e * chain3d_obs_dim<NL>());
+    chain3d_write_obs_rt<Real, NL>(P, q, dq, tgt, obs + e * chain3d_obs_dim_rt<NL>(P.task));
   }
 }
 

@@ -146,7 +146,7 @@ std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
   if (c.act_dim != T::NA || c.act_dof0 != T::NDOF - T::NA) return "action layout";
   if (topo_physics<T>::value != (c.task == DART_TASK_NONE)) return "task";   // PhysTopo variants serve DART_TASK_NONE, the others never
   if (c.obs_dim != obs_dim_of<T>()) return "obs_dim";
-  if (XZ != (c.task == DART_TASK_SNAKE)) return "task";
+  if (!topo_physics<T>::value && XZ != (c.task == DART_TASK_SNAKE)) return "task";   // (a physics-only card's plane shows in its root axes, below)
   if (c.task != DART_TASK_NONE && c.task != DART_TASK_HOPPER && c.task != DART_TASK_WALKER2D && c.task != DART_TASK_HALFCHEETAH &&
       c.task != DART_TASK_SNAKE) return "task";
   for (int d = 0; d < c.ndofs; d++) if (c.joint_friction[d] != 0.0) return "joint Coulomb friction";
@@ -335,8 +335,8 @@ template <class Real, int NP>
 std::string fill_cart(const DartModelCard& c, CartParams<Real, NP>& P) {
   constexpr int N = 1 + NP;
   if (c.ndofs != N || c.nbodies < N) return "body/dof count";
-  if (c.task != DART_TASK_CARTPOLE && c.task != DART_TASK_CARTPOLE_SWINGUP && c.task != DART_TASK_DOUBLE_PENDULUM) return "task";
-  if (c.act_dim != 1 || c.act_dof0 != 0) return "action layout";
+  if (c.task != DART_TASK_NONE && c.task != DART_TASK_CARTPOLE && c.task != DART_TASK_CARTPOLE_SWINGUP && c.task != DART_TASK_DOUBLE_PENDULUM) return "task";
+  if (c.act_dim != (c.task == DART_TASK_NONE ? N : 1) || c.act_dof0 != 0) return "action layout";   // physics-only: a generalized force per dof
   if (c.obs_dim != cart_obs_dim<NP>(c.task)) return "obs_dim";
   if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be along y";
   for (int d = 0; d < c.ndofs; d++) if (c.joint_friction[d] != 0.0) return "joint Coulomb friction";
@@ -467,10 +467,10 @@ struct ArmImplT : Impl {
 // their link.  Task: the 2-D reacher (reacher2d.py).
 template <class Real, int NP>
 std::string fill_arm(const DartModelCard& c, ArmParams<Real, NP>& P) {
-  if (c.task != DART_TASK_REACHER2D) return "task";
+  if (c.task != DART_TASK_REACHER2D && c.task != DART_TASK_NONE) return "task";
   if (c.ndofs != NP || c.nbodies < NP) return "body/dof count";
   if (c.act_dim != NP || c.act_dof0 != 0) return "action layout";
-  if (c.obs_dim != arm_obs_dim<NP>()) return "obs_dim";
+  if (c.obs_dim != arm_obs_dim_rt<NP>(c.task)) return "obs_dim";
   if (c.gravity[0] != 0 || c.gravity[2] != 0) return "gravity must be normal to the plane of motion";
   for (int s = 0; s < c.nshapes; s++) if (c.shape_collidable[s]) return "collidable shapes";
   int link_of_body[DART_MAX_BODIES], body_of_link[NP], nl = 0;
@@ -510,7 +510,7 @@ std::string fill_arm(const DartModelCard& c, ArmParams<Real, NP>& P) {
               mb * ((bx - nx) * (bx - nx) + (by - ny) * (by - ny));
     lm[k] = m; lcx[k] = nx; lcy[k] = ny;
   }
-  const int tb = c.aux_body[0];   // reacher2d.py:31: bodynodes[-1].com()
+  const int tb = c.task == DART_TASK_NONE ? body_of_link[NP - 1] : c.aux_body[0];   // reacher2d.py:31: bodynodes[-1].com() (a physics-only card names no tip)
   if (tb < 0 || tb >= c.nbodies || link_of_body[tb] != NP - 1) return "tip body must ride on the last link";
   if (c.aux_real[1] != 0) return "tip offset off plane";
   P.tipx = (Real)(wx[tb] + c.aux_real[0]); P.tipy = (Real)(wy[tb] + c.aux_real[2]);
@@ -591,8 +591,8 @@ struct Chain3dImplT : Impl {
 // 3-D reacher (reacher.py).
 template <class Real, int NL, bool FRIC>
 std::unique_ptr<Impl> make_chain3d(const DartModelCard& c, std::string& why) {
-  if (c.task != DART_TASK_REACHER3D) { why += "task"; return nullptr; }
-  if (c.ndofs != NL || c.act_dim != NL || c.act_dof0 != 0 || c.obs_dim != chain3d_obs_dim<NL>()) { why += "dof / action / observation layout"; return nullptr; }
+  if (c.task != DART_TASK_REACHER3D && c.task != DART_TASK_NONE) { why += "task"; return nullptr; }
+  if (c.ndofs != NL || c.act_dim != NL || c.act_dof0 != 0 || c.obs_dim != chain3d_obs_dim_rt<NL>(c.task)) { why += "dof / action / observation layout"; return nullptr; }
   auto Mp = std::make_unique<SpatialModel<Real>>();
   SpatialModel<Real>& M = *Mp;
   const std::string w = fill_spatial<Real>(c, M);
@@ -602,7 +602,7 @@ std::unique_ptr<Impl> make_chain3d(const DartModelCard& c, std::string& why) {
   if ((M.has_joint_friction != 0) != FRIC) { why += "joint friction"; return nullptr; }
   for (int i = 0; i < NL; i++)
     if (M.parent[i] != i - 1 || M.jtype[i] != 2 || M.dof[i] != i) { why += "not a chain of revolute links in dof order"; return nullptr; }
-  if (M.aux_link[0] != NL - 1) { why += "tip body must be the last link"; return nullptr; }
+  if (c.task != DART_TASK_NONE && M.aux_link[0] != NL - 1) { why += "tip body must be the last link"; return nullptr; }
   auto p = std::make_unique<Chain3dImplT<Real, NL, FRIC>>();
   Chain3Params<Real, NL>& P = p->P;
   for (int i = 0; i < NL; i++) {
@@ -646,6 +646,11 @@ std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool
   if (auto p = make_for_topology<Real, CheetahTopo, void>(c, why, allow_static)) return p;
   why += "; snake chain in the x-z plane: ";
   if (auto p = make_for_topology<Real, SnakeTopo, void>(c, why, allow_static)) return p;
+  // physics-only cards (a user's .skel through envs.DartEnv) of the two remaining planar shapes (round 5)
+  why += "; half-cheetah tree, physics only: ";
+  if (auto p = make_for_topology<Real, PhysTopo<CheetahTopo>, void>(c, why, allow_static)) return p;
+  why += "; snake chain, physics only: ";
+  if (auto p = make_for_topology<Real, PhysTopo<SnakeTopo>, void>(c, why, allow_static)) return p;
   why += "; cart + 1 link: ";
   if (auto p = make_cart<Real, 1>(c, why)) return p;
   why += "; cart + 2 links: ";

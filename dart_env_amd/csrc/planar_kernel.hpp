@@ -155,20 +155,21 @@ struct SnakeTopo {  // reference assets/snake_7link.skel: seven links in a chain
 // register tiers of these variants cover that: all four capsules of the hopper chain (an 11-row LCP, no fallback path at all), four
 // (fp64: three) slots of the walker tree as a real call with the wave-served fallback behind it, as for the half cheetah.  (With the
 // base topologies' tiers 65 536 fallen pogo hoppers took 2.4 ms per env-step, every lane waiting its turn in the single-lane solver.)
+template <class T, class = void> struct topo_contacts { static constexpr bool value = true; };
+template <class T> struct topo_contacts<T, decltype((void)T::CONTACTS)> { static constexpr bool value = T::CONTACTS; };
 template <class B> struct PhysTopo : B {
   static constexpr bool ANC_TABLES_RT = true;   // see topo_anc_rt
   static constexpr int NA = B::NDOF;
   static constexpr bool PHYSICS = true;
-  static constexpr int TIER1 = B::NC <= 4 ? B::NC : 4, TIER1_F64 = B::NC <= 4 ? B::NC : 3;
-  static constexpr bool ISOLATED_TIER1 = (B::NC > 4);
-  static constexpr bool WAVE_FALLBACK = (B::NC > 4);
+  // (a base topology that cannot touch the floor -- the snake chain -- has no contact tiers to size)
+  static constexpr int TIER1 = !topo_contacts<B>::value ? 0 : (B::NC <= 4 ? B::NC : 4), TIER1_F64 = !topo_contacts<B>::value ? 0 : (B::NC <= 4 ? B::NC : 3);
+  static constexpr bool ISOLATED_TIER1 = topo_contacts<B>::value && (B::NC > 4);
+  static constexpr bool WAVE_FALLBACK = topo_contacts<B>::value && (B::NC > 4);
 };
 // optional traits (default: a robot in the vertical x-y plane with capsules that can touch the floor, no fluid)
 template <class T, class = void> struct topo_physics { static constexpr bool value = false; };
 template <class T> struct topo_physics<T, decltype((void)T::PHYSICS)> { static constexpr bool value = T::PHYSICS; };
 template <class T> __device__ __host__ constexpr int obs_dim_of() { return topo_physics<T>::value ? 2 * T::NDOF : 2 * T::NDOF - 1; }
-template <class T, class = void> struct topo_contacts { static constexpr bool value = true; };
-template <class T> struct topo_contacts<T, decltype((void)T::CONTACTS)> { static constexpr bool value = T::CONTACTS; };
 template <class T, class = void> struct topo_fluid { static constexpr bool value = false; };
 template <class T> struct topo_fluid<T, decltype((void)T::FLUID)> { static constexpr bool value = T::FLUID; };
 template <class T, class = void> struct topo_plane_xz { static constexpr bool value = false; };
@@ -1928,6 +1929,11 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   if (valid) {
     sfor<0, N>([&](auto I) { constexpr int i = I; qs[(int64_t)i * n_envs + e] = q[i]; dqs[(int64_t)i * n_envs + e] = dq[i]; });
     elapsed[e] = el;
+    // (Round 5 tried staging the observations through LDS so that a workgroup's (64 x obs_dim) block leaves as float4 per lane, and with it
+    // a second destination in page-locked host memory -- no copy kernel behind the step kernel.  Measured, profiles/r05_host_path.txt: the
+    // kernels got SLOWER -- Hopper fp64 31.8 -> 32.1 us, Walker2d fp64 101.0 -> 104.1 us: the epilogue's LDS round trip and its extra live
+    // values cost more than eleven scattered dword stores that nobody waits for -- and the host path gained 7 us of 147, because every wave
+    // reaches its epilogue at the same time: the 3.4 MB cross PCIe after the arithmetic either way.  Reverted.)
     write_obs<Real, T, PT>(P, q, dq, height, obs + e * obs_dim_of<T>());
     reward[e] = (float)rew;
     done[e] = dn ? 1 : 0;

@@ -243,3 +243,75 @@ def test_fallen_user_model_stays_in_the_register_tiers(precision, tq, tdq, model
     big.close()
     # (a fallen walker lies on five to seven capsules, beyond its tiers: every lane is served by the wave in turn -- bounded, not fast)
     assert fallen < (1.2e-3 if model == "pogo" else 40e-3)
+
+
+PHYS_SHAPES = [("halfcheetah", [120, 90, 60, 120, 60, 30], 3, True), ("snake7link", [20] * 6, 3, False), ("cartpole", [5.0], 1, False),
+               ("cartpole_swingup", [5.0], 1, False), ("double_pendulum", [3.0, 3.0], 1, False), ("reacher2d", [2.0, 2.0], 0, False),
+               ("reacher3d", [3.0] * 5, 0, False)]
+
+
+@pytest.mark.parametrize("name,scale,nroot,contacts", PHYS_SHAPES, ids=[s[0] for s in PHYS_SHAPES])
+def test_physics_only_card_of_every_compiled_shape_runs_on_a_lane_kernel(name, scale, nroot, contacts):
+    """a user's .skel (envs.DartEnv builds a DART_TASK_NONE card from it: action = generalized forces, obs = [q, dq],
+    reward 0, never done -- reference dart_env.py:28-175) whose tree is one of the compiled shapes -- the half-cheetah tree with its eight
+    capsules, the seven-link chain in the horizontal plane, cart + one / two links, the two-link arm, the five-link 3-D chain -- is served
+    one env per lane (round 4: hopper chain and walker tree only; everything else fell to the tree kernel, 80x slower).  Here on the host
+    build of the lane kernels against oracle worlds, 100 env-steps under random forces on every actuated dof."""
+    from dart_env_amd.model_card import build_card, load_model
+    from tests.batch_oracle import OracleBatch
+    from tests.emu_lib import EmuStepper
+    m = load_model(name)
+    if not contacts:
+        for s in m.shapes:
+            s.collidable = False
+    card = build_card(m, None)
+    card.frame_skip = 4
+    n, nd = 12, card.ndofs
+    g = EmuStepper(card, n, precision=64)          # raises if no lane kernel takes the card
+    assert card.obs_dim == 2 * nd and card.act_dim == nd
+    ora = OracleBatch(card, n)
+    rng = np.random.RandomState(0)
+    qn = rng.uniform(-.02, .02, (n, nd)); vn = rng.uniform(-.02, .02, (n, nd))
+    ora.reset(None, qn, vn)
+    assert np.abs(g.reset(None, qn, vn) - ora.obs()).max() < 1e-6
+    most = 0
+    for t in range(100):
+        a = np.zeros((n, nd), np.float32); a[:, nroot:] = rng.uniform(-1, 1, (n, nd - nroot)) * (scale if len(scale) == nd - nroot else scale[0])
+        o, r, d, tr = g.step(a); oo, ro, do, _ = ora.step(a)
+        assert not r.any() and not d.any() and np.abs(o - oo).max() < 1e-4, t
+        most = max(most, max(len(w.last_contacts()) for w in ora.worlds))
+    qg, dqg = g.get_state(); qo, dqo = ora.state()
+    assert np.abs(qg - qo).max() < 1e-8 and np.abs(dqg - dqo).max() < 1e-7, (np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+    assert most >= (3 if contacts else 0)          # the cheetah tree ends up on three or more capsules: second register tier
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scale,nroot,contacts", PHYS_SHAPES, ids=[s[0] for s in PHYS_SHAPES])
+def test_physics_only_card_of_every_compiled_shape_reports_a_lane_kernel_on_the_gpu(name, scale, nroot, contacts):
+    """... and on the device: DART_Q_LANE_KERNEL = 1, the same card forced onto the tree kernel (generic_kernel) and oracle worlds agree."""
+    from dart_env_amd import stepper as st
+    from dart_env_amd.model_card import build_card, load_model
+    from tests.batch_oracle import OracleBatch
+    m = load_model(name)
+    if not contacts:
+        for s in m.shapes:
+            s.collidable = False
+    card = build_card(m, None); card.frame_skip = 4
+    tcard = build_card(m, None); tcard.frame_skip = 4; tcard.generic_kernel = 1
+    n, nd = 64, card.ndofs
+    lane = st.HipStepper(card, n, precision=64); tree = st.HipStepper(tcard, n, precision=64)
+    assert lane.query(st.Q_LANE_KERNEL) == 1 and tree.query(st.Q_LANE_KERNEL) == 0
+    ora = OracleBatch(card, n)
+    rng = np.random.RandomState(1)
+    qn = rng.uniform(-.02, .02, (n, nd)); vn = rng.uniform(-.02, .02, (n, nd))
+    for s_ in (lane, tree):
+        s_.reset(None, qn, vn, want_obs=False)
+    ora.reset(None, qn, vn)
+    for t in range(40):
+        a = np.zeros((n, nd), np.float32); a[:, nroot:] = rng.uniform(-1, 1, (n, nd - nroot)) * (scale if len(scale) == nd - nroot else scale[0])
+        lane.step(a); tree.step(a); ora.step(a)
+    ql, dql = lane.get_state(); qt, dqt = tree.get_state(); qo, dqo = ora.state()
+    assert np.abs(ql - qo).max() < 1e-7 and np.abs(dql - dqo).max() < 1e-6, (np.abs(ql - qo).max(), np.abs(dql - dqo).max())
+    assert np.abs(qt - qo).max() < 1e-7 and np.abs(dqt - dqo).max() < 1e-6, (np.abs(qt - qo).max(), np.abs(dqt - dqo).max())
+    lane.close(); tree.close()

@@ -60,6 +60,7 @@ def make(dma=None):
 
 s_stage, s_reg, s_blk = make(), make(), make()
 s_blk_copy, s_blk_zc, s_blk_dk, s_reg_copy = make("copy"), make("zc_actions"), make("d2h_kernel"), make("copy")
+
 arr_reg_copy = caller_arrays()
 for x in arr_reg_copy:
     s_reg_copy.register_host_buffer(x)
@@ -80,6 +81,7 @@ variants = {
     "registered ... DART_CFG_HOST_DMA=copy": lambda: s_reg_copy.step_into(*into(arr_reg_copy)),
 }
 for f in variants.values():
+    _cnt[0] = 0                       # every variant sees the same action sequence (the equality check below relies on it)
     for _ in range(600):
         f()
 # the registered path must give the staging path's numbers: same seeds, same actions, same step count so far

@@ -2,7 +2,7 @@
 # Round profile: rocprofv3 kernel-trace --stats and PMC passes of bench.py (run on the GPU box through gpurun).
 # usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/..., summary gpurun_out/<tag>_rocprof.txt
 # Counters are collected in their own passes (FETCH_SIZE / WRITE_SIZE / SQ_*), never together with a trace domain other than the kernel trace.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

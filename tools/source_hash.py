@@ -28,7 +28,10 @@ def family_files(family):
 
 
 def family_hash(family):
+    import __graft_entry__ as g
     h = hashlib.sha256()
+    units = {"planar": ["planar_f32", "planar_f64"], "spatial": ["spatial_f32", "spatial_f64"], "dart_stepper": ["dart_stepper"]}[family]
+    h.update(" ".join(" ".join(g.UNIT_FLAGS.get(u, [])) for u in units).encode())     # the per-unit compiler flags are part of what was measured
     for path in family_files(family):
         h.update(os.path.relpath(path, ROOT).encode())
         with open(path, "rb") as f:

@@ -598,15 +598,6 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
                                                                                  ref=oref, acts=oacts)
             others.append(entry)
         result["other_configs"] = others
-        # ---- an opt-in mode measured beside its default: the half cheetah's wave vote (DART_CFG_WAVE_VOTE)
-        from dart_env_amd import stepper as st
-        ms0, _, _ = time_config("DartHalfCheetah-v1", 65536, local_rank, 64, 100, 20)
-        ms3, _, _ = time_config("DartHalfCheetah-v1", 65536, local_rank, 64, 100, 20, configure=[(st.CFG_WAVE_VOTE, 3)])
-        result["opt_in_modes"] = [{"workload": "DartHalfCheetah-v1 batch 65536", "dtype": "f64", "mode": "DART_CFG_WAVE_VOTE = 3",
-                                   "default": {"value": 65536 / (ms0 * 1e-3), "kernel_ms": ms0}, "with_mode": {"value": 65536 / (ms3 * 1e-3), "kernel_ms": ms3},
-                                   "why_opt_in": "which solver serves an env depends on its wave mates; same LCP solutions, last-bit different states: "
-                                                 "not bitwise independent of the batch an env sits in"}]
-
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -345,7 +345,7 @@ int dart_configure(DartStepper* h, int key, double value) {
       break;
     case DART_CFG_DEBUG_FORCE_FALLBACK: h->impl->set_force_slow(value != 0 ? 1 : 0); break;
     case DART_CFG_WAVE_VOTE:
-      if (value < 0 || value > 63) { h->err = "wave vote must be 0 .. 63"; return DART_E_INVALID; }
+      if (value < 0 || value > 64 || value != (double)(int)value) { h->err = "wave vote must be 0 .. 64"; return DART_E_INVALID; }
       h->impl->set_wave_vote((int)value); break;
     case DART_CFG_LAUNCH_ORDER:
       CHK(h, hipStreamSynchronize(h->stream));

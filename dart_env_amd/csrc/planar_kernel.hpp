@@ -118,7 +118,24 @@ struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded hea
 #define DART_CHEETAH_RT_TABLES true    // (-DDART_CHEETAH_RT_TABLES=false: the build that failed the repeatability test in round 4, for tools/gpu/first_launch_probe.py)
 #endif
   static constexpr bool ANC_TABLES_RT = DART_CHEETAH_RT_TABLES;   // see topo_anc_rt
-  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 4, TIER1_F64 = 3;
+  // Round 5: NO second register tier in the task kernel (TIER1 = TIER1_F64 = 0; rounds 2-4: 4 / 3 slots as a real call).  An env with more
+  // than two touching capsules goes to the wave solvers -- wave_constraints4, four envs per pass, one per row of 16 lanes (up to 16 rows;
+  // beyond: wave_constraints, one at a time).  Measured at 65 536 envs (profiles/r05_halfcheetah_coop4.txt): the tier kept and entered for every
+  // wave with such a lane (round 4's default) fp64 1.383 / fp32 0.514 ms per batched step; the tier kept, every such lane to the wave solvers
+  // (DART_CFG_WAVE_VOTE = 64) 0.785 / 0.476; the tier compiled out 0.620 / 0.394 -- the call and its TierIO block alone cost the step kernel
+  // 3.8 KB of its 6.3 KB of scratch per lane (fp64: 498 -> 193 spilled VGPRs; fp32: 972 B left, 2 spills).  Which solver serves an env is
+  // now a function of the env alone, so a trajectory does not depend on the env's wave mates -- bitwise
+  // (tests/test_gpu_spatial.py::test_half_cheetah_trajectories_do_not_depend_on_wave_mates); with the tier it did, in the last bits: the
+  // hand-off thresholds differ between the tiers and which tier a wave runs is its lanes' vote.  The price: a batch in which EVERY env rests
+  // on exactly three or four capsules pays 16 passes per world step where the tier paid one call (~2x); the physics-only variants
+  // (PhysTopo, a user's model that may live on the floor) keep their tiers.  -DDART_CHEETAH_TIER1=4 -DDART_CHEETAH_TIER1_F64=3 rebuilds rounds 2-4.
+#ifndef DART_CHEETAH_TIER1_F64
+#define DART_CHEETAH_TIER1_F64 0
+#endif
+#ifndef DART_CHEETAH_TIER1
+#define DART_CHEETAH_TIER1 0
+#endif
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = DART_CHEETAH_TIER1, TIER1_F64 = DART_CHEETAH_TIER1_F64;
 #ifndef DART_CHEETAH_ISOLATED_TIER1
 #define DART_CHEETAH_ISOLATED_TIER1 true    // (false: round 2's inlined big tier, for tools/exec_prologue_lint.py -- is it the same toolchain bug?)
 #endif
@@ -129,6 +146,11 @@ struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded hea
   // of a register tier that keep pivoting are handed to the same wave solver (blcp_bpp: coop / handoff), 0.95 -> 0.57 / 1.54 -> 1.50 ms.
   // (Opt-in per topology: with the calls in their kernels Hopper and Walker2d, whose bench workloads never need them, lose 9-12 %.)
   static constexpr bool WAVE_FALLBACK = true;
+  // (a build that keeps the tier: DART_CFG_WAVE_VOTE defaults to 64 -- every lane beyond the small tier to the wave solvers, the tier on request)
+#ifndef DART_CHEETAH_VOTE
+#define DART_CHEETAH_VOTE 64
+#endif
+  static constexpr int WAVE_VOTE = DART_CHEETAH_VOTE;
   static constexpr bool WARM = true;
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 0, 1, 2, 3, 4, 5, 6}; return L[c]; }
@@ -165,6 +187,7 @@ template <class B> struct PhysTopo : B {
   static constexpr int TIER1 = !topo_contacts<B>::value ? 0 : (B::NC <= 4 ? B::NC : 4), TIER1_F64 = !topo_contacts<B>::value ? 0 : (B::NC <= 4 ? B::NC : 3);
   static constexpr bool ISOLATED_TIER1 = topo_contacts<B>::value && (B::NC > 4);
   static constexpr bool WAVE_FALLBACK = topo_contacts<B>::value && (B::NC > 4);
+  static constexpr int WAVE_VOTE = 0;   // a user's model may spend its life on the floor: the register tier stays the default (its worst case is the better one)
 };
 // optional traits (default: a robot in the vertical x-y plane with capsules that can touch the floor, no fluid)
 template <class T, class = void> struct topo_physics { static constexpr bool value = false; };
@@ -186,6 +209,9 @@ template <class T, class = void> struct topo_hinv_lds64 { static constexpr bool 
 template <class T> struct topo_hinv_lds64<T, decltype((void)T::HINV_LDS_F64)> { static constexpr bool value = T::HINV_LDS_F64; };
 template <class T, class = void> struct topo_warm_friction { static constexpr bool value = true; };   // stage-2 start of a persisting contact's friction row from the previous substep (constraint_phase)
 template <class T> struct topo_warm_friction<T, decltype((void)T::WARM_FRICTION)> { static constexpr bool value = T::WARM_FRICTION; };
+// default of DART_CFG_WAVE_VOTE for a topology's kernels (optional trait WAVE_VOTE; 0 = the register tiers)
+template <class T, class = void> struct topo_vote { static constexpr int value = 0; };
+template <class T> struct topo_vote<T, decltype((void)T::WAVE_VOTE)> { static constexpr int value = T::WAVE_VOTE; };
 template <class T, class = void> struct topo_wave_fallback { static constexpr bool value = false; };
 template <class T> struct topo_wave_fallback<T, decltype((void)T::WAVE_FALLBACK)> { static constexpr bool value = T::WAVE_FALLBACK; };
 template <class T, class = void> struct topo_hinv_lds32 { static constexpr bool value = false; };
@@ -640,6 +666,23 @@ __device__ __host__ constexpr int coop_iters(int cap, int budget) {
 // launch as long as its slowest wave: the few lanes that cycle (10-40 iterations where the others need 1-3) then cost iterations of
 // a 16-row wave solve (~3 k cycles) instead of iterations of the whole tier.
 template <int M> __device__ __host__ constexpr int coop_words() { return M * (M + 1) / 2 + 4 * M; }
+// the four LDS blocks of wave_constraints4 (four envs per pass, one per row of 16 lanes; device build, topologies with WAVE_FALLBACK whose
+// candidate capsules and limits fit a row of 16 lanes) -- DART_COOP4 = 0 builds the kernels without it
+#ifndef DART_COOP4
+#define DART_COOP4 1
+#endif
+template <class T> __device__ __host__ constexpr int coop4_words() {
+  constexpr int N = T::NDOF;
+  return N * N + 3 * T::NL + N + 4 * T::NC + 2 * T::NL + 2 * 16 * N + 16 * 17 / 2 + 4 * 16;
+}
+template <class T> __device__ __host__ constexpr bool coop4_fits() { return T::NC + T::NL <= 16 && T::NDOF <= 16; }
+template <class T> __device__ __host__ constexpr int coop4_lds_words() {
+#if defined(DART_WAVE_COOP) && DART_COOP4
+  return (topo_wave_fallback<T>::value && coop4_fits<T>()) ? 4 * coop4_words<T>() : 0;
+#else
+  return 0;
+#endif
+}
 template <class Real, int M, bool ZERO_BOUNDS>
 __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const Real (&b)[M], const Real (&lo)[M],
                                          const Real (&hi)[M], uint32_t pinmask, uint32_t& F, uint32_t& U,
@@ -708,6 +751,10 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
     const int lane = (int)(threadIdx.x & 63);
     unsigned long long todo = __ballot(!conv);
     int budget = DART_COOP_BUDGET;   // wave iterations this hand-off may spend in all (see wave_constraints)
+#ifdef DART_WAVE_TIMING_FALLBACK   // [30] envs handed off, [31] cycles spent serving them
+    const long long th0 = (long long)__builtin_readcyclecounter();
+    if (stats && lane == 0 && todo != 0ull) atomicAdd(&stats[30], (unsigned long long)__popcll(todo));
+#endif
     while (todo != 0ull) {
       const int owner = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
@@ -729,6 +776,9 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
       }
       __syncthreads();
     }
+#ifdef DART_WAVE_TIMING_FALLBACK
+    if (stats && lane == 0) atomicAdd(&stats[31], (unsigned long long)((long long)__builtin_readcyclecounter() - th0));
+#endif
   }
 #endif
   // iteration cap reached without a feasible complementary point: stay in the box
@@ -1487,6 +1537,166 @@ __device__ __attribute__((noinline)) void wave_constraints(const PT& P, Real* me
   }
   __syncthreads();
 }
+
+// ------------------------------------------------------------------ FOUR such envs at a time, one per row of 16 lanes (round 5)
+// An env beyond the small tier has 6-12 rows; served one at a time it keeps 16 lanes of the wave busy at best and costs ~80 k cycles, and
+// the half cheetah has ~3 of them per wave and world step -- at one wave per SIMD that latency IS the kernel's time (no other wave to hide it).
+// Here group g (lanes 16 g ... 16 g + 15) serves one env out of its own LDS block `gblk` (coop4_words<T>() Reals, inputs staged by the owners
+// as for wave_constraints), row-per-lane from the start: lane l < NC owns candidate capsule l, lane NC + k link k's limit (NC + NL <= 16),
+// then lane r holds constraint row r -- its Jacobian row in registers, Y_r = H^-1 J_r^T (N x N FMAs), the Delassus row A_r,c (c <= r) from the
+// other lanes' Y rows in LDS -- and the two pivoting stages run in sp_blcp4_t (wave_blcp.hpp).  Everything a group computes is a function of
+// its own block: an env's result does not depend on the group it lands in nor on the other three envs (the row-of-16 DPP operations are the
+// only cross-lane traffic).  Envs with more than 16 rows (>= 6 contacts on the half cheetah) stay with wave_constraints.
+// `oblk`: the block THIS lane's own env was staged in (an owner in this pass), else null -- only the owner reports (EXTRAS).
+template <class Real, class T, class PT, bool EXTRAS>
+__device__ __attribute__((noinline)) void wave_constraints4(const PT& P, Real* gblk, Real* oblk, Real qx, Real qy, const ReportTo<Real>& rp, int& budget) {
+  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 16;
+  static_assert(coop4_fits<T>(), "wave_constraints4: one lane per candidate capsule and per limit inside a row of 16 lanes");
+  const int lane = (int)(threadIdx.x & 63), l = lane & 15;
+  // (the blocks are LDS: re-typed, or every access below compiles to flat_load / flat_store -- a lane-varying generic pointer in a real call)
+  const auto Hi = DART_LDS_PTR(Real, gblk); const auto px = Hi + N * N; const auto py = px + NL; const auto sg = py + NL; const auto vs = sg + NL;
+  const auto con = vs + N; const auto cPx = con + NC; const auto cPy = cPx + NC; const auto cdep = cPy + NC;
+  const auto lim = cdep + NC; const auto viol = lim + NL;
+  const auto J = viol + NL; const auto Y = J + M * N; const auto A = Y + M * N;
+  const auto b = A + M * (M + 1) / 2; const auto lo = b + M; const auto hi = lo + M; const auto x = hi + M;
+  Real* const gA = gblk + (N * N + 3 * NL + N + 4 * NC + 2 * NL + 2 * M * N);   // the solver takes generic pointers (and re-types them itself)
+  __syncthreads();   // the owners' inputs are in place (idle groups: con = lim = 0)
+#ifdef DART_WAVE_TIMING_FALLBACK   // measurement build: [24] rows + Y + A, [25] stage 1, [26] stage 2, [27] tail, [28] passes, [29] rows m summed over the groups
+  long long tf0 = (long long)__builtin_readcyclecounter();
+  auto tf_mark = [&](int slot) { const long long t = (long long)__builtin_readcyclecounter(); if (P.stats && lane == 0) atomicAdd(&P.stats[slot], (unsigned long long)(t - tf0)); tf0 = t; };
+#endif
+  const bool cact = l < NC && con[l < NC ? l : 0] != Real(0);
+  const uint32_t cbal = row_ballot(cact, lane);
+  const int ncont = __popc(cbal);
+  const int kl = l - NC;
+  const bool lact = kl >= 0 && kl < NL && lim[(kl >= 0 && kl < NL) ? kl : 0] != Real(0);
+  const uint32_t lbal = row_ballot(lact, lane);
+  const int m = 2 * ncont + __popc(lbal);   // (the caller admits m <= 16)
+  if (__ballot(m > 0) == 0ull) return;
+  const uint32_t below = (1u << l) - 1u;
+  if (cact) {
+    const int c = l, row = 2 * __popc(cbal & below);
+    // (the compile-time tables, whatever ANC_TABLES_RT says for the topology's step kernel: evaluated at run time the ancestor table is a
+    // walk over the parent array in constant memory, one dependent s_load per hop -- 14 such loops at the top of this function, found in
+    // the disassembly)
+    const uint32_t am = (uint32_t)((AncTable<T>::value >> (8 * (int)((ClinkTable<T>::value >> (4 * c)) & 0xfull))) & 0xffull);
+    const auto jn = J + row * N; const auto jt = J + (row + 1) * N;
+    jn[0] = Real(0); jn[1] = Real(1); jt[0] = Real(-1); jt[1] = Real(0);
+    Real rn = vs[1], rt = -vs[0];
+    for (int j = 0; j < NL; j++) {
+      const bool a = (am >> j) & 1u;
+      const Real vn = a ? sg[j] * (cPx[c] - px[j]) : Real(0), vt = a ? sg[j] * (cPy[c] - py[j]) : Real(0);
+      jn[2 + j] = vn; jt[2 + j] = vt;
+      rn += vn * vs[2 + j]; rt += vt * vs[2 + j];
+    }
+    b[row] = fmin(cdep[c] * P.erp_dt, P.max_erv) - rn; lo[row] = Real(0); hi[row] = inf_<Real>();
+    b[row + 1] = -rt; lo[row + 1] = Real(0); hi[row + 1] = Real(0);
+    x[row] = Real(0); x[row + 1] = Real(0);
+  }
+  if (lact) {
+    const int row = 2 * ncont + __popc(lbal & below);
+    const auto jl = J + row * N;
+    for (int i = 0; i < N; i++) jl[i] = (i == 2 + kl) ? Real(1) : Real(0);
+    const bool low = lim[kl] < Real(0);
+    b[row] = fmin(fmax(-viol[kl] * P.limit_erp_dt, -P.max_erv), P.max_erv) - vs[2 + kl];
+    lo[row] = low ? Real(0) : -inf_<Real>(); hi[row] = low ? inf_<Real>() : Real(0);
+    x[row] = Real(0);
+  }
+  __syncthreads();
+  // ---- lane r = row r: J_r in registers, Y_r = H^-1 J_r^T, then A_r,c = J_r . Y_c for c <= r (the lower triangle, as wave_constraints builds it)
+  const bool row = l < m;
+  const int ri = row ? l : 0;
+  Real Jr[N];
+  sfor<0, N>([&](auto I) { Jr[I] = row ? J[ri * N + I] : Real(0); });
+  if (row) {
+    sfor<0, N>([&](auto I) {
+      constexpr int i = I;
+      Real t = Real(0);
+      sfor<0, N>([&](auto Jc) { constexpr int j = Jc; t += Hi[i * N + j] * Jr[j]; });
+      Y[ri * N + i] = t;
+    });
+  }
+  __syncthreads();
+  if (row) {
+    for (int cc = 0; cc <= ri; cc++) {
+      Real t = Real(0);
+      sfor<0, N>([&](auto I) { t += Jr[I] * Y[cc * N + I]; });
+      if (cc == ri) t *= (ri >= 2 * ncont) ? P.cfm1 : P.ccfm1;
+      A[TI(ri, cc)] = t;
+    }
+  }
+  __syncthreads();
+  // ---- start sets, stage 1, friction bounds, stage 2 (per group: the lane kernels' rules, as in wave_constraints)
+  const Real bmax0 = row_max_nonneg<Real>(row ? fabs(b[ri]) : Real(0));
+  const Real tol0 = tol_<Real>() * (Real(1) + bmax0);
+  const bool pinned0 = row && !(lo[ri] < hi[ri]);
+  const bool upper = row && !(lo[ri] == Real(0));
+  const bool start_free = row && !pinned0 && (upper ? (b[ri] < -tol0) : (b[ri] > tol0));
+  uint32_t pinmask = row_ballot(pinned0, lane), F = row_ballot(start_free, lane), U = row_ballot(upper && !start_free, lane);
+  auto solve = [&](int cap, bool zero_bounds) {
+    const Blcp4Sets res = sp_blcp4_t<Real>(gA, gA + M * (M + 1) / 2, gA + M * (M + 1) / 2 + M, gA + M * (M + 1) / 2 + 2 * M, gA + M * (M + 1) / 2 + 3 * M, m, pinmask,
+                                           F, U, coop_iters(cap, budget), lane, zero_bounds, true);
+    F = res.F; U = res.U;   // (cap or budget reached: x holds the last iterate, clamped into the box)
+    budget -= res.iters;
+    __syncthreads();
+  };
+#ifdef DART_WAVE_TIMING_FALLBACK
+  tf_mark(24);
+#endif
+  solve(P.iters1, true);
+#ifdef DART_WAVE_TIMING_FALLBACK
+  tf_mark(25);
+#endif
+  if (__ballot(ncont > 0) != 0ull) {
+    const bool fr = row && l < 2 * ncont && (l & 1);
+    const Real hb = fr ? fabs(P.mu * x[fr ? l - 1 : 0]) : Real(0);
+    if (fr) { hi[l] = hb; lo[l] = -hb; }
+    const bool fpin = fr && !(hb > Real(0));
+    const uint32_t frm = row_ballot(fr, lane), fpm = row_ballot(fpin, lane);
+    pinmask = (pinmask & ~frm) | fpm;
+    F = (F & ~frm) | (frm & ~fpm);
+    U &= ~frm;
+    __syncthreads();
+    solve(P.iters2, false);   // (a group without contacts repeats its converged stage-1 solve on the same sets: the same x)
+  }
+#ifdef DART_WAVE_TIMING_FALLBACK
+  tf_mark(26);
+#endif
+  if (l < N) {
+    Real dv = Real(0);
+    for (int rr = 0; rr < m; rr++) dv += Y[rr * N + l] * x[rr];
+    vs[l] += dv;
+  }
+  __syncthreads();
+#ifdef DART_WAVE_TIMING_FALLBACK
+  tf_mark(27);
+  if (P.stats && l == 0 && m > 0) { atomicAdd(&P.stats[29], (unsigned long long)m); if (lane == 0) atomicAdd(&P.stats[28], 1ull); }
+#endif
+  if (EXTRAS && oblk != nullptr && rp.rec != nullptr) {   // the owner reports its env (from the block it was served in)
+    const auto ocon = DART_LDS_PTR(const Real, oblk) + N * N + 3 * NL + N; const auto ocPx = ocon + NC; const auto ocPy = ocPx + NC;
+    const auto oJ = DART_LDS_PTR(const Real, oblk) + N * N + 3 * NL + N + 4 * NC + 2 * NL; const auto ox = oJ + 2 * M * N + M * (M + 1) / 2 + 3 * M;
+    const Real idt = Real(1) / P.dt;
+    int rc = 0, om = 0;
+    for (int c = 0; c < NC; c++) {
+      if (ocon[c] == Real(0)) continue;
+      Real* o = rp.rec + 8 * rc;
+      o[0] = (Real)P.cbody[c]; o[1] = Real(-1);
+      o[2] = P.root_x0 + qx + ocPx[c]; o[3] = P.root_y0 + qy + ocPy[c]; o[4] = Real(0);
+      o[5] = -ox[2 * rc + 1] * idt; o[6] = ox[2 * rc] * idt; o[7] = Real(0);
+      rc++;
+    }
+    *rp.count = rc;
+    const auto olim = ocon + 4 * NC;
+    om = 2 * rc;
+    for (int k = 0; k < NL; k++) om += olim[k] != Real(0) ? 1 : 0;
+    for (int i = 0; i < N; i++) {
+      Real f = Real(0);
+      for (int rr = 0; rr < om; rr++) f += oJ[rr * N + i] * ox[rr];
+      rp.cf[i] = f * idt;
+    }
+  }
+  __syncthreads();
+}
 #endif
 
 // ------------------------------------------------------------------ one World::step (dt) for one env
@@ -1664,15 +1874,13 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   if constexpr (has_slow_path<T, Real>()) {
     slow = nact > last_tier<T, Real>() || (P.force_slow > 0 && nact > 0);
 #ifdef DART_WAVE_COOP
-    // DART_CFG_WAVE_VOTE = K (P.force_slow = -K; opt-in, round 4).  Topologies with the wave-served fallback (half
-    // cheetah): in fp64 the big register tier is spill-bound (6 KB of scratch per lane, ~20 k cycles per masked solve for ALL 64 lanes)
-    // and 94 % of the waves enter it for ~3 lanes.  With the vote, a wave that has at most K lanes beyond the small tier serves those envs
-    // together, one after the other (wave_constraints: exact, any number of contacts), and everybody else stays in the small tier; a
-    // wave with more such lanes -- a batch lying on the floor -- keeps the big tier, so the worst case stays what it was.
-    // A/B on one box, fp64 x 65 536: K = 0 1.452 ms, 1 1.39, 2 1.29, 3 1.26, 4 1.32, 8 1.65 (fp32: no gain at any K).  Why it is NOT the
-    // default: which solver serves a lane then depends on its wave mates, and the two solvers round differently -- same LCP solution,
-    // last-bit different states -- so an env's trajectory is no longer BITWISE independent of the batch around it
-    // (test_other_configs_full_batch_determinism_and_batch_independence compares a 1 000-env batch with the first 1 000 of 65 536).
+    // DART_CFG_WAVE_VOTE = K (P.force_slow = -K): kernels that have BOTH a second register tier and the wave-served fallback -- since round 5
+    // the physics-only walker / cheetah trees (PhysTopo; the half-cheetah task kernel has no second tier any more, see CheetahTopo).  A wave
+    // that has at most K lanes beyond the small tier serves those envs with the wave solvers (wave_constraints4 / wave_constraints) and keeps
+    // everybody else in the small tier; a wave with more such lanes -- a batch lying on the floor -- runs the big tier for all its lanes.
+    // 0 (these kernels' default) = always the tier, 64 = never.  For 0 < K < 64 which solver serves a lane depends on its wave mates and the
+    // two round differently: same LCP solution, last-bit different states.  (Round 4, the cheetah's task kernel with its 3-slot fp64 tier,
+    // one-at-a-time wave solver: K = 0 1.452 ms, 1 1.39, 2 1.29, 3 1.26, 4 1.32, 8 1.65 per batched step of 65 536 envs.)
     if constexpr (topo_wave_fallback<T>::value && tier1<T, Real>() > 0) {
       if (P.force_slow < 0 && blockDim.x == 64) {
         const bool big = !slow && nact > T::TIER0;
@@ -1686,8 +1894,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 #ifdef DART_WAVE_TIMING
       const long long tclk0 = DART_CLK();
 #endif
-      auto stage_inputs = [&]() {   // this lane's env -> the fallback solver's LDS block
-        Real* m = slow_mem;
+      auto stage_inputs = [&](Real* m) {   // this lane's env -> a fallback solver's LDS block
         sfor<0, N>([&](auto I) { constexpr int i = I; sfor<0, N>([&](auto J) { constexpr int j = J; m[i * N + j] = Hv(tri(rev<N>(i), rev<N>(j))); }); });
         m += N * N;
         sfor<0, NL>([&](auto K) { m[K] = px[K]; m[NL + K] = py[K]; m[2 * NL + K] = P.sigma[K]; });
@@ -1710,13 +1917,50 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       Real* mvs = slow_mem + N * N + 3 * NL;
 #ifdef DART_WAVE_COOP
       if (topo_wave_fallback<T>::value && blockDim.x == 64) {   // a full wave: all 64 lanes serve the env together (wave_constraints)
-        unsigned long long todo = __ballot(slow);
         int budget = 2 * DART_COOP_BUDGET;   // both stages of every env served in this world step
+        bool left = slow;
+#if DART_COOP4
+        // four envs per pass, one per row of 16 lanes, for every env of at most 16 rows (wave_constraints4); eligibility is the env's own
+        // business (its contacts and active limits), so which solver serves it does not depend on its wave mates
+        if constexpr (topo_wave_fallback<T>::value && coop4_fits<T>()) {
+          int nlim = 0;
+          sfor<0, NL>([&](auto K) { constexpr int k = K; if constexpr (T::limited(k)) nlim += (q[2 + k] <= P.lo[k] || q[2 + k] >= P.hi[k]) ? 1 : 0; });
+          const bool elig = slow && 2 * nact + nlim <= 16;
+          Real* blocks = slow_mem + constraint_lds_words<T, Real>() + coop_words<16>();
+          const int lane = (int)(threadIdx.x & 63);
+          Real* gblk = blocks + (lane >> 4) * coop4_words<T>();
+          unsigned long long todo4 = __ballot(elig);
+          while (todo4 != 0ull) {
+            const int rank = __popcll(todo4 & ((1ull << lane) - 1ull));
+            const bool served = ((todo4 >> lane) & 1ull) && rank < 4;
+            const int count = __popcll(todo4) < 4 ? __popcll(todo4) : 4;
+            Real* oblk = served ? blocks + rank * coop4_words<T>() : nullptr;
+            if (served) stage_inputs(oblk);
+            if ((lane >> 4) >= count) {   // an idle group: nothing touches, no limit active
+              Real* icon = gblk + N * N + 3 * NL + N;
+              if ((lane & 15) < NC) icon[lane & 15] = Real(0);
+              if ((lane & 15) < NL) icon[4 * NC + (lane & 15)] = Real(0);
+            }
+            wave_constraints4<Real, T, PT, EXTRAS>(P, gblk, oblk, q[0], q[1], rp, budget);
+#ifdef DART_WAVE_TIMING
+            if (P.stats != nullptr && lane == 0) atomicAdd(&P.stats[6], 1ull);   // [6] passes of wave_constraints4, [7] envs served one at a time
+#endif
+            if (served) { const Real* ovs = oblk + N * N + 3 * NL; sfor<0, N>([&](auto I) { vs[I] = ovs[I]; }); }
+            todo4 &= ~__ballot(served);
+            __syncthreads();
+          }
+          left = slow && !elig;
+        }
+#endif
+        unsigned long long todo = __ballot(left);
         while (todo != 0ull) {
           const int owner = __ffsll((long long)todo) - 1;
           todo &= todo - 1ull;
-          if ((int)(threadIdx.x & 63) == owner) stage_inputs();
+          if ((int)(threadIdx.x & 63) == owner) stage_inputs(slow_mem);
           if constexpr (topo_wave_fallback<T>::value) wave_constraints<Real, T, PT, EXTRAS>(P, slow_mem, q[0], q[1], rp, owner, budget);
+#ifdef DART_WAVE_TIMING
+          if (P.stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(&P.stats[7], 1ull);
+#endif
           if ((int)(threadIdx.x & 63) == owner) sfor<0, N>([&](auto I) { vs[I] = mvs[I]; });
           __syncthreads();
         }
@@ -1724,7 +1968,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 #endif
       for (int turn = 0; turn < 64; ++turn) {   // (partial waves, and the host build: the env's own lane, alone)
         if (slow && (int)(threadIdx.x & 63) == turn) {
-          stage_inputs();
+          stage_inputs(slow_mem);
           slow_constraints<Real, T, PT, EXTRAS>(P, slow_mem, q[0], q[1], rp);
           sfor<0, N>([&](auto I) { vs[I] = mvs[I]; });
         }
@@ -1869,7 +2113,7 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   Real dx = Real(0);
   WarmSets warm;
   // LDS of the single-lane fallback solver (only topologies with more candidate capsules than tier slots have one)
-  __shared__ Real slow_lds[constraint_lds_words<T, Real>() + (topo_wave_fallback<T>::value ? coop_words<16>() : 0)];
+  __shared__ Real slow_lds[constraint_lds_words<T, Real>() + (topo_wave_fallback<T>::value ? coop_words<16>() : 0) + coop4_lds_words<T>()];
   // H^-1 of every lane, one 64-lane column per packed entry (topo_hinv_lds64; only the topologies that ask for it)
   __shared__ Real hinv_lds_[hinv_lds<T, Real>() ? 64 * (N * (N + 1) / 2) : 1];
   Real* hl = hinv_lds_ + (threadIdx.x & 63);

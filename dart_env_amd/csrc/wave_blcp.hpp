@@ -192,4 +192,122 @@ static __device__ __attribute__((noinline)) BlcpSets sp_blcp_t(const Real* __res
   return BlcpSets{F, U, converged, EXT ? it : 0};
 }
 
+// ------------------------------------------------------------------ FOUR problems per wavefront: one per row of 16 lanes (round 5)
+// The lane kernels' envs beyond the small register tier are 6-12-row problems: served one at a time (sp_blcp_t above) they keep at most
+// 16 of the 64 lanes busy, and at one wave per SIMD that latency is the kernel's time (half cheetah: ~3 such lanes per wave and world
+// step).  Here lane 16 g + i holds row i of group g's problem and the four problems go through the SAME instruction stream:
+//   * a pivot row travels through DPP `row_newbcast:j` (gfx90a+: lane j of every 16-lane row to all lanes of that row) where the
+//     one-problem solver uses v_readlane -- each group reads its own pivot;
+//   * the sets F / U / pinned are 16-bit group values (the group's slice of the wave's ballot), group-uniform VGPRs;
+//   * "column j is not free" differs between the groups, so it is not a branch: the multiplier of a non-free column is exactly 0 (its row
+//     of the working copy is the identity row) and  x - 0 * y = x  for the finite y a bound row holds -- a column is skipped only
+//     when NO group has it free (wave-uniform), which skips exact no-ops;
+//   * a converged group keeps iterating on unchanged sets while the others finish: the same instructions on the same inputs, the same
+//     result.  So a problem's solution does not depend on the group it sits in nor on its three neighbours (tests/test_gpu_wave_blcp.py).
+// Same start sets, tolerances, patience and single-pivot rule as sp_blcp_t / blcp_bpp.  m <= 16 rows per group (0: an idle group).
+// (device: the type-generic builtin with the value itself as `old` and bound_ctrl -- every lane has a source with row_newbcast -- compiles to
+// ONE v_mov_b64_dpp / v_mov_b32_dpp; written with old = 0 on 32-bit halves it was v_mov 0 + v_mov_dpp per half, four instructions per double)
+template <int J> __device__ __forceinline__ float row_bcast_(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, true);
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xf, 0xf, false));
+#endif
+}
+template <int J> __device__ __forceinline__ double row_bcast_(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, true);
+#else
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + J, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + J, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+#endif
+}
+// maximum of NON-NEGATIVE x over the lane's row of 16, returned to every lane of the row
+template <class Real> __device__ __forceinline__ Real row_max_nonneg(Real x) {
+  x = dpp_max_<0x111, 0xf>(x);
+  x = dpp_max_<0x112, 0xf>(x);
+  x = dpp_max_<0x114, 0xf>(x);
+  x = dpp_max_<0x118, 0xf>(x);
+  return row_bcast_<15>(x);
+}
+// the lane's group's 16 bits of a wave ballot
+__device__ __forceinline__ uint32_t row_ballot(bool p, int lane) { return (uint32_t)(__ballot(p) >> (lane & 48)) & 0xffffu; }
+
+struct Blcp4Sets { uint32_t F, U; bool ok; int iters; };   // F, U, ok: of the lane's group; iters: of the wave (its slowest group)
+template <class Real, int TAG = 0>
+static __device__ __attribute__((noinline)) Blcp4Sets sp_blcp4_t(const Real* __restrict__ Ap_, const Real* __restrict__ bp_, const Real* __restrict__ lop_,
+                                                          const Real* __restrict__ hip_, Real* __restrict__ xp_, int m, uint32_t pinmask, uint32_t F,
+                                                          uint32_t U, int max_iter, int lane, const bool ZERO_BOUNDS, bool keep_last) {
+  constexpr int MP = 16;
+  // the lane's GROUP's operands (LDS, as with every caller of sp_blcp_t); m, pinmask, F, U: group-uniform
+  const auto Ap = DART_LDS_PTR(const Real, Ap_), bp = DART_LDS_PTR(const Real, bp_), lop = DART_LDS_PTR(const Real, lop_), hip = DART_LDS_PTR(const Real, hip_);
+  const auto xp = DART_LDS_PTR(Real, xp_);
+  const int l = lane & 15;
+  const bool row = l < m;
+  Real Ar[MP];
+#pragma unroll
+  for (int j = 0; j < MP; j++) Ar[j] = (row && j < m) ? Ap[TI(l, j)] : Real(0);
+  const Real bi = row ? bp[l] : Real(0), loi = row ? lop[l] : Real(0), hii = row ? hip[l] : Real(0);
+  const Real bmax = row_max_nonneg<Real>(fabs(bi));
+  const Real tol = tol_<Real>() * (Real(1) + bmax);
+  int best = m + 1, patience = 3;
+  bool converged = m == 0;
+  int it = 0;
+  Real rr = Real(0);
+  for (; it < max_iter; ++it) {
+    const bool fi = row && ((F >> l) & 1u), ui = row && ((U >> l) & 1u);
+    const Real xb = row ? (fi ? Real(0) : (ui ? hii : loi)) : Real(0);
+    Real t = bi;
+    if (!ZERO_BOUNDS) sfor<0, MP>([&](auto Jc) { constexpr int j = Jc; t -= Ar[j] * row_bcast_<j>(xb); });
+    rr = fi ? t : xb;
+    Real L[MP];
+#pragma unroll
+    for (int j = 0; j < MP; j++) {
+      const bool fj = (F >> j) & 1u;
+      L[j] = (fi && fj) ? Ar[j] : ((j == l) ? Real(1) : Real(0));
+    }
+    Real invd_own = Real(1);
+    sfor<0, MP>([&](auto Jc) {
+      constexpr int j = Jc;
+      if (__ballot((F >> j) & 1u) != 0ull) {   // wave-uniform: some group has column j free
+        // (a group whose column j is NOT free: lane j's row is the identity row -> inv = 1, every multiplier of the column exactly 0)
+        const Real inv = rcp_<Real>(row_bcast_<j>(L[j]));
+        const Real mi = (l != j) ? L[j] * inv : Real(0);
+        invd_own = (l == j) ? inv : invd_own;
+        sfor<j + 1, MP>([&](auto Kc) { constexpr int k = Kc; L[k] -= mi * row_bcast_<j>(L[k]); });
+        rr -= mi * row_bcast_<j>(rr);
+      }
+    });
+    rr = fi ? rr * invd_own : rr;
+    Real w = -bi;
+    sfor<0, MP>([&](auto Jc) { constexpr int j = Jc; w += Ar[j] * row_bcast_<j>(rr); });
+    bool inf = false, gt = false;
+    if (row) {
+      const bool pinned = (pinmask >> l) & 1u;
+      const bool over = rr > hii + tol * (Real(1) + fabs(hii)), under = rr < loi - tol * (Real(1) + fabs(loi));
+      const bool wbad = ui ? (w > tol) : (w < -tol);
+      inf = fi ? (over || under) : (wbad && !pinned);
+      gt = rr > hii;
+    }
+    const uint32_t B = row_ballot(inf, lane), GT = row_ballot(gt, lane);
+    converged = B == 0u;   // (a group that has converged finds B == 0 again on every later iteration: unchanged sets)
+    if (__ballot(!converged) == 0ull) break;
+    if (!converged) {
+      const int ninf = __popc(B);
+      const bool improved = ninf < best;
+      const bool single = !improved && patience == 0;
+      best = improved ? ninf : best;
+      patience = improved ? 3 : (patience > 0 ? patience - 1 : 0);
+      const uint32_t Bs = single ? (1u << (31 - __clz((int)B))) : B;
+      const uint32_t toBound = Bs & F, toFree = Bs & ~F;
+      F = (F & ~toBound) | toFree;
+      U = (U & ~(toFree | toBound)) | (toBound & GT);
+    }
+  }
+  if ((converged || keep_last) && row) xp[l] = fmin(fmax(rr, loi), hii);
+  return Blcp4Sets{F, U, converged, it};
+}
+
 }  // namespace dartk

@@ -62,11 +62,13 @@ enum {
   DART_CFG_CONTACT_REPORT = 9, /* 1: record the contacts of every env-step's last world step (dart_get_contacts) */
   DART_CFG_DEBUG_FORCE_FALLBACK = 10, /* planar register kernels, tests only: 1 routes every env that touches the floor through the
                                single-lane fallback solver, the path of an env with more contacts than the kernel's slot tiers hold */
-  DART_CFG_WAVE_VOTE = 12,  /* lane kernels with a wave-served fallback (DartHalfCheetah-v1), opt-in: K > 0 = a wavefront with at most K
-                               envs beyond its small register tier serves them cooperatively instead of running the big tier for all 64
-                               lanes (fp64: 1.45 -> 1.26 ms per batched step at 65 536 envs with K = 3).  Same LCP solutions; but which solver
-                               serves an env then depends on its wave mates and the two round differently, so trajectories are no longer
-                               bitwise independent of the batch an env sits in -- hence off (0) by default. */
+  DART_CFG_WAVE_VOTE = 12,  /* lane kernels that have both a second register tier and the wave-served fallback (the physics-only walker / cheetah
+                               trees: a user's .skel on those topologies): K = 0 .. 64.  A wavefront with at most K envs beyond its small register
+                               tier serves them cooperatively -- four envs per pass, one per row of 16 lanes -- instead of running the big tier
+                               for all 64 lanes; 0 (default) = always the tier, 64 = never.  0 < K < 64: which solver serves an env depends on
+                               its wave mates and the two round differently -- same LCP solutions, last-bit different states.  No effect on
+                               DartHalfCheetah-v1 since round 5: its kernel has no second tier (every env beyond two contacts goes to the wave
+                               solvers: 1.38 -> 0.62 ms fp64, 0.51 -> 0.39 ms fp32 per batched step of 65 536 envs). */
   DART_CFG_HOST_DMA = 13,   /* how the host-buffer entry points (dart_step, dart_step_async[_to]) cross PCIe, a bit mask, default 3:
                                bit 0 = the step kernel reads the actions straight from page-locked host memory (no H2D copy),
                                bit 1 = the outputs return through a copy kernel writing the mapped host block (no SDMA copy),

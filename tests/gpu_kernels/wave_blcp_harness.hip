@@ -32,6 +32,33 @@ __global__ void __launch_bounds__(64) blcp_harness_kernel(int n_problems, int mc
   if (threadIdx.x == 0) { F[p] = r.F; U[p] = r.U; ok[p] = r.ok ? 1 : 0; iters[p] = r.iters; }
 }
 
+// four problems per workgroup, one per row of 16 lanes (sp_blcp4_t): problem 4 * blockIdx.x + g in lanes 16 g ... 16 g + 15; `rot` rotates the
+// assignment of problems to groups (a problem's result must not depend on the group it sits in, nor on its neighbours)
+template <class Real>
+__global__ void __launch_bounds__(64) blcp4_harness_kernel(int n_problems, int mcap, const Real* A, const Real* b, const Real* lo, const Real* hi,
+                                                           Real* x, const int* m, const uint64_t* pin, uint64_t* F, uint64_t* U, int* ok, int* iters,
+                                                           int max_iter, int zero_bounds, int keep_last, int rot) {
+  const int lane = (int)threadIdx.x, g = lane >> 4, l = lane & 15;
+  const int p = 4 * (int)blockIdx.x + ((g + rot) & 3);
+  const bool live = p < n_problems;
+  constexpr int W = 16 * 17 / 2 + 4 * 16;
+  __shared__ Real sm[4 * W];
+  Real* sA = sm + g * W; Real* sb = sA + 136; Real* slo = sb + 16; Real* shi = slo + 16; Real* sx = shi + 16;
+  const int tri = mcap * (mcap + 1) / 2;
+  const int mp = live ? m[p] : 0;
+  if (live) {
+    for (int i = l; i < 16; i += 16) for (int j = 0; j <= i; j++) sA[TI(i, j)] = (i < mcap) ? A[(size_t)p * tri + TI(i, j)] : Real(0);
+    sb[l] = l < mcap ? b[(size_t)p * mcap + l] : Real(0); slo[l] = l < mcap ? lo[(size_t)p * mcap + l] : Real(0);
+    shi[l] = l < mcap ? hi[(size_t)p * mcap + l] : Real(0); sx[l] = l < mcap ? x[(size_t)p * mcap + l] : Real(0);
+  }
+  __syncthreads();
+  const Blcp4Sets r = sp_blcp4_t<Real>(sA, sb, slo, shi, sx, mp, live ? (uint32_t)pin[p] : 0u, live ? (uint32_t)F[p] : 0u, live ? (uint32_t)U[p] : 0u, max_iter,
+                                       lane, zero_bounds != 0, keep_last != 0);
+  __syncthreads();
+  if (live && l < mcap) x[(size_t)p * mcap + l] = sx[l];
+  if (live && l == 0) { F[p] = r.F; U[p] = r.U; ok[p] = r.ok ? 1 : 0; iters[p] = r.iters; }
+}
+
 template <class Real>
 static int run(int n, int mp, int ext, int mcap, const Real* A, const Real* b, const Real* lo, const Real* hi, Real* x, const int* m, const uint64_t* pin,
                uint64_t* F, uint64_t* U, int* ok, int* iters, int max_iter, int zero_bounds, int keep_last) {
@@ -47,6 +74,10 @@ static int run(int n, int mp, int ext, int mcap, const Real* A, const Real* b, c
   CK(hipMemcpy(dpin, pin, n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dF, F, n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dU, U, n * 8, hipMemcpyHostToDevice));
 #define LAUNCH(MP, EXT) hipLaunchKernelGGL((blcp_harness_kernel<Real, MP, EXT>), dim3(n), dim3(64), 0, 0, n, mcap, dA, db, dlo, dhi, dx, dm, dpin, dF, dU, dok, dit, max_iter, zero_bounds, keep_last)
   if (mcap > 40) return -2;
+  if (ext >= 4) {   // ext = 4 + rot: the four-problems-per-wave solver (16 rows)
+    if (mp != 16 || mcap > 16) return -2;
+    hipLaunchKernelGGL((blcp4_harness_kernel<Real>), dim3((n + 3) / 4), dim3(64), 0, 0, n, mcap, dA, db, dlo, dhi, dx, dm, dpin, dF, dU, dok, dit, max_iter, zero_bounds, keep_last, ext - 4);
+  } else
   if (mp == 16 && ext) LAUNCH(16, true); else if (mp == 24 && ext) LAUNCH(24, true); else if (mp == 16) LAUNCH(16, false);
   else if (mp == 8) LAUNCH(8, false); else if (mp == 12) LAUNCH(12, false);
   else if (mp == 24) LAUNCH(24, false); else if (mp == 32) LAUNCH(32, false); else if (mp == 40) LAUNCH(40, false); else return -2;
@@ -59,7 +90,8 @@ static int run(int n, int mp, int ext, int mcap, const Real* A, const Real* b, c
 
 extern "C" {
 // n problems of up to `mcap` rows each (row count m[p]); A packed lower triangle (TI), row-major per problem with stride mcap(mcap+1)/2;
-// mp = the register variant (8 / 12 / 16 / 24 / 32 / 40 rows), ext = the lane kernels' instantiation (mp 16 or 24).  Returns 0, -1 (HIP error), -2 (variant).
+// mp = the register variant (8 / 12 / 16 / 24 / 32 / 40 rows), ext = 1: the lane kernels' instantiation (mp 16 or 24); ext = 4 + rot (mp 16, mcap <= 16): sp_blcp4_t,
+// four problems per wave, problem 4 w + ((g + rot) & 3) in group g.  Returns 0, -1 (HIP error), -2 (variant).
 int wave_blcp_run_f64(int n, int mp, int ext, int mcap, const double* A, const double* b, const double* lo, const double* hi, double* x, const int* m,
                       const uint64_t* pin, uint64_t* F, uint64_t* U, int* ok, int* iters, int max_iter, int zero_bounds, int keep_last) {
   return run<double>(n, mp, ext, mcap, A, b, lo, hi, x, m, pin, F, U, ok, iters, max_iter, zero_bounds, keep_last);

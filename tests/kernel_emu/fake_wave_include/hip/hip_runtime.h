@@ -188,6 +188,7 @@ inline void resolve(const dim3& bd) {
           if (d.ctrl >= 0x111 && d.ctrl <= 0x11f) { const int sh = d.ctrl - 0x110; src = pos - sh >= 0 ? i - sh : -1; }   // row_shr:n
           else if (d.ctrl == 0x142) src = (pos >= 0 && row >= 1) ? ((row - 1) << 4 | 15) : -1;   // row_bcast:15 -> next row
           else if (d.ctrl == 0x143) src = row >= 2 ? 31 : -1;                                 // row_bcast:31 -> rows 2, 3
+          else if (d.ctrl >= 0x150 && d.ctrl <= 0x15f) src = (row << 4) | (d.ctrl - 0x150);       // row_newbcast:n (gfx90a+): lane n of the lane's own row
           else { fprintf(stderr, "wave_emu: DPP control 0x%x not modelled\n", d.ctrl); abort(); }
           const bool row_en = (d.row_mask >> row) & 1, bank_en = (d.bank_mask >> (pos >> 2)) & 1;
           uint32_t r = d.old;

@@ -400,7 +400,7 @@ def test_half_cheetah_wave_fallback_matches_oracle(precision, tq, tdq):
     gpu.close()
 
 
-@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("k", [1, 3, 64])
 def test_half_cheetah_wave_vote_matches_oracle_and_is_repeatable(k):
     """DART_CFG_WAVE_VOTE (opt-in, round 4): waves with at most K envs beyond the small register tier serve them cooperatively instead of
     running the big fp64 tier for all 64 lanes.  The trajectories are the oracle's to rounding (4 096 envs x 100 env-steps, the untrimmed
@@ -437,6 +437,39 @@ def test_half_cheetah_wave_vote_matches_oracle_and_is_repeatable(k):
     finally:
         stm.HipStepper.__init__ = orig
     assert stats["done_flag_mismatches"] == 0 and stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])
+
+
+@pytest.mark.parametrize("precision,vote", [(64, None), (64, 0), (32, None), (32, 64)])
+def test_half_cheetah_trajectories_do_not_depend_on_wave_mates(precision, vote):
+    """The two batch-independent settings of the wave vote -- 64 (fp64 default: every env beyond the small tier to wave_constraints4, four per
+    pass, one per row of 16 lanes) and 0 (fp32 default: the big register tier) -- on the device: the same 4 096 envs shuffled across the
+    waves give bitwise the same states, whatever row of whatever pass an env landed in."""
+    from dart_env_amd.stepper import HipStepper, CFG_WAVE_VOTE, CFG_AUTORESET
+    card = card_for("DartHalfCheetah-v1")
+    n, T, nd = 4096, 25, card.ndofs
+    rng = np.random.RandomState(8)
+    q0 = rng.uniform(-0.2, 0.2, (n, nd)); dq0 = rng.uniform(-1, 1, (n, nd))
+    # most envs near standing height, one in eight lying in the floor (two to six capsules touching).  Not more: the wave-served solves of one
+    # world step share an iteration budget (DART_COOP_BUDGET, a bound on the worst case), and a wave in which most lanes need the one-at-a-time
+    # fallback runs it out -- then, and only then, what a lane gets depends on its mates (documented in planar_kernel.hpp)
+    low = rng.uniform(size=n) < 0.125
+    q0[:, 1] = np.where(low, rng.uniform(-0.45, -0.2, n), rng.uniform(-0.12, 0.0, n))
+    acts = rng.uniform(-1, 1, (T, n, card.act_dim)).astype(np.float32)
+    outs = []
+    for order in (np.arange(n), np.random.RandomState(9).permutation(n)):
+        g = HipStepper(card, n, precision=precision)
+        g.configure(CFG_AUTORESET, 0)
+        if vote is not None:
+            g.configure(CFG_WAVE_VOTE, vote)
+        g.set_state(q0[order], dq0[order])
+        for t in range(T):
+            g.step(acts[t][order])
+        q, dq = g.get_state()
+        g.close()
+        inv = np.empty(n, np.int64); inv[order] = np.arange(n)
+        outs.append((q[inv], dq[inv]))
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
 def test_walker3d_link_link_contacts_match_oracle():

@@ -105,7 +105,8 @@ def enumerate_solution(Ap, b, lo, hi):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("real,mp,ext", [("f64", 8, 0), ("f64", 12, 0), ("f64", 16, 0), ("f64", 24, 0), ("f64", 32, 0), ("f64", 40, 0), ("f64", 16, 1), ("f64", 24, 1),
-                                         ("f32", 8, 0), ("f32", 12, 0), ("f32", 16, 0), ("f32", 40, 0), ("f32", 16, 1), ("f32", 24, 1)])
+                                         ("f32", 8, 0), ("f32", 12, 0), ("f32", 16, 0), ("f32", 40, 0), ("f32", 16, 1), ("f32", 24, 1),
+                                         ("f64", 16, 4), ("f64", 16, 6), ("f32", 16, 4)])   # ext >= 4: sp_blcp4_t, four problems per wave
 @pytest.mark.parametrize("zero_bounds,rank_deficient", [(0, False), (1, False), (0, True)])
 def test_wave_solver_returns_the_lcp_solution(real, mp, ext, zero_bounds, rank_deficient):
     L = _lib()
@@ -166,3 +167,41 @@ def test_wave_solver_at_its_cap_keeps_the_last_iterate_inside_the_box():
                 assert np.all(x[p, :k] >= lo[p, :k]) and np.all(x[p, :k] <= hi[p, :k])
             else:
                 assert np.all(x[p, :k] == 123.0)
+
+
+def check_group_independence(L, n=96):
+    """sp_blcp4_t (four problems per wave, one per row of 16 lanes): a problem's solution, final sets and convergence flag are BITWISE the same
+    whichever group it sits in and whoever its three neighbours are -- what keeps an env's trajectory independent of the batch around it
+    (dart_env_amd/csrc/planar_kernel.hpp: wave_constraints4) -- and they agree with the one-problem-per-wave solver on the same problems."""
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    for real, zb in (("f64", 0), ("f64", 1), ("f32", 0)):
+        rng = np.random.RandomState(99 + zb)
+        A, b, lo, hi, m, pin, U, full = make_problems(rng, n, 16, bool(zb), False)
+        dt, ct, fn = (np.float64, C.c_double, L.wave_blcp_run_f64) if real == "f64" else (np.float32, C.c_float, L.wave_blcp_run_f32)
+        arrs = [np.ascontiguousarray(a, dtype=dt) for a in (A, b, lo, hi)]
+
+        def run(ext, order=None):
+            o = np.arange(n) if order is None else order
+            aa = [np.ascontiguousarray(a[o]) for a in arrs]
+            x = np.zeros((n, 16), dtype=dt)
+            mm = np.ascontiguousarray(m[o]); pp = np.ascontiguousarray(pin[o]); F = np.zeros(n, np.uint64); Uio = np.ascontiguousarray(U[o])
+            ok = np.zeros(n, np.int32); it = np.zeros(n, np.int32)
+            assert fn(n, 16, ext, 16, *[P(a, ct) for a in aa], P(x, ct), P(mm, C.c_int), P(pp, C.c_uint64), P(F, C.c_uint64), P(Uio, C.c_uint64),
+                      P(ok, C.c_int), P(it, C.c_int), 200, zb, 1) == 0
+            inv = np.empty(n, np.int64); inv[o] = np.arange(n)
+            return x[inv], F[inv], Uio[inv], ok[inv]
+        base = run(4)
+        assert base[3].all()
+        for rot in (1, 2, 3):
+            r = run(4 + rot)
+            assert all(np.array_equal(a, c) for a, c in zip(base, r)), rot
+        shuffled = run(4, np.random.RandomState(5).permutation(n))       # other neighbours, other groups
+        assert all(np.array_equal(a, c) for a, c in zip(base, shuffled))
+        one = run(1)                                                     # the one-problem solver: same sets, same solution up to rounding
+        assert np.array_equal(one[1], base[1]) and np.array_equal(one[2], base[2])
+        assert np.abs(one[0].astype(np.float64) - base[0]).max() < (1e-10 if real == "f64" else 1e-3) * (1 + np.abs(base[0]).max())
+
+
+@pytest.mark.gpu
+def test_four_problem_solver_is_independent_of_group_and_neighbours():
+    check_group_independence(_lib())

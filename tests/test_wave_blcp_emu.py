@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests.test_gpu_wave_blcp import enumerate_solution, kkt_violation, make_problems
+from tests.test_gpu_wave_blcp import check_group_independence, enumerate_solution, kkt_violation, make_problems
 
 DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_emu")
 
@@ -27,7 +27,8 @@ def _lib():
 
 
 @pytest.mark.parametrize("real,mp,ext", [("f64", 8, 0), ("f64", 12, 0), ("f64", 16, 0), ("f64", 24, 0), ("f64", 32, 0), ("f64", 40, 0), ("f64", 16, 1),
-                                         ("f64", 24, 1), ("f32", 8, 0), ("f32", 16, 0), ("f32", 40, 0), ("f32", 16, 1)])
+                                         ("f64", 24, 1), ("f32", 8, 0), ("f32", 16, 0), ("f32", 40, 0), ("f32", 16, 1),
+                                         ("f64", 16, 4), ("f64", 16, 7), ("f32", 16, 4)])   # ext >= 4: sp_blcp4_t, four problems per wave
 @pytest.mark.parametrize("zero_bounds,rank_deficient", [(0, False), (1, False), (0, True)])
 def test_wave_solver_on_the_host_returns_the_lcp_solution(real, mp, ext, zero_bounds, rank_deficient):
     L = _lib()
@@ -59,3 +60,7 @@ def test_wave_solver_on_the_host_returns_the_lcp_solution(real, mp, ext, zero_bo
         k = int(m[p])
         ref = enumerate_solution(full[p], b[p, :k], lo[p, :k], hi[p, :k])
         assert np.abs(ref - x[p, :k]).max() < (1e-8 if real == "f64" else 5e-3) * (1 if not rank_deficient else 1e3) * (1 + np.abs(ref).max()), p
+
+
+def test_four_problem_solver_on_the_host_is_independent_of_group_and_neighbours():
+    check_group_independence(_lib(), n=48)

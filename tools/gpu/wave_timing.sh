@@ -15,6 +15,7 @@ for l in sys.stdin:
 a, b = h[1], h[2]
 n = a[2]
 print('$ENV f$p  %.3f ms/step;  waves %d: mean %.0f cycles, max %d;  per wave: fallback %.0f, big tier %.0f, small tier %.0f' % (ms, n, a[0]/n, a[1], a[3]/n, a[4]/n, a[5]/n))
+print('  per wave: passes of the four-env solver %.2f, envs served one at a time %.2f' % (a[6]/n, a[7]/n))
 print('  waves by log2(cycles) 14..21+:', a[8:16])
 print('  fallback invocations by log2(cycles) 8..23:', a[16:32])
 print('  big-tier invocations:', b[0:16])

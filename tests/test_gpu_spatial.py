@@ -810,8 +810,8 @@ def test_contact_report_matches_oracle(env_id):
     """dart_get_contacts (pydart2 collision_result.contacts of the last world step, walker2d.py:38-41): bodies, points and forces
     equal the oracle's, fp64; fp32 close.  The planar register kernels (Hopper, Walker2d, HalfCheetah default cards) report from
     their contact slots; `/tree` routes the Hopper through the tree kernel (generic_kernel); `/fallback` routes every touching
-    cheetah through the solver that serves an env with more contacts than the register tiers hold (on the device: the whole wave,
-    wave_constraints in planar_kernel.hpp)."""
+    cheetah through the solvers that serve an env with more contacts than the register tier holds (on the device: four envs per pass,
+    wave_constraints4, or the whole wave for one env beyond 16 rows, wave_constraints -- planar_kernel.hpp)."""
     from dart_env_amd.stepper import HipStepper, StepperError, CFG_CONTACT_REPORT, Q_MAX_CONTACTS, Q_STATIC_KERNEL, CFG_DEBUG_FORCE_FALLBACK
     tree = env_id.endswith("/tree")
     fallback = env_id.endswith("/fallback")

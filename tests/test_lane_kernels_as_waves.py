@@ -88,6 +88,36 @@ def test_wave_served_fallback_follows_the_oracle():
     assert worst[0] < 1e-9 and worst[1] < 1e-7 and most >= 3, (worst, most)
 
 
+def test_wave_served_envs_report_their_contacts():
+    """The reporting instantiation of wave_constraints4 (EXTRAS: each owner writes its env's contact records and constraint forces from the
+    LDS block it was served in): every touching half cheetah through the four-env passes, contacts and J^T lambda / dt against the oracle's."""
+    card = card_for("DartHalfCheetah-v1"); n = 64; nd, na = card.ndofs, card.act_dim
+    rng = np.random.RandomState(6)
+    g = EmuStepper(card, n, precision=64, waves=True); o = OracleBatch(card, n)
+    g.force_slow(True)
+    g.enable_contact_report(True)
+    qn = rng.uniform(-.05, .05, (n, nd)); vn = rng.uniform(-.05, .05, (n, nd))
+    g.reset(None, qn, vn); o.reset(None, qn, vn)
+    seen = most = 0
+    for t in range(25):
+        a = rng.uniform(-1, 1, (n, na)).astype(np.float32)
+        g.step(a); o.step(a)
+        cnt, bod, pt, fc = g.contacts(); cf = g.constraint_forces()
+        qg, dqg = g.get_state(); qo, dqo = o.state()
+        assert np.abs(qg - qo).max() < 1e-9 and np.abs(dqg - dqo).max() < 1e-7, t
+        for i, w in enumerate(o.worlds):
+            rep = w.contact_report(); k = len(rep)
+            assert cnt[i] == k, (t, i)
+            assert np.abs(cf[i] - w.constraint_forces()).max() < 1e-6
+            most = max(most, k)
+            if k:
+                seen += k
+                assert np.array_equal(bod[i, :k, 0], rep[:, 0].astype(np.int32)) and np.all(bod[i, :k, 1] == -1)
+                assert np.abs(pt[i, :k] - rep[:, 2:5]).max() < 1e-9 and np.abs(fc[i, :k] - rep[:, 5:8]).max() < 1e-6
+    g.close()
+    assert seen > 500 and most >= 3, (seen, most)
+
+
 def test_fallen_user_models_on_whole_waves():
     """physics-only cards (no termination): the walker tree lies on up to seven capsules -- second register tier as a real call, hand-off,
     wave-served fallback beyond it; the pogo hopper keeps all four in its register tier"""

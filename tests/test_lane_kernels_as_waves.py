@@ -133,6 +133,17 @@ def test_fallen_user_models_on_whole_waves():
     assert most >= 3 and worst[0] < 1e-8 and worst[1] < 1e-6, (worst, most)
 
 
+@pytest.mark.parametrize("k", [2, 64])
+def test_wave_vote_on_a_physics_only_walker_tree(k):
+    """DART_CFG_WAVE_VOTE where it still chooses (round 5: the kernels that have BOTH a second register tier and the wave-served fallback are the
+    physics-only walker / cheetah trees): with the vote at K a wave with at most K envs beyond the small tier hands them to the four-env wave
+    solver and keeps its big tier for fuller waves; at 64 the tier never runs.  Same LCPs either way: the oracle's trajectory."""
+    wcard = build_card(load_model("walker2d"), None)
+    wcard.frame_skip = 4
+    worst, most = rollout(wcard, 64, 110, noise=0.01, scale=np.array([100, 100, 20, 100, 100, 20.0]), seed=3, wave_vote=k)
+    assert most >= 4 and worst[0] < 1e-7 and worst[1] < 1e-5, (worst, most)
+
+
 _POISON_LANE_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])

@@ -320,7 +320,10 @@ def self_launch(n_ranks: int, argv) -> int:
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DART_BENCH_SELF_LAUNCHED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (dmabuf IPC: what RCCL needs on this driver)
+        if "HSA_ENABLE_IPC_MODE_LEGACY" not in env:
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"           # dmabuf IPC: what RCCL needs on this driver; said once, on stderr
+            if r == 0:
+                print("bench.py: self-launch sets HSA_ENABLE_IPC_MODE_LEGACY=0 for its ranks (it was unset)", file=sys.stderr)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc, live = 0, list(procs)
@@ -371,7 +374,14 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
-        # no launcher around us (torch.distributed.run always sets RANK): start the ranks ourselves
+        # no launcher around us (torch.distributed.run always sets RANK): start the ranks ourselves.  Another launcher's rank
+        # variables without RANK (srun: SLURM_PROCID, mpirun: OMPI_COMM_WORLD_RANK / PMI_RANK, or a bare LOCAL_RANK) mean N processes
+        # like this one already exist: each starting N more would put N^2 processes on the GPUs -- refuse and say what to set.
+        foreign = [v for v in ("SLURM_PROCID", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "PMIX_RANK", "LOCAL_RANK") if v in os.environ]
+        if foreign:
+            raise SystemExit("bench.py: --gpus %d under a launcher that set %s but not RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT: "
+                             "export those per process (as torch.distributed.run does), or run plain `python bench.py --gpus %d` "
+                             "outside the launcher to let it start its own ranks" % (args.gpus, ", ".join(foreign), args.gpus))
         rc = self_launch(args.gpus, argv)
         if rc != 0:
             raise SystemExit("bench.py: a self-launched rank exited with code %d" % rc)

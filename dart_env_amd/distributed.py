@@ -46,7 +46,9 @@ class ShardedDartVectorEnv:
         return self.venv.reset()
 
     def step(self, actions):
-        return self.venv.step(actions)
+        out = self.venv.step(actions)
+        self._last_host_step = out[:3]      # what gather_last_step() / gather_rollout(resident=True) may read from HBM instead
+        return out
 
     def close(self):
         self.venv.close()
@@ -102,21 +104,31 @@ class ShardedDartVectorEnv:
         return (torch.as_tensor(_Mem(po, (n, k), "<f4"), device=dev), torch.as_tensor(_Mem(pr, (n,), "<f4"), device=dev),
                 torch.as_tensor(_Mem(pd, (n,), "|u1"), device=dev))
 
-    def gather_rollout(self, obs, reward, done, force_collective=False):
-        """Host arrays of this rank's last step -> full-batch arrays in global env order on every rank: obs f32 (N, k), reward f64 (N,),
-        done bool (N,).  Requires equal shard sizes (total_envs % world_size == 0) like the 8 x 65 536 config.  Under RCCL the shard is
-        NOT uploaded again: the step that produced `obs` left the same values in HBM (dart_device_outputs), the all-gather reads them
-        there and only the gathered batch crosses PCIe, once (round 5; rounds 1-4 went numpy -> device -> all-gather -> host).  For a
-        learner on the GPU use step_device() + gather_rollout_device(): no host copy at all."""
+    def gather_rollout(self, obs, reward, done, force_collective=False, resident=False):
+        """Host arrays -> full-batch arrays in global env order on every rank: obs f32 (N, k), reward f64 (N,), done bool (N,).
+        Requires equal shard sizes (total_envs % world_size == 0) like the 8 x 65 536 config.
+
+        The ARGUMENTS are what is gathered, under every backend (normalised observations, clipped rewards, arrays of an earlier step:
+        all fine) -- they are uploaded, gathered with one all-gather, and the gathered batch comes back once.
+        resident=True (RCCL only; = gather_last_step()) is the opt-in short cut for the unmodified outputs of the LAST step(): the
+        kernel left the same values in HBM (dart_device_outputs), so nothing is uploaded and only the gathered batch crosses PCIe.
+        It refuses -- ValueError -- when the arrays are not the very objects that step returned, or when a step_device() ran since
+        (the device block then holds that step's outputs or stale ones).  An in-place edit of those arrays cannot be seen: do not
+        ask for the resident path after one.  For a learner on the GPU use step_device() + gather_rollout_device(): no host copy."""
         import torch
         import torch.distributed as dist
         if not dist.is_initialized() or (self.world_size == 1 and not force_collective):
             return obs, reward, done
         assert self.total_envs % self.world_size == 0, "gather_rollout needs equal shards"
         n, k = obs.shape
-        resident = self._resident_outputs() if dist.get_backend() == "nccl" else None
-        if resident is not None:
-            packed = self._pack(*resident)
+        res = None
+        if resident:
+            last = getattr(self, "_last_host_step", None)
+            if last is None or obs is not last[0] or reward is not last[1] or done is not last[2]:
+                raise ValueError("gather_rollout(resident=True): the arrays are not the ones the last step() of this shard returned")
+            res = self._resident_outputs() if dist.get_backend() == "nccl" else None
+        if res is not None:
+            packed = self._pack(*res)
         else:
             packed = self._pack(torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)),
                                 torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)),
@@ -127,12 +139,20 @@ class ShardedDartVectorEnv:
         o, r, d = self._unpack(full, w, n, k)
         return o.cpu().numpy(), r.cpu().numpy().astype(np.float64), d.cpu().numpy() != 0
 
+    def gather_last_step(self, force_collective=False):
+        """The outputs of this shard's last step(), gathered from where the kernel left them in HBM (see gather_rollout, resident=True)."""
+        last = getattr(self, "_last_host_step", None)
+        if last is None:
+            raise ValueError("gather_last_step(): no host-buffer step() since the last step_device() / construction")
+        return self.gather_rollout(*last, force_collective=force_collective, resident=True)
+
     def step_device(self, actions):
         """Device-resident step of this shard for a learner that lives on the GPU: `actions` is a float32 (n, act_dim) torch tensor on
         this rank's device; the outputs stay in HBM (dart_step_device on a stream of this object's own, ordered against torch's
         current stream both ways) and are returned as torch tensors: obs (n, k) f32, reward (n) f32, done (n) u8, truncated (n) u8."""
         import torch
         st = self.venv.env._stepper
+        self._last_host_step = None     # the device output block no longer holds a host step's values (gather_rollout, resident=True)
         if not hasattr(self, "_dev"):
             dev = torch.device("cuda", st.device)
             k = self.venv.env.obs_dim

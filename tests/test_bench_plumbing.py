@@ -144,6 +144,20 @@ def test_world_size_mismatch_is_fatal(monkeypatch):
     assert "WORLD_SIZE" in str(e.value)
 
 
+@pytest.mark.parametrize("var", ["SLURM_PROCID", "OMPI_COMM_WORLD_RANK", "LOCAL_RANK"])
+def test_self_launch_refuses_under_a_foreign_launcher(monkeypatch, var):
+    """srun / mpirun set their own rank variables, not RANK -- N processes each starting N more would be N^2 on the GPUs"""
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SLURM_PROCID", "OMPI_COMM_WORLD_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv(var, "3")
+    monkeypatch.setattr(bench, "self_launch", lambda *a, **k: pytest.fail("started ranks under a foreign launcher"))
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4"], env_factory=EmuBenchEnv, dist_backend="gloo")
+    assert var in str(e.value)
+
+
 def test_shards_are_contiguous_and_disjoint():
     sys.path.insert(0, ROOT)
     import bench

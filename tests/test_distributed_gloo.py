@@ -23,6 +23,17 @@ def _worker(rank, world, port, total, steps, q):
     for t in range(steps):
         obs, rew, done, _ = env.step(acts[t, env.offset:env.offset + env.count])
         out = env.gather_rollout(obs, rew, done)
+    # resident=True is an opt-in for the last step's OWN arrays (round 6): the same result here (gloo has no device block to read),
+    # a ValueError for any other arrays; the default gathers whatever it is given
+    res = env.gather_last_step()
+    assert all(np.array_equal(a, b) for a, b in zip(res, out))
+    try:
+        env.gather_rollout(obs.copy(), rew, done, resident=True)
+        raise AssertionError("resident=True accepted arrays that are not the last step's")
+    except ValueError:
+        pass
+    half = env.gather_rollout(obs * 0.5, rew, done)
+    assert np.array_equal(half[0], out[0] * 0.5)
     # the tensor form of the same exchange (on a GPU: outputs that never left HBM; here CPU tensors over gloo): one packed uint8 block
     import torch
     to, tr, td = env.gather_rollout_device(torch.from_numpy(obs), torch.from_numpy(rew.astype(np.float32)), torch.from_numpy(done.astype(np.uint8)))

@@ -41,12 +41,25 @@ g = buf.gather(force_collective=True)          # the all_gather_into_tensor call
 torch.cuda.synchronize()
 ok = all(torch.equal(g[k][0], getattr(buf, k)) for k in ("obs", "actions", "rewards", "dones", "truncated"))
 ob, r, d, infos = venv.step(buf.actions[0].cpu().numpy())
-fo, fr, fd = venv.gather_rollout(ob, r, d, force_collective=True)     # resident path: the all-gather reads the step's outputs where they sit in HBM
+fo, fr, fd = venv.gather_last_step(force_collective=True)     # resident path (opt-in): the all-gather reads the step's outputs where they sit in HBM
 import numpy as np
 host_ok = bool(venv._resident_outputs() is not None and np.array_equal(fo, ob) and np.array_equal(fr, r) and np.array_equal(fd, d))
+# the default honours its ARGUMENTS under RCCL as it does under gloo: transformed arrays are what comes back, not the device block
+to, tr, td = venv.gather_rollout(ob * 0.5, np.clip(r, -0.25, 0.25), ~d, force_collective=True)
+host_ok = host_ok and bool(np.array_equal(to, ob * 0.5) and np.allclose(tr, np.clip(r, -0.25, 0.25).astype(np.float32)) and np.array_equal(td, ~d))
+try:
+    venv.gather_rollout(ob.copy(), r, d, force_collective=True, resident=True)      # not the step's own arrays: refused
+    host_ok = False
+except ValueError:
+    pass
 # the device-resident form: step in HBM, one packed uint8 all-gather over RCCL, nothing touches the host
 dob, drew, ddone, dtr = venv.step_device(buf.actions[1])
 gob, grew, gdone = venv.gather_rollout_device(force_collective=True)
+try:
+    venv.gather_last_step(force_collective=True)      # a step_device() ran since: the block no longer holds a host step
+    host_ok = False
+except ValueError:
+    pass
 torch.cuda.synchronize()
 dev_ok = bool(gob.is_cuda and gob.dtype == torch.float32 and gdone.dtype == torch.uint8 and torch.equal(gob, dob) and torch.equal(grew, drew)
               and torch.equal(gdone, ddone))

@@ -74,6 +74,11 @@ struct DartStepper {
   // mapped host block with 16-byte coalesced stores, instead of a hipMemcpyAsync (SDMA); split_d2h (bit 2): the four separate copies of
   // rounds 1-2.  0 = the copy-engine path of rounds 1-3 (A/B: tools/gpu/host_path_c.py).
   bool zc_actions = true, d2h_kernel = true, split_d2h = false;
+  // bit 3 (round 6, A/B only): the reference-exact MT19937 auto-reset as two launches behind the step kernel (rounds 1-5) even where the
+  // step kernel can do it in its epilogue (mt_fused: the implementation took the bank's view and the task's reset_model draws nothing
+  // beyond the two noise vectors)
+  bool mt_split = false, mt_fused = false;
+  void* d_mtview = nullptr;      // MtBankView in device memory (mt19937_draw.hpp)
   float *h_act = nullptr, *h_obs = nullptr, *h_rew = nullptr;
   uint8_t *h_done = nullptr, *h_trunc = nullptr, *h_mask = nullptr;
   double *h_qn = nullptr, *h_vn = nullptr;
@@ -257,7 +262,7 @@ int dart_destroy(DartStepper* h) {
   for (auto& r : h->host_ranges) (void)hipHostUnregister(r.first);
   h->host_ranges.clear();
   if (h->d_rew64) hipFree(h->d_rew64);
-  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs /* base of the output block */, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->mt_gauss, h->mt_has_gauss, h->d_init_pos, h->d_init_vel, h->dyn.dev, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
+  void* dev[] = {h->q, h->dq, h->elapsed, h->episode, h->d_act, h->d_obs /* base of the output block */, h->d_mask, h->d_qn, h->d_vn, h->d_stats, h->mt, h->mt_pos, h->mt_gauss, h->mt_has_gauss, h->d_init_pos, h->d_init_vel, h->d_mtview, h->dyn.dev, h->d_dynM, h->d_dync, h->d_tstage, h->d_pose, h->d_tvals, h->d_ep_ret, h->d_last_ret, h->d_ep_tot, h->d_ep_len, h->d_last_len};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {h->h_act, h->h_obs /* base of the pinned output block */, h->h_mask, h->h_qn, h->h_vn};
   for (void* p : host) if (p) hipHostFree(p);
@@ -344,9 +349,8 @@ int dart_configure(DartStepper* h, int key, double value) {
       h->ep_stats = value != 0;
       break;
     case DART_CFG_DEBUG_FORCE_FALLBACK: h->impl->set_force_slow(value != 0 ? 1 : 0); break;
-    case DART_CFG_WAVE_VOTE:
-      if (value < 0 || value > 64 || value != (double)(int)value) { h->err = "wave vote must be 0 .. 64"; return DART_E_INVALID; }
-      h->impl->set_wave_vote((int)value); break;
+    case 12:   // DART_CFG_WAVE_VOTE of rounds 4-5: retired with the second register tier it chose against (include/dart_stepper.h)
+      h->err = "configure key 12 (DART_CFG_WAVE_VOTE) was retired in round 6: no kernel has a per-wave choice of solver any more"; return DART_E_INVALID;
     case DART_CFG_LAUNCH_ORDER:
       CHK(h, hipStreamSynchronize(h->stream));
       if (h->impl->set_launch_order(value != 0 ? 1 : 0) != 0) { h->err = "launch order: allocation failed"; return DART_E_INVALID; }
@@ -355,8 +359,9 @@ int dart_configure(DartStepper* h, int key, double value) {
       if (value != 64 && value != 32 && value != 16) { h->err = "block threads must be 16, 32 or 64"; return DART_E_INVALID; }
       h->impl->block_threads = (int)value; break;
     case DART_CFG_HOST_DMA:
-      if (value < 0 || value > 7 || value != (double)(int)value) { h->err = "host DMA mode: a bit mask 0 .. 7"; return DART_E_INVALID; }
+      if (value < 0 || value > 15 || value != (double)(int)value) { h->err = "host DMA mode: a bit mask 0 .. 15"; return DART_E_INVALID; }
       h->zc_actions = ((int)value & 1) != 0; h->d2h_kernel = ((int)value & 2) != 0; h->split_d2h = ((int)value & 4) != 0;
+      h->mt_split = ((int)value & 8) != 0;
       break;
     default: h->err = "unknown configure key"; return DART_E_INVALID;
   }
@@ -378,6 +383,15 @@ static int episode_restart(DartStepper* h, hipStream_t s, const uint8_t* d_mask)
   hipLaunchKernelGGL(episode_reset_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, h->n, d_mask, h->d_ep_ret, h->d_ep_len);
   CHK(h, hipGetLastError());
   return DART_OK;
+}
+
+// Auto-reset from the MT19937 bank as two more launches behind the step kernel (mt_draw + masked reset)?  Not where the step kernel does
+// it itself: its Extras::mt is set while the bank exists, and `autoreset` on then means "from the bank" (planar_kernel.hpp: step_kernel).
+static bool mt_reset_behind_step(DartStepper* h) {
+  if (!(h->autoreset && h->noise_mode == 1)) return false;
+  const bool fused = h->mt_fused && !h->mt_split;
+  (void)h->impl->set_mt_bank(fused ? h->d_mtview : nullptr);   // (a host-side pointer assignment in the implementation's parameter block)
+  return !fused;
 }
 
 // MT19937 mode: draw reference-exact reset noise on the device for the masked envs into d_qn / d_vn
@@ -415,6 +429,15 @@ int dart_seed_mt19937(DartStepper* h, const uint32_t* keys, const int32_t* key_l
     CHK(h, hipMalloc((void**)&h->d_init_vel, sizeof(double) * nd));
     CHK(h, hipMemcpy(h->d_init_pos, h->card.init_pos, sizeof(double) * nd, hipMemcpyHostToDevice));
     CHK(h, hipMemcpy(h->d_init_vel, h->card.init_vel, sizeof(double) * nd, hipMemcpyHostToDevice));
+    // the bank as the step kernels see it (mt19937_draw.hpp): with it a lane kernel resets a finished env from the env's own stream in
+    // its epilogue -- for the tasks whose reset_model draws the two noise vectors and nothing else (mt_draw: `extra`)
+    const double r = h->card.reset_noise, rv = h->card.reset_noise_vel;
+    const MtBankView view = {h->mt, h->mt_pos, h->d_init_pos, h->d_init_vel, -r, r - (-r), -rv, rv - (-rv)};
+    CHK(h, hipMalloc(&h->d_mtview, sizeof(MtBankView)));
+    CHK(h, hipMemcpy(h->d_mtview, &view, sizeof(MtBankView), hipMemcpyHostToDevice));
+    const int t = h->card.task;
+    const bool plain = !(t == DART_TASK_CARTPOLE_SWINGUP || t == DART_TASK_REACHER2D || t == DART_TASK_REACHER3D || t == DART_TASK_DOUBLE_PENDULUM);
+    h->mt_fused = plain && h->impl->set_mt_bank(h->d_mtview);
   }
   uint32_t* dk = nullptr; int32_t* dl = nullptr;
   CHK(h, hipMalloc((void**)&dk, sizeof(uint32_t) * 2 * N));
@@ -688,7 +711,7 @@ static int step_async_impl(DartStepper* h, const float* actions, void* dst, bool
     CHK(h, hipMemcpyAsync(h->d_act, host_act, 4 * N * h->card.act_dim, hipMemcpyHostToDevice, h->stream));
     kernel_act = h->d_act;
   }
-  const bool mt_reset = h->autoreset && h->noise_mode == 1;
+  const bool mt_reset = mt_reset_behind_step(h);
   CHK(h, h->impl->step(h->stream, h->n, h->q, h->dq, h->elapsed, h->episode, kernel_act, h->d_obs, h->d_rew, h->d_done,
                        h->d_trunc, mt_reset ? 0 : h->autoreset, h->seed, h->env_offset));
   { int rc = episode_accumulate(h, h->stream, h->d_rew, h->d_done); if (rc != DART_OK) return rc; }
@@ -812,7 +835,7 @@ int dart_step_device(DartStepper* h, const float* d_actions, float* d_obs, float
   CHK(h, hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   { int rc = ext_begin(h, s); if (rc != DART_OK) return rc; }
-  const bool mt_reset = h->autoreset && h->noise_mode == 1;
+  const bool mt_reset = mt_reset_behind_step(h);
   float* o = d_obs ? d_obs : h->d_obs;
   uint8_t* dn = d_done ? d_done : h->d_done;
   CHK(h, h->impl->step(s, h->n, h->q, h->dq, h->elapsed, h->episode, d_actions, o, d_reward ? d_reward : h->d_rew, dn,

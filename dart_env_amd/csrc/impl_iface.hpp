@@ -24,8 +24,10 @@ struct Impl {
   virtual hipError_t state_io(hipStream_t s, int64_t n, void* q, void* dq, double* qh, double* dqh, int to_device) = 0;
   virtual void set_solver(int solver, int it1, int it2) = 0;
   virtual void set_stats(unsigned long long* p) = 0;
-  virtual void set_wave_vote(int /*k*/) {}      // planar kernels with a wave-served fallback: DART_CFG_WAVE_VOTE
   virtual void set_force_slow(int /*on*/) {}   // planar kernels: route every touching env through the single-lane fallback solver (tests)
+  // the MT19937 bank's device view (mt19937_draw.hpp: MtBankView*), or null.  true: this implementation's step kernel resets a finished env
+  // from the bank itself when `autoreset` is on -- no mt_draw / reset launches behind it; false (default): it cannot, the caller runs those
+  virtual bool set_mt_bank(const void* /*d_view*/) { return false; }
   virtual hipError_t prepare(int64_t) { return hipSuccess; }   // per-handle device allocations of the implementation
   virtual void release() {}
   virtual hipError_t debug_dump(double*) { return hipErrorInvalidValue; }

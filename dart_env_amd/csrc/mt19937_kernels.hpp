@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "cr_log.hpp"
+#include "mt19937_draw.hpp"   // MtBankView + the one-env draw the lane kernels call from their epilogue (round 6)
 
 namespace dartk {
 

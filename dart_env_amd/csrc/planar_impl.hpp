@@ -53,13 +53,8 @@ struct ImplT : Impl {
     P.solver = solver; P.iters1 = it1 > 0 ? it1 : dflt; P.iters2 = it2 > 0 ? it2 : dflt;
   }
   void set_stats(unsigned long long* p) override { P.stats = p; }
-  // The kernel has ONE parameter for both modes (P.force_slow: 1 = every touching env through the fallback, -K = the wave vote); the two
-  // settings are kept apart here so that neither call cancels the other: the forced fallback (a test mode) wins while it is on,
-  // the vote is back in force when it goes off.
-  int cfg_force_slow = 0, cfg_wave_vote = topo_vote<T>::value;   // (make_for_topology applies the default)
-  void apply_slow_mode() { P.force_slow = cfg_force_slow ? 1 : -cfg_wave_vote; }
-  void set_force_slow(int on) override { cfg_force_slow = on ? 1 : 0; apply_slow_mode(); }
-  void set_wave_vote(int k) override { cfg_wave_vote = k > 0 ? k : 0; apply_slow_mode(); }
+  void set_force_slow(int on) override { P.force_slow = on ? 1 : 0; }   // DART_CFG_DEBUG_FORCE_FALLBACK (a test mode)
+  bool set_mt_bank(const void* d_view) override { P.ex.mt = (const MtBankView*)d_view; return true; }
   // ---- optional extras: external body force, contact report (see Extras in planar_kernel.hpp)
   int link_body[T::NL] = {};                 // card body of each link (welded bodies have no link of their own)
   Real* d_ext = nullptr; Real* d_rec = nullptr; int* d_cnt = nullptr; Real* d_cf = nullptr;
@@ -290,7 +285,7 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
     if (allow_static && Static::matches(R)) {
       auto p = std::make_unique<ImplT<Real, T, Static>>();
       p->P.max_steps = R.max_steps; p->P.solver = R.solver; p->P.iters1 = R.iters1; p->P.iters2 = R.iters2;
-      p->P.stats = nullptr; p->apply_slow_mode(); p->P.ex = Extras<Real>();
+      p->P.stats = nullptr; p->P.force_slow = 0; p->P.ex = Extras<Real>();
       for (int b = 2, k = 0; b < c.nbodies && k < T::NL; b++) if (c.jtype[b] != DART_JT_WELD) p->link_body[k++] = b;
       p->is_static = true;
       return p;
@@ -298,7 +293,7 @@ std::unique_ptr<Impl> make_for_topology(const DartModelCard& c, std::string& why
   }
   auto p = std::make_unique<ImplT<Real, T>>();
   p->P = R;
-  p->apply_slow_mode();
+  p->P.force_slow = 0;
   for (int b = 2, k = 0; b < c.nbodies && k < T::NL; b++) if (c.jtype[b] != DART_JT_WELD) p->link_body[k++] = b;
   return p;
 }

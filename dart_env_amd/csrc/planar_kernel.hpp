@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "mt19937_draw.hpp"
+
 #ifndef DART_PIN_VGPR
 #define DART_PIN_VGPR(x) asm volatile("" : "+v"(x))   // an optimisation barrier on a value that lives in a VGPR
 #endif
@@ -62,7 +64,6 @@ __device__ __host__ constexpr int TI(int i, int j) { return tri(i, j); }   // th
 // (slow_constraints) -- exact for any number of contacts, and never on the path of a workload that stays within the tiers.
 struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - shin - foot; ONLY the foot collides (BASELINE config[1])
   static constexpr int NL = 4, NDOF = NL + 2, NC = 1, NA = 3, TIER0 = 1, TIER1 = 0, TIER1_F64 = 0;
-  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = false;  // warm-started active sets: measured -4 % here (short, violent episodes)
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {3}; return L[c]; }
@@ -70,7 +71,6 @@ struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - s
 };
 struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour, the default card)
   static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2, TIER1_F64 = 2;
-  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = false;   // (round 5, host build over 64-lane groups: 13.75 pivoting solves per wave and env-step, 14.02 with warm starts)
   // (round 4 A/B: H^-1 parked in LDS across the pivoting loops, the walker's HINV_LDS_F64, makes THIS kernel slower -- 31.82 -> 33.24 us
   // fp64, 158 -> 126 AGPRs: the 21 entries cost more as LDS round trips than as accumulator-register moves)
@@ -80,7 +80,6 @@ struct HopperAllTopo {  // the same chain with EVERY capsule tested against the 
 };
 struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin foot) x 2; only the feet collide
   static constexpr int NL = 7, NDOF = NL + 2, NC = 2, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
-  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;   // measured +26 % (persistent double-support contacts)
   static constexpr bool WARM_FRICTION = false;   // round 5: the Schur-complement start beats the previous substep's friction state (constraint_phase)
 #ifndef DART_NO_HINV_LDS
@@ -92,7 +91,6 @@ struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin f
 };
 struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the floor (DART's behaviour, the default card)
   static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
-  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;
   static constexpr bool WARM_FRICTION = false;   // (see Walker2dTopo)
 #ifndef DART_NO_HINV_LDS
@@ -104,54 +102,35 @@ struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the flo
 };
 
 struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded head) - (thigh shin foot) x 2, eight capsules, joint springs
-  // A thrashing cheetah rests on 3 capsules in half of the waves and on 4 in 6 % of them (1 % / 0.1 % of the envs), so a second
-  // register tier of 4 (fp32) / 3 (fp64) slots pays: 0.36 / 1.2 ms per batched step at 65 536 envs against 1.6 / 1.7 with one tier.
-  // That tier is 12 / 14 LCP rows (312 / 420 registers of matrix per lane, KBs of scratch).  INLINED into the step kernel it was
-  // NOT TRUSTWORTHY on gfx950 / ROCm 7.2: some instantiations (fp64 lean 3-slot, fp64 and fp32 reporting 4-slot) produced states
-  // that differed from the host build of the same source, from the fp64 oracle and -- the fp32 reporting kernel -- between the
-  // first and every later launch of one process.  As a real call on copies of its inputs (ISOLATED_TIER1, constraint_phase_call)
-  // every instantiation is bitwise repeatable and 3e-13 (fp64) / 6e-7 (fp32) per step from the oracle with all four slots in
-  // use; tests/test_gpu_repeatability.py and tools/gpu/determinism.py keep watching it.
-  // (Round 3: with the impulse pass on M the cheetah rests on 3 capsules in 4.5 % and on 4 in 0.23 % of its env-world-steps: 94 % of
-  // the waves take the second tier.)
-#ifndef DART_CHEETAH_RT_TABLES
-#define DART_CHEETAH_RT_TABLES true    // (-DDART_CHEETAH_RT_TABLES=false: the build that failed the repeatability test in round 4, for tools/gpu/first_launch_probe.py)
-#endif
-  static constexpr bool ANC_TABLES_RT = DART_CHEETAH_RT_TABLES;   // see topo_anc_rt
-  // Round 5: NO second register tier in the task kernel (TIER1 = TIER1_F64 = 0; rounds 2-4: 4 / 3 slots as a real call).  An env with more
-  // than two touching capsules goes to the wave solvers -- wave_constraints4, four envs per pass, one per row of 16 lanes (up to 16 rows;
-  // beyond: wave_constraints, one at a time).  Measured at 65 536 envs (profiles/r05_halfcheetah_coop4.txt): the tier kept and entered for every
-  // wave with such a lane (round 4's default) fp64 1.383 / fp32 0.514 ms per batched step; the tier kept, every such lane to the wave solvers
-  // (DART_CFG_WAVE_VOTE = 64) 0.785 / 0.476; the tier compiled out 0.620 / 0.394 -- the call and its TierIO block alone cost the step kernel
-  // 3.8 KB of its 6.3 KB of scratch per lane (fp64: 498 -> 193 spilled VGPRs; fp32: 972 B left, 2 spills).  Which solver serves an env is
-  // now a function of the env alone, so a trajectory does not depend on the env's wave mates -- bitwise
-  // (tests/test_gpu_spatial.py::test_half_cheetah_trajectories_do_not_depend_on_wave_mates); with the tier it did, in the last bits: the
-  // hand-off thresholds differ between the tiers and which tier a wave runs is its lanes' vote.  The price: a batch in which EVERY env rests
-  // on exactly three or four capsules pays 16 passes per world step where the tier paid one call (~2x); the physics-only variants
-  // (PhysTopo, a user's model that may live on the floor) keep their tiers.  -DDART_CHEETAH_TIER1=4 -DDART_CHEETAH_TIER1_F64=3 rebuilds rounds 2-4.
-#ifndef DART_CHEETAH_TIER1_F64
-#define DART_CHEETAH_TIER1_F64 0
-#endif
-#ifndef DART_CHEETAH_TIER1
-#define DART_CHEETAH_TIER1 0
-#endif
-  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = DART_CHEETAH_TIER1, TIER1_F64 = DART_CHEETAH_TIER1_F64;
-#ifndef DART_CHEETAH_ISOLATED_TIER1
-#define DART_CHEETAH_ISOLATED_TIER1 true    // (false: round 2's inlined big tier, for tools/exec_prologue_lint.py -- is it the same toolchain bug?)
-#endif
-  static constexpr bool ISOLATED_TIER1 = DART_CHEETAH_ISOLATED_TIER1;
+  // An env beyond the two register slots -- a thrashing cheetah rests on 3 capsules in 4.5 % and on 4 in 0.23 % of its env-world-steps, 94 %
+  // of the waves hold such a lane -- goes to the wave solvers: wave_constraints4, four envs per pass, one per row of 16 lanes (up to 16 rows;
+  // beyond: wave_constraints, one at a time).  Rounds 2-4 had a second register tier of 4 (fp32) / 3 (fp64) slots here, 12 / 14 LCP rows,
+  // first inlined (NOT TRUSTWORTHY on gfx950 / ROCm 7.2: spill copies ahead of an EXEC restore), then as a real call on
+  // copies of its inputs; round 5 compiled it out of this kernel (fp64 1.383 -> 0.620, fp32 0.514 -> 0.394 ms per batched step of 65 536
+  // envs, profiles/r05_halfcheetah_coop4.txt: the call and its argument block alone cost the step kernel 3.8 KB of its 6.3 KB of scratch per
+  // lane), round 6 deleted it everywhere together with DART_CFG_WAVE_VOTE, the per-wave choice between it and the wave solvers (git history
+  // has both).  Which solver serves an env is a function of the env alone, so a trajectory does not depend on the env's wave mates -- bitwise
+  // (tests/test_gpu_spatial.py::test_half_cheetah_trajectories_do_not_depend_on_wave_mates, also with every env lying on the floor).  The
+  // price: a batch in which EVERY env rests on three or four capsules pays 16 passes per world step (tools/gpu/cheetah_floor_probe.py).
+  static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
+  static constexpr bool PLAIN_FRICTION_START = true;   // see topo_plain_friction_start
   // Five touching capsules (four in fp64) are 6e-5 (2.3e-3) of the env-world-steps -- ~20 (~750) per launch of 65 536 envs -- and a
   // launch at one wave per SIMD lasts as long as its slowest wave.  WAVE_FALLBACK: such an env is served by the whole wave
   // (wave_constraints) instead of by its own lane alone, 2.50 -> 0.95 ms (fp32) / 3.43 -> 1.54 ms (fp64) per batched step; and the lanes
   // of a register tier that keep pivoting are handed to the same wave solver (blcp_bpp: coop / handoff), 0.95 -> 0.57 / 1.54 -> 1.50 ms.
   // (Opt-in per topology: with the calls in their kernels Hopper and Walker2d, whose bench workloads never need them, lose 9-12 %.)
   static constexpr bool WAVE_FALLBACK = true;
-  // (a build that keeps the tier: DART_CFG_WAVE_VOTE defaults to 64 -- every lane beyond the small tier to the wave solvers, the tier on request)
-#ifndef DART_CHEETAH_VOTE
-#define DART_CHEETAH_VOTE 64
-#endif
-  static constexpr int WAVE_VOTE = DART_CHEETAH_VOTE;
   static constexpr bool WARM = true;
+  // Round 6: H^-1 out of the registers across the two-slot tier's pivoting loops, as the Walker2d kernels have it (topo_hinv_lds64) --
+  // but the four-env wave solver's blocks (20.6 KB fp64) + an H^-1 block of its own (23 KB) would not fit the 40 KB a workgroup may
+  // take at four workgroups per CU, so the column is parked LATE: after the wave-served phase, INTO its then idle blocks
+  // (topo_hinv_lds_late; world_step).
+#ifndef DART_CHEETAH_HLDS
+#define DART_CHEETAH_HLDS 1
+#endif
+#if DART_CHEETAH_HLDS
+  static constexpr bool HINV_LDS_F64 = (DART_CHEETAH_HLDS & 1) != 0, HINV_LDS_F32 = (DART_CHEETAH_HLDS & 2) != 0, HINV_LDS_LATE = true;
+#endif
   __device__ __host__ static constexpr int parent(int k) { constexpr int P[NL] = {-1, 0, 1, 2, 0, 4, 5}; return P[k]; }
   __device__ __host__ static constexpr int clink(int c) { constexpr int L[NC] = {0, 0, 1, 2, 3, 4, 5, 6}; return L[c]; }
   __device__ __host__ static constexpr bool limited(int k) { return k >= 1; }
@@ -161,7 +140,6 @@ struct SnakeTopo {  // reference assets/snake_7link.skel: seven links in a chain
   // Gravity is normal to the plane of motion and nothing can reach the floor: no contact rows at all (NC = 1 is a placeholder that
   // is never tested, TIER0 = 0), six limit rows, and the fluid force of snake_7link.py:37-47 on every body before every world step.
   static constexpr int NL = 7, NDOF = NL + 2, NC = 1, NA = 6, TIER0 = 0, TIER1 = 0, TIER1_F64 = 0;
-  static constexpr bool ISOLATED_TIER1 = false;
   static constexpr bool WARM = true;
   static constexpr bool CONTACTS = false, FLUID = true, PLANE_XZ = true;
   __device__ __host__ static constexpr int parent(int k) { return k - 1; }
@@ -173,10 +151,11 @@ struct SnakeTopo {  // reference assets/snake_7link.skel: seven links in a chain
 // dart_env.py:28-175 -- runs a user's .skel on): every dof takes a generalized force (action = tau, no clamp, scale 1), the
 // observation is [q, dq], reward 0, never done.  A user model whose tree matches a compiled topology then runs one env per lane
 // instead of on the tree kernel (SURVEY.md 8(f)-1 "model compiler generality").
-// A user model has no termination inside the library -- it may fall over and stay on the floor with every capsule touching -- so the
-// register tiers of these variants cover that: all four capsules of the hopper chain (an 11-row LCP, no fallback path at all), four
-// (fp64: three) slots of the walker tree as a real call with the wave-served fallback behind it, as for the half cheetah.  (With the
-// base topologies' tiers 65 536 fallen pogo hoppers took 2.4 ms per env-step, every lane waiting its turn in the single-lane solver.)
+// A user model has no termination inside the library -- it may fall over and stay on the floor with every capsule touching.  The hopper
+// chain keeps all four capsules in a register tier (an 11-row LCP, no fallback path at all; with the base topology's tiers 65 536 fallen
+// pogo hoppers took 2.4 ms per env-step, every lane waiting its turn in the single-lane solver); the walker / cheetah trees have the two
+// slots of their base and the wave solvers behind them, as the half cheetah (round 6; rounds 2-5: a second register tier of four / three
+// slots as a real call, chosen per wave by DART_CFG_WAVE_VOTE -- results then depended on the wave mates in the last bits).
 template <class T, class = void> struct topo_contacts { static constexpr bool value = true; };
 template <class T> struct topo_contacts<T, decltype((void)T::CONTACTS)> { static constexpr bool value = T::CONTACTS; };
 template <class B> struct PhysTopo : B {
@@ -184,10 +163,11 @@ template <class B> struct PhysTopo : B {
   static constexpr int NA = B::NDOF;
   static constexpr bool PHYSICS = true;
   // (a base topology that cannot touch the floor -- the snake chain -- has no contact tiers to size)
-  static constexpr int TIER1 = !topo_contacts<B>::value ? 0 : (B::NC <= 4 ? B::NC : 4), TIER1_F64 = !topo_contacts<B>::value ? 0 : (B::NC <= 4 ? B::NC : 3);
-  static constexpr bool ISOLATED_TIER1 = topo_contacts<B>::value && (B::NC > 4);
+  static constexpr int TIER1 = (topo_contacts<B>::value && B::NC <= 4) ? B::NC : 0, TIER1_F64 = TIER1;
   static constexpr bool WAVE_FALLBACK = topo_contacts<B>::value && (B::NC > 4);
-  static constexpr int WAVE_VOTE = 0;   // a user's model may spend its life on the floor: the register tier stays the default (its worst case is the better one)
+  static constexpr bool PLAIN_FRICTION_START = topo_contacts<B>::value && (B::NC > 4);   // see topo_plain_friction_start
+  // (a base that parks H^-1 in LDS -- the walker tree -- and gains the four-env blocks here parks it INTO them: both would not fit, see topo_hinv_lds_late)
+  static constexpr bool HINV_LDS_LATE = topo_contacts<B>::value && (B::NC > 4);
 };
 // optional traits (default: a robot in the vertical x-y plane with capsules that can touch the floor, no fluid)
 template <class T, class = void> struct topo_physics { static constexpr bool value = false; };
@@ -209,9 +189,11 @@ template <class T, class = void> struct topo_hinv_lds64 { static constexpr bool 
 template <class T> struct topo_hinv_lds64<T, decltype((void)T::HINV_LDS_F64)> { static constexpr bool value = T::HINV_LDS_F64; };
 template <class T, class = void> struct topo_warm_friction { static constexpr bool value = true; };   // stage-2 start of a persisting contact's friction row from the previous substep (constraint_phase)
 template <class T> struct topo_warm_friction<T, decltype((void)T::WARM_FRICTION)> { static constexpr bool value = T::WARM_FRICTION; };
-// default of DART_CFG_WAVE_VOTE for a topology's kernels (optional trait WAVE_VOTE; 0 = the register tiers)
-template <class T, class = void> struct topo_vote { static constexpr int value = 0; };
-template <class T> struct topo_vote<T, decltype((void)T::WAVE_VOTE)> { static constexpr int value = T::WAVE_VOTE; };
+// PLAIN_FRICTION_START: a friction row's start set from its own stiffness A_tt, not from the Schur complement over the contact's normal row
+// (constraint_phase).  The half cheetah and the physics-only walker / cheetah trees: re-measured in round 5 on the two-slot tier, with /
+// without either rule 30.0-30.6 wave solves per env-step -- nothing to gain, and their kernels were validated with this one.
+template <class T, class = void> struct topo_plain_friction_start { static constexpr bool value = false; };
+template <class T> struct topo_plain_friction_start<T, decltype((void)T::PLAIN_FRICTION_START)> { static constexpr bool value = T::PLAIN_FRICTION_START; };
 template <class T, class = void> struct topo_wave_fallback { static constexpr bool value = false; };
 template <class T> struct topo_wave_fallback<T, decltype((void)T::WAVE_FALLBACK)> { static constexpr bool value = T::WAVE_FALLBACK; };
 template <class T, class = void> struct topo_hinv_lds32 { static constexpr bool value = false; };
@@ -219,6 +201,11 @@ template <class T> struct topo_hinv_lds32<T, decltype((void)T::HINV_LDS_F32)> { 
 template <class T, class Real> __device__ __host__ constexpr bool hinv_lds() {
   return sizeof(Real) == 8 ? topo_hinv_lds64<T>::value : topo_hinv_lds32<T>::value;
 }
+// HINV_LDS_LATE: the column is written after the wave-served phase of the world step, into the LDS that phase used (the four-env blocks
+// of wave_constraints4, idle from then on) -- topologies whose LDS budget has no room for both.  Until then H^-1 stays where it was computed.
+template <class T, class = void> struct topo_hinv_lds_late { static constexpr bool value = false; };
+template <class T> struct topo_hinv_lds_late<T, decltype((void)T::HINV_LDS_LATE)> { static constexpr bool value = T::HINV_LDS_LATE; };
+template <class T, class Real> __device__ __host__ constexpr bool hinv_lds_late() { return hinv_lds<T, Real>() && topo_hinv_lds_late<T>::value; }
 #ifndef DART_COMPILER_FENCE
 #define DART_COMPILER_FENCE() asm volatile("" ::: "memory")   // no load / store of the compiler's moves across (it emits nothing)
 #endif
@@ -297,6 +284,8 @@ __device__ __host__ constexpr int constraint_lds_words() { return has_slow_path<
 //   creport        [n_envs][NC][8] contacts of the env-step's LAST world step {body, -1, point xyz, force on the body xyz} --
 //                  world.collision_result.contacts as walker2d.py:38-41 reads it; creport_count [n_envs]; cf_report [n_envs][NDOF] =
 //                  skel.constraint_forces() of that step (J^T lambda / dt)
+//   mt             the per-env MT19937 bank (mt19937_draw.hpp): with it, an env that finishes draws its reset noise from ITS numpy stream in
+//                  the step kernel's epilogue -- the reference-exact auto-reset, no second and third launch; null: Philox (or none)
 template <class Real>
 struct Extras {
   const Real* ext_force = nullptr;
@@ -304,6 +293,7 @@ struct Extras {
   Real* creport = nullptr;
   int* creport_count = nullptr;
   Real* cf_report = nullptr;
+  const MtBankView* mt = nullptr;
 };
 // where a world step reports to (null record pointer: nothing to report)
 template <class Real>
@@ -329,7 +319,7 @@ struct Params {
   Real alive, ctrl_cost, pen_each, pen_margin, h_lo, h_hi, ang_max, s_max, v_clip, inv_envdt, noise, noise_v;
   int frame_skip, max_steps, penalty_link, task;
   int solver, iters1, iters2;  // solver 0: block principal pivoting (exact); 1: PGS sweeps
-  int force_slow;              // > 0: debug / test knob, every lane with a contact takes the fallback solver; < 0: -K of DART_CFG_WAVE_VOTE (step_kernel)
+  int force_slow;              // 1: debug / test knob (DART_CFG_DEBUG_FORCE_FALLBACK), every lane with a contact takes the fallback solver
   unsigned long long* stats;   // optional [2][32] histogram of wave-level pivoting iterations per stage (debug), or null
   int cbody[T::NC];            // card body index of each candidate capsule (contact report)
   Extras<Real> ex;
@@ -646,18 +636,25 @@ __device__ __forceinline__ void wave_timing_add(unsigned long long* st, int sum_
 }
 #endif
 
-// Wave-served solves run one env after the other, so a wave whose lanes ALL have problems that do not converge (a simulation that is
-// blowing up, fp32 on an ill-conditioned pile-up) would pay the iteration cap once per lane instead of once per wave.  Each place that
-// serves lanes this way therefore has a budget of wave iterations for all its lanes together: a lane may use what is left of it, at
-// least DART_COOP_MIN (enough for a problem that is merely large); when it runs out the remaining lanes keep their last iterate,
-// clamped into the box, as a lane does at its own cap.  Workloads within the documented statistics never get near it.
+// Wave-served solves (the hand-off of a register tier, wave_constraints, wave_constraints4) run one env -- or four -- after the other.
+// Round 6: what a solve may spend is ITS OWN business -- per env and stage min(the stage's cap, DART_COOP_BUDGET) wave
+// iterations, whatever its wave mates needed (every half-cheetah problem of the 65 536-env statistics converges within 60) -- so a result
+// is a function of the env alone also in a wave whose lanes all lie on the floor.  (Rounds 3-5 shared ONE budget of 96 / 192 iterations
+// among all the solves of a wave and world step: sized for rare fallbacks, it ran out in contact-heavy waves once the half cheetah's
+// second register tier was gone -- up to 16 passes a world step -- and the late envs kept a clamped, unconverged iterate that depended
+// on how much the early ones had used.)  What is left of the shared budget is a RUNAWAY GUARD of 64 x DART_COOP_BUDGET iterations per
+// serving place and world step: it can bind only when the equivalent of every lane of the wave runs into its cap -- a simulation that
+// is blowing up -- and then the remaining lanes get DART_COOP_MIN iterations each and keep their last iterate, clamped into the box,
+// as a lane does at its own cap.
 #ifndef DART_COOP_BUDGET
 #define DART_COOP_BUDGET 96
 #define DART_COOP_MIN 8
 #endif
-__device__ __host__ constexpr int coop_iters(int cap, int budget) {
-  const int b = budget > DART_COOP_MIN ? budget : DART_COOP_MIN;
-  return cap < b ? cap : b;
+#define DART_COOP_GUARD (64 * DART_COOP_BUDGET)
+__device__ __host__ constexpr int coop_iters(int cap, int guard) {   // iterations one wave-served solve may run
+  const int c = cap < DART_COOP_BUDGET ? cap : DART_COOP_BUDGET;
+  const int b = guard > DART_COOP_MIN ? guard : DART_COOP_MIN;
+  return c < b ? c : b;
 }
 
 // coop / handoff (topologies with WAVE_FALLBACK, device build): after `handoff` iterations the lanes that have not converged are
@@ -750,7 +747,7 @@ __device__ __forceinline__ void blcp_bpp(const Real (&A)[M * (M + 1) / 2], const
     static_assert(M <= 16, "hand-off uses the 16-row register solver");
     const int lane = (int)(threadIdx.x & 63);
     unsigned long long todo = __ballot(!conv);
-    int budget = DART_COOP_BUDGET;   // wave iterations this hand-off may spend in all (see wave_constraints)
+    int budget = DART_COOP_GUARD;   // runaway guard over all the lanes handed off here (see coop_iters)
 #ifdef DART_WAVE_TIMING_FALLBACK   // [30] envs handed off, [31] cycles spent serving them
     const long long th0 = (long long)__builtin_readcyclecounter();
     if (stats && lane == 0 && todo != 0ull) atomicAdd(&stats[30], (unsigned long long)__popcll(todo));
@@ -862,10 +859,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   constexpr int HO_[4] = {DART_HANDOFF_BIG, DART_HANDOFF_SMALL};
   constexpr bool BIGT = tier1<T, Real>() > 0 && NCA == tier1<T, Real>();
   constexpr int HO1 = BIGT ? HO_[0] : HO_[2], HO2 = BIGT ? HO_[1] : HO_[3];
-#ifndef DART_PRESOLVE32_BIG_TIER
-#define DART_PRESOLVE32_BIG_TIER 1
-#endif
-  constexpr bool PRE32 = DART_PRESOLVE32_BIG_TIER != 0 && BIGT && T::ISOLATED_TIER1 && sizeof(Real) == 8;   // see blcp_bpp_mixed
+  constexpr bool PRE32 = false;   // (blcp_bpp_mixed: the fp32 pre-search paid only for the 12-row fp64 tier of rounds 2-5)
   auto Hv = [&](int k) -> Real { if constexpr (HLDS) return hl[64 * k]; else return H[k]; };
   constexpr bool IDENT = (NCA == NC);   // slot s IS candidate s: links are compile-time constants
   constexpr int NS = NCA > 0 ? NCA : 1;   // array extent of the slot arrays (a tier without contact slots still declares them)
@@ -1125,10 +1119,9 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       // complement A_tt - A_tn^2 / A_nn.  (tests/diag/diag_lcp_active_sets.py: with the plain A_tt 92 % of the wrong stage-2 guesses
       // were friction rows guessed sticking that ended up sliding; with the complement a Hopper lane needs one stage-2 solve in 98 %
       // instead of 84 % of the substeps, which takes a wave -- the maximum over its lanes -- from 3 solves to 2 or 1: 34.1 -> 31.2 us.)
-      // (Topologies whose big tier is an isolated call -- the half cheetah -- keep the plain A_tt: their kernels were validated on
-      // the GPU, repeatability included, before this change and the round's GPU budget ended with the Hopper / Walker2d measurement.)
+      // (topo_plain_friction_start: the half cheetah and the physics-only walker / cheetah trees keep the plain A_tt)
       Real att = A[tri(stt, stt)];
-      if constexpr (!T::ISOLATED_TIER1) {
+      if constexpr (!topo_plain_friction_start<T>::value) {
         const bool nfree = (F >> sn) & 1u;
         att = nfree ? att - A[tri(stt, sn)] * A[tri(stt, sn)] * rcp_<Real>(A[tri(sn, sn)]) : att;
       }
@@ -1196,20 +1189,6 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     });
     vs[i] += dv;
   });
-}
-
-// A tier as a real function call on copies of its inputs (topologies with ISOLATED_TIER1).
-template <class Real, class T>
-struct TierIO {
-  Real q[T::NDOF], H[T::NDOF * (T::NDOF + 1) / 2], px[T::NL], py[T::NL], vs[T::NDOF], cPx[T::NC], cPy[T::NC], cdep[T::NC];
-  bool con[T::NC], off;
-  WarmSets warm;
-  ReportTo<Real> rp;
-  Real* cm;   // LDS block of the wave solver's hand-off (topologies with WAVE_FALLBACK), else null
-};
-template <class Real, class T, class PT, int NCA, bool EXTRAS>
-__device__ __attribute__((noinline)) void constraint_phase_call(PT P, TierIO<Real, T>& io) {
-  constraint_phase<Real, T, PT, NCA, EXTRAS>(P, io.q, io.H, io.px, io.py, io.vs, io.con, io.cPx, io.cPy, io.cdep, io.off, io.warm, io.rp, nullptr, io.cm);
 }
 
 // ------------------------------------------------------------------ single-lane fallback: any number of contacts, loops over LDS
@@ -1393,8 +1372,8 @@ __device__ __attribute__((noinline)) void slow_constraints(const PT& P, Real* me
 // and the Delassus matrix, and the two pivoting solves run in registers with lane i holding row i (wave_blcp.hpp: the tree kernel's
 // solver, same start sets, tolerances, patience and single-pivot rule as slow_blcp / blcp_bpp).  Same memory layout as slow_constraints;
 // `owner` is the lane whose env this is (it wrote the inputs and takes vs back; only its `rp` is used).  A solve that reaches its
-// iteration cap -- or the wave's budget for all the envs it serves in this world step (DART_COOP_BUDGET) -- ends on its last iterate,
-// clamped into the box, as a lane of a register tier does at its cap.
+// iteration cap (coop_iters: min of the stage's cap and DART_COOP_BUDGET, the env's own) ends on its last iterate, clamped into the box,
+// as a lane of a register tier does at its cap.
 // Measured need (DartHalfCheetah-v1, 65 536 envs): 6e-5 of the env-world-steps have five touching capsules -- ~20 per launch -- and a
 // launch takes as long as its slowest wave: served by one lane (~1 M cycles each) they set the kernel time, 2.5 ms instead of 0.4.
 template <class Real, class T, class PT, bool EXTRAS>
@@ -1840,12 +1819,12 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     if (impulse_M) implicit_accel<Real, N, REV, ImplicitDofs<PT, N>>(P, H, acc);
     sfor<0, N>([&](auto I) { constexpr int i = I; vs[i] = dq[i] + P.dt * acc[i]; });
   }
-  constexpr bool HLDS = hinv_lds<T, Real>();
-  if constexpr (HLDS) {   // park H^-1 in this lane's LDS column (topo_hinv_lds64); from here on it is read from there
+  constexpr bool HLDS = hinv_lds<T, Real>(), HLATE = hinv_lds_late<T, Real>();
+  if constexpr (HLDS && !HLATE) {   // park H^-1 in this lane's LDS column (topo_hinv_lds64); from here on it is read from there
     sfor<0, N*(N + 1) / 2>([&](auto I) { constexpr int i = I; hl[64 * i] = H[i]; });
     DART_COMPILER_FENCE();
   }
-  auto Hv = [&](int k) -> Real { if constexpr (HLDS) return hl[64 * k]; else return H[k]; };
+  auto Hv = [&](int k) -> Real { if constexpr (HLDS && !HLATE) return hl[64 * k]; else return H[k]; };   // (up to the register tiers)
 
   // ---- candidate contacts at q_t: every capsule's lowest segment endpoint against the floor (ODE capsule-plane as DART
   // uses it: one contact, position in the middle of the penetration)
@@ -1873,22 +1852,6 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   bool slow = false;
   if constexpr (has_slow_path<T, Real>()) {
     slow = nact > last_tier<T, Real>() || (P.force_slow > 0 && nact > 0);
-#ifdef DART_WAVE_COOP
-    // DART_CFG_WAVE_VOTE = K (P.force_slow = -K): kernels that have BOTH a second register tier and the wave-served fallback -- since round 5
-    // the physics-only walker / cheetah trees (PhysTopo; the half-cheetah task kernel has no second tier any more, see CheetahTopo).  A wave
-    // that has at most K lanes beyond the small tier serves those envs with the wave solvers (wave_constraints4 / wave_constraints) and keeps
-    // everybody else in the small tier; a wave with more such lanes -- a batch lying on the floor -- runs the big tier for all its lanes.
-    // 0 (these kernels' default) = always the tier, 64 = never.  For 0 < K < 64 which solver serves a lane depends on its wave mates and the
-    // two round differently: same LCP solution, last-bit different states.  (Round 4, the cheetah's task kernel with its 3-slot fp64 tier,
-    // one-at-a-time wave solver: K = 0 1.452 ms, 1 1.39, 2 1.29, 3 1.26, 4 1.32, 8 1.65 per batched step of 65 536 envs.)
-    if constexpr (topo_wave_fallback<T>::value && tier1<T, Real>() > 0) {
-      if (P.force_slow < 0 && blockDim.x == 64) {
-        const bool big = !slow && nact > T::TIER0;
-        const int nbig = __popcll(__ballot(big));
-        if (nbig > 0 && nbig <= -P.force_slow) slow = slow || big;
-      }
-    }
-#endif
     if (__any(slow)) {
       // the rare lanes whose env touches the floor with more capsules than the tiers hold: one after the other
 #ifdef DART_WAVE_TIMING
@@ -1917,7 +1880,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
       Real* mvs = slow_mem + N * N + 3 * NL;
 #ifdef DART_WAVE_COOP
       if (topo_wave_fallback<T>::value && blockDim.x == 64) {   // a full wave: all 64 lanes serve the env together (wave_constraints)
-        int budget = 2 * DART_COOP_BUDGET;   // both stages of every env served in this world step
+        int budget = DART_COOP_GUARD;   // runaway guard over every env served in this world step (coop_iters: a solve's cap is its own)
         bool left = slow;
 #if DART_COOP4
         // four envs per pass, one per row of 16 lanes, for every env of at most 16 rows (wave_constraints4); eligibility is the env's own
@@ -1978,6 +1941,10 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 #endif
     }
   }
+  if constexpr (HLATE) {   // the wave-served phase is over (its last pass ended on a barrier): its blocks take this wave's H^-1 columns
+    sfor<0, N*(N + 1) / 2>([&](auto I) { constexpr int i = I; hl[64 * i] = H[i]; });
+    DART_COMPILER_FENCE();
+  }
   // ---- register tiers: the smallest one that holds every (remaining) lane's contacts
   const int nreg = slow ? 0 : nact;
 #ifdef DART_WAVE_TIMING
@@ -1993,20 +1960,7 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 #ifdef DART_WAVE_TIMING
       big_tier = true;
 #endif
-      if constexpr (T::ISOLATED_TIER1) {   // a real call on copies of the inputs: the big tier gets a register allocation of its own
-        TierIO<Real, T> io;
-        sfor<0, N>([&](auto I) { io.q[I] = q[I]; io.vs[I] = vs[I]; });
-        sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = Hv(I); });
-        sfor<0, NL>([&](auto K) { io.px[K] = px[K]; io.py[K] = py[K]; });
-        sfor<0, NC>([&](auto Cc) { io.con[Cc] = con[Cc]; io.cPx[Cc] = cPx[Cc]; io.cPy[Cc] = cPy[Cc]; io.cdep[Cc] = cdep[Cc]; });
-        io.off = slow; io.warm = warm; io.rp = rp;
-        io.cm = cm;
-        constraint_phase_call<Real, T, PT, tier1<T, Real>(), EXTRAS>(P, io);
-        sfor<0, N>([&](auto I) { vs[I] = io.vs[I]; });
-        warm = io.warm;
-      } else {
-        constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
-      }
+      constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     }
     else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
   } else {
@@ -2113,10 +2067,13 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   Real dx = Real(0);
   WarmSets warm;
   // LDS of the single-lane fallback solver (only topologies with more candidate capsules than tier slots have one)
-  __shared__ Real slow_lds[constraint_lds_words<T, Real>() + (topo_wave_fallback<T>::value ? coop_words<16>() : 0) + coop4_lds_words<T>()];
-  // H^-1 of every lane, one 64-lane column per packed entry (topo_hinv_lds64; only the topologies that ask for it)
-  __shared__ Real hinv_lds_[hinv_lds<T, Real>() ? 64 * (N * (N + 1) / 2) : 1];
-  Real* hl = hinv_lds_ + (threadIdx.x & 63);
+  // H^-1 of every lane, one 64-lane column per packed entry (topo_hinv_lds64; only the topologies that ask for it) -- a block of its
+  // own, or (topo_hinv_lds_late) the four-env blocks behind the fallback solver's, which are idle once the wave-served phase is over
+  constexpr int HL_WORDS = 64 * (N * (N + 1) / 2), SLOW_HEAD = constraint_lds_words<T, Real>() + (topo_wave_fallback<T>::value ? coop_words<16>() : 0);
+  constexpr bool HL_LATE = hinv_lds_late<T, Real>();
+  __shared__ Real slow_lds[SLOW_HEAD + ((HL_LATE && HL_WORDS > coop4_lds_words<T>()) ? HL_WORDS : coop4_lds_words<T>())];
+  __shared__ Real hinv_lds_[(hinv_lds<T, Real>() && !HL_LATE) ? HL_WORDS : 1];
+  Real* hl = (HL_LATE ? slow_lds + SLOW_HEAD : hinv_lds_) + (threadIdx.x & 63);
 #pragma unroll 1
   for (int f = 0; f < P.frame_skip; ++f) {
     ReportTo<Real> rp;
@@ -2163,12 +2120,16 @@ __global__ void __launch_bounds__(64) step_kernel(PT P, int64_t n_envs, Real* __
   bool trunc = (P.max_steps > 0) && (el >= P.max_steps);
   bool dn = task_done || trunc;
   if (autoreset && dn) {
-    uint32_t ep = ep_in + 1;
-    reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, P.noise_v, q, dq);
-    sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
+    if (P.ex.mt != nullptr) {   // (wave-uniform) reference-exact reset: this env's own numpy stream (the episode counter keys Philox only)
+      if (valid) mt_reset_draw<Real, N>(*P.ex.mt, n_envs, e, q, dq);
+    } else {
+      uint32_t ep = ep_in + 1;
+      reset_noise<Real, N>(seed, env_offset + (uint64_t)ec, ep, P.noise, P.noise_v, q, dq);
+      sfor<0, N>([&](auto I) { constexpr int i = I; q[i] += P.q0[i]; dq[i] += P.dq0[i]; });
+      if (valid) episode[e] = ep;
+    }
     el = 0;
     height = (P.task == 6 || P.task == 9) ? q[1] : root_height<Real, T, PT>(P, q);
-    if (valid) episode[e] = ep;
   }
   if (valid) {
     sfor<0, N>([&](auto I) { constexpr int i = I; qs[(int64_t)i * n_envs + e] = q[i]; dqs[(int64_t)i * n_envs + e] = dq[i]; });

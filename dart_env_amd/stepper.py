@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("DART_STEPPER_LIB", os.path.join(_HERE, LIB_NAME))
 DART_OK, E_INVALID, E_NO_DEVICE, E_UNSUPPORTED, E_HIP, E_PENDING, E_NOT_PENDING = 0, -1, -2, -3, -4, -5, -6
 Q_NUM_ENVS, Q_NDOFS, Q_OBS_DIM, Q_ACT_DIM, Q_FRAME_SKIP, Q_PRECISION, Q_DEVICE, Q_LCP_SLOTS, Q_STATIC_KERNEL, Q_MAX_CONTACTS, Q_LDS_BYTES, Q_LANE_KERNEL = range(12)
 (CFG_SOLVER, CFG_ITERS_STAGE1, CFG_ITERS_STAGE2, CFG_AUTORESET, CFG_SEED, CFG_ENV_OFFSET, CFG_BLOCK_THREADS, CFG_STATS,
- CFG_EPISODE_STATS, CFG_CONTACT_REPORT, CFG_DEBUG_FORCE_FALLBACK, CFG_LAUNCH_ORDER, CFG_WAVE_VOTE, CFG_HOST_DMA) = range(14)
+ CFG_EPISODE_STATS, CFG_CONTACT_REPORT, CFG_DEBUG_FORCE_FALLBACK, CFG_LAUNCH_ORDER, _CFG_RETIRED_12, CFG_HOST_DMA) = range(14)
 SOLVER_BPP, SOLVER_PGS = 0, 1
 
 EXPORTS = [

@@ -62,18 +62,19 @@ enum {
   DART_CFG_CONTACT_REPORT = 9, /* 1: record the contacts of every env-step's last world step (dart_get_contacts) */
   DART_CFG_DEBUG_FORCE_FALLBACK = 10, /* planar register kernels, tests only: 1 routes every env that touches the floor through the
                                single-lane fallback solver, the path of an env with more contacts than the kernel's slot tiers hold */
-  DART_CFG_WAVE_VOTE = 12,  /* lane kernels that have both a second register tier and the wave-served fallback (the physics-only walker / cheetah
-                               trees: a user's .skel on those topologies): K = 0 .. 64.  A wavefront with at most K envs beyond its small register
-                               tier serves them cooperatively -- four envs per pass, one per row of 16 lanes -- instead of running the big tier
-                               for all 64 lanes; 0 (default) = always the tier, 64 = never.  0 < K < 64: which solver serves an env depends on
-                               its wave mates and the two round differently -- same LCP solutions, last-bit different states.  No effect on
-                               DartHalfCheetah-v1 since round 5: its kernel has no second tier (every env beyond two contacts goes to the wave
-                               solvers: 1.38 -> 0.62 ms fp64, 0.51 -> 0.39 ms fp32 per batched step of 65 536 envs). */
+  /* 12: retired (DART_CFG_WAVE_VOTE of rounds 4-5, the per-wave choice between a second register tier and the wave solvers in the physics-only
+         walker / cheetah kernels).  Round 6 deleted that tier: every env beyond two touching capsules goes to the wave solvers, which solver serves
+         an env -- and how many iterations it may spend -- is a function of the env alone, so results no longer depend on the wave mates.
+         dart_configure returns DART_E_INVALID for it. */
   DART_CFG_HOST_DMA = 13,   /* how the host-buffer entry points (dart_step, dart_step_async[_to]) cross PCIe, a bit mask, default 3:
                                bit 0 = the step kernel reads the actions straight from page-locked host memory (no H2D copy),
                                bit 1 = the outputs return through a copy kernel writing the mapped host block (no SDMA copy),
-                               bit 2 = the four outputs as four separate copies (rounds 1-2).  0 = copy engines both ways.  Results do
-                               not depend on it; it exists for A/B measurements (tools/gpu/host_path_c.py). */
+                               bit 2 = the four outputs as four separate copies (rounds 1-2),
+                               bit 3 = (round 6) the reference-exact MT19937 auto-reset as two launches behind the step kernel, as rounds 1-5
+                                       ran it, also where the step kernel now does it in its epilogue (the lane kernels of the tasks whose
+                                       reset_model draws the two noise vectors and nothing else).
+                               0 = copy engines both ways.  Results do not depend on it; it exists for A/B measurements
+                               (tools/gpu/host_path_c.py). */
   DART_CFG_LAUNCH_ORDER = 11 /* tree kernel (one env per workgroup): 1 (default) = the workgroups of a step are dispatched in the order
                                of the envs' durations at the previous step, longest first -- a launch ends when its last workgroup
                                does, and an env that was expensive (many contacts, a long pivoting run) mostly still is; 0 = index

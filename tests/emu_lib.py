@@ -39,7 +39,6 @@ def lib(tree=False, waves=False):
         L.emu_set_solver.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.emu_enable_stats.argtypes = [vp, C.c_int]
         L.emu_force_slow.argtypes = [vp, C.c_int]
-        L.emu_wave_vote.argtypes = [vp, C.c_int]
         L.emu_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), dp]
         L.emu_set_ext_force.argtypes = [vp, C.c_int, dp]
         L.emu_contact_report.argtypes = [vp, C.c_int]
@@ -118,7 +117,6 @@ class EmuStepper:
             self._solver_cfg = sv
             self.L.emu_set_solver(self.h, sv[0], sv[1], sv[2])
         elif key == st.CFG_STATS: self.L.emu_enable_stats(self.h, int(value != 0))
-        elif key == st.CFG_WAVE_VOTE: self.L.emu_wave_vote(self.h, int(value))
         else: raise ValueError(key)
 
     def set_ext_force(self, body, force):

@@ -85,7 +85,6 @@ int emu_max_contacts(Emu* h) { return h->impl->max_contacts(); }
 int emu_get_contacts(Emu* h, int32_t* count, int32_t* bodies, double* point_force, int maxc) { return h->impl->get_contacts(nullptr, h->n, count, bodies, point_force, maxc); }
 int emu_get_constraint_forces(Emu* h, double* out) { return h->impl->get_constraint_forces(nullptr, h->n, out); }
 void emu_force_slow(Emu* h, int on) { h->impl->set_force_slow(on); }
-void emu_wave_vote(Emu* h, int k) { h->impl->set_wave_vote(k); }
 int emu_set_task_state(Emu* h, const uint8_t* mask, const double* values4) { return h->impl->set_task_state(nullptr, mask, values4, h->n); }
 void emu_enable_stats(Emu* h, int on) { h->stats.assign(64, 0); h->impl->set_stats(on ? h->stats.data() : nullptr); }
 void emu_get_stats(Emu* h, unsigned long long* out64) { memcpy(out64, h->stats.data(), 64 * sizeof(unsigned long long)); }

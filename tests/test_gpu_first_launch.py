@@ -20,9 +20,9 @@ CASES = [("DartHopper-v1", 64), ("DartHopper-v1", 32), ("DartWalker2d-v1", 64), 
          ("DartHumanWalker-v1", 64)]
 
 
-def _probe(env_id, prec, extra):
-    n = "16384" if env_id == "DartHumanWalker-v1" else "65536"
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "gpu", "first_launch_probe.py"), "--env", env_id, "--prec", str(prec), "--n", n, "--steps", "3"] + extra
+def _probe(env_id, prec, extra, n=None):
+    n = n or ("16384" if env_id == "DartHumanWalker-v1" else "65536")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "gpu", "first_launch_probe.py"), "--env", env_id, "--prec", str(prec), "--n", str(n), "--steps", "3"] + extra
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if "digests" in l][-1]
@@ -35,3 +35,29 @@ def test_results_do_not_depend_on_leftovers_in_registers_scratch_or_lds(env_id, 
     assert len(set(plain)) == 1, plain                                # the round-4 form of the test: first launch == later launches
     d = _probe(env_id, prec, ["--poison", "all", "--when", "both", "--pattern", "random"])     # registers, scratch and LDS, a fresh pattern before every rollout
     assert len(set(d)) == 1 and d[0] == plain[0], (d, plain)          # same bits every time, and the plain run's
+
+
+# Round 6: the exec-prologue lint matches ONE manifestation of the toolchain defect; the poison test is the real gate, and
+# the same toolchain builds every kernel family.  So: the rest of the lane kernels (snake chain, cart + 1 / 2 links, the two-link arm, the
+# 3-D chain), the tree kernel's other instantiations (link-link contacts: Walker3d; FreeJoint root + LDS solver: Dog; the fp32 pattern
+# kernel), and a physics-only card (`envs.DartEnv` on a user's .skel: the PhysTopo kernels / task 0 of the cart, arm and chain kernels) of
+# every compiled shape.  One fresh process per case (--when combined: two undisturbed rollouts, then every rollout behind a fresh random
+# poisoning of registers, scratch and LDS), smaller batches than the bench configs above -- whole waves either way.
+MORE_ENVS = [("DartSnake7Link-v1", 64, 16384), ("DartSnake7Link-v1", 32, 16384), ("DartCartPole-v1", 64, 16384), ("DartCartPoleSwingUp-v1", 32, 16384),
+             ("DartDoubleInvertedPendulumEnv-v1", 64, 16384), ("DartReacher-v1", 64, 16384), ("DartReacher3d-v1", 64, 16384), ("DartReacher3d-v1", 32, 16384),
+             ("DartWalker3d-v1", 64, 4096), ("DartWalker3d-v1", 32, 4096), ("DartDog-v1", 64, 4096), ("DartDog-v1", 32, 4096), ("DartHumanWalker-v1", 32, 4096),
+             ("DartWalker3dSPD-v1", 64, 2048)]
+PHYS = [("hopper", 64), ("walker2d", 64), ("walker2d", 32), ("halfcheetah", 64), ("halfcheetah", 32), ("snake7link", 64), ("cartpole", 64), ("double_pendulum", 64),
+        ("reacher2d", 64), ("reacher3d", 64)]
+
+
+@pytest.mark.parametrize("env_id,prec,n", MORE_ENVS)
+def test_every_other_kernel_family_is_independent_of_leftovers(env_id, prec, n):
+    d = _probe(env_id, prec, ["--poison", "all", "--when", "combined", "--pattern", "random", "--reps", "5"], n=n)
+    assert len(d) == 5 and len(set(d)) == 1, d
+
+
+@pytest.mark.parametrize("model,prec", PHYS)
+def test_physics_only_kernels_are_independent_of_leftovers(model, prec):
+    d = _probe("-", prec, ["--phys", model, "--poison", "all", "--when", "combined", "--pattern", "random", "--reps", "5"], n=16384)
+    assert len(d) == 5 and len(set(d)) == 1, d

@@ -345,6 +345,63 @@ def test_device_mt19937_bank_is_bit_exact_with_numpy_streams():
     s.close()
 
 
+@pytest.mark.parametrize("env_id,precision", [("DartHopper-v1", 64), ("DartHopper-v1", 32), ("DartWalker2d-v1", 64), ("DartHalfCheetah-v1", 64),
+                                              ("DartSnake7Link-v1", 64)])
+def test_mt19937_reset_in_the_step_kernel_equals_the_two_launch_path(env_id, precision):
+    """Round 6: a lane kernel draws a finished env's reset noise from the env's MT19937 stream in its own epilogue (mt19937_draw.hpp)
+    instead of two more launches behind it (mt_draw_kernel + the masked reset kernel; DART_CFG_HOST_DMA bit 3 keeps those for this A/B).
+    Same streams, same order, same roundings: observations, rewards, done flags, states and the generators' positions agree bitwise over
+    a rollout in which every env resets several times -- and the fused draws ARE numpy's (hopper: checked against RandomState directly)."""
+    from dart_env_amd import seeding
+    card = card_for(env_id)
+    n, T = 640, 150 if env_id != "DartHalfCheetah-v1" else 60
+    card.max_episode_steps = 23          # TimeLimit truncations on top of the task's own terminations: several resets per env
+    keys, klen = seeding.mt_keys(list(range(11, 11 + n)))
+    acts = np.random.RandomState(4).uniform(-1, 1, (T, n, card.act_dim)).astype(np.float32)
+    outs = []
+    for dma in (3, 3 | 8):
+        g = st.HipStepper(card, n, precision=precision)
+        g.seed_mt19937(keys, klen)
+        g.configure(st.CFG_AUTORESET, 1); g.configure(st.CFG_HOST_DMA, dma)
+        g.reset(None, None, None, want_obs=False)
+        rec = []
+        for t in range(T):
+            o, r, d, tr = g.step(acts[t])
+            rec.append((o.copy(), r.copy(), d.copy(), tr.copy()))
+        q, dq = g.get_state()
+        el, ep = g.counters()
+        outs.append((rec, q, dq, el, g.snapshot()))
+        g.close()
+    (ra, qa, dqa, ela, sa), (rb, qb, dqb, elb, sb) = outs
+    resets = sum(int(x[2].sum()) for x in ra)
+    assert resets > 3 * n, resets
+    for t in range(T):
+        for k in range(4):
+            assert np.array_equal(ra[t][k], rb[t][k]), (t, k)
+    assert np.array_equal(qa, qb) and np.array_equal(dqa, dqb) and np.array_equal(ela, elb)
+    assert np.array_equal(sa, sb)        # the whole checkpoint: state, counters, MT19937 words and positions
+    if env_id == "DartHopper-v1" and precision == 64:
+        # env 0's post-reset states are numpy's: replay its stream
+        r0, _ = seeding.np_random(11)
+        g = st.HipStepper(card, n, precision=64)
+        g.seed_mt19937(keys, klen); g.configure(st.CFG_AUTORESET, 1)
+        g.reset(None, None, None, want_obs=False)
+        q, dq = g.get_state()
+        assert np.array_equal(q[0], card_init(card)[0] + r0.uniform(-.005, .005, 6)) and np.array_equal(dq[0], card_init(card)[1] + r0.uniform(-.005, .005, 6))
+        for t in range(60):
+            o, r, d, tr = g.step(acts[t])
+            if d[0]:
+                q, dq = g.get_state()
+                eq = card_init(card)[0] + r0.uniform(-.005, .005, 6); ev = card_init(card)[1] + r0.uniform(-.005, .005, 6)
+                assert np.array_equal(q[0], eq) and np.array_equal(dq[0], ev), t
+        g.close()
+
+
+def card_init(card):
+    nd = card.ndofs
+    return np.array(card.init_pos[:nd]), np.array(card.init_vel[:nd])
+
+
 @pytest.mark.parametrize("tag", ["hopper", "walker2d"])
 def test_vector_env_device_mt19937_matches_reference_fixture(tag):
     """Default noise mode: generators in HBM, resets inside dart_step -- still the reference's SyncVectorEnv stream."""

@@ -1,7 +1,7 @@
 """Launch-to-launch repeatability of the lane-per-env kernels: the same states and actions stepped again in the same process must
 give bitwise identical observations, states and contact reports.  (Round 2 found register tiers of 12+ LCP rows inlined into
-the step kernel giving a first launch that differed from the later ones on gfx950; the big tier is now a separate function --
-csrc/planar_kernel.hpp constraint_phase_call -- and this test keeps it honest.)"""
+the step kernel giving a first launch that differed from the later ones on gfx950 -- round 5: spill copies ahead of an EXEC restore,
+tools/exec_prologue_lint.py; round 6 deleted those tiers -- and this test keeps watching every lane kernel.)"""
 import numpy as np
 import pytest
 

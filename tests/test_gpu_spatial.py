@@ -400,67 +400,37 @@ def test_half_cheetah_wave_fallback_matches_oracle(precision, tq, tdq):
     gpu.close()
 
 
-@pytest.mark.parametrize("k", [1, 3, 64])
-def test_half_cheetah_wave_vote_matches_oracle_and_is_repeatable(k):
-    """DART_CFG_WAVE_VOTE (opt-in, round 4): waves with at most K envs beyond the small register tier serve them cooperatively instead of
-    running the big fp64 tier for all 64 lanes.  The trajectories are the oracle's to rounding (4 096 envs x 100 env-steps, the untrimmed
-    protocol's bound), run-to-run bitwise repeatable, and -- the reason the mode is opt-in -- NOT bitwise those of the default mode."""
-    from dart_env_amd.stepper import HipStepper, CFG_WAVE_VOTE, CFG_AUTORESET, CFG_SEED
-    card = card_for("DartHalfCheetah-v1")
-    n, T = 4096, 40
-    acts = np.random.RandomState(5).uniform(-1, 1, (T, n, card.act_dim)).astype(np.float32)
-
-    def run(vote):
-        g = HipStepper(card, n, precision=64)
-        g.configure(CFG_AUTORESET, 1); g.configure(CFG_SEED, 3); g.configure(CFG_WAVE_VOTE, vote)
-        g.reset(None, None, None, want_obs=False)
-        for t in range(T):
-            g.step(acts[t])
-        out = g.get_state()
-        g.close()
-        return out
-    (qa, dqa), (qb, dqb), (q0, dq0) = run(k), run(k), run(0)
-    assert np.array_equal(qa, qb) and np.array_equal(dqa, dqb)            # repeatable
-    assert np.isfinite(qa).all()
-    # the same LCP solutions through another solver: rounding-level differences, amplified by 40 env-steps of a thrashing cheetah
-    assert np.sqrt(np.mean((qa - q0) ** 2)) < 1e-9 and np.sqrt(np.mean((dqa - dq0) ** 2)) < 1e-7
-    from tests.parity_protocol import parity_check
-    import dart_env_amd.stepper as stm
-    orig = stm.HipStepper.__init__
-
-    def patched(self, *a, **kw):                                           # the protocol builds its own stepper: switch the vote on in it
-        orig(self, *a, **kw)
-        self.configure(CFG_WAVE_VOTE, k)
-    stm.HipStepper.__init__ = patched
-    try:
-        stats, _, _ = parity_check("DartHalfCheetah-v1", 64, 4096, 100, 0)
-    finally:
-        stm.HipStepper.__init__ = orig
-    assert stats["done_flag_mismatches"] == 0 and stats["q"] < 1e-7 and stats["dq"] < 1e-6, (stats["q"], stats["dq"])
+def test_retired_configure_key_is_refused():
+    """DART_CFG_WAVE_VOTE (key 12, rounds 4-5) went with the second register tier it chose against: dart_configure says so instead of
+    silently accepting a key that selects nothing."""
+    from dart_env_amd.stepper import HipStepper, StepperError
+    g = HipStepper(card_for("DartHalfCheetah-v1"), 64, precision=64)
+    with pytest.raises(StepperError) as e:
+        g.configure(12, 3)
+    assert "retired" in str(e.value)
+    g.close()
 
 
-@pytest.mark.parametrize("precision,vote", [(64, None), (64, 0), (32, None), (32, 64)])
-def test_half_cheetah_trajectories_do_not_depend_on_wave_mates(precision, vote):
-    """The two batch-independent settings of the wave vote -- 64 (fp64 default: every env beyond the small tier to wave_constraints4, four per
-    pass, one per row of 16 lanes) and 0 (fp32 default: the big register tier) -- on the device: the same 4 096 envs shuffled across the
-    waves give bitwise the same states, whatever row of whatever pass an env landed in."""
-    from dart_env_amd.stepper import HipStepper, CFG_WAVE_VOTE, CFG_AUTORESET
+@pytest.mark.parametrize("precision,low_share", [(64, 0.125), (64, 1.0), (32, 0.125), (32, 1.0)])
+def test_half_cheetah_trajectories_do_not_depend_on_wave_mates(precision, low_share):
+    """Which solver serves a half cheetah is a function of the env alone (two register slots; beyond them wave_constraints4, four envs
+    per pass, one per row of 16 lanes; beyond 16 rows the whole wave, one env at a time), and so is what a wave-served solve may spend
+    (round 6: per env and stage min(cap, DART_COOP_BUDGET) iterations; rounds 3-5 shared one budget per wave and world step, which a
+    wave full of envs lying on the floor ran out of).  So the same 4 096 envs shuffled across the waves give bitwise the same states,
+    whatever row of whatever pass an env landed in -- with one env in eight lying in the floor, and with ALL of them there
+    (low_share = 1: every lane of every wave goes through the wave solvers, 16+ passes per world step)."""
+    from dart_env_amd.stepper import HipStepper, CFG_AUTORESET
     card = card_for("DartHalfCheetah-v1")
     n, T, nd = 4096, 25, card.ndofs
     rng = np.random.RandomState(8)
     q0 = rng.uniform(-0.2, 0.2, (n, nd)); dq0 = rng.uniform(-1, 1, (n, nd))
-    # most envs near standing height, one in eight lying in the floor (two to six capsules touching).  Not more: the wave-served solves of one
-    # world step share an iteration budget (DART_COOP_BUDGET, a bound on the worst case), and a wave in which most lanes need the one-at-a-time
-    # fallback runs it out -- then, and only then, what a lane gets depends on its mates (documented in planar_kernel.hpp)
-    low = rng.uniform(size=n) < 0.125
+    low = rng.uniform(size=n) < low_share        # lying in the floor: two to six capsules touching
     q0[:, 1] = np.where(low, rng.uniform(-0.45, -0.2, n), rng.uniform(-0.12, 0.0, n))
     acts = rng.uniform(-1, 1, (T, n, card.act_dim)).astype(np.float32)
     outs = []
     for order in (np.arange(n), np.random.RandomState(9).permutation(n)):
         g = HipStepper(card, n, precision=precision)
         g.configure(CFG_AUTORESET, 0)
-        if vote is not None:
-            g.configure(CFG_WAVE_VOTE, vote)
         g.set_state(q0[order], dq0[order])
         for t in range(T):
             g.step(acts[t][order])
@@ -470,6 +440,42 @@ def test_half_cheetah_trajectories_do_not_depend_on_wave_mates(precision, vote):
         outs.append((q[inv], dq[inv]))
     assert np.isfinite(outs[0][0]).all()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("precision,tq,tdq", [(64, 1e-7, 1e-5), (32, 2e-3, 5e-2)])
+def test_half_cheetah_batch_lying_on_the_floor_matches_oracle(precision, tq, tdq):
+    """a batch in which EVERY env rests on three or more capsules -- every lane of every wave is wave-served, pass after pass --
+    held to the oracle step by step (the floor probe of round 5 checked finiteness and time only, and the shared iteration budget of
+    rounds 3-5 left the late envs of such a wave with a clamped, unconverged iterate).  256 envs = four full waves dropped at three
+    root heights / pitches, small random actions, no auto-reset; fp32: put back on the oracle's trajectory after every step."""
+    from dart_env_amd.stepper import HipStepper, CFG_AUTORESET
+    card = card_for("DartHalfCheetah-v1")
+    n, nd, na = 256, card.ndofs, card.act_dim
+    rng = np.random.RandomState(21)
+    gpu = HipStepper(card, n, precision=precision)
+    gpu.configure(CFG_AUTORESET, 0)
+    worlds = [OracleWorld(card) for _ in range(n)]
+    q0 = rng.uniform(-0.05, 0.05, (n, nd)); v0 = rng.uniform(-0.2, 0.2, (n, nd))
+    kind = np.arange(n) % 3
+    q0[:, 1] += np.where(kind == 0, -0.25, -0.45)
+    q0[:, 2] += np.where(kind == 2, 1.4, 0.0)
+    gpu.set_state(q0, v0)
+    for i, w in enumerate(worlds):
+        w.set_state(q0[i], v0[i])
+    many = 0
+    for t in range(30):
+        a = rng.uniform(-0.3, 0.3, (n, na)).astype(np.float32)
+        gpu.step(a)
+        for i, w in enumerate(worlds):
+            w.env_step(a[i].astype(np.float64))
+        many += sum(1 for w in worlds if len(w.last_contacts()) >= 3)
+        qg, dqg = gpu.get_state()
+        qo = np.stack([w.get_state()[0] for w in worlds]); dqo = np.stack([w.get_state()[1] for w in worlds])
+        assert np.abs(qg - qo).max() < tq and np.abs(dqg - dqo).max() < tdq, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        if precision == 32:
+            gpu.set_state(qo, dqo)
+    assert many > 0.8 * 30 * n, many      # the batch really lay on three or more capsules
+    gpu.close()
 
 
 def test_walker3d_link_link_contacts_match_oracle():

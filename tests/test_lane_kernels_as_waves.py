@@ -11,13 +11,10 @@ from tests.batch_oracle import OracleBatch
 from tests.emu_lib import EmuStepper
 
 
-def rollout(card, n, T, force_fallback=False, noise=0.1, scale=None, seed=0, wave_vote=0):
+def rollout(card, n, T, force_fallback=False, noise=0.1, scale=None, seed=0):
     g = EmuStepper(card, n, precision=64, waves=True)
     if force_fallback:
         g.force_slow(True)
-    if wave_vote:
-        from dart_env_amd import stepper as st
-        g.configure(st.CFG_WAVE_VOTE, wave_vote)
     ora = OracleBatch(card, n)
     rng = np.random.RandomState(seed)
     nd = card.ndofs
@@ -46,19 +43,11 @@ def test_whole_waves_follow_the_oracle(env_id, n, T):
     assert worst[0] < 1e-9 and worst[1] < 1e-7, worst
 
 
-@pytest.mark.parametrize("k", [1, 3, 64])
-def test_wave_vote_follows_the_oracle(k):
-    """DART_CFG_WAVE_VOTE (opt-in, round 4): a wave with at most K half cheetahs beyond the small register tier serves them together
-    instead of running the big tier for all its lanes -- the same LCPs, solved by the other solver: the oracle's trajectories to rounding"""
-    worst, most = rollout(card_for("DartHalfCheetah-v1"), 128, 40, wave_vote=k)
-    assert worst[0] < 1e-9 and worst[1] < 1e-7 and most >= 3, (worst, most)
-
-
 def test_four_env_wave_solver_keeps_an_env_independent_of_its_wave_mates():
-    """Round 5: with the vote at 64 (the fp64 half cheetah's default on the device) every lane beyond the small tier is served by
-    wave_constraints4, four envs per pass, one per row of 16 lanes.  Which row an env lands in and who shares the pass depends on its wave
-    mates; its trajectory must not -- bitwise: the same 128 envs, shuffled across the two waves, give the same states."""
-    from dart_env_amd import stepper as st
+    """Every half cheetah beyond the two register slots is served by wave_constraints4, four envs per pass, one per row of 16 lanes.  Which
+    row an env lands in and who shares the pass depends on its wave mates; its trajectory must not -- bitwise: the same 128 envs, shuffled
+    across the two waves, give the same states.  (That the mode follows the oracle: test_whole_waves_follow_the_oracle, and below with
+    every env on the floor.)"""
     card = card_for("DartHalfCheetah-v1")
     n, T, nd = 128, 30, card.ndofs
     rng = np.random.RandomState(2)
@@ -69,7 +58,6 @@ def test_four_env_wave_solver_keeps_an_env_independent_of_its_wave_mates():
     out = []
     for order in (np.arange(n), perm):
         g = EmuStepper(card, n, precision=64, waves=True)
-        g.configure(st.CFG_WAVE_VOTE, 64)
         g.reset(None, qn[order], vn[order])
         for t in range(T):
             g.step(acts[t][order])
@@ -78,7 +66,6 @@ def test_four_env_wave_solver_keeps_an_env_independent_of_its_wave_mates():
         out.append((q[inv], dq[inv]))
         g.close()
     assert np.isfinite(out[0][0]).all() and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    # (and the mode follows the oracle: test_wave_vote_follows_the_oracle[64])
 
 
 def test_wave_served_fallback_follows_the_oracle():
@@ -119,12 +106,12 @@ def test_wave_served_envs_report_their_contacts():
 
 
 def test_fallen_user_models_on_whole_waves():
-    """physics-only cards (no termination): the walker tree lies on up to seven capsules -- second register tier as a real call, hand-off,
-    wave-served fallback beyond it; the pogo hopper keeps all four in its register tier"""
+    """physics-only cards (no termination): the walker tree lies on up to seven capsules -- two register slots, beyond them the wave solvers
+    (round 6: no second register tier any more); the pogo hopper keeps all four in its register tier"""
     wcard = build_card(load_model("walker2d"), None)
     wcard.frame_skip = 4
     worst, most = rollout(wcard, 64, 110, noise=0.01, scale=np.array([100, 100, 20, 100, 100, 20.0]), seed=3)
-    assert most >= 4 and worst[0] < 1e-7 and worst[1] < 1e-5, (worst, most)      # four capsules: one more than the fp64 tier holds -> served by the wave
+    assert most >= 4 and worst[0] < 1e-7 and worst[1] < 1e-5, (worst, most)      # four capsules: two more than the register slots hold -> served by the wave
     from dart_env_amd.skel import parse_skel
     from tests.pogo_env import SKEL as POGO, SCALE
     pcard = build_card(parse_skel(POGO), None)
@@ -133,15 +120,42 @@ def test_fallen_user_models_on_whole_waves():
     assert most >= 3 and worst[0] < 1e-8 and worst[1] < 1e-6, (worst, most)
 
 
-@pytest.mark.parametrize("k", [2, 64])
-def test_wave_vote_on_a_physics_only_walker_tree(k):
-    """DART_CFG_WAVE_VOTE where it still chooses (round 5: the kernels that have BOTH a second register tier and the wave-served fallback are the
-    physics-only walker / cheetah trees): with the vote at K a wave with at most K envs beyond the small tier hands them to the four-env wave
-    solver and keeps its big tier for fuller waves; at 64 the tier never runs.  Same LCPs either way: the oracle's trajectory."""
-    wcard = build_card(load_model("walker2d"), None)
-    wcard.frame_skip = 4
-    worst, most = rollout(wcard, 64, 110, noise=0.01, scale=np.array([100, 100, 20, 100, 100, 20.0]), seed=3, wave_vote=k)
-    assert most >= 4 and worst[0] < 1e-7 and worst[1] < 1e-5, (worst, most)
+def test_a_wave_of_half_cheetahs_lying_on_the_floor_follows_the_oracle_and_its_envs_stay_independent():
+    """ADVICE r5 (round 6): EVERY lane of the wave beyond the two register slots -- 16+ passes of the four-env solver per world step, the
+    regime in which rounds 3-5's shared iteration budget ran out and left the late envs with a clamped, unconverged iterate that depended
+    on their wave mates.  Now a solve's cap is its own (coop_iters): the wave follows the oracle, and the same envs in another lane order
+    give bitwise the same states."""
+    card = card_for("DartHalfCheetah-v1")
+    n, T, nd, na = 64, 12, card.ndofs, card.act_dim
+    rng = np.random.RandomState(21)
+    q0 = rng.uniform(-0.05, 0.05, (n, nd)); v0 = rng.uniform(-0.2, 0.2, (n, nd))
+    kind = np.arange(n) % 3
+    q0[:, 1] += np.where(kind == 0, -0.25, -0.45)
+    q0[:, 2] += np.where(kind == 2, 1.4, 0.0)
+    acts = rng.uniform(-0.3, 0.3, (T, n, na)).astype(np.float32)
+    from tests.oracle_lib import OracleWorld
+    worlds = [OracleWorld(card) for _ in range(n)]
+    for i, w in enumerate(worlds):
+        w.set_state(q0[i], v0[i])
+    outs, many = [], 0
+    for order in (np.arange(n), np.random.RandomState(5).permutation(n)):
+        g = EmuStepper(card, n, precision=64, waves=True)
+        g.set_state(q0[order], v0[order])
+        inv = np.empty(n, np.int64); inv[order] = np.arange(n)
+        for t in range(T):
+            g.step(acts[t][order])
+            if order[0] == 0 and order[1] == 1:      # the index-order pass is the one held to the oracle, step by step
+                for i, w in enumerate(worlds):
+                    w.env_step(acts[t][i].astype(np.float64))
+                many += sum(1 for w in worlds if len(w.last_contacts()) >= 3)
+                qg, dqg = g.get_state()
+                qo = np.stack([w.get_state()[0] for w in worlds]); dqo = np.stack([w.get_state()[1] for w in worlds])
+                assert np.abs(qg - qo).max() < 1e-8 and np.abs(dqg - dqo).max() < 1e-6, (t, np.abs(qg - qo).max(), np.abs(dqg - dqo).max())
+        q, dq = g.get_state()
+        outs.append((q[inv], dq[inv]))
+        g.close()
+    assert many > 0.8 * T * n, many
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
 _POISON_LANE_SCRIPT = r"""

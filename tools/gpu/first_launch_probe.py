@@ -3,7 +3,11 @@
 before writing -- scratch, LDS, vector / accumulator registers -- poisoned on demand before the first and / or the later rollouts.
 
     python tools/gpu/first_launch_probe.py --env DartHalfCheetah-v1 --prec 32 [--report] [--n 256]
-           [--poison none|scratch|lds|regs|all] [--pattern 0x7fc00000] [--when first|later|both]
+           [--poison none|scratch|lds|regs|all] [--pattern 0x7fc00000] [--when first|later|both|combined]
+           [--phys hopper|walker2d|halfcheetah|snake7link|cartpole|double_pendulum|reacher2d|reacher3d]   a physics-only card of that model
+                                                                                                          (envs.DartEnv on a user's .skel) instead of --env
+    --when combined (round 6): the first two rollouts undisturbed, every later one behind a fresh poisoning -- one process answers both
+    "first launch == later launches" and "nothing read before it is written"
     DART_STEPPER_LIB=abtest/lib_ctab.so ...   the build with compile-time ancestor tables that failed in round 4
 
 Prints one line: the digest of each of four identical rollouts (same state, same actions).  Reading it:
@@ -20,6 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--env", default="DartHalfCheetah-v1"); ap.add_argument("--prec", type=int, default=32); ap.add_argument("--report", action="store_true")
 ap.add_argument("--n", type=int, default=256); ap.add_argument("--poison", default="none"); ap.add_argument("--pattern", default="0x7fc00000")
 ap.add_argument("--when", default="later"); ap.add_argument("--reps", type=int, default=4); ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--phys", default="")
 a = ap.parse_args()
 H = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "gpu_kernels", "libpoison_harness.so"))
 _prng = __import__("random").Random(12345)
@@ -37,19 +42,28 @@ def poison():
             assert rc == 0, (k, rc)
 
 
-card = card_for(a.env); n = a.n; nd, na = card.ndofs, card.act_dim
+if a.phys:
+    from dart_env_amd.model_card import build_card, load_model
+    card = build_card(load_model(a.phys), None); card.frame_skip = 4
+    a.env = "phys:" + a.phys
+else:
+    card = card_for(a.env)
+n = a.n; nd, na = card.ndofs, card.act_dim
 rng = np.random.RandomState(5)
 q0 = rng.uniform(-0.3, 0.3, (n, nd)); dq0 = rng.uniform(-2, 2, (n, nd))
 if card.ground_y > -1e9:
     q0[:, 1] = rng.uniform(-0.65, -0.3, n)
 acts = rng.uniform(-1, 1, (a.steps, n, na)).astype(np.float32)
+if a.phys:
+    acts *= 20.0                      # generalized forces, not normalised actions
+    acts[:, :, :min(3, na - 1)] = 0   # (nothing pushes the root / the cart)
 g = HipStepper(card, n, precision=a.prec)
 if a.report:
     g.configure(CFG_CONTACT_REPORT, 1)
 digests, outs_all = [], []
 for rep in range(a.reps):
     g.set_state(q0, dq0)
-    if (rep == 0 and a.when in ("first", "both")) or (rep > 0 and a.when in ("later", "both")):
+    if (rep == 0 and a.when in ("first", "both")) or (rep > 0 and a.when in ("later", "both")) or (rep > 1 and a.when == "combined"):
         poison()
     outs = []
     for t in range(a.steps):

@@ -25,6 +25,8 @@ ap.add_argument("--env", default="DartHalfCheetah-v1"); ap.add_argument("--prec"
 ap.add_argument("--n", type=int, default=256); ap.add_argument("--poison", default="none"); ap.add_argument("--pattern", default="0x7fc00000")
 ap.add_argument("--when", default="later"); ap.add_argument("--reps", type=int, default=4); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--phys", default="")
+ap.add_argument("--fresh", action="store_true", help="a new handle for every rollout: tasks that carry more than (q, dq) from step to step -- "
+                "DartWalker3dSPD-v1 feeds the previous step's constraint forces into its controller, walker3d_spd.py:40-55 -- start equal only then")
 a = ap.parse_args()
 H = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "gpu_kernels", "libpoison_harness.so"))
 _prng = __import__("random").Random(12345)
@@ -62,6 +64,9 @@ if a.report:
     g.configure(CFG_CONTACT_REPORT, 1)
 digests, outs_all = [], []
 for rep in range(a.reps):
+    if a.fresh and rep > 0:
+        g.close()
+        g = HipStepper(card, n, precision=a.prec)
     g.set_state(q0, dq0)
     if (rep == 0 and a.when in ("first", "both")) or (rep > 0 and a.when in ("later", "both")) or (rep > 1 and a.when == "combined"):
         poison()

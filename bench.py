@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+RING_DEFAULT = 64               # distinct random action batches resident in HBM (time_config)
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X_MICROARCH.md: FP32 vector peak; the FP64 vector FMA runs at half that rate
 
 
@@ -64,7 +65,7 @@ def default_envs(env_id: str) -> int:
 class HipBenchEnv:
     """One shard of envs on one GPU with its inputs and outputs resident in HBM (the thing bench.py times)."""
 
-    def __init__(self, env_id, n, local_rank, precision, env_offset, ring=16, ring_seed=1234, all_bodies_collide=None, configure=()):
+    def __init__(self, env_id, n, local_rank, precision, env_offset, ring=RING_DEFAULT, ring_seed=1234, all_bodies_collide=None, configure=()):
         import torch
         from dart_env_amd import stepper as st
         from dart_env_amd.model_card import card_for
@@ -248,11 +249,12 @@ def host_surface(env_id, n, local_rank, precision, budget_s=1.0, max_steps=200):
 
 
 def time_config(env_id, n, local_rank, precision, steps, warmup, all_bodies_collide=None, configure=()):
-    # ring = 16 as the headline's timed region (round 6; it was 8): "random actions" approximated by a ring of resident batches is a periodic
-    # forcing, and a SHORT period changes what the robots do -- DartWalker2d-v1 fp64 113.5 us per step with a ring of 8 against 104 with 16,
-    # flat over 3 000 steps from reset (tools/gpu/kernel_time_windows.py, profiles/r06_walker2d_windows.txt): the two numbers rounds 4-5 quoted
-    # for the same kernel (other_configs vs the rocprof run of the headline path) differed by the ring, not by the window
-    b = HipBenchEnv(env_id, n, local_rank, precision, 0, ring=16, all_bodies_collide=all_bodies_collide, configure=configure)
+    # The workload is "random actions"; a ring of resident batches approximates it by a PERIODIC forcing, and a short period changes what the
+    # robots do.  Measured (tools/gpu/kernel_time_windows.py, profiles/r06_walker2d_windows.txt; fp64, 65 536 envs, flat over 1 200+ steps from
+    # reset): DartWalker2d-v1 122.8 us per step with a ring of 8, 103.8 with 16, 101.9 with 64, 101.4 with 256; DartHopper-v1 32.0-32.4 whatever
+    # the ring.  Rounds 1-5 used 16 for the headline and 8 here -- which is why the same Walker2d kernel was quoted at 101.9 (rocprof of the
+    # headline path) and 113.5 us (other_configs).  Round 6: 64 everywhere (within 0.5 % of the long-ring limit; 100 MB of actions at most).
+    b = HipBenchEnv(env_id, n, local_rank, precision, 0, ring=RING_DEFAULT, all_bodies_collide=all_bodies_collide, configure=configure)
     b.reset()
     b.run(warmup)
     b.sync()
@@ -363,7 +365,7 @@ def main(argv=None, env_factory=None, dist_backend="nccl"):
     ap.add_argument("--all-bodies-collide", type=int, default=-1, help="1 / 0: force every capsule vs feet only (default: the card's default)")
     ap.add_argument("--env-id", default="DartHopper-v1")
     ap.add_argument("--precision", type=int, default=64, choices=[32, 64])
-    ap.add_argument("--ring", type=int, default=16, help="distinct action batches resident in HBM")
+    ap.add_argument("--ring", type=int, default=64, help="distinct action batches resident in HBM, cycled through (round 6: 64, was 16 -- see time_config)")
     ap.add_argument("--spinup-ms", type=float, default=60.0, help="untimed device spin-up on a scratch batch before the measured one is created (0: none)")
     ap.add_argument("--block", type=int, default=0, help="envs per wave64 workgroup (0 = library default)")
     ap.add_argument("--stats", action="store_true", help="print wave-level pivoting iteration histograms")

@@ -131,6 +131,10 @@ static inline bool is_identity3(const double* T16, double tol = 1e-12) {
 // collision shapes; a moving joint on a welded body is declined.
 template <class Real, class T>
 std::string fill_params(const DartModelCard& c, Params<Real, T>& P) {
+  // No fp contraction in here: tools/gen_static_models.py restates this function in Python and prints the doubles it computes (welded
+  // bodies folded into their link, capsule end points) as the baked models' constants; a baked kernel is selected only when the block built
+  // here is bit-identical to them (Static::matches), and an fma in one of these expressions would round differently from Python's * and +.
+#pragma clang fp contract(off)
   constexpr int NL = T::NL;
   // plane of motion: x-y (rotations about +-z, gravity along -y) or, for topologies with PLANE_XZ, the horizontal x-z plane
   // (rotations about +-y -- a turn about +y is clockwise seen in (x, z) coordinates, hence the opposite sigma; gravity is normal
@@ -639,7 +643,7 @@ std::unique_ptr<Impl> make_planar(const DartModelCard& c, std::string& why, bool
   why += "; walker2d-tree, physics only: ";
   if (auto p = make_for_topology<Real, PhysTopo<Walker2dAllTopo>, void>(c, why, allow_static)) return p;
   why += "; half-cheetah: ";
-  if (auto p = make_for_topology<Real, CheetahTopo, void>(c, why, allow_static)) return p;
+  if (auto p = make_for_topology<Real, CheetahTopo, CheetahStatic<Real>>(c, why, allow_static)) return p;
   why += "; snake chain in the x-z plane: ";
   if (auto p = make_for_topology<Real, SnakeTopo, void>(c, why, allow_static)) return p;
   // physics-only cards (a user's .skel through envs.DartEnv) of the two remaining planar shapes (round 5)

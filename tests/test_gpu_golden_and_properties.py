@@ -374,7 +374,7 @@ def test_mt19937_reset_in_the_step_kernel_equals_the_two_launch_path(env_id, pre
         g.close()
     (ra, qa, dqa, ela, sa), (rb, qb, dqb, elb, sb) = outs
     resets = sum(int(x[2].sum()) for x in ra)
-    assert resets > 3 * n, resets
+    assert resets >= 2 * n, resets       # (the half cheetah never terminates on its own: the 23-step TimeLimit twice in 60 steps)
     for t in range(T):
         for k in range(4):
             assert np.array_equal(ra[t][k], rb[t][k]), (t, k)

@@ -21,7 +21,11 @@ TOPOS = {
     "HopperAllStatic": ("DartHopper-v1", True, "HopperAllTopo", 4, 4, 3, [0, 1, 2, 3]),
     "Walker2dStatic": ("DartWalker2d-v1", False, "Walker2dTopo", 7, 2, 6, [3, 6]),
     "Walker2dAllStatic": ("DartWalker2d-v1", True, "Walker2dAllTopo", 7, 7, 6, [0, 1, 2, 3, 4, 5, 6]),
+    # round 6: the half cheetah (welded head folded into the torso link, joint springs, eight capsules).  With the runtime block its fp64
+    # kernel spilled 226 SGPRs into VGPR lanes and 2.1 KB per lane into scratch; the Walker2d kernels show what baking buys: 1 936 -> 352 B.
+    "CheetahStatic": ("DartHalfCheetah-v1", True, "CheetahTopo", 7, 8, 6, [0, 0, 1, 2, 3, 4, 5, 6]),
 }
+JT_WELD = 0
 
 
 def lit(x):
@@ -39,16 +43,41 @@ def params_from_card(c, NL, NC, NA, clinks):
     P["root_x0"], P["root_y0"] = x0, y0
     for name in ("sigma", "mass", "cx", "cy", "izz", "jx", "jy", "lo", "hi"):
         P[name] = [0.0] * NL
+    # bodies -> links: a welded body shares its parent's link, shifted by the weld offset (fill_params: same expressions, same order --
+    # that function evaluates them without fp contraction so that the doubles printed here are the ones it computes)
+    link_of_body, body_of_link = {}, []
+    wx, wy = [0.0] * c.nbodies, [0.0] * c.nbodies
+    for b in range(2, c.nbodies):
+        if c.jtype[b] == JT_WELD:
+            pb = c.parent[b]
+            link_of_body[b] = link_of_body[pb]
+            wx[b] = wx[pb] + c.T_pj[b][3] - c.T_cj[b][3]
+            wy[b] = wy[pb] + c.T_pj[b][7] - c.T_cj[b][7]
+        else:
+            link_of_body[b] = len(body_of_link)
+            body_of_link.append(b)
+    assert len(body_of_link) == NL
     for k in range(NL):
-        b = k + 2
+        b = body_of_link[k]
         P["jx"][k] = c.T_pj[b][3] if k > 0 else 0.0
         P["jy"][k] = c.T_pj[b][7] if k > 0 else 0.0
         P["sigma"][k] = 1.0 if c.axes[b][2] > 0 else -1.0
         P["mass"][k], P["cx"][k], P["cy"][k], P["izz"][k] = c.mass[b], c.com[b][0], c.com[b][1], c.inertia[b][8]
         d = 2 + k
+        assert c.dof_offset[b] == d
         lim = c.limited[d] != 0
         P["lo"][k] = c.lower[d] if lim else -math.inf
         P["hi"][k] = c.upper[d] if lim else math.inf
+    for b in range(2, c.nbodies):   # fold the welded bodies in: composite mass, COM, inertia about the new COM
+        if c.jtype[b] != JT_WELD or c.mass[b] == 0:
+            continue
+        k = link_of_body[b]
+        lm, lcx, lcy, lizz = P["mass"][k], P["cx"][k], P["cy"][k], P["izz"][k]
+        mb, bx, by = c.mass[b], wx[b] + c.com[b][0], wy[b] + c.com[b][1]
+        m = lm + mb
+        nx, ny = (lm * lcx + mb * bx) / m, (lm * lcy + mb * by) / m
+        lizz = lizz + lm * ((lcx - nx) * (lcx - nx) + (lcy - ny) * (lcy - ny)) + c.inertia[b][8] + mb * ((bx - nx) * (bx - nx) + (by - ny) * (by - ny))
+        P["mass"][k], P["cx"][k], P["cy"][k], P["izz"][k] = m, nx, ny, lizz
     P["damp"] = [c.damping[d] for d in range(nd)]
     P["stiff"] = [c.stiffness[d] for d in range(nd)]
     P["rest"] = [c.rest[d] for d in range(nd)]
@@ -62,8 +91,10 @@ def params_from_card(c, NL, NC, NA, clinks):
             continue
         S = c.shape_pose[s]
         hl = 0.5 * c.shape_size[s][1]
-        P["e1x"].append(S[3] + hl * S[2]); P["e1y"].append(S[7] + hl * S[6])
-        P["e2x"].append(S[3] - hl * S[2]); P["e2y"].append(S[7] - hl * S[6])
+        sb = c.shape_body[s]
+        assert link_of_body[sb] == clinks[len(P["rad"])]
+        P["e1x"].append(wx[sb] + S[3] + hl * S[2]); P["e1y"].append(wy[sb] + S[7] + hl * S[6])
+        P["e2x"].append(wx[sb] + S[3] - hl * S[2]); P["e2y"].append(wy[sb] + S[7] - hl * S[6])
         P["rad"].append(c.shape_size[s][0])
     assert len(P["rad"]) == NC
     P["dt"], P["ground_y"], P["g"], P["mu"] = c.dt, c.ground_y, -c.gravity[1], c.friction

@@ -71,6 +71,10 @@ struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - s
 };
 struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour, the default card)
   static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2, TIER1_F64 = 2;
+#ifndef DART_HOPPER_LIMIT_SLOTS
+#define DART_HOPPER_LIMIT_SLOTS 2
+#endif
+  static constexpr int LIMIT_SLOTS = DART_HOPPER_LIMIT_SLOTS;   // see topo_limit_slots (3 = one row per limited joint, rounds 1-5)
   static constexpr bool WARM = false;   // (round 5, host build over 64-lane groups: 13.75 pivoting solves per wave and env-step, 14.02 with warm starts)
   // (round 4 A/B: H^-1 parked in LDS across the pivoting loops, the walker's HINV_LDS_F64, makes THIS kernel slower -- 31.82 -> 33.24 us
   // fp64, 158 -> 126 AGPRs: the 21 entries cost more as LDS round trips than as accumulator-register moves)
@@ -91,6 +95,10 @@ struct Walker2dTopo {  // reference assets/walker2d.skel: pelvis - (thigh shin f
 };
 struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the floor (DART's behaviour, the default card)
   static constexpr int NL = 7, NDOF = NL + 2, NC = 7, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
+#ifndef DART_WALKER2D_LIMIT_SLOTS
+#define DART_WALKER2D_LIMIT_SLOTS 4
+#endif
+  static constexpr int LIMIT_SLOTS = DART_WALKER2D_LIMIT_SLOTS;   // see topo_limit_slots (6 = one row per limited joint, rounds 1-5)
   static constexpr bool WARM = true;
   static constexpr bool WARM_FRICTION = false;   // (see Walker2dTopo)
 #ifndef DART_NO_HINV_LDS
@@ -229,6 +237,28 @@ __device__ __host__ constexpr int limit_slot(int k) {  // LCP slot of link k's l
   int s = 2 * NCA;
   for (int j = 0; j < k; j++) s += T::limited(j) ? 1 : 0;
   return s;
+}
+template <class T> __device__ __host__ constexpr int lim_ord(int k) {   // ordinal of limited link k among the limited links
+  int o = 0;
+  for (int j = 0; j < k; j++) o += T::limited(j) ? 1 : 0;
+  return o;
+}
+template <class T> __device__ __host__ constexpr int lim_link(int o) {  // the o-th limited link
+  int c = 0;
+  for (int k = 0; k < T::NL; k++) { if (T::limited(k)) { if (c == o) return k; c++; } }
+  return 0;
+}
+// LIMIT_SLOTS (optional trait; round 6): the register tiers carry this many joint-limit rows instead of one per limited joint -- slot s
+// holds the s-th joint that IS at a limit this substep, as the contact slots hold the s-th touching capsule -- and a wave in which some
+// lane has more joints at their limits runs the tier with all of them.  Measured on the host build over 64-lane groups (random-action
+// rollouts, 2 048 envs): a Hopper lane has 0 / 1 / 2 / 3 of its 3 limited joints at a limit in 8 / 78 / 14 / 0.008 % of its substeps and a
+// wave's maximum is 2 in 99.5 %; a Walker2d lane 0 / 1 / 2 / 3 / 4 of 6 in 36 / 44 / 17 / 2.4 / 0.7 %, never more, a wave's maximum 2 / 3 / 4 in
+// 24 / 48 / 27 %.  The pivoting loops cost ~M^3: Hopper's LCPs shrink from 4 / 5 rows (frictionless / friction stage) to 3 / 4, Walker2d's
+// from 8 / 10 to 6 / 8.
+template <class T, class = void> struct topo_limit_slots { static constexpr int value = -1; };
+template <class T> struct topo_limit_slots<T, decltype((void)T::LIMIT_SLOTS)> { static constexpr int value = T::LIMIT_SLOTS; };
+template <class T> __device__ __host__ constexpr int small_limit_slots() {
+  return (topo_limit_slots<T>::value >= 0 && topo_limit_slots<T>::value < n_limited<T>()) ? topo_limit_slots<T>::value : n_limited<T>();
 }
 template <class T, class Real> __device__ __host__ constexpr int tier1() { return sizeof(Real) == 8 ? T::TIER1_F64 : T::TIER1; }
 template <class T, class Real> __device__ __host__ constexpr int last_tier() { return tier1<T, Real>() > 0 ? tier1<T, Real>() : T::TIER0; }
@@ -833,6 +863,7 @@ __device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const
 struct WarmSets {
   uint32_t cid = 0;                // candidate capsule held by each contact slot (4 bits per slot)
   uint32_t nca = 0;                // contact slots of the tier that wrote these sets (row positions differ between tiers)
+  uint32_t lid = 0, nls = 0;       // limited-joint ordinal held by each limit slot (4 bits per slot), limit slots of that tier
   uint32_t sig = 0, up = 0;        // which rows were active / which of them rested on their upper bound
   uint32_t F1 = 0, U1 = 0;         // final sets of the frictionless stage
   uint32_t F2 = 0, U2 = 0;         // final sets of the friction stage
@@ -843,13 +874,17 @@ struct WarmSets {
 // contacts (con / cPx / cPy / cdep over the T::NC capsules) and the state q (limits).  A lane with `off` set takes no part
 // (it is served by slow_constraints): all its rows are inactive and its vs comes back unchanged.
 // HLDS: H^-1 is read from this lane's LDS column `hl` (entry k at hl[64 k]) instead of from H (topo_hinv_lds64).
-template <class Real, class T, class PT, int NCA, bool EXTRAS, bool HLDS = false>
+// NLS: limit slots (topo_limit_slots); -1 = one row per limited joint.
+template <class Real, class T, class PT, int NCA, bool EXTRAS, bool HLDS = false, int NLS = -1>
 __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T::NDOF], const Real (&H)[T::NDOF * (T::NDOF + 1) / 2],
                                                  const Real (&px)[T::NL], const Real (&py)[T::NL], Real (&vs)[T::NDOF],
                                                  const bool (&con)[T::NC], const Real (&cPx)[T::NC], const Real (&cPy)[T::NC],
                                                  const Real (&cdep)[T::NC], bool off, WarmSets& warm, const ReportTo<Real>& rp,
                                                  const Real* hl = nullptr, Real* cm = nullptr) {
-  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * NCA + n_limited<T>();
+  constexpr int NLIM = n_limited<T>(), NLSE = (NLS < 0 || NLS >= NLIM) ? NLIM : NLS;
+  constexpr bool LIDENT = NLSE == NLIM;   // limit row o IS limited joint o
+  constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * NCA + NLSE;
+  constexpr int NLA = NLIM > 0 ? NLIM : 1, NLSA = NLSE > 0 ? NLSE : 1;
   // hand-off of the lanes that keep pivoting to the wave solver (blcp_bpp; cm = its LDS block, null = never): after how many
   // iterations of the frictionless / the friction stage, for the big tier (whose iterations are the expensive ones) and the others
 #ifndef DART_HANDOFF_BIG
@@ -931,6 +966,8 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     lo[stt] = Real(0); hi[stt] = Real(0);  // friction rows are pinned at 0 during stage 1
     any = any || on;
   });
+  uint32_t lid = 0;   // compacted limit rows: ordinal of the limited joint each slot holds
+  if constexpr (LIDENT) {
   sfor<0, NL>([&](auto K) {
     constexpr int k = K;
     if constexpr (T::limited(k)) {
@@ -946,6 +983,31 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       any = any || on;
     }
   });
+  } else {
+    // slot s takes the s-th joint that is at a limit (joint order); a lane with more such joints than slots never gets here (world_step's vote)
+    sfor<0, NLSE>([&](auto S) { constexpr int r = 2 * NCA + S; act[r] = false; b[r] = Real(0); lo[r] = Real(0); hi[r] = Real(0); });
+    int lrank = 0;
+    sfor<0, NL>([&](auto K) {
+      constexpr int k = K;
+      if constexpr (T::limited(k)) {
+        constexpr int o = lim_ord<T>(k), i = 2 + k;
+        const bool low = !off && q[i] <= P.lo[k], up = !off && (!low) && (q[i] >= P.hi[k]);
+        const Real viol = low ? (q[i] - P.lo[k]) : (q[i] - P.hi[k]);
+        const Real bounce = fmin(fmax(-viol * P.limit_erp_dt, -P.max_erv), P.max_erv);
+        const bool on = low || up;
+        const Real bk = bounce - vs[i], lok = low ? Real(0) : -inf_<Real>(), hik = low ? inf_<Real>() : Real(0);
+        sfor<0, NLSE>([&](auto S) {
+          constexpr int r = 2 * NCA + S;
+          const bool take = on && lrank == (int)S;
+          act[r] = act[r] || take;
+          b[r] = take ? bk : b[r]; lo[r] = take ? lok : lo[r]; hi[r] = take ? hik : hi[r];
+          lid = take ? (lid | ((uint32_t)o << (4 * (int)S))) : lid;
+        });
+        lrank += on ? 1 : 0;
+        any = any || on;
+      }
+    });
+  }
   if (!__any(any)) return;
 
   // Y = H^-1 J^T for contact rows (limit rows: columns of H^-1), Delassus matrix A = J H^-1 J^T
@@ -989,6 +1051,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       if constexpr (a != bb) A[tri(2 * a, 2 * bb + 1)] = nt;
     });
   });
+  if constexpr (LIDENT) {
   sfor<0, NL>([&](auto K) {
     constexpr int k = K;
     if constexpr (T::limited(k)) {
@@ -1004,6 +1067,48 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       });
     }
   });
+  } else {
+    // compacted limit rows: the row of slot s is the unit vector of ITS joint -- a lane-varying index.  Contact couplings: a select over the
+    // limited joints' entries of Y; limit-limit entries of H^-1: one indexed read of the lane's LDS column (HLDS), else a two-level select.
+    sfor<0, NLSE>([&](auto S) {
+      constexpr int sl = S, r = 2 * NCA + sl;
+      const uint32_t os = (lid >> (4 * sl)) & 15u;
+      sfor<0, NCA>([&](auto C) {
+        constexpr int cs = C;
+        Real yn = Yn[cs][2 + lim_link<T>(0)], yt = Yt[cs][2 + lim_link<T>(0)];
+        sfor<1, NLIM>([&](auto O) { constexpr int o = O; const bool is = os == (uint32_t)o; yn = is ? Yn[cs][2 + lim_link<T>(o)] : yn; yt = is ? Yt[cs][2 + lim_link<T>(o)] : yt; });
+        A[tri(r, 2 * cs)] = yn;
+        A[tri(r, 2 * cs + 1)] = yt;
+      });
+      if constexpr (HLDS) {
+        int is_ = 0;   // storage index of the slot's dof: rev<N>(2 + link)
+        sfor<0, NLIM>([&](auto O) { constexpr int o = O; is_ = os == (uint32_t)o ? rev<N>(2 + lim_link<T>(o)) : is_; });
+        sfor<0, sl + 1>([&](auto Tt) {
+          constexpr int tl = Tt, rt = 2 * NCA + tl;
+          const uint32_t ot = (lid >> (4 * tl)) & 15u;
+          int it_ = 0;
+          sfor<0, NLIM>([&](auto O) { constexpr int o = O; it_ = ot == (uint32_t)o ? rev<N>(2 + lim_link<T>(o)) : it_; });
+          const int hi_ = is_ > it_ ? is_ : it_, lo_ = is_ > it_ ? it_ : is_;
+          A[tri(r, rt)] = hl[64 * (hi_ * (hi_ + 1) / 2 + lo_)];
+        });
+      } else {
+        Real hrow[NLA];   // H^-1 [joint of slot s][limited joint o2]
+        sfor<0, NLIM>([&](auto O2) {
+          constexpr int o2 = O2;
+          Real v = H[tri(rev<N>(2 + lim_link<T>(0)), rev<N>(2 + lim_link<T>(o2)))];
+          sfor<1, NLIM>([&](auto O1) { constexpr int o1 = O1; v = os == (uint32_t)o1 ? H[tri(rev<N>(2 + lim_link<T>(o1)), rev<N>(2 + lim_link<T>(o2)))] : v; });
+          hrow[o2] = v;
+        });
+        sfor<0, sl + 1>([&](auto Tt) {
+          constexpr int tl = Tt, rt = 2 * NCA + tl;
+          const uint32_t ot = (lid >> (4 * tl)) & 15u;
+          Real v = hrow[0];
+          sfor<1, NLIM>([&](auto O) { constexpr int o = O; v = ot == (uint32_t)o ? hrow[o] : v; });
+          A[tri(r, rt)] = v;
+        });
+      }
+    });
+  }
   // inactive slots: decouple (unit diagonal keeps the factorisations regular)
   sfor<0, M>([&](auto I) {
     constexpr int i = I;
@@ -1055,7 +1160,14 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   sfor<0, NCA>([&](auto S) { has_contact = has_contact || act[2 * S]; });
   // rows that were active on the same side in the previous substep (contact slots: and hold the same capsule) inherit
   // that substep's final set
-  uint32_t keep = (warm.nca == (uint32_t)NCA) ? ~0u : 0u;
+  uint32_t keep = (warm.nca == (uint32_t)NCA && warm.nls == (uint32_t)NLSE) ? ~0u : 0u;
+  if constexpr (!LIDENT) {   // a limit slot inherits only what the SAME joint left in it
+    sfor<0, NLSE>([&](auto S) {
+      constexpr int sl = S;
+      const bool same_joint = ((warm.lid >> (4 * sl)) & 15u) == ((lid >> (4 * sl)) & 15u);
+      keep = same_joint ? keep : (keep & ~(1u << (2 * NCA + sl)));
+    });
+  }
   if constexpr (!IDENT) {
     sfor<0, NCA>([&](auto S) {
       constexpr int sl = S;
@@ -1148,7 +1260,18 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     }
     warm.F2 = F; warm.U2 = U;
   }
-  warm.sig = sig; warm.up = up; warm.cid = cid; warm.nca = (uint32_t)NCA;
+  warm.sig = sig; warm.up = up; warm.cid = cid; warm.nca = (uint32_t)NCA; warm.lid = lid; warm.nls = (uint32_t)NLSE;
+  // impulse of every limited joint's row (compacted rows: scattered back to their joints)
+  Real xl[NLA];
+  sfor<0, NLIM>([&](auto O) {
+    constexpr int o = O;
+    if constexpr (LIDENT) xl[o] = x[2 * NCA + o];
+    else {
+      Real v = Real(0);
+      sfor<0, NLSE>([&](auto S) { constexpr int sl = S; v = (act[2 * NCA + sl] && ((lid >> (4 * sl)) & 15u) == (uint32_t)o) ? x[2 * NCA + sl] : v; });
+      xl[o] = v;
+    }
+  });
   if (EXTRAS && rp.rec != nullptr && !off) {   // contact records in capsule order, constraint forces J^T lambda / dt
     const Real idt = Real(1) / P.dt;
     int r = 0;
@@ -1170,7 +1293,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       constexpr int i = I;
       Real f = Real(0);
       sfor<0, NCA>([&](auto S) { constexpr int cs = S; f += Jn[cs][i] * x[2 * cs] + Jt[cs][i] * x[2 * cs + 1]; });
-      if constexpr (i >= 3) { if constexpr (T::limited(i - 2)) f += x[limit_slot<T, NCA>(i - 2)]; }
+      if constexpr (i >= 3) { if constexpr (T::limited(i - 2)) f += xl[lim_ord<T>(i - 2)]; }
       rp.cf[i] = f * idt;
     });
   }
@@ -1185,7 +1308,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     sfor<0, NCA>([&](auto S) { constexpr int cs = S; dv += Yn[cs][i] * x[2 * cs] + Yt[cs][i] * x[2 * cs + 1]; });
     sfor<0, NL>([&](auto K) {
       constexpr int k = K;
-      if constexpr (T::limited(k)) dv += Hv(tri(rev<N>(i), rev<N>(2 + k))) * x[limit_slot<T, NCA>(k)];
+      if constexpr (T::limited(k)) dv += Hv(tri(rev<N>(i), rev<N>(2 + k))) * xl[lim_ord<T>(k)];
     });
     vs[i] += dv;
   });
@@ -1955,6 +2078,24 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 #ifdef DART_WAVE_COOP
   if constexpr (topo_wave_fallback<T>::value) cm = blockDim.x == 64 ? slow_mem + constraint_lds_words<T, Real>() : nullptr;
 #endif
+  // limit rows: the small tier carries small_limit_slots<T>() of them (topo_limit_slots); a wave with a lane that has more joints at their
+  // limits runs the instantiation with one row per limited joint -- the wave's vote, as for the contact slots; either way a lane's LCP has
+  // the same rows that can move, so its solution is the same up to rounding
+  constexpr int NLSS = small_limit_slots<T>();
+  bool lim_all = false;   // (wave-uniform)
+  if constexpr (NLSS < n_limited<T>()) {
+    int nla = 0;
+    sfor<0, T::NL>([&](auto K) { constexpr int k = K; if constexpr (T::limited(k)) nla += (q[2 + k] <= P.lo[k] || q[2 + k] >= P.hi[k]) ? 1 : 0; });
+    lim_all = __any(!slow && nla > NLSS);
+  }
+  auto small_tier = [&]() {
+    if constexpr (NLSS < n_limited<T>()) {
+      if (lim_all) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+      else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+    } else {
+      constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+    }
+  };
   if constexpr (tier1<T, Real>() > 0) {
     if (__any(nreg > T::TIER0)) {
 #ifdef DART_WAVE_TIMING
@@ -1962,9 +2103,9 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 #endif
       constraint_phase<Real, T, PT, tier1<T, Real>(), EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     }
-    else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+    else small_tier();
   } else {
-    constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+    small_tier();
   }
 #ifdef DART_WAVE_TIMING
   wave_timing_add(P.stats, big_tier ? 4 : 5, big_tier ? 32 : 48, 8, 16, DART_CLK() - tclk1);

@@ -43,6 +43,40 @@ def test_whole_waves_follow_the_oracle(env_id, n, T):
     assert worst[0] < 1e-9 and worst[1] < 1e-7, worst
 
 
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1"])
+def test_limit_slot_vote_and_the_all_limits_tier_follow_the_oracle(env_id):
+    """Round 6: the small register tier carries 2 (Hopper) / 4 (Walker2d) compacted joint-limit rows -- slot s = the s-th joint that is at a
+    limit -- and a wave in which some lane has more joints at their limits runs the instantiation with one row per limited joint (the wave's
+    vote, planar_kernel.hpp: topo_limit_slots).  Two waves here: the first starts with EVERY joint of a few lanes beyond its limits (so that
+    wave takes the all-limits tier while those lanes recover), the second with ordinary states (compacted rows, joints entering and leaving
+    their limits from substep to substep: slots change owners, the warm sets must not follow them).  Both against the oracle, step by step."""
+    card = card_for(env_id)
+    n, T, nd = 128, 25, card.ndofs
+    g = EmuStepper(card, n, precision=64, waves=True)
+    ora = OracleBatch(card, n)
+    rng = np.random.RandomState(12)
+    qn = rng.uniform(-0.02, 0.02, (n, nd)); vn = rng.uniform(-0.5, 0.5, (n, nd))
+    lo = np.array([card.lower[d] for d in range(nd)]); hi = np.array([card.upper[d] for d in range(nd)])
+    lim = np.array([bool(card.limited[d]) for d in range(nd)])
+    init = np.array(card.init_pos[:nd])
+    for e in range(0, 64, 5):            # every limited joint 0.02 rad beyond its upper (even lanes) / lower (odd) limit
+        target = (hi + 0.02) if (e // 5) % 2 == 0 else (lo - 0.02)
+        qn[e, lim] = (target - init)[lim]
+    g.reset(None, qn, vn); ora.reset(None, qn, vn)
+    worst = [0.0, 0.0]
+    for t in range(T):
+        a = rng.uniform(-1, 1, (n, card.act_dim)).astype(np.float32)
+        o, r, d, tr = g.step(a); oo, ro, do, to = ora.step(a)
+        qg, dqg = g.get_state(); qo, dqo = ora.state()
+        worst = [max(worst[0], np.abs(qg - qo).max()), max(worst[1], np.abs(dqg - dqo).max())]
+        assert np.array_equal(d.astype(bool), np.asarray(do, bool)), t
+        if np.any(do):
+            qr = rng.uniform(-0.02, 0.02, (n, nd)); vr = rng.uniform(-0.5, 0.5, (n, nd))
+            g.reset(np.asarray(do, np.uint8), qr, vr, want_obs=False); ora.reset(np.asarray(do, bool), qr, vr)
+    g.close()
+    assert worst[0] < 1e-9 and worst[1] < 1e-7, worst
+
+
 def test_four_env_wave_solver_keeps_an_env_independent_of_its_wave_mates():
     """Every half cheetah beyond the two register slots is served by wave_constraints4, four envs per pass, one per row of 16 lanes.  Which
     row an env lands in and who shares the pass depends on its wave mates; its trajectory must not -- bitwise: the same 128 envs, shuffled

@@ -72,9 +72,12 @@ struct HopperTopo {  // reference assets/hopper_capsule.skel: pelvis - thigh - s
 struct HopperAllTopo {  // the same chain with EVERY capsule tested against the floor (DART's behaviour, the default card)
   static constexpr int NL = 4, NDOF = NL + 2, NC = 4, NA = 3, TIER0 = 1, TIER1 = 2, TIER1_F64 = 2;
 #ifndef DART_HOPPER_LIMIT_SLOTS
-#define DART_HOPPER_LIMIT_SLOTS 2
+#define DART_HOPPER_LIMIT_SLOTS 3
 #endif
-  static constexpr int LIMIT_SLOTS = DART_HOPPER_LIMIT_SLOTS;   // see topo_limit_slots (3 = one row per limited joint, rounds 1-5)
+  // see topo_limit_slots.  3 = one row per limited joint.  With 2 compacted rows (a wave's maximum in 99.5 % of its substeps) the LCPs shrink
+  // from 4 / 5 to 3 / 4 rows -- and the kernel got SLOWER on the device: fp64 32.0 -> 33.8 us, fp32 27.5 -> 49.9 us (profiles/r06_limit_slots.txt):
+  // at these sizes the selects that build the compacted rows and the second inlined tier cost more than the smaller factorisations give back.
+  static constexpr int LIMIT_SLOTS = DART_HOPPER_LIMIT_SLOTS;
   static constexpr bool WARM = false;   // (round 5, host build over 64-lane groups: 13.75 pivoting solves per wave and env-step, 14.02 with warm starts)
   // (round 4 A/B: H^-1 parked in LDS across the pivoting loops, the walker's HINV_LDS_F64, makes THIS kernel slower -- 31.82 -> 33.24 us
   // fp64, 158 -> 126 AGPRs: the 21 entries cost more as LDS round trips than as accumulator-register moves)
@@ -98,7 +101,9 @@ struct Walker2dAllTopo {  // all seven capsules of walker2d.skel against the flo
 #ifndef DART_WALKER2D_LIMIT_SLOTS
 #define DART_WALKER2D_LIMIT_SLOTS 4
 #endif
-  static constexpr int LIMIT_SLOTS = DART_WALKER2D_LIMIT_SLOTS;   // see topo_limit_slots (6 = one row per limited joint, rounds 1-5)
+  // see topo_limit_slots (6 = one row per limited joint, rounds 1-5).  Measured, A/B on one box (profiles/r06_limit_slots.txt): 4 slots
+  // fp64 101.2 -> 90.8 us, fp32 79.5 -> 72.1 us; 3 slots (a wave's maximum in 73 % of its substeps, the all-limits tier for the rest) 114.7 us.
+  static constexpr int LIMIT_SLOTS = DART_WALKER2D_LIMIT_SLOTS;
   static constexpr bool WARM = true;
   static constexpr bool WARM_FRICTION = false;   // (see Walker2dTopo)
 #ifndef DART_NO_HINV_LDS
@@ -122,6 +127,12 @@ struct CheetahTopo {  // reference assets/half_cheetah.skel: torso (+ welded hea
   // price: a batch in which EVERY env rests on three or four capsules pays 16 passes per world step (tools/gpu/cheetah_floor_probe.py).
   static constexpr int NL = 7, NDOF = NL + 2, NC = 8, NA = 6, TIER0 = 2, TIER1 = 0, TIER1_F64 = 0;
   static constexpr bool PLAIN_FRICTION_START = true;   // see topo_plain_friction_start
+#ifndef DART_CHEETAH_LIMIT_SLOTS
+#define DART_CHEETAH_LIMIT_SLOTS 3
+#endif
+  // see topo_limit_slots: a half cheetah's wave has at most 1 / 2 / 3 joints at their limits in 5 / 93.6 / 1.5 % of its substeps (host build,
+  // 64-lane groups), never more in the sample: 3 of 6 limit rows -- the two-slot tier's LCPs shrink from 8 / 10 to 5 / 7 rows
+  static constexpr int LIMIT_SLOTS = DART_CHEETAH_LIMIT_SLOTS;
   // Five touching capsules (four in fp64) are 6e-5 (2.3e-3) of the env-world-steps -- ~20 (~750) per launch of 65 536 envs -- and a
   // launch at one wave per SIMD lasts as long as its slowest wave.  WAVE_FALLBACK: such an env is served by the whole wave
   // (wave_constraints) instead of by its own lane alone, 2.50 -> 0.95 ms (fp32) / 3.43 -> 1.54 ms (fp64) per batched step; and the lanes
@@ -2087,6 +2098,9 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     int nla = 0;
     sfor<0, T::NL>([&](auto K) { constexpr int k = K; if constexpr (T::limited(k)) nla += (q[2 + k] <= P.lo[k] || q[2 + k] >= P.hi[k]) ? 1 : 0; });
     lim_all = __any(!slow && nla > NLSS);
+#ifdef DART_LIMIT_NO_FALLBACK   // (timing experiments only: the compacted tier whatever the count -- WRONG for a lane with more joints at their limits)
+    lim_all = false;
+#endif
   }
   auto small_tier = [&]() {
     if constexpr (NLSS < n_limited<T>()) {

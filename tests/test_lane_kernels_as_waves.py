@@ -43,11 +43,11 @@ def test_whole_waves_follow_the_oracle(env_id, n, T):
     assert worst[0] < 1e-9 and worst[1] < 1e-7, worst
 
 
-@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1"])
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1"])
 def test_limit_slot_vote_and_the_all_limits_tier_follow_the_oracle(env_id):
-    """Round 6: the small register tier carries 2 (Hopper) / 4 (Walker2d) compacted joint-limit rows -- slot s = the s-th joint that is at a
-    limit -- and a wave in which some lane has more joints at their limits runs the instantiation with one row per limited joint (the wave's
-    vote, planar_kernel.hpp: topo_limit_slots).  Two waves here: the first starts with EVERY joint of a few lanes beyond its limits (so that
+    """Round 6: the small register tier of the Walker2d / half-cheetah kernels carries 4 / 3 compacted joint-limit rows instead of 6 -- slot s =
+    the s-th joint that is at a limit -- and a wave in which some lane has more joints at their limits runs the instantiation with one row per
+    limited joint (the wave's vote, planar_kernel.hpp: topo_limit_slots; the Hopper kernel keeps one row per joint: measured slower compacted).  Two waves here: the first starts with EVERY joint of a few lanes beyond its limits (so that
     wave takes the all-limits tier while those lanes recover), the second with ordinary states (compacted rows, joints entering and leaving
     their limits from substep to substep: slots change owners, the warm sets must not follow them).  Both against the oracle, step by step."""
     card = card_for(env_id)

@@ -874,7 +874,7 @@ __device__ __forceinline__ void blcp_pgs(const Real (&A)[M * (M + 1) / 2], const
 struct WarmSets {
   uint32_t cid = 0;                // candidate capsule held by each contact slot (4 bits per slot)
   uint32_t nca = 0;                // contact slots of the tier that wrote these sets (row positions differ between tiers)
-  uint32_t lid = 0, nls = 0;       // limited-joint ordinal held by each limit slot (4 bits per slot), limit slots of that tier
+  // (limit rows: one bit per limited joint behind the 2 nca contact bits, whatever the tier's limit slots -- constraint_phase translates)
   uint32_t sig = 0, up = 0;        // which rows were active / which of them rested on their upper bound
   uint32_t F1 = 0, U1 = 0;         // final sets of the frictionless stage
   uint32_t F2 = 0, U2 = 0;         // final sets of the friction stage
@@ -1171,14 +1171,29 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   sfor<0, NCA>([&](auto S) { has_contact = has_contact || act[2 * S]; });
   // rows that were active on the same side in the previous substep (contact slots: and hold the same capsule) inherit
   // that substep's final set
-  uint32_t keep = (warm.nca == (uint32_t)NCA && warm.nls == (uint32_t)NLSE) ? ~0u : 0u;
-  if constexpr (!LIDENT) {   // a limit slot inherits only what the SAME joint left in it
-    sfor<0, NLSE>([&](auto S) {
-      constexpr int sl = S;
-      const bool same_joint = ((warm.lid >> (4 * sl)) & 15u) == ((lid >> (4 * sl)) & 15u);
-      keep = same_joint ? keep : (keep & ~(1u << (2 * NCA + sl)));
-    });
-  }
+  // The warm sets are kept in the layout of the all-limits tier -- contact rows, then ONE BIT PER LIMITED JOINT -- whatever tier wrote them, and
+  // translated into this tier's slots here and back at the end: a joint's row inherits its own set across a change of slot AND across a change of
+  // tier.  With that, which of the two limit layouts a wave votes for cannot change a lane's numbers: the masked factorisation of the all-limits
+  // tier only ever adds exact zeros for the rows that are not there in the compacted one, the rows that are there keep their relative order (slot
+  // order = joint order), and both start from the same sets -- the batch-independence tests hold bitwise across the vote.
+  auto from_joint_bits = [&](uint32_t m) -> uint32_t {
+    if constexpr (LIDENT) return m;
+    else {
+      uint32_t r = m & ((1u << (2 * NCA)) - 1u);
+      sfor<0, NLSE>([&](auto S) { constexpr int sl = S; r |= (act[2 * NCA + sl] ? ((m >> (2 * NCA + ((lid >> (4 * sl)) & 15u))) & 1u) : 0u) << (2 * NCA + sl); });
+      return r;
+    }
+  };
+  auto to_joint_bits = [&](uint32_t m) -> uint32_t {
+    if constexpr (LIDENT) return m;
+    else {
+      uint32_t r = m & ((1u << (2 * NCA)) - 1u);
+      sfor<0, NLSE>([&](auto S) { constexpr int sl = S; r |= (act[2 * NCA + sl] ? ((m >> (2 * NCA + sl)) & 1u) : 0u) << (2 * NCA + ((lid >> (4 * sl)) & 15u)); });
+      return r;
+    }
+  };
+  const uint32_t wsig = from_joint_bits(warm.sig), wup = from_joint_bits(warm.up), wF1 = from_joint_bits(warm.F1), wU1 = from_joint_bits(warm.U1);
+  uint32_t keep = (warm.nca == (uint32_t)NCA) ? ~0u : 0u;
   if constexpr (!IDENT) {
     sfor<0, NCA>([&](auto S) {
       constexpr int sl = S;
@@ -1186,9 +1201,9 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       keep = same_capsule ? keep : (keep & ~(3u << (2 * sl)));
     });
   }
-  const uint32_t same = T::WARM ? (sig & warm.sig & ~(up ^ warm.up) & ~pinmask & keep) : 0u;
-  F = (F & ~same) | (warm.F1 & same);
-  U = (U & ~same) | (warm.U1 & same);
+  const uint32_t same = T::WARM ? (sig & wsig & ~(up ^ wup) & ~pinmask & keep) : 0u;
+  F = (F & ~same) | (wF1 & same);
+  U = (U & ~same) | (wU1 & same);
 
   if (P.solver == 0) {
     if constexpr (NCA > 0) {
@@ -1224,7 +1239,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     blcp_pgs<Real, M>(A, b, lo, hi, skip, x, P.iters1);
   }
 
-  warm.F1 = F; warm.U1 = U;
+  warm.F1 = to_joint_bits(F); warm.U1 = to_joint_bits(U);
   if (__any(has_contact)) {
     // ODE/DART friction bounds: +-mu * (normal impulse of the frictionless solve), then the full problem
     uint32_t fric = 0;
@@ -1271,7 +1286,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     }
     warm.F2 = F; warm.U2 = U;
   }
-  warm.sig = sig; warm.up = up; warm.cid = cid; warm.nca = (uint32_t)NCA; warm.lid = lid; warm.nls = (uint32_t)NLSE;
+  warm.sig = to_joint_bits(sig); warm.up = to_joint_bits(up); warm.cid = cid; warm.nca = (uint32_t)NCA;
   // impulse of every limited joint's row (compacted rows: scattered back to their joints)
   Real xl[NLA];
   sfor<0, NLIM>([&](auto O) {

@@ -77,6 +77,34 @@ def test_limit_slot_vote_and_the_all_limits_tier_follow_the_oracle(env_id):
     assert worst[0] < 1e-9 and worst[1] < 1e-7, worst
 
 
+@pytest.mark.parametrize("env_id", ["DartWalker2d-v1", "DartHalfCheetah-v1"])
+def test_limit_slot_vote_does_not_change_a_lanes_numbers(env_id):
+    """Which limit layout a wave runs -- the compacted slots, or one row per limited joint because some lane has more joints at their limits than
+    slots -- is the wave's vote; a lane's numbers must not depend on it, bitwise: the all-limits factorisation only adds exact zeros for the
+    rows the compacted one leaves out, the rows keep their order, and the warm sets travel in joint layout.  The same 128 envs in two lane
+    orders: in one, the envs with every joint beyond its limits share a wave with ordinary ones; in the other they are spread differently."""
+    card = card_for(env_id)
+    n, T, nd = 128, 20, card.ndofs
+    rng = np.random.RandomState(31)
+    qn = rng.uniform(-0.02, 0.02, (n, nd)); vn = rng.uniform(-0.5, 0.5, (n, nd))
+    lo = np.array([card.lower[d] for d in range(nd)]); hi = np.array([card.upper[d] for d in range(nd)])
+    lim = np.array([bool(card.limited[d]) for d in range(nd)]); init = np.array(card.init_pos[:nd])
+    for e in range(0, 32, 3):            # eleven envs of the first half-wave: all limited joints beyond a limit
+        qn[e, lim] = (((hi + 0.02) if e % 2 == 0 else (lo - 0.02)) - init)[lim]
+    acts = rng.uniform(-1, 1, (T, n, card.act_dim)).astype(np.float32)
+    out = []
+    for order in (np.arange(n), np.random.RandomState(32).permutation(n)):
+        g = EmuStepper(card, n, precision=64, waves=True)
+        g.reset(None, qn[order], vn[order])
+        for t in range(T):
+            g.step(acts[t][order])
+        q, dq = g.get_state()
+        inv = np.empty(n, np.int64); inv[order] = np.arange(n)
+        out.append((q[inv], dq[inv]))
+        g.close()
+    assert np.isfinite(out[0][0]).all() and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_four_env_wave_solver_keeps_an_env_independent_of_its_wave_mates():
     """Every half cheetah beyond the two register slots is served by wave_constraints4, four envs per pass, one per row of 16 lanes.  Which
     row an env lands in and who shares the pass depends on its wave mates; its trajectory must not -- bitwise: the same 128 envs, shuffled

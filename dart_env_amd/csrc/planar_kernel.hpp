@@ -1999,8 +1999,17 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     sfor<0, N>([&](auto I) { rp.cf[I] = Real(0); });
   }
   bool slow = false;
+  // joints at a limit (topologies with limit slots): a lane with more of them than the small tier has slots ...
+  constexpr int NLSS = small_limit_slots<T>();
+  constexpr bool LIM_SLOTS = NLSS < n_limited<T>();
+  // ... is served by the wave solvers where the topology has them (half cheetah, physics-only walker / cheetah trees): which solver serves an env
+  // stays a function of the env alone and the kernel carries ONE register tier; elsewhere (Walker2d) the wave votes for the all-limits tier
+  constexpr bool LIM_TO_WAVE = LIM_SLOTS && topo_wave_fallback<T>::value && has_slow_path<T, Real>();
+  int nla = 0;
+  if constexpr (LIM_SLOTS) sfor<0, NL>([&](auto K) { constexpr int k = K; if constexpr (T::limited(k)) nla += (q[2 + k] <= P.lo[k] || q[2 + k] >= P.hi[k]) ? 1 : 0; });
   if constexpr (has_slow_path<T, Real>()) {
     slow = nact > last_tier<T, Real>() || (P.force_slow > 0 && nact > 0);
+    if constexpr (LIM_TO_WAVE) slow = slow || nla > NLSS;
     if (__any(slow)) {
       // the rare lanes whose env touches the floor with more capsules than the tiers hold: one after the other
 #ifdef DART_WAVE_TIMING
@@ -2104,21 +2113,24 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
 #ifdef DART_WAVE_COOP
   if constexpr (topo_wave_fallback<T>::value) cm = blockDim.x == 64 ? slow_mem + constraint_lds_words<T, Real>() : nullptr;
 #endif
-  // limit rows: the small tier carries small_limit_slots<T>() of them (topo_limit_slots); a wave with a lane that has more joints at their
-  // limits runs the instantiation with one row per limited joint -- the wave's vote, as for the contact slots; either way a lane's LCP has
-  // the same rows that can move, so its solution is the same up to rounding
-  constexpr int NLSS = small_limit_slots<T>();
+  // limit rows: the small tier carries small_limit_slots<T>() of them (topo_limit_slots).  Topologies without wave solvers (Walker2d): a wave
+  // with a lane that has more joints at their limits runs the instantiation with one row per limited joint -- the wave's vote, as for the contact
+  // slots.  A lane's LCP has the same rows that can move either way and the same start sets (warm sets travel in joint layout), so on the host
+  // build the two give bitwise the same numbers (tests/test_lane_kernels_as_waves.py); on the device the two instantiations round differently
+  // in the last bits (measured: profiles/r06_limit_slots.txt), so THERE the vote can show in the last bits of the wave mates of a lane with five
+  // or six of its six joints at their limits -- never seen in 245 k lane-substeps of random-action rollouts, nor by the 65 536-env
+  // batch-independence test.  Topologies with wave solvers never vote: such a lane is `slow` (above).
   bool lim_all = false;   // (wave-uniform)
-  if constexpr (NLSS < n_limited<T>()) {
-    int nla = 0;
-    sfor<0, T::NL>([&](auto K) { constexpr int k = K; if constexpr (T::limited(k)) nla += (q[2 + k] <= P.lo[k] || q[2 + k] >= P.hi[k]) ? 1 : 0; });
+  if constexpr (LIM_SLOTS && !LIM_TO_WAVE) {
     lim_all = __any(!slow && nla > NLSS);
 #ifdef DART_LIMIT_NO_FALLBACK   // (timing experiments only: the compacted tier whatever the count -- WRONG for a lane with more joints at their limits)
     lim_all = false;
 #endif
   }
   auto small_tier = [&]() {
-    if constexpr (NLSS < n_limited<T>()) {
+    if constexpr (LIM_TO_WAVE) {
+      constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+    } else if constexpr (LIM_SLOTS) {
       if (lim_all) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
       else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     } else {

@@ -1340,6 +1340,24 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   });
 }
 
+// The all-limits tier of a topology whose waves vote between it and the compacted limit slots (world_step), as a REAL CALL on copies of its
+// inputs: the tier almost never runs (Walker2d: some lane with five or six of its six joints at their limits), and inlined next to the
+// compacted tier it cost the hot path its registers -- Walker2d fp64 352 -> 864 B of scratch per lane, HBM traffic per launch 49 -> 143 MB
+// (profiles/r06_limit_slots.txt).  The copies are made in the rare branch only.
+template <class Real, class T>
+struct TierIO {
+  Real q[T::NDOF], H[T::NDOF * (T::NDOF + 1) / 2], px[T::NL], py[T::NL], vs[T::NDOF], cPx[T::NC], cPy[T::NC], cdep[T::NC];
+  bool con[T::NC], off;
+  WarmSets warm;
+  ReportTo<Real> rp;
+  const Real* hl;   // the lane's H^-1 column in LDS (HLDS), else null
+  Real* cm;         // LDS block of the wave solver's hand-off (topologies with WAVE_FALLBACK), else null
+};
+template <class Real, class T, class PT, int NCA, bool EXTRAS, bool HLDS>
+__device__ __attribute__((noinline)) void constraint_phase_call(PT P, TierIO<Real, T>& io) {
+  constraint_phase<Real, T, PT, NCA, EXTRAS, HLDS>(P, io.q, io.H, io.px, io.py, io.vs, io.con, io.cPx, io.cPy, io.cdep, io.off, io.warm, io.rp, io.hl, io.cm);
+}
+
 // ------------------------------------------------------------------ single-lane fallback: any number of contacts, loops over LDS
 // Executed by ONE lane at a time (the others of its wave wait) for an env with more touching capsules than the register
 // tiers hold -- the robot lying on the floor.  Same LCP, same two-stage pivoting with the same start sets and tolerances
@@ -2131,7 +2149,17 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     if constexpr (LIM_TO_WAVE) {
       constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     } else if constexpr (LIM_SLOTS) {
-      if (lim_all) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+      if (lim_all) {   // (rare: a real call on copies, see constraint_phase_call)
+        TierIO<Real, T> io;
+        sfor<0, N>([&](auto I) { io.q[I] = q[I]; io.vs[I] = vs[I]; });
+        if constexpr (!HLDS) sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = H[I]; });
+        sfor<0, NL>([&](auto K) { io.px[K] = px[K]; io.py[K] = py[K]; });
+        sfor<0, NC>([&](auto Cc) { io.con[Cc] = con[Cc]; io.cPx[Cc] = cPx[Cc]; io.cPy[Cc] = cPy[Cc]; io.cdep[Cc] = cdep[Cc]; });
+        io.off = slow; io.warm = warm; io.rp = rp; io.hl = hl; io.cm = cm;
+        constraint_phase_call<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, io);
+        sfor<0, N>([&](auto I) { vs[I] = io.vs[I]; });
+        warm = io.warm;
+      }
       else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     } else {
       constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);

@@ -78,6 +78,10 @@ struct HopperAllTopo {  // the same chain with EVERY capsule tested against the 
   // from 4 / 5 to 3 / 4 rows -- and the kernel got SLOWER on the device: fp64 32.0 -> 33.8 us, fp32 27.5 -> 49.9 us (profiles/r06_limit_slots.txt):
   // at these sizes the selects that build the compacted rows and the second inlined tier cost more than the smaller factorisations give back.
   static constexpr int LIMIT_SLOTS = DART_HOPPER_LIMIT_SLOTS;
+#ifndef DART_HOPPER_LIMIT_PREFIX
+#define DART_HOPPER_LIMIT_PREFIX 2
+#endif
+  static constexpr int LIMIT_PREFIX = DART_HOPPER_LIMIT_PREFIX;   // see topo_limit_prefix (3 = all limit rows always, rounds 1-5)
   static constexpr bool WARM = false;   // (round 5, host build over 64-lane groups: 13.75 pivoting solves per wave and env-step, 14.02 with warm starts)
   // (round 4 A/B: H^-1 parked in LDS across the pivoting loops, the walker's HINV_LDS_F64, makes THIS kernel slower -- 31.82 -> 33.24 us
   // fp64, 158 -> 126 AGPRs: the 21 entries cost more as LDS round trips than as accumulator-register moves)
@@ -268,6 +272,14 @@ template <class T> __device__ __host__ constexpr int lim_link(int o) {  // the o
 // from 8 / 10 to 6 / 8.
 template <class T, class = void> struct topo_limit_slots { static constexpr int value = -1; };
 template <class T> struct topo_limit_slots<T, decltype((void)T::LIMIT_SLOTS)> { static constexpr int value = T::LIMIT_SLOTS; };
+// LIMIT_PREFIX (optional trait; round 6): the small tier carries the limit rows of the FIRST LIMIT_PREFIX limited joints only, each in its own
+// row -- no compaction, none of its selects -- and a wave in which some lane has a LATER joint at its limit runs the tier with all of them.  For
+// a chain whose last joint practically never reaches its limits: the Hopper's foot joint does in 8e-5 of the lane-substeps (a wave: 0.5 %).
+template <class T, class = void> struct topo_limit_prefix { static constexpr int value = -1; };
+template <class T> struct topo_limit_prefix<T, decltype((void)T::LIMIT_PREFIX)> { static constexpr int value = T::LIMIT_PREFIX; };
+template <class T> __device__ __host__ constexpr int small_limit_prefix() {
+  return (topo_limit_prefix<T>::value >= 0 && topo_limit_prefix<T>::value < n_limited<T>()) ? topo_limit_prefix<T>::value : n_limited<T>();
+}
 template <class T> __device__ __host__ constexpr int small_limit_slots() {
   return (topo_limit_slots<T>::value >= 0 && topo_limit_slots<T>::value < n_limited<T>()) ? topo_limit_slots<T>::value : n_limited<T>();
 }
@@ -885,15 +897,16 @@ struct WarmSets {
 // contacts (con / cPx / cPy / cdep over the T::NC capsules) and the state q (limits).  A lane with `off` set takes no part
 // (it is served by slow_constraints): all its rows are inactive and its vs comes back unchanged.
 // HLDS: H^-1 is read from this lane's LDS column `hl` (entry k at hl[64 k]) instead of from H (topo_hinv_lds64).
-// NLS: limit slots (topo_limit_slots); -1 = one row per limited joint.
-template <class Real, class T, class PT, int NCA, bool EXTRAS, bool HLDS = false, int NLS = -1>
+// NLS: limit slots (topo_limit_slots); -1 = one row per limited joint.  LPFX (topo_limit_prefix): the NLS rows are the FIRST NLS limited joints,
+// each in its own row (no compaction) -- the caller guarantees that no lane of the wave has a later joint at its limit.
+template <class Real, class T, class PT, int NCA, bool EXTRAS, bool HLDS = false, int NLS = -1, bool LPFX = false>
 __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T::NDOF], const Real (&H)[T::NDOF * (T::NDOF + 1) / 2],
                                                  const Real (&px)[T::NL], const Real (&py)[T::NL], Real (&vs)[T::NDOF],
                                                  const bool (&con)[T::NC], const Real (&cPx)[T::NC], const Real (&cPy)[T::NC],
                                                  const Real (&cdep)[T::NC], bool off, WarmSets& warm, const ReportTo<Real>& rp,
                                                  const Real* hl = nullptr, Real* cm = nullptr) {
   constexpr int NLIM = n_limited<T>(), NLSE = (NLS < 0 || NLS >= NLIM) ? NLIM : NLS;
-  constexpr bool LIDENT = NLSE == NLIM;   // limit row o IS limited joint o
+  constexpr bool LIDENT = NLSE == NLIM || LPFX;   // limit row o IS limited joint o (all of them, or the first NLSE: LPFX)
   constexpr int NL = T::NL, N = T::NDOF, NC = T::NC, M = 2 * NCA + NLSE;
   constexpr int NLA = NLIM > 0 ? NLIM : 1, NLSA = NLSE > 0 ? NLSE : 1;
   // hand-off of the lanes that keep pivoting to the wave solver (blcp_bpp; cm = its LDS block, null = never): after how many
@@ -981,7 +994,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   if constexpr (LIDENT) {
   sfor<0, NL>([&](auto K) {
     constexpr int k = K;
-    if constexpr (T::limited(k)) {
+    if constexpr (T::limited(k) && lim_ord<T>(k) < NLSE) {
       constexpr int sl = limit_slot<T, NCA>(k), i = 2 + k;
       const bool low = !off && q[i] <= P.lo[k], up = !off && (!low) && (q[i] >= P.hi[k]);
       const Real viol = low ? (q[i] - P.lo[k]) : (q[i] - P.hi[k]);
@@ -1065,7 +1078,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   if constexpr (LIDENT) {
   sfor<0, NL>([&](auto K) {
     constexpr int k = K;
-    if constexpr (T::limited(k)) {
+    if constexpr (T::limited(k) && lim_ord<T>(k) < NLSE) {
       constexpr int sl = limit_slot<T, NCA>(k), i = 2 + k;
       sfor<0, NCA>([&](auto S) {
         constexpr int cs = S;
@@ -1074,7 +1087,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
       });
       sfor<0, k + 1>([&](auto J) {
         constexpr int j = J;
-        if constexpr (T::limited(j)) A[tri(sl, limit_slot<T, NCA>(j))] = Hv(tri(rev<N>(i), rev<N>(2 + j)));
+        if constexpr (T::limited(j)) A[tri(sl, limit_slot<T, NCA>(j))] = Hv(tri(rev<N>(i), rev<N>(2 + j)));   // (j <= k: its ordinal is below NLSE too)
       });
     }
   });
@@ -1291,7 +1304,7 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
   Real xl[NLA];
   sfor<0, NLIM>([&](auto O) {
     constexpr int o = O;
-    if constexpr (LIDENT) xl[o] = x[2 * NCA + o];
+    if constexpr (LIDENT) { if constexpr (o < NLSE) xl[o] = x[2 * NCA + o]; else xl[o] = Real(0); }
     else {
       Real v = Real(0);
       sfor<0, NLSE>([&](auto S) { constexpr int sl = S; v = (act[2 * NCA + sl] && ((lid >> (4 * sl)) & 15u) == (uint32_t)o) ? x[2 * NCA + sl] : v; });
@@ -1338,24 +1351,6 @@ __device__ __forceinline__ void constraint_phase(const PT& P, const Real (&q)[T:
     });
     vs[i] += dv;
   });
-}
-
-// The all-limits tier of a topology whose waves vote between it and the compacted limit slots (world_step), as a REAL CALL on copies of its
-// inputs: the tier almost never runs (Walker2d: some lane with five or six of its six joints at their limits), and inlined next to the
-// compacted tier it cost the hot path its registers -- Walker2d fp64 352 -> 864 B of scratch per lane, HBM traffic per launch 49 -> 143 MB
-// (profiles/r06_limit_slots.txt).  The copies are made in the rare branch only.
-template <class Real, class T>
-struct TierIO {
-  Real q[T::NDOF], H[T::NDOF * (T::NDOF + 1) / 2], px[T::NL], py[T::NL], vs[T::NDOF], cPx[T::NC], cPy[T::NC], cdep[T::NC];
-  bool con[T::NC], off;
-  WarmSets warm;
-  ReportTo<Real> rp;
-  const Real* hl;   // the lane's H^-1 column in LDS (HLDS), else null
-  Real* cm;         // LDS block of the wave solver's hand-off (topologies with WAVE_FALLBACK), else null
-};
-template <class Real, class T, class PT, int NCA, bool EXTRAS, bool HLDS>
-__device__ __attribute__((noinline)) void constraint_phase_call(PT P, TierIO<Real, T>& io) {
-  constraint_phase<Real, T, PT, NCA, EXTRAS, HLDS>(P, io.q, io.H, io.px, io.py, io.vs, io.con, io.cPx, io.cPy, io.cdep, io.off, io.warm, io.rp, io.hl, io.cm);
 }
 
 // ------------------------------------------------------------------ single-lane fallback: any number of contacts, loops over LDS
@@ -2145,21 +2140,24 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
     lim_all = false;
 #endif
   }
+  // (topo_limit_prefix: the same vote on "some lane has a joint beyond the prefix at its limit")
+  constexpr int NLPF = small_limit_prefix<T>();
+  constexpr bool LIM_PFX = !LIM_SLOTS && NLPF < n_limited<T>();
+  if constexpr (LIM_PFX) {
+    bool later = false;
+    sfor<0, NL>([&](auto K) { constexpr int k = K; if constexpr (T::limited(k) && lim_ord<T>(k) >= NLPF) later = later || q[2 + k] <= P.lo[k] || q[2 + k] >= P.hi[k]; });
+    lim_all = __any(!slow && later);
+  }
   auto small_tier = [&]() {
-    if constexpr (LIM_TO_WAVE) {
+    if constexpr (LIM_PFX) {
+      if (lim_all) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+      else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLPF, true>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+    } else if constexpr (LIM_TO_WAVE) {
       constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     } else if constexpr (LIM_SLOTS) {
-      if (lim_all) {   // (rare: a real call on copies, see constraint_phase_call)
-        TierIO<Real, T> io;
-        sfor<0, N>([&](auto I) { io.q[I] = q[I]; io.vs[I] = vs[I]; });
-        if constexpr (!HLDS) sfor<0, N*(N + 1) / 2>([&](auto I) { io.H[I] = H[I]; });
-        sfor<0, NL>([&](auto K) { io.px[K] = px[K]; io.py[K] = py[K]; });
-        sfor<0, NC>([&](auto Cc) { io.con[Cc] = con[Cc]; io.cPx[Cc] = cPx[Cc]; io.cPy[Cc] = cPy[Cc]; io.cdep[Cc] = cdep[Cc]; });
-        io.off = slow; io.warm = warm; io.rp = rp; io.hl = hl; io.cm = cm;
-        constraint_phase_call<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, io);
-        sfor<0, N>([&](auto I) { vs[I] = io.vs[I]; });
-        warm = io.warm;
-      }
+      // (inlined, although it almost never runs: as a real call on copies of its inputs -- built and measured in round 6 -- the call's mere
+      // presence cost the compacted tier its registers: Walker2d fp64 89.5 -> 114.4 us, HBM traffic per launch 143 -> 326 MB)
+      if (lim_all) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
       else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     } else {
       constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);

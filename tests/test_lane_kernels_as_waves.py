@@ -47,7 +47,8 @@ def test_whole_waves_follow_the_oracle(env_id, n, T):
 def test_limit_slot_vote_and_the_all_limits_tier_follow_the_oracle(env_id):
     """Round 6: the small register tier of the Walker2d / half-cheetah kernels carries 4 / 3 compacted joint-limit rows instead of 6 -- slot s =
     the s-th joint that is at a limit -- and a wave in which some lane has more joints at their limits runs the instantiation with one row per
-    limited joint (the wave's vote, planar_kernel.hpp: topo_limit_slots; the Hopper kernel keeps one row per joint: measured slower compacted).  Two waves here: the first starts with EVERY joint of a few lanes beyond its limits (so that
+    limited joint (the wave's vote, planar_kernel.hpp: topo_limit_slots); the Hopper's small tier carries the limit rows of its first two
+    joints, uncompacted, and a wave in which some lane has the foot joint at a limit runs the tier with all three (topo_limit_prefix).  Two waves here: the first starts with EVERY joint of a few lanes beyond its limits (so that
     wave takes the all-limits tier while those lanes recover), the second with ordinary states (compacted rows, joints entering and leaving
     their limits from substep to substep: slots change owners, the warm sets must not follow them).  Both against the oracle, step by step."""
     card = card_for(env_id)
@@ -77,7 +78,7 @@ def test_limit_slot_vote_and_the_all_limits_tier_follow_the_oracle(env_id):
     assert worst[0] < 1e-9 and worst[1] < 1e-7, worst
 
 
-@pytest.mark.parametrize("env_id", ["DartWalker2d-v1", "DartHalfCheetah-v1"])
+@pytest.mark.parametrize("env_id", ["DartHopper-v1", "DartWalker2d-v1", "DartHalfCheetah-v1"])
 def test_limit_slot_vote_does_not_change_a_lanes_numbers(env_id):
     """Which limit layout a wave runs -- the compacted slots, or one row per limited joint because some lane has more joints at their limits than
     slots -- is the wave's vote; a lane's numbers must not depend on it, bitwise: the all-limits factorisation only adds exact zeros for the

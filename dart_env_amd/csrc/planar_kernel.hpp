@@ -1719,7 +1719,11 @@ __device__ __attribute__((noinline)) void wave_constraints4(const PT& P, Real* g
     const int c = l, row = 2 * __popc(cbal & below);
     // (the compile-time tables, whatever ANC_TABLES_RT says for the topology's step kernel: evaluated at run time the ancestor table is a
     // walk over the parent array in constant memory, one dependent s_load per hop -- 14 such loops at the top of this function, found in
-    // the disassembly)
+    // the disassembly.  ADVICE r5 asked why that is safe where ANC_TABLES_RT exists because compile-time tables once tripped the toolchain's
+    // EXEC-prologue defect: the defect is a property of a COMPILATION, not of the construct -- every build's assembly of this function is
+    // linted (tools/exec_prologue_lint.py: 0 hits in 94 functions of each planar unit), and the poison test holds the half cheetah's kernels,
+    // which run this path for 5 % of their env-steps, and the physics-only walker / cheetah trees to identical bits with registers, scratch
+    // and LDS disturbed, fp64 and fp32 (tests/test_gpu_first_launch.py; tests/test_gpu_spatial.py's floor batches run it for every lane).)
     const uint32_t am = (uint32_t)((AncTable<T>::value >> (8 * (int)((ClinkTable<T>::value >> (4 * c)) & 0xfull))) & 0xffull);
     const auto jn = J + row * N; const auto jt = J + (row + 1) * N;
     jn[0] = Real(0); jn[1] = Real(1); jt[0] = Real(-1); jt[1] = Real(0);

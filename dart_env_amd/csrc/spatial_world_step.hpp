@@ -271,34 +271,6 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
           const V3<Real> ad = ld3(Ld + LK_A), od = ld3(Ld + LK_JO);
           const bool drev = topo_jtype(S.topo[dlive ? dlk : 0]) == 2;
           const uint32_t dbit = 1u << dcol;
-#ifndef SP_J_PER_POINT
-#define SP_J_PER_POINT 1
-#endif
-          if constexpr (!PAIRS && (SP_J_PER_POINT != 0)) {
-            // Ground contacts only (round 6): the three rows of a contact point -- normal +y, tangents -x and +z -- are the COMPONENTS of one
-            // vector c = a_d x (P - o_d) (revolute; a_d itself for a prismatic dof), so the lane of column d computes c once per contact
-            // point and stores three entries, instead of one cross product + one dot product with an axis per ROW behind a descriptor of
-            // nine LDS reads: ~100 instead of ~450 instructions per lane for eight contact points, two dependent LDS trips instead of seven,
-            // and no descriptor pass at all (the link records are not overwritten here: no barrier in front).  Same numbers: a dot product
-            // with a unit axis adds exact zeros.  Limit / joint-friction rows: the unit vector of their dof.
-            const int col = n - 1 - dcol;
-            for (int c = half; c < ncp; c += 2) {
-              const V3<Real> P = ld3(S.cpP + 4 * c);
-              const uint32_t ma = (uint32_t)S.ancd[S.cplink[c]];
-              const V3<Real> cr = drev ? cross(ad, P - od) : ad;
-              const bool on = (ma & dbit) != 0u;
-              const int rt = m1 + 2 * c;
-              if (dlive) {
-                S.W[c * n + col] = on ? cr.y : Real(0);
-                if (rt < m) S.W[rt * n + col] = on ? -cr.x : Real(0);
-                if (rt + 1 < m) S.W[(rt + 1) * n + col] = on ? cr.z : Real(0);
-              }
-            }
-            for (int i = ncp + half; i < m1; i += 2) {
-              const int rd = S.rdof[i];
-              if (dlive) S.W[i * n + col] = (rd == dcol) ? Real(1) : Real(0);
-            }
-          } else {
           Real* const rowd = S.A;                            // [m][8]: dir (3), P (3), then two ints in the last two slots
           int* const rowi = (int*)(S.A + 8 * maxm);       // [m][4]: limit dof (-1: contact row), mask a, mask b
           __syncthreads();                                   // every lane holds its dof's axis / origin: the link records may go
@@ -341,7 +313,6 @@ __device__ __forceinline__ void sp_world_step(const SpatialModel<Real>& Md, cons
             if (dlive) { S.W[i * n + (n - 1 - dcol)] = v0; S.W[(i + 2) * n + (n - 1 - dcol)] = v1; }
           }
           if (i < m) { const Real v0 = entry(i); if (dlive) S.W[i * n + (n - 1 - dcol)] = v0; }
-          }
         }
         __syncthreads();
         if (lane < m) {   // right-hand side and bounds of row `lane`: b = bounce - J v*

@@ -26,6 +26,11 @@
 
 #include "mt19937_draw.hpp"
 
+// a branch the workloads practically never take (the tiers behind the wave votes): block frequencies steer the register allocator's spill
+// placement -- the cold tier's live ranges are split around IT, not around the hot one
+#ifndef DART_UNLIKELY
+#define DART_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
 #ifndef DART_PIN_VGPR
 #define DART_PIN_VGPR(x) asm volatile("" : "+v"(x))   // an optimisation barrier on a value that lives in a VGPR
 #endif
@@ -2154,21 +2159,21 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   }
   auto small_tier = [&]() {
     if constexpr (LIM_PFX) {
-      if (lim_all) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+      if (DART_UNLIKELY(lim_all)) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
       else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLPF, true>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     } else if constexpr (LIM_TO_WAVE) {
       constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     } else if constexpr (LIM_SLOTS) {
       // (inlined, although it almost never runs: as a real call on copies of its inputs -- built and measured in round 6 -- the call's mere
       // presence cost the compacted tier its registers: Walker2d fp64 89.5 -> 114.4 us, HBM traffic per launch 143 -> 326 MB)
-      if (lim_all) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
+      if (DART_UNLIKELY(lim_all)) constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
       else constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS, NLSS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     } else {
       constraint_phase<Real, T, PT, T::TIER0, EXTRAS, HLDS>(P, q, H, px, py, vs, con, cPx, cPy, cdep, slow, warm, rp, hl, cm);
     }
   };
   if constexpr (tier1<T, Real>() > 0) {
-    if (__any(nreg > T::TIER0)) {
+    if (DART_UNLIKELY(__any(nreg > T::TIER0))) {
 #ifdef DART_WAVE_TIMING
       big_tier = true;
 #endif

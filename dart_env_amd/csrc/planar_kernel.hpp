@@ -2036,7 +2036,9 @@ __device__ __forceinline__ void world_step(const PT& P, Real (&q)[T::NDOF], Real
   if constexpr (has_slow_path<T, Real>()) {
     slow = nact > last_tier<T, Real>() || (P.force_slow > 0 && nact > 0);
     if constexpr (LIM_TO_WAVE) slow = slow || nla > NLSS;
-    if (__any(slow)) {
+    // (unlikely only where the fallback is the single-lane loop -- Hopper, Walker2d: a handful of lanes per launch; the half cheetah's wave
+    // solvers run in 94 % of its waves)
+    if (topo_wave_fallback<T>::value ? __any(slow) : DART_UNLIKELY(__any(slow))) {
       // the rare lanes whose env touches the floor with more capsules than the tiers hold: one after the other
 #ifdef DART_WAVE_TIMING
       const long long tclk0 = DART_CLK();

@@ -99,7 +99,7 @@ def load_library(path: Optional[str] = None):
     L.dart_output_layout.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dart_register_output.argtypes = [vp, C.c_void_p]
     L.dart_unregister_output.argtypes = [vp, C.c_void_p]
-    L.dart_step_async_to.argtypes = [vp, C.POINTER(C.c_float), C.c_void_p]
+    L.dart_step_async_to.argtypes = [vp, C.c_void_p, C.c_void_p]     # (const float* actions as an address: see _addr)
     L.dart_register_host_buffer.argtypes = [vp, C.c_void_p, C.c_uint64]
     L.dart_unregister_host_buffer.argtypes = [vp, C.c_void_p]
     L.dart_device_outputs.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -122,6 +122,30 @@ def load_library(path: Optional[str] = None):
 
 def _ptr(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _addr(a):
+    """address of a numpy array's first byte (for a void* / float* argument): `a.ctypes.data_as(...)` builds a helper object and a typed
+    pointer per call -- 4 us -- which is real money on a 150 us step (round 6: 20 us of Python per host step, measured with a no-op library)"""
+    return a.__array_interface__["data"][0]
+
+
+class _Lease:
+    """What the arrays of one step are views of: exposes the step's output block through the array interface and gives the block back to
+    the pool when the last array derived from it is garbage (numpy keeps this object alive as their base).  Round 6: replaces a ctypes
+    array + weakref.finalize per step (3.8 us) by one slotted object (1.6 us); same ownership rule (see HipStepper._free_block)."""
+    __slots__ = ("__array_interface__", "ent")
+
+    def __init__(self, ai, ent):
+        self.__array_interface__ = ai
+        self.ent = ent
+        ent[1] = True
+
+    def __del__(self):
+        try:
+            self.ent[1] = False
+        except Exception:      # interpreter shutdown
+            pass
 
 
 class HipStepper:
@@ -285,13 +309,14 @@ class HipStepper:
         off).  Layout of a block: [obs | reward f32 | done | truncated] exactly as the device block, then (N) float64 rewards -- the
         type gym.vector returns -- written by the same copy kernel (round 5; rounds 3-4 converted them on the host after every step).
         Ownership is explicit (round 4; it used to be inferred from sys.getrefcount): the arrays a step returns are views of a LEASE --
-        a ctypes array aliasing the block, made for that one step -- and numpy keeps the lease alive as the base of every view derived
-        from them; a weakref finalizer on the lease returns the block to the pool when the last such view is gone.  copy=True semantics
+        a small object exposing the block through the array interface, made for that one step (_Lease; rounds 4-5: a ctypes array with a
+        weakref finalizer) -- and numpy keeps the lease alive as the base of every view derived from them; when the last such view is gone
+        the lease's destructor returns the block to the pool.  copy=True semantics
         of sync_vector_env.py:83 without a copy (and without the page faults of fresh multi-MB arrays every step), independent of
         who else holds references to the block itself (debuggers, profilers, a test's own bookkeeping)."""
         if not self.__dict__.get("output_pool", True):     # (attribute set by tools/bench_host_path.py for its A/B: round 2's staging path)
             return None
-        pool = self.__dict__.setdefault("_blocks", [])      # [block array, leased?]
+        pool = self.__dict__.setdefault("_blocks", [])      # [block array, leased?, its address (c_void_p), its array interface]
         for ent in pool:
             if not ent[1]:
                 return ent[0]
@@ -302,19 +327,13 @@ class HipStepper:
         rc = self.L.dart_register_output(self.h, blk.ctypes.data_as(C.c_void_p))
         if rc != DART_OK:
             return None
-        pool.append([blk, False])
+        pool.append([blk, False, C.c_void_p(_addr(blk)), dict(blk.__array_interface__)])
         return blk
 
     def _lease(self, blk):
         """-> a uint8 array over `blk` whose views keep the block out of the pool until all of them are garbage"""
         ent = next(e for e in self._blocks if e[0] is blk)
-        ent[1] = True
-        ca = (C.c_uint8 * blk.size).from_buffer(blk)
-
-        def release(ent=ent):
-            ent[1] = False
-        weakref.finalize(ca, release)
-        return np.frombuffer(ca, dtype=np.uint8)
+        return np.asarray(_Lease(ent[3], ent))
 
     def register_host_buffer(self, arr):
         """page-lock a caller-owned numpy array for direct DMA (dart_register_host_buffer): `dart_step` arguments inside it skip the
@@ -339,7 +358,6 @@ class HipStepper:
         total, off = self._layout()
         blk = self._lease(blk)          # every array below is a view of this step's lease (see _free_block)
         obs = blk[off[0]:off[0] + 4 * n * self.obs_dim].view(np.float32).reshape(n, self.obs_dim)
-        r32 = blk[off[1]:off[1] + 4 * n].view(np.float32)
         done = blk[off[2]:off[2] + n].view(np.bool_)        # the kernels write exactly 0 / 1
         trunc = blk[off[3]:off[3] + n].view(np.bool_)
         r64 = total - ((8 * n + 255) & ~255)     # the block's tail: float64 rewards, converted by the copy kernel (include/dart_stepper.h)
@@ -364,7 +382,8 @@ class HipStepper:
         if blk is None:
             self._check(self.L.dart_step_async(self.h, _ptr(a, C.c_float)))
         else:
-            self._check(self.L.dart_step_async_to(self.h, _ptr(a, C.c_float), blk.ctypes.data_as(C.c_void_p)))
+            ent = next(e for e in self._blocks if e[0] is blk)
+            self._check(self.L.dart_step_async_to(self.h, _addr(a), ent[2]))
         self._pending_block = blk
 
     def _views(self):

@@ -65,6 +65,7 @@ struct DartStepper {
   size_t out_bytes = 0, out_off[4] = {0, 0, 0, 0};   // offsets of obs / reward / done / truncated inside the block
   size_t out_bytes_host = 0;     // a caller's output block (dart_step_async_to): the device block + (N) float64 rewards behind it, made by the copy kernel
   std::vector<void*> registered;   // caller-owned output blocks page-locked by dart_register_output
+  std::vector<void*> pinned;       // output blocks of dart_alloc_output (hipHostMalloc; the caller frees them: dart_free_output)
   // caller-owned host buffers page-locked by dart_register_host_buffer: dart_step DMAs straight from / into arguments that lie inside
   std::vector<std::pair<char*, size_t>> host_ranges;
   double* d_rew64 = nullptr;       // float64 rewards for the direct path of dart_step (the reference's reward type), made on the device
@@ -259,6 +260,7 @@ int dart_destroy(DartStepper* h) {
   if (h->impl) h->impl->release();
   for (void* p : h->registered) (void)hipHostUnregister(p);
   h->registered.clear();
+  h->pinned.clear();               // (the caller's to free -- arrays it handed out may outlive the handle: dart_free_output)
   for (auto& r : h->host_ranges) (void)hipHostUnregister(r.first);
   h->host_ranges.clear();
   if (h->d_rew64) hipFree(h->d_rew64);
@@ -570,9 +572,27 @@ int dart_register_output(DartStepper* h, void* block) {
   h->registered.push_back(block);
   return DART_OK;
 }
+// Output blocks in memory the DRIVER page-locks (hipHostMalloc) instead of the caller's pageable memory locked after the fact (hipHostRegister,
+// a "userptr" mapping).  Round 6: GPU writes into registered numpy memory faulted about once in ten runs of the GPU suite -- "Memory access
+// fault ... Write access to a read-only page" on an address inside a registered block (profiles/r06_crash_hunt.txt, part 2).
+int dart_alloc_output(DartStepper* h, void** block) {
+  if (!h || !block) return DART_E_INVALID;
+  CHK(h, hipSetDevice(h->device));
+  void* p = nullptr;
+  CHK(h, hipHostMalloc(&p, h->out_bytes_host, hipHostMallocDefault));
+  h->pinned.push_back(p);
+  *block = p;
+  return DART_OK;
+}
+int dart_free_output(void* block) {
+  if (!block) return DART_E_INVALID;
+  return hipHostFree(block) == hipSuccess ? DART_OK : DART_E_HIP;
+}
 int dart_unregister_output(DartStepper* h, void* block) {
   if (!h || !block) return DART_E_INVALID;
   if (h->pending) { h->err = "dart_unregister_output while a step is pending"; return DART_E_PENDING; }
+  for (size_t i = 0; i < h->pinned.size(); i++)
+    if (h->pinned[i] == block) { h->pinned.erase(h->pinned.begin() + i); return DART_OK; }   // forgotten, not freed (dart_free_output)
   for (size_t i = 0; i < h->registered.size(); i++)
     if (h->registered[i] == block) {
       CHK(h, hipSetDevice(h->device));
@@ -587,7 +607,8 @@ int dart_step_async_to(DartStepper* h, const float* actions, void* block) {
   if (!h || !block) return DART_E_INVALID;
   bool known = false;
   for (void* p : h->registered) known = known || p == block;
-  if (!known) { h->err = "dart_step_async_to: the block is not registered (dart_register_output)"; return DART_E_INVALID; }
+  for (void* p : h->pinned) known = known || p == block;
+  if (!known) { h->err = "dart_step_async_to: the block is neither dart_alloc_output's nor registered (dart_register_output)"; return DART_E_INVALID; }
   return step_async_impl(h, actions, block, false);
 }
 

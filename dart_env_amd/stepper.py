@@ -31,7 +31,7 @@ EXPORTS = [
     "dart_last_error", "dart_create", "dart_destroy", "dart_query", "dart_configure", "dart_reset",
     "dart_set_state", "dart_get_state", "dart_step", "dart_step_async", "dart_step_wait",
     "dart_step_device", "dart_reset_device", "dart_sync", "dart_time_steps", "dart_get_counters", "dart_get_stats", "dart_debug_dump", "dart_seed_mt19937", "dart_get_dynamics", "dart_get_episode_stats", "dart_set_ext_force", "dart_set_task_state", "dart_host_views", "dart_get_contacts", "dart_get_constraint_forces", "dart_get_body_poses", "dart_snapshot", "dart_restore", "dart_timer_mark", "dart_timer_elapsed",
-    "dart_output_layout", "dart_register_output", "dart_unregister_output", "dart_step_async_to",
+    "dart_output_layout", "dart_alloc_output", "dart_free_output", "dart_register_output", "dart_unregister_output", "dart_step_async_to",
     "dart_register_host_buffer", "dart_unregister_host_buffer", "dart_device_outputs",
 ]
 
@@ -97,6 +97,8 @@ def load_library(path: Optional[str] = None):
     L.dart_set_ext_force.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.dart_set_task_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
     L.dart_output_layout.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.dart_alloc_output.argtypes = [vp, C.POINTER(C.c_void_p)]
+    L.dart_free_output.argtypes = [C.c_void_p]
     L.dart_register_output.argtypes = [vp, C.c_void_p]
     L.dart_unregister_output.argtypes = [vp, C.c_void_p]
     L.dart_step_async_to.argtypes = [vp, C.c_void_p, C.c_void_p]     # (const float* actions as an address: see _addr)
@@ -144,6 +146,23 @@ class _Lease:
     def __del__(self):
         try:
             self.ent[1] = False
+        except Exception:      # interpreter shutdown
+            pass
+
+
+class _PinnedBlock:
+    """Owner of one output block allocated by dart_alloc_output (driver page-locked memory; round 6): numpy arrays made from it keep it
+    alive as their base, and the memory goes back (dart_free_output, which needs no handle) when the last of them is garbage -- the lifetime
+    rule numpy's own memory had while the blocks were numpy arrays locked with hipHostRegister: results stay readable after close()."""
+    __slots__ = ("__array_interface__", "_free", "_addr")
+
+    def __init__(self, lib, addr, nbytes):
+        self._free, self._addr = lib.dart_free_output, addr
+        self.__array_interface__ = {"data": (addr, False), "shape": (int(nbytes),), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self._free(self._addr)
         except Exception:      # interpreter shutdown
             pass
 
@@ -305,7 +324,7 @@ class HipStepper:
         return self._out_layout
 
     def _free_block(self):
-        """A registered output block no caller array refers to any more, or a new one (None when the pool is exhausted or pooling is
+        """An output block no caller array refers to any more, or a new one (None when the pool is exhausted or pooling is
         off).  Layout of a block: [obs | reward f32 | done | truncated] exactly as the device block, then (N) float64 rewards -- the
         type gym.vector returns -- written by the same copy kernel (round 5; rounds 3-4 converted them on the host after every step).
         Ownership is explicit (round 4; it used to be inferred from sys.getrefcount): the arrays a step returns are views of a LEASE --
@@ -323,11 +342,13 @@ class HipStepper:
         if len(pool) >= self._POOL_SETS:
             return None
         total, _ = self._layout()
-        blk = np.empty(total, dtype=np.uint8)
-        rc = self.L.dart_register_output(self.h, blk.ctypes.data_as(C.c_void_p))
-        if rc != DART_OK:
+        # memory the driver page-locks (dart_alloc_output), not a numpy array locked after the fact (dart_register_output: round 6 saw GPU
+        # writes into such arrays fault, rarely -- "write access to a read-only page"; include/dart_stepper.h, profiles/r06_crash_hunt.txt)
+        p = C.c_void_p()
+        if self.L.dart_alloc_output(self.h, C.byref(p)) != DART_OK or not p.value:
             return None
-        pool.append([blk, False, C.c_void_p(_addr(blk)), dict(blk.__array_interface__)])
+        blk = np.asarray(_PinnedBlock(self.L, p.value, total))
+        pool.append([blk, False, C.c_void_p(p.value), dict(blk.__array_interface__)])
         return blk
 
     def _lease(self, blk):

@@ -199,10 +199,21 @@ int dart_device_outputs(DartStepper* h, const float** d_obs, const float** d_rew
  * dart_step_async_to enqueues H2D actions, kernel, auto-reset and a SINGLE D2H copy straight into the block;
  * dart_step_wait(h, NULL, NULL, NULL, NULL) then only synchronises.  A step's results stay valid for as long as the caller does
  * not hand the same block to another step: dart_env_amd/stepper.py rotates a small pool of blocks and reuses one only when the
- * caller holds no array of it any more, which keeps gym.vector's copy=True contract without a copy. */
+ * caller holds no array of it any more, which keeps gym.vector's copy=True contract without a copy.
+ *
+ * Where the block's memory comes from (round 6): PREFER dart_alloc_output -- total_bytes of memory the driver itself page-locks
+ * (hipHostMalloc), known to the handle as a block for dart_step_async_to, and OWNED BY THE CALLER: dart_destroy forgets it, dart_free_output
+ * (no handle: arrays a binding handed out may outlive the handle) releases it.  dart_register_output, for a caller that must have the
+ * results in memory of its own, locks pageable memory after the fact (hipHostRegister: a "userptr" mapping the driver keeps coherent with
+ * the process's page tables) -- on this stack (ROCm 7.2, MI355X) a GPU write into such memory faulted about once in ten runs of this
+ * repository's GPU suite ("Memory access fault ... Write access to a read-only page" at an address inside a registered numpy array of a
+ * process that had forked; profiles/r06_crash_hunt.txt part 2), never into hipHostMalloc'ed memory; dart_env_amd/stepper.py moved to
+ * dart_alloc_output for that reason.  The same caveat holds for dart_register_host_buffer. */
 int dart_output_layout(const DartStepper* h, int64_t* total_bytes, int64_t* offsets4);
+int dart_alloc_output(DartStepper* h, void** block);
+int dart_free_output(void* block);
 int dart_register_output(DartStepper* h, void* block);
-int dart_unregister_output(DartStepper* h, void* block);
+int dart_unregister_output(DartStepper* h, void* block);   /* (of a dart_alloc_output block: the handle forgets it; it is not freed) */
 int dart_step_async_to(DartStepper* h, const float* actions, void* block);
 
 /* Per-env task state that reset_model draws besides (q, dq): the reach target of DartReacher-v1 / DartReacher3d-v1

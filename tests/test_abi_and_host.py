@@ -252,20 +252,33 @@ def test_output_blocks_are_leased_to_the_callers_arrays_explicitly():
     the last array derived from the step's outputs is garbage -- however many other references to the block itself exist."""
     import gc
 
-    class FakeLib:                      # the two entry points the pool needs; no device behind them
+    import ctypes as C
+
+    class FakeLib:                      # the three entry points the pool needs; no device behind them
+        def __init__(self):
+            self.bufs, self.freed, self.total = {}, [], 0
+
         def dart_output_layout(self, h, tot, off):
             n, k = 8, 3
             ob, rb, db = 4 * n * k, 4 * n, n
-            tot._obj.value = ob + rb + 2 * db + ((8 * n + 255) & ~255)     # ... + the float64 rewards behind the device block (round 5)
+            self.total = tot._obj.value = ob + rb + 2 * db + ((8 * n + 255) & ~255)     # ... + the float64 rewards behind the device block (round 5)
             for i, v in enumerate((0, ob, ob + rb, ob + rb + db)):
                 off[i] = v
             return st.DART_OK
 
-        def dart_register_output(self, h, blk):
+        def dart_alloc_output(self, h, p):          # round 6: the blocks are the library's page-locked memory, owned by the caller
+            b = C.create_string_buffer(self.total)
+            self.bufs[C.addressof(b)] = b
+            p._obj.value = C.addressof(b)
             return st.DART_OK
 
+        def dart_free_output(self, addr):
+            self.freed.append(addr)
+            return st.DART_OK
+
+    lib = FakeLib()
     s = object.__new__(st.HipStepper)
-    s.L, s.h, s.num_envs, s.obs_dim = FakeLib(), None, 8, 3
+    s.L, s.h, s.num_envs, s.obs_dim = lib, None, 8, 3
     b0 = s._free_block()
     snoop = [b0, b0, b0]                # a tool holding extra references to the block (what broke the refcount test)
     obs, rew, done, trunc = s._block_views(b0)
@@ -282,4 +295,14 @@ def test_output_blocks_are_leased_to_the_callers_arrays_explicitly():
     del row
     gc.collect()
     assert s._free_block() is b0        # the last view is gone: b0 is free again, `snoop` notwithstanding
-    del o1, snoop
+    # a block's memory goes back only when nothing refers to it any more -- the pool (the handle) AND every array handed out
+    addrs = {b.__array_interface__["data"][0] for b in (b0, b1, b2)}
+    keep = o1[0]                        # b1's observations, still held by the caller when the handle goes
+    del o1, snoop, b0, b1, b2
+    s.__dict__.clear(); del s
+    gc.collect()
+    assert len(lib.freed) == 2 and set(lib.freed) < addrs, lib.freed
+    assert keep.shape == (8, 3)
+    del keep
+    gc.collect()
+    assert set(lib.freed) == addrs and len(lib.freed) == 3

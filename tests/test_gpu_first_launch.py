@@ -22,7 +22,7 @@ CASES = [("DartHopper-v1", 64), ("DartHopper-v1", 32), ("DartWalker2d-v1", 64), 
 
 def _probe(env_id, prec, extra, n=None):
     n = n or ("16384" if env_id == "DartHumanWalker-v1" else "65536")
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "gpu", "first_launch_probe.py"), "--env", env_id, "--prec", str(prec), "--n", str(n), "--steps", "3"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "gpu", "first_launch_probe.py"), "--env", env_id, "--prec", str(prec), "--n", str(n)] + (["--steps", "3"] if "--steps" not in extra else []) + extra
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if "digests" in l][-1]
@@ -64,3 +64,22 @@ def test_every_other_kernel_family_is_independent_of_leftovers(env_id, prec, n):
 def test_physics_only_kernels_are_independent_of_leftovers(model, prec):
     d = _probe("-", prec, ["--phys", model, "--poison", "all", "--when", "combined", "--pattern", "random", "--reps", "5"], n=16384)
     assert len(d) == 5 and len(set(d)) == 1, d
+
+
+# Round 6, late: none of the cases above resets an env -- and the one abort the GPU suite produced with a traceback (profiles/r06_crash_hunt.txt,
+# part 2) had its main thread in a step of the MT19937 auto-reset test.  So the reset epilogues get the same treatment: the step kernel's own
+# Philox reset, its MT19937 reset (mt19937_draw.hpp) and the two launches the latter replaced (mt_draw + masked reset: "mt-split"), with a
+# 2-step TimeLimit on top of the tasks' own terminations and a fresh, equally seeded handle per rollout.
+RESETS = [("DartHopper-v1", 64, 65536, "mt"), ("DartHopper-v1", 32, 65536, "mt"), ("DartHopper-v1", 64, 65536, "philox"), ("DartWalker2d-v1", 64, 65536, "mt"),
+          ("DartHalfCheetah-v1", 64, 65536, "philox"), ("DartHalfCheetah-v1", 32, 65536, "mt"), ("DartSnake7Link-v1", 64, 16384, "mt"),
+          ("DartReacher3d-v1", 64, 16384, "mt"), ("DartHumanWalker-v1", 64, 4096, "philox"), ("DartDog-v1", 32, 4096, "mt")]
+
+
+@pytest.mark.parametrize("env_id,prec,n,mode", RESETS)
+def test_reset_epilogues_are_independent_of_leftovers(env_id, prec, n, mode):
+    common = ["--poison", "all", "--when", "combined", "--pattern", "random", "--reps", "5", "--steps", "6"]
+    d = _probe(env_id, prec, common + ["--autoreset", mode], n=n)
+    assert len(d) == 5 and len(set(d)) == 1, d
+    if mode == "mt" and env_id == "DartHopper-v1":      # and the fused reset is the two-launch reset, bit for bit, at the bench's batch size
+        s = _probe(env_id, prec, common + ["--autoreset", "mt-split"], n=n)
+        assert set(s) == set(d), (s, d)

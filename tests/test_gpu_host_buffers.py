@@ -98,3 +98,49 @@ def test_vector_env_outputs_are_leased_blocks():
     first = venv.step(a)[0].__array_interface__["data"][0]
     assert first == pool[0][0].__array_interface__["data"][0]
     venv.close()
+
+
+def test_output_blocks_are_driver_pinned_memory_that_outlives_the_handle():
+    """Round 6: the blocks a step's results arrive in are dart_alloc_output's (hipHostMalloc) -- not numpy arrays locked with hipHostRegister,
+    into which GPU writes faulted about once in ten runs of this suite (profiles/r06_crash_hunt.txt part 2) -- and they belong to the arrays
+    handed out: results stay readable after close() and after the handle is garbage; the caller-registered form of the ABI still works and
+    gives the same bits."""
+    import ctypes as C
+    card = card_for("DartHopper-v1")
+    n = 640
+    acts = np.random.RandomState(2).uniform(-1, 1, (8, n, 3)).astype(np.float32)
+
+    def start():
+        s = st.HipStepper(card, n, precision=64)
+        s.configure(st.CFG_AUTORESET, 1); s.configure(st.CFG_SEED, 9)
+        s.reset(None, None, None, want_obs=False)
+        return s
+
+    s = start()
+    outs = [s.step(a) for a in acts]
+    copies = [tuple(np.array(x, copy=True) for x in o) for o in outs]
+    assert all(isinstance(e[0].base, st._PinnedBlock) for e in s._blocks) and 1 <= len(s._blocks) <= st.HipStepper._POOL_SETS
+    s.close()
+    del s
+    gc.collect()
+    for o, c in zip(outs, copies):                       # the memory is the arrays', not the handle's
+        assert all(np.array_equal(x, y) for x, y in zip(o, c))
+    # the same rollout through a caller-registered numpy block (dart_register_output: kept for callers that need their own memory)
+    s = start()
+    total, off = s._layout()
+    blk = np.zeros(total, dtype=np.uint8)
+    s._check(s.L.dart_register_output(s.h, blk.ctypes.data_as(C.c_void_p)))
+    for t, a in enumerate(acts):
+        s._check(s.L.dart_step_async_to(s.h, a.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p)))
+        s._check(s.L.dart_step_wait(s.h, None, None, None, None))
+        obs = blk[off[0]:off[0] + 4 * n * card.obs_dim].view(np.float32).reshape(n, card.obs_dim)
+        rew = blk[total - ((8 * n + 255) & ~255):][:8 * n].view(np.float64)
+        assert np.array_equal(obs, copies[t][0]) and np.array_equal(rew, copies[t][1]) and np.array_equal(blk[off[2]:off[2] + n].view(np.bool_), copies[t][2])
+    s._check(s.L.dart_unregister_output(s.h, blk.ctypes.data_as(C.c_void_p)))
+    # a block of dart_alloc_output can be withdrawn from the handle and freed by hand, and is refused afterwards
+    p = C.c_void_p()
+    s._check(s.L.dart_alloc_output(s.h, C.byref(p)))
+    s._check(s.L.dart_unregister_output(s.h, p))
+    assert s.L.dart_step_async_to(s.h, acts[0].ctypes.data_as(C.c_void_p), p) == st.E_INVALID
+    assert s.L.dart_free_output(p) == st.DART_OK
+    s.close()
